@@ -1,0 +1,240 @@
+"""ctypes binding of libdehalo.so (C ABI: include/dehalo.h).  Fails loudly when the HIP
+library is missing or no gfx950 device is present -- there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SYMBOLS = [
+    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize",
+    "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len",
+    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_best_multiexp", "dehalo_to_affine",
+    "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
+    "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
+    "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
+]
+
+K_MSM_ACCUMULATE, K_MSM_SORT, K_MSM_REDUCE, K_NTT_PASS = 0, 1, 2, 3
+
+
+class DehaloError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("dehalo error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libdehalo.so")
+
+
+def load_library():
+    """Loads libdehalo.so.  If torch is importable it is imported FIRST so that the process
+    holds a single HIP runtime (torch bundles libamdhip64.so.7; same soname as /opt/rocm's)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise DehaloError(-2, "libdehalo.so is not built (run `make` or __graft_entry__.build()); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(path)
+    P, sz, u32, u64p = C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p
+    lib.dehalo_version.restype = C.c_char_p
+    lib.dehalo_last_error.restype = C.c_char_p
+    lib.dehalo_last_error.argtypes = [P]
+    lib.dehalo_ctx_create.argtypes = [C.c_int, C.POINTER(P)]
+    lib.dehalo_ctx_destroy.argtypes = [P]
+    lib.dehalo_ctx_destroy.restype = None
+    lib.dehalo_ctx_synchronize.argtypes = [P]
+    lib.dehalo_bases_register.argtypes = [P, C.c_int, u64p, sz, sz, C.c_int, C.c_int, C.POINTER(P)]
+    lib.dehalo_bases_release.argtypes = [P, P]
+    lib.dehalo_bases_len.argtypes = [P]
+    lib.dehalo_bases_len.restype = sz
+    lib.dehalo_msm.argtypes = [P, P, u64p, sz, u64p]
+    lib.dehalo_msm_batch.argtypes = [P, P, C.POINTER(C.c_void_p), sz, sz, u64p]
+    lib.dehalo_msm_device.argtypes = [P, P, u64p, sz, sz, u64p, P]
+    lib.dehalo_best_multiexp.argtypes = [P, C.c_int, u64p, u64p, sz, u64p]
+    lib.dehalo_to_affine.argtypes = [P, C.c_int, u64p, sz, u64p]
+    lib.dehalo_ntt.argtypes = [P, C.c_int, u64p, u32, u64p]
+    lib.dehalo_ntt_device.argtypes = [P, C.c_int, u64p, u32, u64p, sz, P]
+    lib.dehalo_intt_scaled.argtypes = [P, C.c_int, u64p, u32, u64p, u64p]
+    lib.dehalo_coset_ntt.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p]
+    lib.dehalo_coset_intt.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p]
+    lib.dehalo_intt_scaled_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, sz, P]
+    lib.dehalo_coset_ntt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p, sz, P]
+    lib.dehalo_coset_intt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p, sz, P]
+    lib.dehalo_field_op.argtypes = [P, C.c_int, C.c_int, u64p, u64p, u64p, sz]
+    lib.dehalo_timing_enable.argtypes = [P, C.c_int]
+    lib.dehalo_timing_reset.argtypes = [P]
+    lib.dehalo_timing_get.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    _LIB = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "expected contiguous uint64 array"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a, shape_last: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, shape_last)
+
+
+class Bases:
+    """Device-resident SRS (ParamsKZG.g / g_lagrange)."""
+
+    def __init__(self, ctx: "Context", handle, curve: int, n: int):
+        self.ctx, self.handle, self.curve, self.n = ctx, handle, curve, n
+
+    def release(self):
+        if self.handle is not None:
+            self.ctx._check(self.ctx.lib.dehalo_bases_release(self.ctx.handle, self.handle))
+            self.handle = None
+
+    def __len__(self):
+        return self.n
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.dehalo_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise DehaloError(rc, "dehalo_ctx_create failed (no gfx950 device?); there is no CPU fallback")
+        self.handle = h
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.dehalo_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise DehaloError(rc, self.lib.dehalo_last_error(self.handle).decode())
+
+    def synchronize(self):
+        self._check(self.lib.dehalo_ctx_synchronize(self.handle))
+
+    # ---- bases / MSM ----
+    def register_bases(self, curve: int, affine_xy, window_bits: int = 0, precompute: bool = True) -> Bases:
+        a = _u64(affine_xy, 8)
+        h = C.c_void_p()
+        self._check(self.lib.dehalo_bases_register(self.handle, curve, _ptr(a), a.shape[0], 64, window_bits, int(precompute), C.byref(h)))
+        return Bases(self, h, curve, a.shape[0])
+
+    def msm(self, bases: Bases, scalars) -> np.ndarray:
+        s = _u64(scalars, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        self._check(self.lib.dehalo_msm(self.handle, bases.handle, _ptr(s), s.shape[0], _ptr(out)))
+        return out
+
+    def msm_batch(self, bases: Bases, columns: Sequence) -> np.ndarray:
+        cols = [_u64(c, 4) for c in columns]
+        n = cols[0].shape[0] if cols else 0
+        assert all(c.shape[0] == n for c in cols)
+        ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        out = np.zeros((len(cols), 12), dtype=np.uint64)
+        self._check(self.lib.dehalo_msm_batch(self.handle, bases.handle, ptrs, n, len(cols), _ptr(out)))
+        return out
+
+    def msm_device(self, bases: Bases, d_scalars: int, length: int, batch: int, d_out: int, stream: int = 0):
+        self._check(self.lib.dehalo_msm_device(self.handle, bases.handle, d_scalars, length, batch, d_out, stream or None))
+
+    def best_multiexp(self, curve: int, scalars, affine_xy) -> np.ndarray:
+        s, a = _u64(scalars, 4), _u64(affine_xy, 8)
+        if s.shape[0] != a.shape[0]:
+            raise ValueError("best_multiexp: coeffs.len() != bases.len()")  # upstream assert_eq!
+        out = np.zeros(12, dtype=np.uint64)
+        self._check(self.lib.dehalo_best_multiexp(self.handle, curve, _ptr(s), _ptr(a), s.shape[0], _ptr(out)))
+        return out
+
+    def to_affine(self, curve: int, jacobian) -> np.ndarray:
+        j = _u64(jacobian, 12)
+        out = np.zeros((j.shape[0], 8), dtype=np.uint64)
+        self._check(self.lib.dehalo_to_affine(self.handle, curve, _ptr(j), j.shape[0], _ptr(out)))
+        return out
+
+    # ---- NTT family (host buffers; in place on a copy, returned) ----
+    def ntt(self, field: int, a, log_n: int, omega) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+        if a.shape[0] != 1 << log_n:
+            raise ValueError("best_fft: a.len() != 1 << log_n")  # upstream assert_eq!
+        self._check(self.lib.dehalo_ntt(self.handle, field, _ptr(a), log_n, _ptr(_u64(omega, 4))))
+        return a
+
+    def intt_scaled(self, field: int, a, log_n: int, omega_inv, n_inv) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+        if a.shape[0] != 1 << log_n:
+            raise ValueError("a.len() != 1 << log_n")
+        self._check(self.lib.dehalo_intt_scaled(self.handle, field, _ptr(a), log_n, _ptr(_u64(omega_inv, 4)), _ptr(_u64(n_inv, 4))))
+        return a
+
+    def coset_ntt(self, field: int, coeffs, log_n: int, log_ext: int, omega_ext, zeta) -> np.ndarray:
+        c = _u64(coeffs, 4)
+        if c.shape[0] != 1 << log_n:
+            raise ValueError("coeffs.len() != 1 << log_n")
+        out = np.zeros((1 << log_ext, 4), dtype=np.uint64)
+        self._check(self.lib.dehalo_coset_ntt(self.handle, field, _ptr(c), log_n, _ptr(out), log_ext, _ptr(_u64(omega_ext, 4)), _ptr(_u64(zeta, 4))))
+        return out
+
+    def coset_intt(self, field: int, a, log_ext: int, omega_ext_inv, ext_n_inv, zeta) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+        if a.shape[0] != 1 << log_ext:
+            raise ValueError("a.len() != 1 << log_ext")
+        self._check(self.lib.dehalo_coset_intt(self.handle, field, _ptr(a), log_ext, _ptr(_u64(omega_ext_inv, 4)), _ptr(_u64(ext_n_inv, 4)),
+                                               _ptr(_u64(zeta, 4))))
+        return a
+
+    # device-resident forms: raw device pointers (e.g. torch tensor .data_ptr()) and a hipStream_t
+    def ntt_device(self, field: int, d_a: int, log_n: int, omega, batch: int = 1, stream: int = 0):
+        self._check(self.lib.dehalo_ntt_device(self.handle, field, d_a, log_n, _ptr(_u64(omega, 4)), batch, stream or None))
+
+    def intt_scaled_device(self, field: int, d_a: int, log_n: int, omega_inv, n_inv, batch: int = 1, stream: int = 0):
+        self._check(self.lib.dehalo_intt_scaled_device(self.handle, field, d_a, log_n, _ptr(_u64(omega_inv, 4)), _ptr(_u64(n_inv, 4)), batch, stream or None))
+
+    def coset_ntt_device(self, field: int, d_coeffs: int, log_n: int, d_ext: int, log_ext: int, omega_ext, zeta, batch: int = 1, stream: int = 0):
+        self._check(self.lib.dehalo_coset_ntt_device(self.handle, field, d_coeffs, log_n, d_ext, log_ext, _ptr(_u64(omega_ext, 4)), _ptr(_u64(zeta, 4)), batch,
+                                                     stream or None))
+
+    def coset_intt_device(self, field: int, d_a: int, log_ext: int, omega_ext_inv, ext_n_inv, zeta, batch: int = 1, stream: int = 0):
+        self._check(self.lib.dehalo_coset_intt_device(self.handle, field, d_a, log_ext, _ptr(_u64(omega_ext_inv, 4)), _ptr(_u64(ext_n_inv, 4)),
+                                                      _ptr(_u64(zeta, 4)), batch, stream or None))
+
+    # ---- element-wise field ops ----
+    OPS = {"add": 0, "sub": 1, "mul": 2, "inv": 3, "to_mont": 4, "from_mont": 5}
+
+    def field_op(self, field: int, op: str, a, b=None) -> np.ndarray:
+        a = _u64(a, 4)
+        out = np.empty_like(a)
+        bp = _ptr(_u64(b, 4)) if b is not None else None
+        self._check(self.lib.dehalo_field_op(self.handle, field, self.OPS[op], _ptr(a), bp, _ptr(out), a.shape[0]))
+        return out
+
+    # ---- measurement ----
+    def timing_enable(self, on: bool = True):
+        self._check(self.lib.dehalo_timing_enable(self.handle, int(on)))
+
+    def timing_reset(self):
+        self._check(self.lib.dehalo_timing_reset(self.handle))
+
+    def timing_get(self, kernel_id: int):
+        ms, cnt = C.c_double(), C.c_uint64()
+        self._check(self.lib.dehalo_timing_get(self.handle, kernel_id, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -1,0 +1,244 @@
+// ntt.cuh -- radix-2 NTT over a 255-bit prime field for gfx950 (replaces upstream
+// halo2_proofs::arithmetic::best_fft and the EvaluationDomain wrappers around it,
+// halo2_proofs/src/arithmetic.rs + src/poly/domain.rs @ v2023_04_20).
+//
+// Same function as best_fft -- a'[i] = sum_j a[j] * omega^(i*j), natural order in and
+// out -- but not its algorithm.  best_fft bit-reverses, then runs log n radix-2 sweeps
+// over the whole array; here the transform is factored N = R_1 * R_2 * ... * R_L
+// (Cooley-Tukey, L <= 4) so each pass moves every element through HBM once:
+//
+//   pass p < L : for every sub-problem of size M and every column n', an R_p-point DIF
+//                transform along the stride-M/R_p axis inside LDS, times the inter-pass
+//                twiddle omega_M^(n' * k), stored back at the same positions;
+//   pass L     : R_L-point transforms of contiguous rows; the store performs the digit
+//                reversal (k = k_1 + R_1 k_2 + ...), so no separate bit-reverse pass.
+//
+// A workgroup owns a tile of R x C elements (R*C <= 2048, 64 KiB of the CU's 160 KiB
+// LDS, two workgroups per CU), kept as two 16-byte planes so that consecutive lanes
+// touch consecutive LDS slots (conflict-free ds_read/write_b128).  Global accesses are
+// C*32-byte contiguous segments.  Twiddles omega^j (j < N/2) live in an HBM/L2-resident
+// table built once per (field, omega, log_n); the R/2 roots of the sub-transform are
+// staged in LDS.  Pre-/post-scaling of lagrange_to_coeff / coeff_to_extended /
+// extended_to_coeff (x n^-1, x zeta^(i mod 3), zero padding) is fused into the first
+// load and the last store.  HBM-bound by design (64 B/element algorithmic); measured
+// bound on gfx950 is the VALU (v_mad_u64_u32) -- see DESIGN.md.
+#pragma once
+#include "fp.cuh"
+
+#define NTT_TILE_LOG 11
+#define NTT_TILE (1 << NTT_TILE_LOG)
+#define NTT_THREADS 256
+#define NTT_MAX_PASSES 4
+
+struct NttPassParams {
+    const fe* src;
+    fe* dst;
+    const fe* tw;        // omega^j, j < N/2
+    u32 log_n;           // N
+    u32 log_m;           // sub-problem size at this pass
+    u32 r;               // log2 of this pass's radix
+    u32 log_c;           // log2 of columns per tile
+    u32 is_final;
+    u32 r1;              // log2 of the first pass's radix (final pass store)
+    u32 nrev;            // number of middle digits to reverse in the final pass
+    u32 rev_r[NTT_MAX_PASSES];  // their log2 radices, most significant first
+    u64 src_len;         // elements valid in src per polynomial (zero beyond)
+    u64 src_stride;      // elements between consecutive polynomials in src
+    u64 dst_stride;
+    u32 pre_mode;        // 1: x [1, z, z^2][i % 3] on the very first load (z = pre_z)
+    u32 post_mode;       // 1: x post0 ; 2: x post0 * [1, z^2, z][i % 3] on the last store (z = post_z)
+    fe pre_z;
+    fe post0, post_z;
+};
+
+FP_DEV u32 bitrev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// omega^e for e < N from the half table (omega^(N/2) = -1)
+template <class F>
+FP_DEV fe tw_lookup(const fe* tw, u64 e, u32 log_n) {
+    u64 half = 1ull << (log_n - 1);
+    bool neg = e >= half;
+    fe w = f_load(&tw[neg ? e - half : e]);
+    return neg ? f_neg<F>(w) : w;
+}
+
+template <class F>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint4* lo = reinterpret_cast<uint4*>(smem_raw);
+    uint4* hi = lo + NTT_TILE;
+    fe* ltw = reinterpret_cast<fe*>(hi + NTT_TILE);  // R/2 sub-transform roots
+
+    const u32 tid = threadIdx.x;
+    const u32 r = P.r, log_c = P.log_c;
+    const u32 R = 1u << r, Cc = 1u << log_c;
+    const u32 tile = R << log_c;
+    const u64 N = 1ull << P.log_n;
+    const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
+    fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
+
+    // stage omega_R^j = omega_N^(j * N/R), j < R/2
+    for (u32 j = tid; j < (R >> 1); j += NTT_THREADS) {
+        fe w = f_load(&P.tw[(u64)j << (P.log_n - r)]);
+        f_store(&ltw[j], w);
+    }
+
+    // ---- tile coordinates ----
+    u64 q = 0, np0 = 0;          // non-final: sub-problem index, first column
+    u32 k1blk = 0; u64 rest = 0; // final
+    const u32 log_cols = P.log_m - r;  // log2(M/R) columns per sub-problem
+    if (!P.is_final) {
+        u32 tiles_per_sub_log = log_cols - log_c;
+        q = (u64)blockIdx.x >> tiles_per_sub_log;
+        np0 = ((u64)blockIdx.x & ((1ull << tiles_per_sub_log) - 1)) << log_c;
+    } else {
+        u32 kb_log = P.r1 - log_c;  // k1 blocks
+        k1blk = blockIdx.x & ((1u << kb_log) - 1);
+        rest = (u64)blockIdx.x >> kb_log;
+    }
+    const u32 log_q_per_k1 = P.log_n - r - P.r1;  // final: Q / R1
+
+    fe pre2 = f_zero();
+    if (P.pre_mode) pre2 = f_sqr<F>(P.pre_z);
+
+    // ---- load ----
+    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
+        u32 j, c;
+        u64 g;
+        if (!P.is_final) {
+            j = idx >> log_c; c = idx & (Cc - 1);
+            g = (q << P.log_m) + ((u64)j << log_cols) + np0 + c;
+        } else {
+            c = idx >> r; j = idx & (R - 1);
+            u64 qq = (((u64)k1blk << log_c) + c) << log_q_per_k1;
+            qq += rest;
+            g = (qq << r) + j;
+        }
+        fe v;
+        if (g < P.src_len) {
+            v = f_load(&src[g]);
+            if (P.pre_mode) {
+                u32 m3 = (u32)(g % 3);
+                if (m3 == 1) v = f_mul<F>(v, P.pre_z);
+                else if (m3 == 2) v = f_mul<F>(v, pre2);
+            }
+        } else {
+            v = f_zero();
+        }
+        u32 li = (j << log_c) + c;
+        lo[li] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        hi[li] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+    }
+    __syncthreads();
+
+    // ---- r DIF stages in LDS: (u, v) -> (u + v, (u - v) * w) ----
+    const u32 nbf = tile >> 1;
+    for (u32 s = 0; s < r; s++) {
+        const u32 log_half = r - s - 1;
+        const u32 half = 1u << log_half;
+        for (u32 bidx = tid; bidx < nbf; bidx += NTT_THREADS) {
+            u32 c = bidx & (Cc - 1), b = bidx >> log_c;
+            u32 pos = b & (half - 1), grp = b >> log_half;
+            u32 i0 = (((grp << (log_half + 1)) + pos) << log_c) + c;
+            u32 i1 = i0 + (half << log_c);
+            uint4 a0 = lo[i0], a1 = hi[i0], b0 = lo[i1], b1 = hi[i1];
+            fe u, v;
+            u.v[0] = a0.x; u.v[1] = a0.y; u.v[2] = a0.z; u.v[3] = a0.w;
+            u.v[4] = a1.x; u.v[5] = a1.y; u.v[6] = a1.z; u.v[7] = a1.w;
+            v.v[0] = b0.x; v.v[1] = b0.y; v.v[2] = b0.z; v.v[3] = b0.w;
+            v.v[4] = b1.x; v.v[5] = b1.y; v.v[6] = b1.z; v.v[7] = b1.w;
+            fe w = f_load(&ltw[pos << s]);
+            fe sum = f_add<F>(u, v);
+            fe dif = f_mul<F>(f_sub<F>(u, v), w);
+            lo[i0] = make_uint4(sum.v[0], sum.v[1], sum.v[2], sum.v[3]);
+            hi[i0] = make_uint4(sum.v[4], sum.v[5], sum.v[6], sum.v[7]);
+            lo[i1] = make_uint4(dif.v[0], dif.v[1], dif.v[2], dif.v[3]);
+            hi[i1] = make_uint4(dif.v[4], dif.v[5], dif.v[6], dif.v[7]);
+        }
+        __syncthreads();
+    }
+
+    // ---- store (LDS row j holds output digit k = bitrev_r(j)) ----
+    fe post1m, post2m;
+    if (P.is_final && P.post_mode == 2) {
+        post2m = f_mul<F>(P.post0, P.post_z);
+        post1m = f_mul<F>(post2m, P.post_z);
+    }
+    u64 revrest = 0;
+    if (P.is_final) {
+        // rest holds the middle digits (k_2 .. k_{L-1}), k_2 most significant; reverse them
+        u64 rem = rest;
+        u32 bits_left = log_q_per_k1, mult = 0;
+        for (u32 i = 0; i < P.nrev; i++) {
+            bits_left -= P.rev_r[i];
+            u64 d = rem >> bits_left;
+            rem -= d << bits_left;
+            revrest += d << mult;
+            mult += P.rev_r[i];
+        }
+    }
+    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
+        u32 k = idx >> log_c, c = idx & (Cc - 1);
+        u32 j = bitrev32(k, r);
+        u32 li = (j << log_c) + c;
+        uint4 a0 = lo[li], a1 = hi[li];
+        fe v;
+        v.v[0] = a0.x; v.v[1] = a0.y; v.v[2] = a0.z; v.v[3] = a0.w;
+        v.v[4] = a1.x; v.v[5] = a1.y; v.v[6] = a1.z; v.v[7] = a1.w;
+        u64 o;
+        if (!P.is_final) {
+            u64 np = np0 + c;
+            u64 e = (np * k) << (P.log_n - P.log_m);
+            if (e) v = f_mul<F>(v, tw_lookup<F>(P.tw, e, P.log_n));
+            o = (q << P.log_m) + ((u64)k << log_cols) + np;
+        } else {
+            o = (((u64)k1blk << log_c) + c) + (revrest << P.r1) + ((u64)k << (P.log_n - r));
+            if (P.post_mode == 1) v = f_mul<F>(v, P.post0);
+            else if (P.post_mode == 2) {
+                u32 m3 = (u32)(o % 3);
+                v = f_mul<F>(v, m3 == 0 ? P.post0 : (m3 == 1 ? post1m : post2m));
+            }
+        }
+        f_store(&dst[o], v);
+    }
+    (void)N;
+}
+
+// tw[j] = omega^j, j < half.  Thread t fills a run of 64 starting from omega^(64 t).
+template <class F>
+__global__ void k_twiddle_gen(fe* tw, fe omega, u64 half) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 start = t * 64;
+    if (start >= half) return;
+    // omega^start by square-and-multiply
+    fe acc = f_one<F>();
+    fe base = omega;
+    for (u64 e = start; e; e >>= 1) {
+        if (e & 1) acc = f_mul<F>(acc, base);
+        base = f_sqr<F>(base);
+    }
+    u64 end = start + 64 < half ? start + 64 : half;
+    for (u64 j = start; j < end; j++) {
+        f_store(&tw[j], acc);
+        acc = f_mul<F>(acc, omega);
+    }
+}
+
+// element-wise field ops for the parity tests (dehalo_field_op)
+template <class F>
+__global__ void k_field_op(int op, const fe* a, const fe* b, fe* out, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x = f_load(&a[i]);
+    fe y = b ? f_load(&b[i]) : x;
+    fe r;
+    switch (op) {
+        case 0: r = f_add<F>(x, y); break;
+        case 1: r = f_sub<F>(x, y); break;
+        case 2: r = f_mul<F>(x, y); break;
+        case 3: r = f_is_zero(x) ? f_zero() : f_inv<F>(x); break;
+        case 4: r = f_to_mont<F>(x); break;
+        default: r = f_from_mont<F>(x); break;
+    }
+    f_store(&out[i], r);
+}

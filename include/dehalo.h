@@ -1,0 +1,153 @@
+/*
+ * dehalo.h -- C ABI of the MI355X (gfx950) MSM / NTT prover backend.
+ *
+ * Drop-in boundary for the hot path of radiusxyz/delay-encryption-in-halo2: the
+ * commitments and FFTs that `create_proof` (reference call sites
+ * benches/delay_enc.rs:123-131, benches/mod_pow.rs:201-209, benches/pose_enc.rs:127-135;
+ * keygen at benches/delay_enc.rs:86,103) performs through the un-vendored dependency
+ * halo2_proofs @ tag v2023_04_20 (Cargo.toml:17).  Each entry point names the upstream
+ * function a patched halo2_proofs forwards to it (bindings: INTEGRATION.md).
+ *
+ * Conventions (all entry points):
+ *  - plain pointers and sizes only; caller-owned buffers, never retained after return
+ *    (except bases handed to dehalo_bases_register, which are COPIED to the device);
+ *  - field element  = 4 x u64 little-endian limbs, MONTGOMERY form, R = 2^256: exactly the
+ *    in-memory representation of halo2curves' bn256::{Fr,Fq} / pasta::{Fp,Fq};
+ *  - affine point   = {x, y} (64 B), identity encoded as x = y = 0;
+ *  - projective out = Jacobian {x, y, z} (96 B), identity z = 0.  Any representative of the
+ *    class may be returned (as with rayon's thread-count-dependent summation order
+ *    upstream); compare after to_affine();
+ *  - return 0 on success, a negative dehalo_status otherwise; never aborts, never throws;
+ *  - "host" entry points take host pointers and are synchronous; "_device" entry points
+ *    take device pointers and a hipStream_t (as void*; NULL = the context's stream) and
+ *    are asynchronous on that stream;
+ *  - a context is bound to one device; calls on one context are serialised by the caller
+ *    or by stream order.  There is NO CPU fallback: without a usable gfx950 device
+ *    dehalo_ctx_create fails with DEHALO_ERR_NO_DEVICE.
+ */
+#ifndef DEHALO_H
+#define DEHALO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DEHALO_OK = 0,
+    DEHALO_ERR_INVALID = -1,    /* bad argument: null pointer, length mismatch, log_n out of range */
+    DEHALO_ERR_NO_DEVICE = -2,  /* no HIP device / wrong architecture */
+    DEHALO_ERR_OOM = -3,        /* device allocation failed */
+    DEHALO_ERR_HIP = -4,        /* any other HIP runtime error (see dehalo_last_error) */
+    DEHALO_ERR_UNSUPPORTED = -5 /* e.g. NTT over a field whose two-adicity is too small */
+} dehalo_status;
+
+/* halo2curves curve / field identities */
+typedef enum { DEHALO_CURVE_BN254_G1 = 0, DEHALO_CURVE_PALLAS = 1, DEHALO_CURVE_VESTA = 2 } dehalo_curve;
+typedef enum { DEHALO_FIELD_BN254_FR = 0, DEHALO_FIELD_BN254_FQ = 1, DEHALO_FIELD_PASTA_FP = 2, DEHALO_FIELD_PASTA_FQ = 3 } dehalo_field;
+
+typedef struct dehalo_ctx dehalo_ctx;
+typedef struct dehalo_bases dehalo_bases;
+
+/* ---- context --------------------------------------------------------------------------- */
+int dehalo_ctx_create(int device, dehalo_ctx** out);
+void dehalo_ctx_destroy(dehalo_ctx* ctx);
+/* Human-readable text of the last error on this context (valid until the next call). */
+const char* dehalo_last_error(const dehalo_ctx* ctx);
+/* Blocks until everything queued on the context's own stream has finished. */
+int dehalo_ctx_synchronize(dehalo_ctx* ctx);
+
+/* ---- SRS / bases ------------------------------------------------------------------------
+ * Replaces the `g` / `g_lagrange` vectors of ParamsKZG / ParamsIPA
+ * [halo2_proofs/src/poly/kzg/commitment.rs, .../ipa/commitment.rs; built at
+ * benches/delay_enc.rs:41-54].  Bases are constant per SRS, so they are uploaded once and
+ * stay resident in HBM.
+ *   affine_xy     n points, `stride_bytes` apart (>= 64; 64 for halo2curves' {x, y} structs)
+ *   window_bits   0 = choose from n; otherwise the Pippenger window c in [4, 16]
+ *   precompute    1 = also store [2^(c*w)]P_i for every window w (n * ceil(256/c) * 64 B of
+ *                 HBM): all windows then share one bucket set and the per-window doublings
+ *                 vanish.  0 = store the n points only.
+ */
+int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes,
+                          int window_bits, int precompute, dehalo_bases** out);
+int dehalo_bases_release(dehalo_ctx* ctx, dehalo_bases* bases);
+size_t dehalo_bases_len(const dehalo_bases* bases);
+
+/* ---- MSM == halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve ------------
+ * [halo2_proofs/src/arithmetic.rs; reached from ParamsKZG::commit / commit_lagrange].
+ * out = sum_{i < len} scalars[i] * bases[i]; len may be smaller than the registered n
+ * (a prefix is used, as commit() does).  scalars: len x 4 u64 (Montgomery).
+ * out_jacobian: 12 u64.  upstream's `assert_eq!(coeffs.len(), bases.len())` becomes
+ * DEHALO_ERR_INVALID when len > registered n.                                              */
+int dehalo_msm(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* scalars, size_t len, uint64_t out_jacobian[12]);
+/* `batch` independent MSMs over the same bases (one per committed column):
+ * scalars[b] points to len x 4 u64; out_jacobian receives batch x 12 u64.                   */
+int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* const* scalars, size_t len, size_t batch,
+                     uint64_t* out_jacobian);
+/* Device-resident form: d_scalars = batch x len x 4 u64 contiguous in HBM, d_out = batch x 12 u64 in HBM. */
+int dehalo_msm_device(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* d_scalars, size_t len, size_t batch,
+                      uint64_t* d_out_jacobian, void* stream);
+/* One-shot best_multiexp over bases that are not registered (uploaded, used, dropped). */
+int dehalo_best_multiexp(dehalo_ctx* ctx, int curve, const uint64_t* scalars, const uint64_t* affine_xy, size_t len,
+                         uint64_t out_jacobian[12]);
+/* G1::to_affine / batch_normalize of MSM outputs: count x 12 u64 -> count x 8 u64 (host buffers). */
+int dehalo_to_affine(dehalo_ctx* ctx, int curve, const uint64_t* jacobian, size_t count, uint64_t* affine_xy);
+
+/* ---- NTT == halo2_proofs::arithmetic::best_fft(a, omega, log_n) ---------------------------
+ * [halo2_proofs/src/arithmetic.rs].  In place, natural order in and out,
+ * a'[i] = sum_j a[j] * omega^(i*j), no scaling.  a: 2^log_n x 4 u64.  omega must be a
+ * primitive 2^log_n-th root of unity (forward or inverse), Montgomery form.
+ * upstream's `assert_eq!(a.len(), 1 << log_n)` is the caller's contract here.              */
+int dehalo_ntt(dehalo_ctx* ctx, int field, uint64_t* a, uint32_t log_n, const uint64_t omega[4]);
+int dehalo_ntt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_n, const uint64_t omega[4], size_t batch,
+                      void* stream);
+
+/* ---- EvaluationDomain conveniences [halo2_proofs/src/poly/domain.rs] ----------------------
+ * lagrange_to_coeff:  best_fft(a, omega_inv, k); a[i] *= n_inv                              */
+int dehalo_intt_scaled(dehalo_ctx* ctx, int field, uint64_t* a, uint32_t log_n, const uint64_t omega_inv[4], const uint64_t n_inv[4]);
+/* coeff_to_extended:  ext[i] = coeffs[i] * [1, zeta, zeta^2][i % 3] for i < 2^log_n, zero
+ * above; best_fft(ext, omega_ext, log_ext).  coeffs and ext_out may not alias.              */
+int dehalo_coset_ntt(dehalo_ctx* ctx, int field, const uint64_t* coeffs, uint32_t log_n, uint64_t* ext_out, uint32_t log_ext,
+                     const uint64_t omega_ext[4], const uint64_t zeta[4]);
+/* extended_to_coeff:  best_fft(a, omega_ext_inv, log_ext); a[i] *= ext_n_inv * [1, zeta^2, zeta][i % 3].
+ * (The caller truncates to n * quotient_poly_degree, as upstream does.)                     */
+int dehalo_coset_intt(dehalo_ctx* ctx, int field, uint64_t* a, uint32_t log_ext, const uint64_t omega_ext_inv[4],
+                      const uint64_t ext_n_inv[4], const uint64_t zeta[4]);
+/* Device-resident forms (batch polynomials contiguous in HBM). */
+int dehalo_intt_scaled_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_n, const uint64_t omega_inv[4],
+                              const uint64_t n_inv[4], size_t batch, void* stream);
+int dehalo_coset_ntt_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, uint32_t log_n, uint64_t* d_ext_out,
+                            uint32_t log_ext, const uint64_t omega_ext[4], const uint64_t zeta[4], size_t batch, void* stream);
+int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_ext, const uint64_t omega_ext_inv[4],
+                             const uint64_t ext_n_inv[4], const uint64_t zeta[4], size_t batch, void* stream);
+
+/* ---- element-wise field ops (halo2curves Fr/Fq/Fp::{add,sub,mul,invert,to_repr,from_repr})
+ * Used by the parity tests to pin the device field arithmetic directly (e.g. against the
+ * reference's Poseidon known-answer vectors).  Host buffers, n elements each.
+ * op: 0 add, 1 sub, 2 mul, 3 invert, 4 canonical->Montgomery, 5 Montgomery->canonical.     */
+int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * Per-kernel device time measured with HIP events on the launching stream (bench.py's
+ * roofline leg).  kernel ids: see dehalo_kernel_id.                                          */
+typedef enum {
+    DEHALO_K_MSM_ACCUMULATE = 0, /* bucket accumulation (the dominant MSM kernel) */
+    DEHALO_K_MSM_SORT = 1,       /* digit histogram + scatter                       */
+    DEHALO_K_MSM_REDUCE = 2,     /* partial merge + bucket reduction                */
+    DEHALO_K_NTT_PASS = 3,       /* all NTT passes of one transform                 */
+    DEHALO_K_COUNT = 4
+} dehalo_kernel_id;
+int dehalo_timing_enable(dehalo_ctx* ctx, int on);
+int dehalo_timing_reset(dehalo_ctx* ctx);
+/* Synchronises the context, then returns total milliseconds and number of timed regions. */
+int dehalo_timing_get(dehalo_ctx* ctx, int kernel_id, double* total_ms, uint64_t* count);
+
+/* Library / build info, e.g. "dehalo 0.1 gfx950". */
+const char* dehalo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEHALO_H */

@@ -1,0 +1,118 @@
+"""ctypes wrapper of oracle/liboracle.so (the C restatement).  TEST INFRASTRUCTURE ONLY:
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build() -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        P = C.c_void_p
+        _LIB.orc_best_multiexp.argtypes = [C.c_int, P, P, C.c_size_t, C.c_int, P]
+        _LIB.orc_to_affine.argtypes = [C.c_int, P, P]
+        _LIB.orc_best_fft.argtypes = [C.c_int, P, P, C.c_uint32, C.c_int]
+        _LIB.orc_lagrange_to_coeff.argtypes = [C.c_int, P, C.c_uint32, P, P, C.c_int]
+        _LIB.orc_coeff_to_extended.argtypes = [C.c_int, P, C.c_uint32, P, C.c_uint32, P, P, C.c_int]
+        _LIB.orc_extended_to_coeff.argtypes = [C.c_int, P, C.c_uint32, P, P, P, C.c_int]
+        _LIB.orc_field_op.argtypes = [C.c_int, C.c_int, P, P, P, C.c_size_t]
+        _LIB.orc_field_info.argtypes = [C.c_int, P, P, P, P]
+        _LIB.orc_fill_scalars.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_size_t, P]
+        _LIB.orc_synth_bases.argtypes = [C.c_int, C.c_size_t, P]
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def limbs(x: int) -> np.ndarray:
+    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+OPS = {"add": 0, "sub": 1, "mul": 2, "inv": 3, "to_mont": 4, "from_mont": 5}
+
+
+def field_op(field: int, op: str, a: np.ndarray, b: np.ndarray | None = None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty_like(a)
+    bp = _p(np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)) if b is not None else None
+    rc = lib().orc_field_op(field, OPS[op], _p(a), bp, _p(out), a.shape[0])
+    assert rc == 0
+    return out
+
+
+def best_multiexp(curve: int, scalars: np.ndarray, bases: np.ndarray, threads: int = 1) -> np.ndarray:
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+    assert scalars.shape[0] == bases.shape[0]
+    out = np.zeros(12, dtype=np.uint64)
+    rc = lib().orc_best_multiexp(curve, _p(scalars), _p(bases), scalars.shape[0], threads, _p(out))
+    assert rc == 0
+    return out
+
+
+def to_affine(curve: int, jac: np.ndarray) -> np.ndarray:
+    jac = np.ascontiguousarray(jac, dtype=np.uint64).reshape(12)
+    out = np.zeros(8, dtype=np.uint64)
+    assert lib().orc_to_affine(curve, _p(jac), _p(out)) == 0
+    return out
+
+
+def best_fft(field: int, a: np.ndarray, omega: np.ndarray, log_n: int, threads: int = 1) -> np.ndarray:
+    a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+    assert a.shape[0] == 1 << log_n
+    omega = np.ascontiguousarray(omega, dtype=np.uint64)
+    assert lib().orc_best_fft(field, _p(a), _p(omega), log_n, threads) == 0
+    return a
+
+
+def lagrange_to_coeff(field, a, k, omega_inv, divisor, threads=1):
+    a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+    assert lib().orc_lagrange_to_coeff(field, _p(a), k, _p(np.ascontiguousarray(omega_inv)), _p(np.ascontiguousarray(divisor)), threads) == 0
+    return a
+
+
+def coeff_to_extended(field, coeffs, k, ext_k, ext_omega, zeta, threads=1):
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    ext = np.zeros(((1 << ext_k), 4), dtype=np.uint64)
+    assert lib().orc_coeff_to_extended(field, _p(coeffs), k, _p(ext), ext_k, _p(np.ascontiguousarray(ext_omega)), _p(np.ascontiguousarray(zeta)), threads) == 0
+    return ext
+
+
+def extended_to_coeff(field, a, ext_k, ext_omega_inv, divisor, zeta, threads=1):
+    a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+    assert lib().orc_extended_to_coeff(field, _p(a), ext_k, _p(np.ascontiguousarray(ext_omega_inv)), _p(np.ascontiguousarray(divisor)), _p(np.ascontiguousarray(zeta)), threads) == 0
+    return a
+
+
+DISTS = {"uniform": 0, "witness": 1, "lookup": 2}
+
+
+def fill_scalars(field: int, dist: str, n: int, seed: int = 0x64656C6179656E63) -> np.ndarray:
+    out = np.zeros((n, 4), dtype=np.uint64)
+    assert lib().orc_fill_scalars(field, DISTS[dist], seed, n, _p(out)) == 0
+    return out
+
+
+def synth_bases(curve: int, n: int) -> np.ndarray:
+    out = np.zeros((n, 8), dtype=np.uint64)
+    assert lib().orc_synth_bases(curve, n, _p(out)) == 0
+    return out

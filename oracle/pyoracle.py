@@ -1,0 +1,673 @@
+"""Pure-Python big-integer oracle for the MSM / NTT hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is imported, linked or
+executed by the product path (``delay-encryption-in-halo2_amd/``); only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may use it, and only as the checker.
+
+PARITY UNPINNED at the MSM/NTT boundary: the reference repository holds no
+golden vector for ``best_multiexp`` / ``best_fft`` (the arithmetic lives in the
+un-vendored crates halo2_proofs @ v2023_04_20 and halo2curves, Cargo.toml:17)
+and cannot be compiled here (no rustc/cargo).  What *is* pinned:
+
+* ``bn256::Fr`` field arithmetic, by the reference's two Poseidon
+  known-answer vectors (src/poseidon/permutation.rs:154-158,190-196), through
+  the Grain/MDS/permutation restated below
+  (src/poseidon/grain.rs:12-69,74-157, src/poseidon/spec.rs:170-180,
+  src/poseidon/permutation.rs:60-80);
+* all field / curve constants, re-derived here from the moduli alone and
+  cross-checked (primality, two-adicity, ``[order]G = O``).
+
+MSM and NTT are exact functions with unique answers, so "bit-exact vs
+best_multiexp/best_fft" is equality with the mathematical definition computed
+here with Python integers (affine (x, y) for the MSM; canonical field elements
+for the NTT), re-encoded in halo2curves' in-memory format (4 x u64
+little-endian limbs, Montgomery form, R = 2^256).
+
+Semantics followed (upstream halo2_proofs/src/arithmetic.rs
+and halo2_proofs/src/poly/domain.rs at tag v2023_04_20):
+
+* ``best_multiexp(coeffs, bases)``  -> sum_i coeffs[i] * bases[i]
+* ``best_fft(a, omega, log_n)``     -> a'[i] = sum_j a[j] * omega^(i*j), natural order
+* ``EvaluationDomain::{lagrange_to_coeff, coeff_to_extended, extended_to_coeff}``
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+MASK64 = (1 << 64) - 1
+R_BITS = 256
+
+
+# ----------------------------------------------------------------------------
+# Fields
+# ----------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Field:
+    name: str
+    p: int
+    gen: int  # multiplicative generator used by upstream for ROOT_OF_UNITY
+
+    @property
+    def S(self) -> int:  # two-adicity
+        t, s = self.p - 1, 0
+        while t % 2 == 0:
+            t //= 2
+            s += 1
+        return s
+
+    @property
+    def R(self) -> int:
+        return (1 << R_BITS) % self.p
+
+    @property
+    def R2(self) -> int:
+        return pow(1 << R_BITS, 2, self.p)
+
+    @property
+    def R_inv(self) -> int:
+        return pow(self.R, -1, self.p)
+
+    @property
+    def inv64(self) -> int:  # -p^-1 mod 2^64
+        return (-pow(self.p, -1, 1 << 64)) % (1 << 64)
+
+    @property
+    def inv32(self) -> int:
+        return (-pow(self.p, -1, 1 << 32)) % (1 << 32)
+
+    @property
+    def root_of_unity(self) -> int:  # primitive 2^S-th root
+        return pow(self.gen, (self.p - 1) >> self.S, self.p)
+
+    def omega(self, log_n: int) -> int:
+        """Primitive 2^log_n-th root, as EvaluationDomain::new derives it."""
+        assert log_n <= self.S
+        w = self.root_of_unity
+        for _ in range(self.S - log_n):
+            w = w * w % self.p
+        return w
+
+    @property
+    def cube_root(self) -> int:
+        """g^((p-1)/3)."""
+        assert (self.p - 1) % 3 == 0
+        return pow(self.gen, (self.p - 1) // 3, self.p)
+
+    # Montgomery codec: in-memory halo2curves element = 4 u64 LE limbs of a*R mod p
+    def to_mont(self, a: int) -> int:
+        return a * self.R % self.p
+
+    def from_mont(self, a: int) -> int:
+        return a * self.R_inv % self.p
+
+    def inv(self, a: int) -> int:
+        return pow(a, self.p - 2, self.p)
+
+
+PASTA_FP = Field("pasta_fp", 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001, 5)
+PASTA_FQ = Field("pasta_fq", 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001, 5)
+BN254_FR = Field("bn254_fr", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 7)
+BN254_FQ = Field("bn254_fq", 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47, 3)
+
+FIELDS = {f.name: f for f in (BN254_FR, BN254_FQ, PASTA_FP, PASTA_FQ)}
+# ids shared with include/dehalo.h
+FIELD_IDS = {"bn254_fr": 0, "bn254_fq": 1, "pasta_fp": 2, "pasta_fq": 3}
+
+
+def zeta(field: Field) -> int:
+    """F::ZETA as upstream defines it [UPSTREAM, from memory; SURVEY.md A.3 risk].
+
+    pasta::Fp and bn256::Fr use (g^((p-1)/3))^2; pasta::Fq uses g^((p-1)/3).
+    zeta is always a caller-supplied argument at the C-ABI, so this choice only
+    affects the host mirror's default.
+    """
+    c = field.cube_root
+    if field.name == "pasta_fq":
+        return c
+    return c * c % field.p
+
+
+def limbs64(a: int) -> List[int]:
+    return [(a >> (64 * i)) & MASK64 for i in range(4)]
+
+
+def from_limbs64(l: Sequence[int]) -> int:
+    return sum(int(x) << (64 * i) for i, x in enumerate(l))
+
+
+# ----------------------------------------------------------------------------
+# Curves: short Weierstrass y^2 = x^3 + b, a = 0, prime order, cofactor 1
+# ----------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Curve:
+    name: str
+    base: Field
+    scalar: Field
+    b: int
+    gx: int
+    gy: int
+
+
+PALLAS = Curve("pallas", PASTA_FP, PASTA_FQ, 5, PASTA_FP.p - 1, 2)
+VESTA = Curve("vesta", PASTA_FQ, PASTA_FP, 5, PASTA_FQ.p - 1, 2)
+BN254 = Curve("bn254", BN254_FQ, BN254_FR, 3, 1, 2)
+CURVES = {c.name: c for c in (BN254, PALLAS, VESTA)}
+CURVE_IDS = {"bn254": 0, "pallas": 1, "vesta": 2}
+
+Affine = Optional[Tuple[int, int]]  # None = identity
+
+
+def on_curve(c: Curve, P: Affine) -> bool:
+    if P is None:
+        return True
+    x, y = P
+    p = c.base.p
+    return (y * y - x * x * x - c.b) % p == 0
+
+
+def ec_neg(c: Curve, P: Affine) -> Affine:
+    if P is None:
+        return None
+    return (P[0], (-P[1]) % c.base.p)
+
+
+def ec_add(c: Curve, P: Affine, Q: Affine) -> Affine:
+    p = c.base.p
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if (y1 + y2) % p == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+    x3 = (lam * lam - x1 - x2) % p
+    y3 = (lam * (x1 - x3) - y1) % p
+    return (x3, y3)
+
+
+# Jacobian arithmetic (plain integers) for speed in larger oracle runs
+def _jac_double(p, P):
+    X, Y, Z = P
+    if Z == 0:
+        return P
+    A = X * X % p
+    B = Y * Y % p
+    C = B * B % p
+    D = 2 * ((X + B) * (X + B) - A - C) % p
+    E = 3 * A % p
+    F = E * E % p
+    X3 = (F - 2 * D) % p
+    Y3 = (E * (D - X3) - 8 * C) % p
+    Z3 = 2 * Y * Z % p
+    return (X3, Y3, Z3)
+
+
+def _jac_add(p, P, Q):
+    X1, Y1, Z1 = P
+    X2, Y2, Z2 = Q
+    if Z1 == 0:
+        return Q
+    if Z2 == 0:
+        return P
+    Z1Z1 = Z1 * Z1 % p
+    Z2Z2 = Z2 * Z2 % p
+    U1 = X1 * Z2Z2 % p
+    U2 = X2 * Z1Z1 % p
+    S1 = Y1 * Z2 * Z2Z2 % p
+    S2 = Y2 * Z1 * Z1Z1 % p
+    if U1 == U2:
+        if S1 == S2:
+            return _jac_double(p, P)
+        return (1, 1, 0)
+    H = (U2 - U1) % p
+    Rr = (S2 - S1) % p
+    HH = H * H % p
+    HHH = H * HH % p
+    V = U1 * HH % p
+    X3 = (Rr * Rr - HHH - 2 * V) % p
+    Y3 = (Rr * (V - X3) - S1 * HHH) % p
+    Z3 = Z1 * Z2 * H % p
+    return (X3, Y3, Z3)
+
+
+def _to_jac(P: Affine):
+    return (1, 1, 0) if P is None else (P[0], P[1], 1)
+
+
+def _from_jac(p, P) -> Affine:
+    X, Y, Z = P
+    if Z == 0:
+        return None
+    zi = pow(Z, -1, p)
+    zi2 = zi * zi % p
+    return (X * zi2 % p, Y * zi2 * zi % p)
+
+
+def ec_mul(c: Curve, k: int, P: Affine) -> Affine:
+    p = c.base.p
+    k %= c.scalar.p
+    acc = (1, 1, 0)
+    base = _to_jac(P)
+    while k:
+        if k & 1:
+            acc = _jac_add(p, acc, base)
+        base = _jac_double(p, base)
+        k >>= 1
+    return _from_jac(p, acc)
+
+
+def msm_naive(c: Curve, scalars: Sequence[int], points: Sequence[Affine]) -> Affine:
+    """Definition of best_multiexp: sum_i s_i * P_i, by double-and-add (small n)."""
+    assert len(scalars) == len(points)
+    p = c.base.p
+    acc = (1, 1, 0)
+    for s, P in zip(scalars, points):
+        acc = _jac_add(p, acc, _to_jac(ec_mul(c, s, P)))
+    return _from_jac(p, acc)
+
+
+def msm_pippenger(c: Curve, scalars: Sequence[int], points: Sequence[Affine], window: Optional[int] = None) -> Affine:
+    """multiexp_serial as upstream writes it: unsigned c-bit
+    digits, 2^c - 1 buckets, MSB window first, summation by parts."""
+    import math
+
+    n = len(scalars)
+    assert n == len(points)
+    p = c.base.p
+    if window is None:
+        window = 1 if n < 4 else 3 if n < 32 else math.ceil(math.log(n))
+    cbits = window
+    segments = 256 // cbits + 1
+    acc = (1, 1, 0)
+    jpts = [_to_jac(P) for P in points]
+    for seg in reversed(range(segments)):
+        for _ in range(cbits):
+            acc = _jac_double(p, acc)
+        buckets = [(1, 1, 0)] * ((1 << cbits) - 1)
+        for s, P in zip(scalars, jpts):
+            d = (s >> (seg * cbits)) & ((1 << cbits) - 1)
+            if d:
+                buckets[d - 1] = _jac_add(p, buckets[d - 1], P)
+        running = (1, 1, 0)
+        for b in reversed(buckets):
+            running = _jac_add(p, running, b)
+            acc = _jac_add(p, acc, running)
+    return _from_jac(p, acc)
+
+
+def synth_bases(c: Curve, n: int) -> List[Affine]:
+    """P0 = G, P_i = P_{i-1} + G', G' = [0x9e3779b97f4a7c15]G."""
+    G = (c.gx, c.gy)
+    Gp = ec_mul(c, 0x9E3779B97F4A7C15, G)
+    out = [G]
+    p = c.base.p
+    cur = _to_jac(G)
+    jgp = _to_jac(Gp)
+    js = [cur]
+    for _ in range(1, n):
+        cur = _jac_add(p, cur, jgp)
+        js.append(cur)
+    return [_from_jac(p, j) for j in js]
+
+
+# ----------------------------------------------------------------------------
+# NTT (best_fft) and EvaluationDomain wrappers
+# ----------------------------------------------------------------------------
+def dft_naive(f: Field, a: Sequence[int], omega: int) -> List[int]:
+    n = len(a)
+    p = f.p
+    return [sum(a[j] * pow(omega, i * j, p) for j in range(n)) % p for i in range(n)]
+
+
+def best_fft(f: Field, a: Sequence[int], omega: int, log_n: int) -> List[int]:
+    """a'[i] = sum_j a[j] omega^(ij); bit-reverse then radix-2 DIT."""
+    n = 1 << log_n
+    assert len(a) == n
+    p = f.p
+    a = list(a)
+    for k in range(n):
+        rk = int(format(k, "0%db" % log_n)[::-1], 2) if log_n else 0
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    m = 1
+    for _ in range(log_n):
+        w_m = pow(omega, n // (2 * m), p)
+        for k in range(0, n, 2 * m):
+            w = 1
+            for j in range(m):
+                t = a[k + j + m] * w % p
+                a[k + j + m] = (a[k + j] - t) % p
+                a[k + j] = (a[k + j] + t) % p
+                w = w * w_m % p
+        m *= 2
+    return a
+
+
+@dataclass
+class Domain:
+    """EvaluationDomain::new(j, k)."""
+
+    f: Field
+    k: int
+    j: int  # max gate degree
+
+    @property
+    def n(self) -> int:
+        return 1 << self.k
+
+    @property
+    def quotient_poly_degree(self) -> int:
+        return self.j - 1
+
+    @property
+    def extended_k(self) -> int:
+        ek = self.k
+        while (1 << ek) < self.n * self.quotient_poly_degree:
+            ek += 1
+        return ek
+
+    @property
+    def omega(self) -> int:
+        return self.f.omega(self.k)
+
+    @property
+    def omega_inv(self) -> int:
+        return self.f.inv(self.omega)
+
+    @property
+    def ext_omega(self) -> int:
+        return self.f.omega(self.extended_k)
+
+    @property
+    def ext_omega_inv(self) -> int:
+        return self.f.inv(self.ext_omega)
+
+    @property
+    def ifft_divisor(self) -> int:
+        return self.f.inv(self.n % self.f.p)
+
+    @property
+    def ext_ifft_divisor(self) -> int:
+        return self.f.inv((1 << self.extended_k) % self.f.p)
+
+    @property
+    def g_coset(self) -> int:
+        return zeta(self.f)
+
+    @property
+    def g_coset_inv(self) -> int:
+        z = zeta(self.f)
+        return z * z % self.f.p
+
+    def lagrange_to_coeff(self, a: Sequence[int]) -> List[int]:
+        p = self.f.p
+        out = best_fft(self.f, a, self.omega_inv, self.k)
+        d = self.ifft_divisor
+        return [x * d % p for x in out]
+
+    def coeff_to_extended(self, a: Sequence[int]) -> List[int]:
+        p = self.f.p
+        assert len(a) == self.n
+        pw = [1, self.g_coset, self.g_coset_inv]
+        a = [x * pw[i % 3] % p for i, x in enumerate(a)]
+        a += [0] * ((1 << self.extended_k) - len(a))
+        return best_fft(self.f, a, self.ext_omega, self.extended_k)
+
+    def extended_to_coeff(self, a: Sequence[int]) -> List[int]:
+        p = self.f.p
+        out = best_fft(self.f, a, self.ext_omega_inv, self.extended_k)
+        d = self.ext_ifft_divisor
+        pw = [1, self.g_coset_inv, self.g_coset]
+        out = [x * d % p * pw[i % 3] % p for i, x in enumerate(out)]
+        return out[: self.n * self.quotient_poly_degree]
+
+
+# ----------------------------------------------------------------------------
+# Poseidon (only to pin bn256::Fr arithmetic against the reference's KATs)
+# ----------------------------------------------------------------------------
+class Grain:
+    """src/poseidon/grain.rs:12-157 restated."""
+
+    def __init__(self, f: Field, t: int, r_f: int, r_p: int):
+        self.f = f
+        self.nbits = f.p.bit_length()
+        bits: List[int] = []
+
+        def app(n, v):
+            for i in reversed(range(n)):
+                bits.append((v >> i) & 1)
+
+        app(2, 1)  # FIELD_TYPE prime
+        app(4, 0)  # SBOX_TYPE alpha
+        app(12, self.nbits)
+        app(12, t)
+        app(10, r_f)
+        app(10, r_p)
+        app(30, (1 << 30) - 1)
+        assert len(bits) == 80
+        self.bits = bits
+        for _ in range(160):
+            self._new_bit()
+
+    def _new_bit(self) -> int:
+        b = self.bits
+        nb = b[0] ^ b[62] ^ b[51] ^ b[38] ^ b[23] ^ b[13]
+        b.pop(0)
+        b.append(nb)
+        return nb
+
+    def _next(self) -> int:
+        # grain.rs:145-152: discard pairs whose first bit is 0
+        while not self._new_bit():
+            self._new_bit()
+        return self._new_bit()
+
+    def _draw(self) -> int:
+        v = 0
+        for _ in range(self.nbits):  # MSB first (grain.rs:86-92)
+            v = (v << 1) | self._next()
+        return v
+
+    def next_field_element(self) -> int:
+        while True:
+            v = self._draw()
+            if v < self.f.p:
+                return v
+
+    def next_field_element_without_rejection(self) -> int:
+        return self._draw() % self.f.p
+
+
+def poseidon_spec_ref(f: Field, t: int, r_f: int, r_p: int):
+    g = Grain(f, t, r_f, r_p)
+    constants = [[g.next_field_element() for _ in range(t)] for _ in range(r_f + r_p)]
+    xs = [g.next_field_element_without_rejection() for _ in range(t)]
+    ys = [g.next_field_element_without_rejection() for _ in range(t)]
+    mds = [[f.inv((x + y) % f.p) for y in ys] for x in xs]  # spec.rs:170-180
+    return constants, mds
+
+
+def poseidon_permute_ref(f: Field, state: Sequence[int], r_f: int, r_p: int, mul=None, add=None):
+    """SpecRef::permute (src/poseidon/permutation.rs:60-80).  ``mul``/``add`` may
+    be swapped for another implementation's field ops (C oracle, GPU)."""
+    p = f.p
+    mul = mul or (lambda a, b: a * b % p)
+    add = add or (lambda a, b: (a + b) % p)
+    t = len(state)
+    constants, mds = poseidon_spec_ref(f, t, r_f, r_p)
+    st = list(state)
+
+    def sbox(e):
+        tmp = mul(e, e)
+        e = mul(e, tmp)
+        return mul(e, tmp)
+
+    def apply_mds(v):
+        out = []
+        for row in mds:
+            acc = 0
+            for a_i, v_i in zip(row, v):
+                acc = add(acc, mul(v_i, a_i))
+            out.append(acc)
+        return out
+
+    half = r_f // 2
+    for r, rc in enumerate(constants):
+        st = [add(e, c) for e, c in zip(st, rc)]
+        if r < half or r >= half + r_p:
+            st = [sbox(e) for e in st]
+        else:
+            st[0] = sbox(st[0])
+        st = apply_mds(st)
+    return st
+
+
+POSEIDON_KATS = [
+    # (t, r_f, r_p, expected) -- src/poseidon/permutation.rs:154-158 and :190-196
+    (3, 8, 57, [
+        7853200120776062878684798364095072458815029376092732009249414926327459813530,
+        7142104613055408817911962100316808866448378443474503659992478482890339429929,
+        6549537674122432311777789598043107870002137484850126429160507761192163713804,
+    ]),
+    (5, 8, 60, [
+        18821383157269793795438455681495246036402687001665670618754263018637548127333,
+        7817711165059374331357136443537800893307845083525445872661165200086166013245,
+        16733335996448830230979566039396561240864200624113062088822991822580465420551,
+        6644334865470350789317807668685953492649391266180911382577082600917830417726,
+        3372108894677221197912083238087960099443657816445944159266857514496320565191,
+    ]),
+]
+
+
+# ----------------------------------------------------------------------------
+# Deterministic synthetic inputs: splitmix64 -> xoshiro256**
+# ----------------------------------------------------------------------------
+SEED = 0x64656C6179656E63  # "delayenc"
+
+
+class Xoshiro:
+    def __init__(self, seed: int = SEED):
+        s = seed & MASK64
+        st = []
+        for _ in range(4):
+            s = (s + 0x9E3779B97F4A7C15) & MASK64
+            z = s
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+            st.append(z ^ (z >> 31))
+        self.s = st
+
+    def next64(self) -> int:
+        s = self.s
+        rotl = lambda x, k: ((x << k) | (x >> (64 - k))) & MASK64
+        r = (rotl((s[1] * 5) & MASK64, 7) * 9) & MASK64
+        t = (s[1] << 17) & MASK64
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rotl(s[3], 45)
+        return r
+
+    def below(self, bound: int) -> int:
+        """uniform in [0, bound) by rejection on the needed bit length."""
+        nb = max(1, (bound - 1).bit_length())
+        words = (nb + 63) // 64
+        while True:
+            v = 0
+            for i in range(words):
+                v |= self.next64() << (64 * i)
+            v &= (1 << nb) - 1
+            if v < bound:
+                return v
+
+
+def scalars_uniform(f: Field, n: int, rng: Xoshiro) -> List[int]:
+    return [rng.below(f.p) for _ in range(n)]
+
+
+def scalars_witness_like(f: Field, n: int, rng: Xoshiro) -> List[int]:
+    out = []
+    for _ in range(n):
+        u = rng.next64() % 100
+        if u < 30:
+            out.append(0)
+        elif u < 45:
+            out.append(rng.below(1 << 8))
+        elif u < 70:
+            out.append(rng.below(1 << 64))
+        elif u < 95:
+            out.append(rng.below(1 << 134))
+        else:
+            out.append(rng.below(f.p))
+    return out
+
+
+def scalars_lookup_like(f: Field, n: int, rng: Xoshiro) -> List[int]:
+    table = [rng.below(f.p) for _ in range(340)]
+    out = []
+    for _ in range(n):
+        if rng.next64() % 100 < 60:
+            out.append(0)
+        else:
+            out.append(table[rng.next64() % 340])
+    return out
+
+
+# ----------------------------------------------------------------------------
+# Self-check of the constants (run: python oracle/pyoracle.py)
+# ----------------------------------------------------------------------------
+def _is_probable_prime(n: int) -> bool:
+    if n < 2:
+        return False
+    for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % q == 0:
+            return n == q
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def self_check() -> None:
+    for f in FIELDS.values():
+        assert _is_probable_prime(f.p), f.name
+        r = f.root_of_unity
+        assert pow(r, 1 << f.S, f.p) == 1 and pow(r, 1 << (f.S - 1), f.p) == f.p - 1, f.name
+    assert (PASTA_FP.S, PASTA_FQ.S, BN254_FR.S, BN254_FQ.S) == (32, 32, 28, 1)
+    for c in CURVES.values():
+        G = (c.gx, c.gy)
+        assert on_curve(c, G)
+        assert ec_mul(c, c.scalar.p - 1, G) == ec_neg(c, G), c.name  # [order]G = O
+    for f in (PASTA_FP, PASTA_FQ, BN254_FR):
+        z = zeta(f)
+        assert z != 1 and pow(z, 3, f.p) == 1
+    for t, r_f, r_p, exp in POSEIDON_KATS:
+        assert poseidon_permute_ref(BN254_FR, list(range(t)), r_f, r_p) == exp
+
+
+if __name__ == "__main__":
+    self_check()
+    for f in FIELDS.values():
+        print(f.name, "S", f.S, "INV64", hex(f.inv64), "R", [hex(x) for x in limbs64(f.R)])
+        print("   ROOT", hex(f.root_of_unity))
+    print("self-check ok (incl. both Poseidon KATs of the reference)")

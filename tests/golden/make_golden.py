@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json with oracle/pyoracle.py (Python big integers).
+
+The reference holds no MSM/NTT vectors and cannot run here, so these are the
+build's own definition-level vectors: NTT outputs from the O(n^2) DFT definition, MSM outputs
+from per-term double-and-add.  Values are canonical integers in hex; the tests re-encode
+them into halo2curves' Montgomery limbs.  Re-run: python tests/golden/make_golden.py"""
+import json, os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import pyoracle as po
+
+def hx(x): return hex(x)
+
+def ntt_vectors():
+    out = []
+    for fname in ("bn254_fr", "pasta_fp", "pasta_fq"):
+        f = po.FIELDS[fname]
+        rng = po.Xoshiro(po.SEED ^ po.FIELD_IDS[fname])
+        for log_n in (0, 1, 2, 3, 5, 8):
+            n = 1 << log_n
+            a = po.scalars_uniform(f, n, rng)
+            w = f.omega(log_n)
+            fwd = po.dft_naive(f, a, w)
+            assert fwd == po.best_fft(f, a, w, log_n)
+            out.append({"field": fname, "log_n": log_n, "omega": hx(w), "input": [hx(x) for x in a], "output": [hx(x) for x in fwd]})
+    return out
+
+def domain_vectors():
+    out = []
+    for fname, j in (("bn254_fr", 5), ("bn254_fr", 3), ("pasta_fp", 5), ("pasta_fq", 4)):
+        f = po.FIELDS[fname]
+        rng = po.Xoshiro(po.SEED + 17 * po.FIELD_IDS[fname] + j)
+        for k in (2, 4):
+            d = po.Domain(f, k, j)
+            a = po.scalars_uniform(f, d.n, rng)
+            coeffs = d.lagrange_to_coeff(a)
+            ext = d.coeff_to_extended(coeffs)
+            back = d.extended_to_coeff(ext)
+            assert back[: d.n] == coeffs and all(x == 0 for x in back[d.n:])
+            # definition check: ext[i] = poly(zeta * ext_omega^i)
+            z = po.zeta(f)
+            for i in (0, 1, len(ext) - 1):
+                x = z * pow(d.ext_omega, i, f.p) % f.p
+                assert ext[i] == sum(c * pow(x, e, f.p) for e, c in enumerate(coeffs)) % f.p
+            out.append({"field": fname, "k": k, "j": j, "extended_k": d.extended_k, "zeta": hx(z), "lagrange": [hx(x) for x in a],
+                        "coeffs": [hx(x) for x in coeffs], "extended": [hx(x) for x in ext], "back": [hx(x) for x in back]})
+    return out
+
+def msm_vectors():
+    out = []
+    for cname in ("bn254", "pallas", "vesta"):
+        c = po.CURVES[cname]
+        fs = c.scalar
+        bases = po.synth_bases(c, 256)
+        rng = po.Xoshiro(po.SEED ^ (0x1000 + po.CURVE_IDS[cname]))
+        for n, dist in ((1, "uniform"), (2, "uniform"), (3, "witness"), (31, "uniform"), (32, "lookup"), (33, "witness"), (256, "uniform")):
+            gen = {"uniform": po.scalars_uniform, "witness": po.scalars_witness_like, "lookup": po.scalars_lookup_like}[dist]
+            s = gen(fs, n, rng)
+            res = po.msm_naive(c, s, bases[:n])
+            assert res == po.msm_pippenger(c, s, bases[:n])
+            out.append({"curve": cname, "n": n, "dist": dist, "scalars": [hx(x) for x in s],
+                        "result": None if res is None else [hx(res[0]), hx(res[1])]})
+        # edge cases: 0, 1, r-1, 2^253, all-equal scalars, duplicated points, identity points, cancelling pair
+        r = fs.p
+        pts = list(bases[:8])
+        pts[3] = pts[2]                      # duplicate point
+        pts[5] = None                        # identity
+        pts[7] = po.ec_neg(c, pts[6])        # P, -P
+        sc = [0, 1, r - 1, 1 << 253, 5, 12345, 77, 77]
+        res = po.msm_naive(c, sc, pts)
+        out.append({"curve": cname, "n": 8, "dist": "edge", "scalars": [hx(x) for x in sc],
+                    "points": [None if P is None else [hx(P[0]), hx(P[1])] for P in pts],
+                    "result": None if res is None else [hx(res[0]), hx(res[1])]})
+        sc = [r - 1] * 16                    # all-equal scalars
+        res = po.msm_naive(c, sc, bases[:16])
+        out.append({"curve": cname, "n": 16, "dist": "all_equal", "scalars": [hx(x) for x in sc],
+                    "result": None if res is None else [hx(res[0]), hx(res[1])]})
+        sc = [3, r - 3]                      # result = identity
+        res = po.msm_naive(c, sc, [bases[0], bases[0]])
+        assert res is None
+        out.append({"curve": cname, "n": 2, "dist": "cancel", "scalars": [hx(x) for x in sc],
+                    "points": [[hx(bases[0][0]), hx(bases[0][1])]] * 2, "result": None})
+    return out
+
+def bases_vectors():
+    return {cname: [[hx(P[0]), hx(P[1])] for P in po.synth_bases(po.CURVES[cname], 256)] for cname in ("bn254", "pallas", "vesta")}
+
+if __name__ == "__main__":
+    po.self_check()
+    for name, fn in (("ntt", ntt_vectors), ("domain", domain_vectors), ("msm", msm_vectors), ("bases", bases_vectors)):
+        with open(os.path.join(HERE, name + ".json"), "w") as fh:
+            json.dump(fn(), fh, separators=(",", ":"))
+        print("wrote", name)
+    with open(os.path.join(HERE, "poseidon_kat.json"), "w") as fh:
+        # the reference's own known-answer vectors (src/poseidon/permutation.rs:154-158,190-196): data, not code
+        json.dump([{"field": "bn254_fr", "t": t, "r_f": rf, "r_p": rp, "input": list(range(t)), "expected": [str(x) for x in e]} for t, rf, rp, e in po.POSEIDON_KATS], fh)
+    print("wrote poseidon_kat")

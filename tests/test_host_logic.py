@@ -1,0 +1,49 @@
+"""CPU suite: host-side mirror logic (constants, EvaluationDomain setup, argument checks)."""
+import numpy as np
+import pytest
+
+
+def test_field_specs_match_oracle_constants(pkg, po):
+    for name, spec in pkg.fields.FIELDS.items():
+        f = po.FIELDS[name]
+        assert spec.p == f.p and spec.id == po.FIELD_IDS[name]
+        assert spec.two_adicity == f.S and spec.root_of_unity == f.root_of_unity
+        if (f.p - 1) % 3 == 0 and name != "bn254_fq":
+            assert spec.zeta == po.zeta(f)
+        for x in (0, 1, f.p - 1, 12345678901234567890):
+            assert po.from_limbs64(spec.encode(x)) == f.to_mont(x)
+            assert spec.decode(spec.encode(x)) == x % f.p
+    for name, c in pkg.fields.CURVES.items():
+        oc = po.CURVES[name]
+        assert c.id == po.CURVE_IDS[name] and c.base.p == oc.base.p and c.scalar.p == oc.scalar.p and c.b == oc.b
+
+
+def test_upstream_zeta_prefixes(pkg):
+    # upstream ZETA(pasta::Fp) = 0x12ccca83..., ZETA(bn256::Fr) = 0x30644e72...6f23
+    assert hex(pkg.fields.PASTA_FP.zeta).startswith("0x12ccca83") and hex(pkg.fields.PASTA_FP.zeta).endswith("4ab9")
+    assert hex(pkg.fields.BN254_FR.zeta).startswith("0x30644e72") and hex(pkg.fields.BN254_FR.zeta).endswith("6f23")
+    assert hex(pkg.fields.PASTA_FQ.zeta).startswith("0x6819a58")
+
+
+@pytest.mark.parametrize("fname,j,k", [("bn254_fr", 5, 17), ("bn254_fr", 3, 11), ("pasta_fp", 5, 14), ("pasta_fq", 4, 6)])
+def test_domain_setup_matches_oracle(pkg, po, fname, j, k):
+    class NoCtx:  # the constructor performs no device work
+        pass
+    d = pkg.EvaluationDomain(NoCtx(), pkg.fields.FIELDS[fname], j, k)
+    o = po.Domain(po.FIELDS[fname], k, j)
+    assert (d.n, d.extended_k, d.quotient_poly_degree) == (o.n, o.extended_k, o.quotient_poly_degree)
+    assert (d.omega, d.omega_inv, d.extended_omega, d.extended_omega_inv) == (o.omega, o.omega_inv, o.ext_omega, o.ext_omega_inv)
+    assert (d.ifft_divisor, d.extended_ifft_divisor, d.g_coset, d.g_coset_inv) == (o.ifft_divisor, o.ext_ifft_divisor, o.g_coset, o.g_coset_inv)
+    assert d.extended_len() == 1 << o.extended_k
+    # delay_enc shape: degree 5 -> extended = 4n; pose_enc: degree 3 -> 2n
+    if j == 5:
+        assert d.extended_k == k + 2
+    if j == 3:
+        assert d.extended_k == k + 1
+
+
+def test_domain_rejects_oversized_extension(pkg):
+    class NoCtx:
+        pass
+    with pytest.raises(ValueError):
+        pkg.EvaluationDomain(NoCtx(), pkg.fields.BN254_FR, 5, 27)  # 2^29 > two-adicity 28

@@ -1,0 +1,164 @@
+"""CPU suite: pins the oracle (the checker) itself.  pyoracle (Python integers) is pinned by the
+reference's Poseidon KATs and by definition-level identities; the C restatement is pinned by
+pyoracle and by the committed golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import dec_point, enc_points, golden
+
+
+def test_pyoracle_self_check(po):
+    po.self_check()  # primes, two-adicity, [order]G = O, zeta^3 = 1, both Poseidon KATs
+
+
+def test_poseidon_kats_reference_vectors(po):
+    # src/poseidon/permutation.rs:154-158 and :190-196 (data committed in tests/golden/poseidon_kat.json)
+    for kat in golden("poseidon_kat"):
+        f = po.FIELDS[kat["field"]]
+        out = po.poseidon_permute_ref(f, kat["input"], kat["r_f"], kat["r_p"])
+        assert out == [int(x) for x in kat["expected"]]
+
+
+def test_poseidon_kats_through_c_oracle_field_ops(po, co):
+    """Same permutation, but every mul/add goes through oracle.c's Montgomery arithmetic:
+    pins the C restatement's bn256::Fr mul/add (and to/from Montgomery)."""
+    f = po.BN254_FR
+    fid = po.FIELD_IDS[f.name]
+
+    def enc(a):
+        return co.limbs(f.to_mont(a)).reshape(1, 4)
+
+    def dec(l):
+        return f.from_mont(po.from_limbs64(l.reshape(4)))
+
+    mul = lambda a, b: dec(co.field_op(fid, "mul", enc(a), enc(b)))
+    add = lambda a, b: dec(co.field_op(fid, "add", enc(a), enc(b)))
+    kat = golden("poseidon_kat")[0]
+    out = po.poseidon_permute_ref(f, kat["input"], kat["r_f"], kat["r_p"], mul=mul, add=add)
+    assert out == [int(x) for x in kat["expected"]]
+
+
+@pytest.mark.parametrize("fname", ["bn254_fr", "bn254_fq", "pasta_fp", "pasta_fq"])
+def test_c_field_ops_vs_python(po, co, fname):
+    f = po.FIELDS[fname]
+    fid = po.FIELD_IDS[fname]
+    p = f.p
+    rng = po.Xoshiro(1234 + fid)
+    vals = [0, 1, 2, p - 1, p - 2, (1 << 255) % p, f.R % p, (p - 1) // 2] + [rng.below(p) for _ in range(200)]
+    vb = list(reversed(vals))
+    a = np.stack([co.limbs(f.to_mont(x)) for x in vals])
+    b = np.stack([co.limbs(f.to_mont(x)) for x in vb])
+    dec = lambda arr: [f.from_mont(po.from_limbs64(r)) for r in arr]
+    assert dec(co.field_op(fid, "add", a, b)) == [(x + y) % p for x, y in zip(vals, vb)]
+    assert dec(co.field_op(fid, "sub", a, b)) == [(x - y) % p for x, y in zip(vals, vb)]
+    assert dec(co.field_op(fid, "mul", a, b)) == [(x * y) % p for x, y in zip(vals, vb)]
+    nz = [x for x in vals if x]
+    an = np.stack([co.limbs(f.to_mont(x)) for x in nz])
+    assert dec(co.field_op(fid, "inv", an)) == [pow(x, -1, p) for x in nz]
+    canon = np.stack([co.limbs(x) for x in vals])
+    assert np.array_equal(co.field_op(fid, "to_mont", canon), a)
+    assert np.array_equal(co.field_op(fid, "from_mont", a), canon)
+
+
+def test_c_field_constants(po, co):
+    import ctypes as C
+    for name, f in po.FIELDS.items():
+        p = np.zeros(4, np.uint64); r = np.zeros(4, np.uint64); r2 = np.zeros(4, np.uint64); inv = C.c_uint64()
+        assert co.lib().orc_field_info(po.FIELD_IDS[name], p.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), r2.ctypes.data_as(C.c_void_p), C.byref(inv)) == 0
+        assert po.from_limbs64(p) == f.p and po.from_limbs64(r) == f.R and po.from_limbs64(r2) == f.R2 and inv.value == f.inv64
+
+
+def test_golden_ntt_vs_c_oracle(po, co):
+    for v in golden("ntt"):
+        f = po.FIELDS[v["field"]]
+        fid = po.FIELD_IDS[v["field"]]
+        a = np.stack([co.limbs(f.to_mont(int(x, 16))) for x in v["input"]])
+        w = co.limbs(f.to_mont(int(v["omega"], 16)))
+        for threads in (1, 4):
+            out = co.best_fft(fid, a, w, v["log_n"], threads)
+            assert [f.from_mont(po.from_limbs64(r)) for r in out] == [int(x, 16) for x in v["output"]]
+
+
+def test_golden_domain_vs_c_oracle(po, co):
+    for v in golden("domain"):
+        f = po.FIELDS[v["field"]]
+        fid = po.FIELD_IDS[v["field"]]
+        d = po.Domain(f, v["k"], v["j"])
+        assert d.extended_k == v["extended_k"]
+        enc = lambda xs: np.stack([co.limbs(f.to_mont(int(x, 16))) for x in xs])
+        dec = lambda arr: [f.from_mont(po.from_limbs64(r)) for r in arr]
+        m = lambda x: co.limbs(f.to_mont(x))
+        coeffs = co.lagrange_to_coeff(fid, enc(v["lagrange"]), d.k, m(d.omega_inv), m(d.ifft_divisor))
+        assert dec(coeffs) == [int(x, 16) for x in v["coeffs"]]
+        ext = co.coeff_to_extended(fid, coeffs, d.k, d.extended_k, m(d.ext_omega), m(int(v["zeta"], 16)))
+        assert dec(ext) == [int(x, 16) for x in v["extended"]]
+        back = co.extended_to_coeff(fid, ext, d.extended_k, m(d.ext_omega_inv), m(d.ext_ifft_divisor), m(int(v["zeta"], 16)))
+        assert dec(back)[: d.n * d.quotient_poly_degree] == [int(x, 16) for x in v["back"]]
+
+
+def _golden_points(po, fb_enc, v, bases_json):
+    if "points" in v:
+        pts = [None if P is None else (int(P[0], 16), int(P[1], 16)) for P in v["points"]]
+    else:
+        pts = [(int(P[0], 16), int(P[1], 16)) for P in bases_json[v["curve"]][: v["n"]]]
+    return pts
+
+
+def test_golden_msm_vs_c_oracle(po, co, pkg):
+    bases_json = golden("bases")
+    for v in golden("msm"):
+        c = po.CURVES[v["curve"]]
+        cid = po.CURVE_IDS[v["curve"]]
+        spec = pkg.fields.CURVES[v["curve"]]
+        pts = _golden_points(po, None, v, bases_json)
+        bases = enc_points(spec.base, pts)
+        scalars = np.stack([co.limbs(c.scalar.to_mont(int(x, 16))) for x in v["scalars"]])
+        want = None if v["result"] is None else (int(v["result"][0], 16), int(v["result"][1], 16))
+        for threads in (1, 3):
+            got = dec_point(spec.base, co.to_affine(cid, co.best_multiexp(cid, scalars, bases, threads)))
+            assert got == want, (v["curve"], v["n"], v["dist"], threads)
+
+
+def test_c_generators_match_python(po, co):
+    for cname, cid in po.CURVE_IDS.items():
+        c = po.CURVES[cname]
+        b = co.synth_bases(cid, 20)
+        pb = po.synth_bases(c, 20)
+        for i in range(20):
+            assert po.from_limbs64(b[i, :4]) == c.base.to_mont(pb[i][0]) and po.from_limbs64(b[i, 4:]) == c.base.to_mont(pb[i][1])
+    for dist, gen in (("uniform", po.scalars_uniform), ("witness", po.scalars_witness_like), ("lookup", po.scalars_lookup_like)):
+        f = po.PASTA_FQ
+        s = co.fill_scalars(po.FIELD_IDS[f.name], dist, 500)
+        assert [f.from_mont(po.from_limbs64(x)) for x in s] == gen(f, 500, po.Xoshiro())
+
+
+def test_c_msm_random_vs_python_pippenger(po, co):
+    c = po.PALLAS
+    cid = po.CURVE_IDS["pallas"]
+    n = 300
+    b = co.synth_bases(cid, n)
+    pb = po.synth_bases(c, n)
+    for dist in ("uniform", "witness", "lookup"):
+        s = co.fill_scalars(po.FIELD_IDS[c.scalar.name], dist, n, 99)
+        ps = [c.scalar.from_mont(po.from_limbs64(x)) for x in s]
+        want = po.msm_pippenger(c, ps, pb)
+        for threads in (1, 7):
+            a = co.to_affine(cid, co.best_multiexp(cid, s, b, threads))
+            got = None if not a.any() else (c.base.from_mont(po.from_limbs64(a[:4])), c.base.from_mont(po.from_limbs64(a[4:])))
+            assert got == want
+
+
+def test_c_fft_roundtrip_and_threads(po, co):
+    f = po.BN254_FR
+    fid = po.FIELD_IDS[f.name]
+    k = 12
+    a = co.fill_scalars(fid, "uniform", 1 << k, 5)
+    w = co.limbs(f.to_mont(f.omega(k)))
+    wi = co.limbs(f.to_mont(f.inv(f.omega(k))))
+    one = co.best_fft(fid, a, w, k, 1)
+    for t in (2, 3, 8):
+        assert np.array_equal(co.best_fft(fid, a, w, k, t), one)
+    back = co.best_fft(fid, one, wi, k, 4)
+    ninv = co.limbs(f.to_mont(f.inv(1 << k)))
+    back = co.field_op(fid, "mul", back, np.tile(ninv, (1 << k, 1)))
+    assert np.array_equal(back, a)
