@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- one JSON line for BASELINE.json's metric on its configs[1]:
+"Standalone 2^20 Pallas MSM + 2^20 pasta-Fp NTT on 1 MI355X".
+
+A step = one pass of the hot path over one batch of synthetic input, inputs already resident
+in HBM: one 2^20-term Pallas MSM (== best_multiexp / commit over a registered SRS) plus one
+2^20-point NTT over pasta::Fp (== best_fft), then -- because the north star names it -- the
+all-gather of the commitment vector across ranks (a no-op at N = 1).  One process per GPU;
+N > 1 is launched by torch.distributed.run, units are independent per rank (weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--no-cpu-baseline]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+MSM_BYTES_PER_TERM = 96  # 64 B affine base + 32 B scalar
+NTT_BYTES_PER_ELEM = 64  # read once + write once
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--curve", default="pallas")
+    ap.add_argument("--ntt-field", default="pasta_fp")
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "witness", "lookup"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-bits", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(co, po, curve, field, log_n, dist):
+    """The oracle's C restatement of best_multiexp + best_fft (same chunk-per-thread split as
+    upstream's rayon code) on this host's cores: a reported baseline, not the target."""
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+    n = 1 << log_n
+    bases = co.synth_bases(curve.id, n)
+    scalars = co.fill_scalars(curve.scalar.id, dist, n, 1)
+    a = co.fill_scalars(field.id, "uniform", n, 2)
+    omega = field.encode(po.FIELDS[field.name].omega(log_n))
+    reps, t_msm, t_ntt = 0, 0.0, 0.0
+    t_start = time.time()
+    while reps < 3 and (reps == 0 or time.time() - t_start < 20.0):
+        t0 = time.time()
+        co.best_multiexp(curve.id, scalars, bases, cores)
+        t1 = time.time()
+        co.best_fft(field.id, a, omega, log_n, cores)
+        t2 = time.time()
+        t_msm += t1 - t0
+        t_ntt += t2 - t1
+        reps += 1
+    step_s = (t_msm + t_ntt) / reps
+    return {
+        "value": round(n / step_s / 1e6, 4), "unit": "Mpoints/s", "cores": cores, "kind": "port",
+        "sample": "%d x (2^%d-term MSM + 2^%d-point NTT), oracle/oracle.c best_multiexp+best_fft, %d threads" % (reps, log_n, log_n, cores),
+        "msm_ms": round(1e3 * t_msm / reps, 2), "ntt_ms": round(1e3 * t_ntt / reps, 2),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the measured path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL over xGMI
+
+    pkg = entry.load_package()
+    po, co = entry.load_oracle()  # synthetic-input generators + the cpu_baseline leg only
+    from dehalo2_amd import _lib, sharding
+
+    curve = pkg.fields.CURVES[args.curve]
+    field = pkg.fields.FIELDS[args.ntt_field]
+    log_n, n = args.log_n, 1 << args.log_n
+
+    ctx = pkg.Context(local_rank)
+    # synthetic SRS and witnesses; every rank gets its own scalar column
+    bases_h = co.synth_bases(curve.id, n)
+    scalars_h = co.fill_scalars(curve.scalar.id, args.dist, n, 1000 + rank)
+    poly_h = co.fill_scalars(field.id, "uniform", n, 2000 + rank)
+    bases = ctx.register_bases(curve.id, bases_h, args.window_bits, True)  # resident SRS tables
+    d_scalars = torch.from_numpy(scalars_h.view(np.int64)).cuda()
+    d_poly = torch.from_numpy(poly_h.view(np.int64)).cuda()
+    d_out = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    omega = field.encode(po.FIELDS[field.name].omega(log_n))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.msm_device(bases, d_scalars.data_ptr(), n, 1, d_out.data_ptr(), stream)
+        ctx.ntt_device(field.id, d_poly.data_ptr(), log_n, omega, 1, stream)
+        return sharding.all_gather_commitments(d_out, world, rank, world) if world > 1 else d_out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # parity spot-check of the measured configuration, outside the timed region (rank 0, once)
+    fence()
+    if rank == 0 and log_n <= 14:
+        got = ctx.to_affine(curve.id, d_out.cpu().numpy().view(np.uint64))[0]
+        want = co.to_affine(curve.id, co.best_multiexp(curve.id, scalars_h, bases_h, 4))
+        assert np.array_equal(got, want), "bench MSM result differs from the oracle"
+
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed)
+    ctx.timing_enable(False)
+
+    if rank == 0:
+        acc_ms, acc_cnt = ctx.timing_get(_lib.K_MSM_ACCUMULATE)
+        sort_ms, sort_cnt = ctx.timing_get(_lib.K_MSM_SORT)
+        red_ms, red_cnt = ctx.timing_get(_lib.K_MSM_REDUCE)
+        ntt_ms, ntt_cnt = ctx.timing_get(_lib.K_NTT_PASS)
+        acc_avg_ms = acc_ms / max(acc_cnt, 1)
+        achieved = MSM_BYTES_PER_TERM * n / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("log_n") == log_n and rec.get("curve") == args.curve:
+                    traffic = rec.get("msm_accumulate_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "pallas_msm_mpoints_per_s_at_2^%d" % log_n if args.curve == "pallas" else "%s_msm_mpoints_per_s_at_2^%d" % (args.curve, log_n),
+            "value": round(world * n * args.steps / elapsed / 1e6, 3),
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)",
+            "data": "synthetic",
+            "config": {"workload": "1 x MSM(2^%d, %s) + 1 x NTT(2^%d, %s) per step per GPU, %s scalars, SRS tables resident" % (log_n, args.curve, log_n, args.ntt_field, args.dist),
+                       "configs_index": 1, "parallelism": "independent units per rank; RCCL all-gather of commitments" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accum0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": MSM_BYTES_PER_TERM * n, "avg_kernel_ms": round(acc_avg_ms, 4),
+                         "note": "MSM is integer-VALU-bound (group adds), not HBM-bound: a low HBM fraction is expected (SURVEY.md 8d)"},
+            "breakdown_ms_per_step": {"msm_sort": round(sort_ms / max(sort_cnt, 1), 4), "msm_accumulate": round(acc_avg_ms, 4),
+                                      "msm_reduce": round(red_ms / max(red_cnt, 1), 4), "ntt": round(ntt_ms / max(ntt_cnt, 1), 4)},
+            "ntt_roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEM * n / (ntt_ms / max(ntt_cnt, 1) * 1e-3) / 1e9, 2) if ntt_ms > 0 else 0.0,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+        }
+        out["ntt_roofline"]["frac"] = round(out["ntt_roofline"]["achieved"] / HBM_PEAK_GBS, 5)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(co, po, curve, field, log_n, args.dist)
+        print(json.dumps(out), flush=True)
+
+    bases.release()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
