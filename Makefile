@@ -1,14 +1,23 @@
-# Builds libdehalo.so (HIP, gfx950 only) and the oracle (test infrastructure).
+# Builds libdehalo.so (HIP, gfx950 only; one translation unit per curve / field so that
+# `make -j` compiles them in parallel) and the oracle (test infrastructure).
 HIPCC ?= /opt/rocm/bin/hipcc
 PKG := delay-encryption-in-halo2_amd
 CSRC := $(PKG)/csrc
+OBJDIR := $(CSRC)/obj
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off
 LIB := $(PKG)/libdehalo.so
+UNITS := capi msm_bn254 msm_pallas msm_vesta ntt_bn254_fr ntt_bn254_fq ntt_pasta_fp ntt_pasta_fq
+OBJS := $(UNITS:%=$(OBJDIR)/%.o)
+HDRS := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/dehalo.h
 
 all: $(LIB) oracle host_example
 
-$(LIB): $(CSRC)/capi.hip $(CSRC)/fp.cuh $(CSRC)/ec.cuh $(CSRC)/ntt.cuh $(CSRC)/msm.cuh $(CSRC)/field_constants.h include/dehalo.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/capi.hip -Wl,-rpath,/opt/rocm/lib
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(OBJS) -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle liboracle.so
@@ -17,5 +26,5 @@ host_example: $(LIB) $(PKG)/host/halo2_backend.hpp $(PKG)/host/example.cpp
 	g++ -std=c++17 -O1 -Wall -o $(PKG)/host/example $(PKG)/host/example.cpp -L$(PKG) -ldehalo -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
 clean:
-	rm -f $(LIB); $(MAKE) -C oracle clean
+	rm -rf $(LIB) $(OBJDIR) $(PKG)/host/example; $(MAKE) -C oracle clean
 .PHONY: all oracle clean host_example

@@ -218,7 +218,7 @@ class Context:
                                                       _ptr(_u64(zeta, 4)), batch, stream or None))
 
     # ---- element-wise field ops ----
-    OPS = {"add": 0, "sub": 1, "mul": 2, "inv": 3, "to_mont": 4, "from_mont": 5}
+    OPS = {"add": 0, "sub": 1, "mul": 2, "inv": 3, "to_mont": 4, "from_mont": 5, "mul29": 6}
 
     def field_op(self, field: int, op: str, a, b=None) -> np.ndarray:
         a = _u64(a, 4)

@@ -1,0 +1,170 @@
+// ec29.cuh -- XYZZ group arithmetic (a = 0 short-Weierstrass: BN254 G1, Pallas, Vesta) on the
+// lazily reduced 9 x 29-bit field of fp29.cuh.  Same group elements as halo2curves'
+// G1/Ep/Eq::{add, double, add_mixed} [UPSTREAM, SURVEY.md Appendix B]; formulas
+// madd-2008-s / add-2008-s / dbl-2008-s-1 (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2).
+//
+// Lazy-reduction contract (proved by interval analysis in DESIGN.md section 3 and asserted
+// limb by limb in tools/fp29_model.py):
+//   * stored coordinates have normalized limbs; X, Y < 9.5 p; ZZ, ZZZ < 1.1 p;
+//   * products are < 3 p; the identity is ANY point with ZZ = 0 (mod p) -- all-zero limbs
+//     when built here, but a result that became the identity through P + (-P) carries
+//     ZZ = 0 or p and garbage elsewhere;
+//   * exceptional cases (an identity operand, P == Q, P == -Q) all force ZZ3 = 0 (mod p), so
+//     one test on ZZ3 (< 2p: equal to 0 or to p) guards the fast path, and only when its
+//     one-limb filter fires is anything decided exactly.
+#pragma once
+#include "ec.cuh"
+#include "fp29.cuh"
+
+struct xyzz29 {
+    f29 x, y, zz, zzz;
+};
+struct aff29 {
+    f29 x, y;
+};
+
+// 144-byte record: 4 x 9 limbs, 16-byte aligned (9 x dwordx4)
+struct alignas(16) xyzz29_rec {
+    u32 w[36];
+};
+
+FP_DEV xyzz29 x29_identity() {
+    xyzz29 r;
+    r.x = f29_zero(); r.y = f29_zero(); r.zz = f29_zero(); r.zzz = f29_zero();
+    return r;
+}
+
+FP_DEV xyzz29 x29_load(const xyzz29_rec* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        uint4 t = q[i];
+        w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+    }
+    xyzz29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r.x.v[i] = w[i]; r.y.v[i] = w[9 + i]; r.zz.v[i] = w[18 + i]; r.zzz.v[i] = w[27 + i]; }
+    return r;
+}
+FP_DEV void x29_store(xyzz29_rec* p, const xyzz29& a) {
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { w[i] = a.x.v[i]; w[9 + i] = a.y.v[i]; w[18 + i] = a.zz.v[i]; w[27 + i] = a.zzz.v[i]; }
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// table entry (internal canonical, packed 2 x 32 B; identity = all zero) -> limbs
+FP_DEV aff29 a29_from_packed(const affine_t& p) {
+    aff29 r;
+    r.x = f29_unpack(p.x);
+    r.y = f29_unpack(p.y);
+    return r;
+}
+
+template <class F>
+FP_DEV xyzz29 x29_from_affine(const aff29& q, bool q_is_identity) {
+    if (q_is_identity) return x29_identity();
+    xyzz29 r;
+    r.x = q.x; r.y = q.y; r.zz = f29_one<F>(); r.zzz = f29_one<F>();
+    return r;
+}
+
+// 2 * A  (identity in -> identity out: ZZ3 = V * ZZ1 = 0 mod p)
+template <class F>
+FP_DEV xyzz29 x29_double(const xyzz29& a) {
+    f29 u = f29_dbl(a.y);                       // limbs < 2^30
+    f29 v = f29_sqr<F>(u);
+    f29 w = f29_mul<F>(u, v);
+    f29 s = f29_mul<F>(a.x, v);
+    f29 xx = f29_sqr<F>(a.x);
+    f29 m = f29_norm(f29_add(f29_dbl(xx), xx));
+    f29 mm = f29_sqr<F>(m);
+    xyzz29 r;
+    r.x = f29_norm(f29_sub(mm, f29_dbl(s), F::KB));
+    f29 t = f29_sub(s, r.x, F::KA);
+    r.y = f29_norm(f29_sub(f29_mul<F>(m, t), f29_mul<F>(w, a.y), F::KM));
+    r.zz = f29_mul<F>(v, a.zz);
+    r.zzz = f29_mul<F>(w, a.zzz);
+    return r;
+}
+
+// A + q, q affine (internal, canonical or negated-loose y), q != identity
+template <class F>
+FP_DEV xyzz29 x29_add_mixed(const xyzz29& a, const aff29& q) {
+    f29 u2 = f29_mul<F>(q.x, a.zz);
+    f29 s2 = f29_mul<F>(q.y, a.zzz);
+    f29 p = f29_norm(f29_sub(u2, a.x, F::KA));
+    f29 rr = f29_norm(f29_sub(s2, a.y, F::KA));
+    f29 pp = f29_sqr<F>(p);
+    f29 ppp = f29_mul<F>(p, pp);
+    f29 qq = f29_mul<F>(a.x, pp);
+    f29 r2 = f29_sqr<F>(rr);
+    xyzz29 r;
+    r.x = f29_norm(f29_sub(r2, f29_add(ppp, f29_dbl(qq)), F::KB));
+    f29 t = f29_sub(qq, r.x, F::KA);
+    r.y = f29_norm(f29_sub(f29_mul<F>(rr, t), f29_mul<F>(a.y, ppp), F::KM));
+    r.zz = f29_mul<F>(a.zz, pp);
+    r.zzz = f29_mul<F>(a.zzz, ppp);
+    if (__builtin_expect(f29_maybe_zero_lt2p<F>(r.zz), 0)) {
+        if (f29_is_zero_lt2p<F>(r.zz)) {
+            // exact resolution (rare): identity accumulator, doubling, or cancellation
+            if (f29_is_zero_slow<F>(a.zz)) {
+                r.x = q.x; r.y = f29_norm(q.y); r.zz = f29_one<F>(); r.zzz = f29_one<F>();
+            } else if (f29_is_zero_slow<F>(rr)) {
+                xyzz29 qa;
+                qa.x = q.x; qa.y = f29_norm(q.y); qa.zz = f29_one<F>(); qa.zzz = f29_one<F>();
+                r = x29_double<F>(qa);
+            } else {
+                r = x29_identity();
+            }
+        }
+    }
+    return r;
+}
+
+// A + B
+template <class F>
+FP_DEV xyzz29 x29_add(const xyzz29& a, const xyzz29& b) {
+    f29 u1 = f29_mul<F>(a.x, b.zz);
+    f29 u2 = f29_mul<F>(b.x, a.zz);
+    f29 s1 = f29_mul<F>(a.y, b.zzz);
+    f29 s2 = f29_mul<F>(b.y, a.zzz);
+    f29 p = f29_norm(f29_sub(u2, u1, F::KM));
+    f29 rr = f29_norm(f29_sub(s2, s1, F::KM));
+    f29 pp = f29_sqr<F>(p);
+    f29 ppp = f29_mul<F>(p, pp);
+    f29 qq = f29_mul<F>(u1, pp);
+    f29 r2 = f29_sqr<F>(rr);
+    xyzz29 r;
+    r.x = f29_norm(f29_sub(r2, f29_add(ppp, f29_dbl(qq)), F::KB));
+    f29 t = f29_sub(qq, r.x, F::KA);
+    r.y = f29_norm(f29_sub(f29_mul<F>(rr, t), f29_mul<F>(s1, ppp), F::KM));
+    r.zz = f29_mul<F>(f29_mul<F>(a.zz, b.zz), pp);
+    r.zzz = f29_mul<F>(f29_mul<F>(a.zzz, b.zzz), ppp);
+    if (__builtin_expect(f29_maybe_zero_lt2p<F>(r.zz), 0)) {
+        if (f29_is_zero_lt2p<F>(r.zz)) {
+            if (f29_is_zero_slow<F>(a.zz)) r = b;
+            else if (f29_is_zero_slow<F>(b.zz)) r = a;
+            else if (f29_is_zero_slow<F>(rr)) r = x29_double<F>(a);
+            else r = x29_identity();
+        }
+    }
+    return r;
+}
+
+// internal XYZZ -> upstream Jacobian {x, y, z} in standard memory form (Z = ZZ: X' = X*ZZ, Y' = Y*ZZZ)
+template <class F>
+FP_DEV jacobian_t x29_to_jacobian_std(const xyzz29& p) {
+    jacobian_t r;
+    if (f29_is_zero_slow<F>(p.zz)) {
+        r.x = f_zero(); r.y = f_zero(); r.z = f_zero();
+        return r;
+    }
+    r.x = f29_to_std<F>(f29_mul<F>(p.x, p.zz));
+    r.y = f29_to_std<F>(f29_mul<F>(p.y, p.zzz));
+    r.z = f29_to_std<F>(p.zz);
+    return r;
+}

@@ -1,0 +1,246 @@
+// fp29.cuh -- carry-free, lazily reduced Montgomery arithmetic for gfx950:
+// 9 limbs x 29 bits in u32 registers, R' = 2^261, 64-bit in-place column accumulators.
+//
+// Why not 8 x 32-bit limbs (fp.cuh): on CDNA4 v_mad_u64_u32 issues in ~4 cycles per wave64,
+// but it has no carry-in, and every carry step of a 32-bit-limb CIOS costs as much as the
+// multiply itself (v_lshl_add_u64 ~4.5 cycles, v_add_co/v_addc ~4.75 each, plus v_mov to build
+// zero-extended register pairs: the 32-bit f_mul compiles to 128 mads + 135 64-bit adds +
+// 297 moves; profiles/r01_ubench_instruction_rates.txt).  With 29-bit limbs a 64-bit
+// accumulator absorbs every product of a column (<= 9 products of <= 2^60 plus 9 reduction
+// terms of <= 2^58 < 2^64) with the multiply-add itself: D = a_i * b_j + D, in place, no carry
+// instruction, no moves.  81 + 81 mads (81 + 45 for the Pasta primes, whose limbs 5..7 are
+// zero) against 64 + 64, but nothing else in the inner loop.
+//
+// Values are kept lazily reduced: a product is < a*b/2^261 + p, sums are limb-wise adds,
+// differences add a multiple of p whose limbs dominate the subtrahend's (constants KM/KA/KB/KN,
+// derived and range-checked by tools/fp29_model.py, a bit-accurate Python model of this file
+// that asserts every u32 limb and u64 accumulator bound on random and adversarial inputs).
+//
+// Restates the VALUES of halo2curves' field mul/add/sub [UPSTREAM, SURVEY.md Appendix B]; the
+// memory format at the C ABI stays upstream's (4 x u64, R = 2^256): from_std / to_std convert.
+#pragma once
+#include "fp.cuh"
+#include "fp29_constants.h"
+
+#define F29_BITS 29
+#define F29_MASK 0x1fffffffu
+
+struct f29 {
+    u32 v[9];
+};
+
+template <class F>
+FP_DEV f29 f29_const(const u32 (&c)[9]) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = c[i];
+    return r;
+}
+FP_DEV f29 f29_zero() {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
+    return r;
+}
+template <class F> FP_DEV f29 f29_one() { return f29_const<F>(F::ONE); }
+
+FP_DEV bool f29_all_zero(const f29& a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.v[i];
+    return o == 0;
+}
+
+// 8 x 32-bit words (a value < 2^256) -> 9 x 29-bit limbs
+FP_DEV f29 f29_unpack(const fe& w) {
+    f29 r;
+    r.v[0] = w.v[0] & F29_MASK;
+    r.v[1] = ((w.v[0] >> 29) | (w.v[1] << 3)) & F29_MASK;
+    r.v[2] = ((w.v[1] >> 26) | (w.v[2] << 6)) & F29_MASK;
+    r.v[3] = ((w.v[2] >> 23) | (w.v[3] << 9)) & F29_MASK;
+    r.v[4] = ((w.v[3] >> 20) | (w.v[4] << 12)) & F29_MASK;
+    r.v[5] = ((w.v[4] >> 17) | (w.v[5] << 15)) & F29_MASK;
+    r.v[6] = ((w.v[5] >> 14) | (w.v[6] << 18)) & F29_MASK;
+    r.v[7] = ((w.v[6] >> 11) | (w.v[7] << 21)) & F29_MASK;
+    r.v[8] = w.v[7] >> 8;
+    return r;
+}
+// normalized limbs of a value < 2^256 -> 8 words
+FP_DEV fe f29_pack(const f29& a) {
+    fe w;
+    w.v[0] = a.v[0] | (a.v[1] << 29);
+    w.v[1] = (a.v[1] >> 3) | (a.v[2] << 26);
+    w.v[2] = (a.v[2] >> 6) | (a.v[3] << 23);
+    w.v[3] = (a.v[3] >> 9) | (a.v[4] << 20);
+    w.v[4] = (a.v[4] >> 12) | (a.v[5] << 17);
+    w.v[5] = (a.v[5] >> 15) | (a.v[6] << 14);
+    w.v[6] = (a.v[6] >> 18) | (a.v[7] << 11);
+    w.v[7] = (a.v[7] >> 21) | (a.v[8] << 8);
+    return w;
+}
+
+// carry propagation: limbs < 2^32 (value < 2^261) -> limbs < 2^29
+FP_DEV f29 f29_norm(const f29& a) {
+    f29 r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 t = a.v[i] + c;        // a.v[i] <= 2^32 - 2^29: see the limb bounds in fp29_model.py
+        r.v[i] = t & F29_MASK;
+        c = t >> F29_BITS;
+    }
+    r.v[8] = a.v[8] + c;
+    return r;
+}
+
+FP_DEV f29 f29_add(const f29& a, const f29& b) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+FP_DEV f29 f29_dbl(const f29& a) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] << 1;
+    return r;
+}
+// a - b + K  (K = k*p in a limb form that dominates b's limbs; no borrow can occur)
+FP_DEV f29 f29_sub(const f29& a, const f29& b, const u32 (&K)[9]) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (K[i] - b.v[i]);
+    return r;
+}
+
+FP_DEV u64 mad_wide(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+
+// a * b * 2^-261 mod p, lazily reduced: result limbs normalized, value < a*b/2^261 + p.
+// Limb-size contract: bits(max a limb) + bits(max b limb) <= 60.
+template <class F>
+FP_DEV f29 f29_mul(const f29& a, const f29& b) {
+    u64 acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) acc[i + j] = mad_wide(a.v[i], b.v[j], acc[i + j]);
+        u32 m;
+        if (F::INV == F29_MASK) m = (0u - (u32)acc[i]) & F29_MASK;   // p = 1 mod 2^29 (Pasta)
+        else m = ((u32)acc[i] * F::INV) & F29_MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (F::P[j] != 0) acc[i + j] = mad_wide(m, F::P[j], acc[i + j]);
+        acc[i + 1] += acc[i] >> F29_BITS;
+    }
+    f29 r;
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u64 t = acc[9 + j] + c;
+        r.v[j] = (u32)t & F29_MASK;
+        c = t >> F29_BITS;
+    }
+    r.v[8] = (u32)(acc[17] + c);
+    return r;
+}
+
+// a^2 * 2^-261: cross products once, against the doubled operand (limbs < 2^30 for a normalized a)
+template <class F>
+FP_DEV f29 f29_sqr(const f29& a) {
+    u64 acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) acc[i] = 0;
+    u32 d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        // column contributions whose smaller index is i: a_i^2 and 2 a_i a_j (j > i)
+        acc[2 * i] = mad_wide(a.v[i], a.v[i], acc[2 * i]);
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) acc[i + j] = mad_wide(d[i], a.v[j], acc[i + j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 m;
+        if (F::INV == F29_MASK) m = (0u - (u32)acc[i]) & F29_MASK;
+        else m = ((u32)acc[i] * F::INV) & F29_MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (F::P[j] != 0) acc[i + j] = mad_wide(m, F::P[j], acc[i + j]);
+        acc[i + 1] += acc[i] >> F29_BITS;
+    }
+    f29 r;
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u64 t = acc[9 + j] + c;
+        r.v[j] = (u32)t & F29_MASK;
+        c = t >> F29_BITS;
+    }
+    r.v[8] = (u32)(acc[17] + c);
+    return r;
+}
+
+// v >= c ? v - c : v   on normalized limbs (c a normalized constant)
+FP_DEV f29 f29_cond_sub(const f29& a, const u32 (&C)[9]) {
+    f29 d;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int32_t t = (int32_t)a.v[i] - (int32_t)C[i] + borrow;
+        d.v[i] = (u32)t & F29_MASK;
+        borrow = t >> 31;
+    }
+    int32_t top = (int32_t)a.v[8] - (int32_t)C[8] + borrow;
+    d.v[8] = (u32)top;
+    bool ge = top >= 0;
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = ge ? d.v[i] : a.v[i];
+    return r;
+}
+
+// fully reduced representative in [0, p) of a normalized value < 16 p  (slow paths, stores)
+template <class F>
+FP_DEV f29 f29_canon(const f29& a) {
+    f29 r = f29_cond_sub(a, F::P8);
+    r = f29_cond_sub(r, F::P4);
+    r = f29_cond_sub(r, F::P2);
+    r = f29_cond_sub(r, F::P);
+    return r;
+}
+
+// is a normalized value < 2p congruent to 0?  (v == 0 or v == p)
+template <class F>
+FP_DEV bool f29_is_zero_lt2p(const f29& a) {
+    u32 z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { z |= a.v[i]; e |= a.v[i] ^ F::P[i]; }
+    return (z == 0) | (e == 0);
+}
+// cheap necessary condition for the above (limb 0 only): filters all but ~2^-28 of inputs
+template <class F>
+FP_DEV bool f29_maybe_zero_lt2p(const f29& a) { return (a.v[0] == 0) | (a.v[0] == F::P[0]); }
+
+// exact zero test of any lazily reduced value (< 16 p, limbs < 2^31): one multiplication by R' mod p
+template <class F>
+FP_DEV bool f29_is_zero_slow(const f29& a) {
+    f29 w = f29_mul<F>(a, f29_one<F>());     // = a mod p, value < (1 + 16 p / 2^261) p < 2p
+    return f29_is_zero_lt2p<F>(w);
+}
+
+// standard memory form (x * 2^256 mod p, 8 words) <-> internal (x * 2^261, lazily reduced)
+template <class F>
+FP_DEV f29 f29_from_std(const fe& m) { return f29_mul<F>(f29_unpack(m), f29_const<F>(F::TO29)); }
+// internal (any lazily reduced value < 16p with normalized limbs) -> canonical standard form
+template <class F>
+FP_DEV fe f29_to_std(const f29& a) {
+    f29 t = f29_mul<F>(a, f29_const<F>(F::FROM29));   // < 2p
+    return f29_pack(f29_cond_sub(t, F::P));
+}
+// internal lazily reduced -> internal canonical, packed in 8 words (SRS table format)
+template <class F>
+FP_DEV fe f29_to_packed_canon(const f29& a_norm) { return f29_pack(f29_canon<F>(a_norm)); }

@@ -1,0 +1,151 @@
+// internal.hpp -- host-side state shared by the translation units of libdehalo.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dehalo.h"
+#include "ec.cuh"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct TwiddleEntry {
+    int field;
+    uint32_t log_n;
+    int form;  // 0: standard Montgomery (R = 2^256)
+    uint64_t omega[4];
+    fe* tw;
+};
+
+struct TimedRegion {
+    int kernel_id;
+    hipEvent_t a, b;
+};
+
+struct dehalo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::mutex mu;
+    // workspace (grow-only)
+    DevBuf ws_scalars, ws_out, ws_count, ws_cursor, ws_off, ws_toff0, ws_cnt1, ws_off1, ws_toff1, ws_bsum, ws_idx, ws_partial0, ws_partial1,
+        ws_buckets, ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases;
+    std::vector<TwiddleEntry> twiddles;
+    bool timing = false;
+    std::vector<TimedRegion> regions;
+    double timing_ms[DEHALO_K_COUNT] = {0, 0, 0, 0};
+    uint64_t timing_cnt[DEHALO_K_COUNT] = {0, 0, 0, 0};
+};
+
+struct dehalo_bases {
+    int curve;
+    size_t n;
+    uint32_t c, W;
+    int precomp;
+    affine_t* table;  // n * (precomp ? W : 1) affine points in HBM, internal (R' = 2^261) canonical form
+};
+
+inline int dh_fail(dehalo_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            int code_ = (e_ == hipErrorOutOfMemory) ? DEHALO_ERR_OOM : DEHALO_ERR_HIP;        \
+            return dh_fail(ctx, code_, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+        }                                                                                    \
+    } while (0)
+
+#define TRY(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+inline int dh_ensure(dehalo_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+struct ScopedTimer {
+    dehalo_ctx* ctx;
+    hipStream_t s;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(dehalo_ctx* c, hipStream_t st, int kid) : ctx(c), s(st), id(kid) {
+        if (ctx->timing) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+                a = b = nullptr;
+                return;
+            }
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ScopedTimer() {
+        if (a && b) {
+            (void)hipEventRecord(b, s);
+            ctx->regions.push_back({id, a, b});
+        }
+    }
+};
+
+inline fe fe_from_u64(const uint64_t v[4]) {
+    fe r;
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (u32)v[i];
+        r.v[2 * i + 1] = (u32)(v[i] >> 32);
+    }
+    return r;
+}
+
+inline uint32_t log2_ceil(size_t n) {
+    uint32_t l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+struct NttScale {
+    uint32_t pre_mode = 0, post_mode = 0;
+    fe pre_z{}, post0{}, post_z{};
+};
+
+// per-curve / per-field entry points (one translation unit each: msm_*.hip, ntt_*.hip)
+#define DECL_MSM(NAME)                                                                                                                   \
+    int run_msm_##NAME(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, size_t len, size_t batch, jacobian_t* d_out,     \
+                       hipStream_t s);                                                                                                   \
+    int build_table_##NAME(dehalo_ctx* ctx, dehalo_bases* b, const affine_t* d_std_points, hipStream_t s);                               \
+    int to_affine_##NAME(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32_t count, hipStream_t s);
+DECL_MSM(bn254)
+DECL_MSM(pallas)
+DECL_MSM(vesta)
+#undef DECL_MSM
+
+#define DECL_NTT(NAME)                                                                                                                       \
+    int run_ntt_##NAME(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_stride, fe* dst, uint64_t dst_stride, uint32_t log_n, \
+                       const uint64_t omega[4], size_t batch, const NttScale& sc, hipStream_t s);                                            \
+    int field_op_##NAME(dehalo_ctx* ctx, int op, const fe* a, const fe* b, fe* out, uint64_t n, hipStream_t s);
+DECL_NTT(bn254_fr)
+DECL_NTT(bn254_fq)
+DECL_NTT(pasta_fp)
+DECL_NTT(pasta_fq)
+#undef DECL_NTT

@@ -6,7 +6,8 @@
 //  * SRS tables resident in HBM.  dehalo_bases_register may store [2^(c*w)]P_i for every
 //    window w (n * W * 64 B; 1 GiB at n = 2^20, c = 16 -- 0.35 % of the 288 GB).  Then all W
 //    windows of one MSM share ONE set of 2^(c-1) buckets: no per-window bucket reduction, no
-//    doublings between windows.
+//    doublings between windows.  Table entries are kept in the kernels' internal field form
+//    (x * 2^261 mod p, canonical, packed in 32 B) so the hot loop never converts.
 //  * Signed c-bit digits (buckets halve), digit = 0 skipped (witness columns are mostly
 //    small values: SURVEY.md 8(d)).
 //  * Counting sort of (bucket, point) pairs with a whole-bucket-range histogram in LDS
@@ -14,15 +15,18 @@
 //    array in HBM (digits are recomputed from the scalar, ~1 % of the group-add work).
 //  * Bucket accumulation split into fixed-length tasks of <= L points regardless of bucket
 //    size (a bucket that receives 300 k points of a 0/1 column costs the same per lane as a
-//    uniform one), one lane per task, XYZZ mixed additions (8M + 2S); partial sums are merged
-//    by two further levels of the same scheme.
+//    uniform one), one lane per task, XYZZ mixed additions on the carry-free 9 x 29-bit field
+//    (fp29.cuh / ec29.cuh); partial sums are merged by two further levels of the same scheme.
 //  * Bucket reduction sum_k k*B_k: lanes take 4 consecutive buckets (local running sums),
 //    weight their run by the block offset with double-and-add, then a tree of group additions.
 //
 // Group adds are sequential per lane; a wave64 executes 64 independent bucket chains in
 // lock-step.  Integer-only (v_mad_u64_u32); no MFMA (nothing here is a contraction).
 #pragma once
-#include "ec.cuh"
+#include <algorithm>
+
+#include "ec29.cuh"
+#include "internal.hpp"
 
 #define MSM_SORT_THREADS 1024
 #define MSM_ACC_THREADS 128
@@ -46,7 +50,7 @@ struct MsmGeom {
 // canonical scalar s < 2^255, digits d_w in [-(2^(c-1) - 1), 2^(c-1)], sum d_w 2^(cw) = s.
 // Calls f(w, bucket, neg) for every non-zero digit with w in [w_lo, w_hi).
 template <class FS, class Fn>
-FP_DEV void for_each_digit(const fe& mont_scalar, u32 c, u32 W, u32 w_lo, u32 w_hi, Fn f) {
+FP_DEV void for_each_digit(const fe& mont_scalar, u32 c, u32 w_lo, u32 w_hi, Fn f) {
     fe s = f_from_mont<FS>(mont_scalar);
     const u32 mask = (1u << c) - 1, halfv = 1u << (c - 1);
     u32 carry = 0;
@@ -61,7 +65,6 @@ FP_DEV void for_each_digit(const fe& mont_scalar, u32 c, u32 W, u32 w_lo, u32 w_
         u32 mag = neg ? (1u << c) - raw : raw;
         if (mag != 0 && w >= w_lo) f(w, mag - 1, neg);
     }
-    (void)W;
 }
 
 // ---- sort step 1: per-bucket counts ------------------------------------------------------
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_hist(MsmGeom g, const 
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
     for (u32 i = beg + threadIdx.x; i < end; i += blockDim.x) {
         fe s = f_load(&sc[i]);
-        for_each_digit<FS>(s, g.c, g.W, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
+        for_each_digit<FS>(s, g.c, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
     }
     __syncthreads();
     u32* gc = count + ((u64)bat * g.G + grp) * g.nb;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_hist(MsmGeom g, const 
 
 FP_DEV u32 ceil_div_u32(u32 a, u32 b) { return (a + b - 1) / b; }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u32* cnt, u32 total, u32 L, u32* bsum_items, u32* bsum_tasks) {
+static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u32* cnt, u32 total, u32 L, u32* bsum_items, u32* bsum_tasks) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
     u32 si = 0, st = 0;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u32* cnt
 }
 
 // single block: exclusive scan of the block sums in place (nblocks <= a few thousand)
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks) {
+static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     __shared__ u32 carry_i, carry_t;
     if (threadIdx.x == 0) { carry_i = 0; carry_t = 0; }
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32*
     }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32 total, u32 L, const u32* bsum_items, const u32* bsum_tasks,
-                                                             u32* off, u32* toff) {
+static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32 total, u32 L, const u32* bsum_items, const u32* bsum_tasks,
+                                                                    u32* off, u32* toff) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
     u32 vi[SCAN_PER_THREAD], vt[SCAN_PER_THREAD];
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32
 }
 
 // cnt_out[b] = toff[b + 1] - toff[b]   (number of partials per bucket = next level's item count)
-__global__ void k_diff(const u32* toff, u32 total, u32* cnt_out) {
+static __global__ void k_diff(const u32* toff, u32 total, u32* cnt_out) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) cnt_out[i] = toff[i + 1] - toff[i];
 }
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_scatter(MsmGeom g, con
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
     for (u32 i = beg + threadIdx.x; i < end; i += blockDim.x) {
         fe s = f_load(&sc[i]);
-        for_each_digit<FS>(s, g.c, g.W, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
+        for_each_digit<FS>(s, g.c, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
     }
     __syncthreads();
     const u64 gb = ((u64)bat * g.G + grp) * g.nb;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_scatter(MsmGeom g, con
     __syncthreads();
     for (u32 i = beg + threadIdx.x; i < end; i += blockDim.x) {
         fe s = f_load(&sc[i]);
-        for_each_digit<FS>(s, g.c, g.W, w_lo, w_hi, [&](u32 w, u32 bucket, bool neg) {
+        for_each_digit<FS>(s, g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool neg) {
             u32 pos = atomicAdd(&lhist[bucket], 1u);
             u32 tidx = g.G == 1 ? w * g.table_n + i : i;
             idx_out[pos] = tidx | (neg ? 0x80000000u : 0u);
@@ -220,11 +223,21 @@ FP_DEV u32 find_segment(const u32* toff, u32 total, u32 t) {
     return lo;
 }
 
+// table entry -> (affine limbs, is_identity); bit 31 of the reference negates y
+template <class F>
+FP_DEV aff29 load_point(const affine_t* table, u32 e, bool& is_id) {
+    affine_t pk = aff_load(&table[e & 0x7fffffffu]);
+    is_id = aff_is_identity(pk);
+    aff29 q = a29_from_packed(pk);
+    if (e >> 31) q.y = f29_sub(f29_zero(), q.y, F::KN);   // 2p - y, limbs < 2^30
+    return q;
+}
+
 // ---- level 0: one lane = one task of <= L0 points of one bucket ---------------------------
 template <class CV>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* toff,
-                                                               const affine_t* table, xyzz_t* partial) {
-    typedef typename CV::Base F;
+                                                               const affine_t* table, xyzz29_rec* partial) {
+    typedef typename f29_of<typename CV::Base>::type F;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 ntasks = toff[total_buckets];
     if (t >= ntasks) return;
@@ -232,22 +245,23 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_accum0(MsmGeom g, u32 t
     u32 j = t - toff[b];
     u32 beg = off[b] + j * g.L0;
     u32 end = min(beg + g.L0, off[b + 1]);
-    xyzz_t acc = xyzz_identity();
-    for (u32 p = beg; p < end; p++) {
-        u32 e = idx[p];
-        affine_t q = aff_load(&table[e & 0x7fffffffu]);
-        if (e >> 31) q.y = f_neg<F>(q.y);
-        acc = xyzz_add_mixed<F>(acc, q);
+    bool is_id;
+    aff29 q = load_point<F>(table, idx[beg], is_id);
+    xyzz29 acc = x29_from_affine<F>(q, is_id);
+    if (!is_id) acc.y = f29_norm(acc.y);
+    for (u32 p = beg + 1; p < end; p++) {
+        q = load_point<F>(table, idx[p], is_id);
+        if (!is_id) acc = x29_add_mixed<F>(acc, q);
     }
-    xyzz_store(&partial[t], acc);
+    x29_store(&partial[t], acc);
 }
 
 // ---- merge levels: segments of XYZZ partials --------------------------------------------
-// level 1: task = <= L consecutive partials of one bucket; level 2 (L = 0xffffffff): whole segment
+// level 1: task = <= L consecutive partials of one bucket; level 2 (per_bucket): whole segment
 template <class CV>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge(u32 total_buckets, u32 L, const u32* seg_off, const u32* toff, const xyzz_t* in,
-                                                              xyzz_t* out, u32 per_bucket) {
-    typedef typename CV::Base F;
+__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge(u32 total_buckets, u32 L, const u32* seg_off, const u32* toff, const xyzz29_rec* in,
+                                                              xyzz29_rec* out, u32 per_bucket) {
+    typedef typename f29_of<typename CV::Base>::type F;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 b, beg, end;
     if (per_bucket) {
@@ -261,110 +275,125 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge(u32 total_buckets
         beg = seg_off[b] + j * L;
         end = min(beg + L, seg_off[b + 1]);
     }
-    xyzz_t acc = xyzz_identity();
-    for (u32 p = beg; p < end; p++) acc = xyzz_add<F>(acc, xyzz_load(&in[p]));
-    xyzz_store(&out[t], acc);
+    xyzz29 acc = x29_identity();
+    if (beg < end) acc = x29_load(&in[beg]);
+    for (u32 p = beg + 1; p < end; p++) acc = x29_add<F>(acc, x29_load(&in[p]));
+    x29_store(&out[t], acc);
 }
 
 // ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
 // lane (group, t) takes buckets [t*M, t*M + M): contribution = sum (k - k0 + 1) B_k + k0 * sum B_k
 template <class CV>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz_t* buckets, xyzz_t* contrib) {
-    typedef typename CV::Base F;
+__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
+    typedef typename f29_of<typename CV::Base>::type F;
     const u32 per_group = (nb + MSM_RED_M - 1) / MSM_RED_M;
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= per_group * total_groups) return;
     u32 grp = gid / per_group, t = gid % per_group;
     u32 k0 = t * MSM_RED_M, k1 = min(k0 + MSM_RED_M, nb);
-    const xyzz_t* B = buckets + (u64)grp * nb;
-    xyzz_t run = xyzz_identity(), acc = xyzz_identity();
-    for (u32 k = k1; k-- > k0;) {
-        run = xyzz_add<F>(run, xyzz_load(&B[k]));
-        acc = xyzz_add<F>(acc, run);
+    const xyzz29_rec* B = buckets + (u64)grp * nb;
+    xyzz29 run = x29_load(&B[k1 - 1]);
+    xyzz29 acc = run;
+    for (u32 k = k1 - 1; k-- > k0;) {
+        run = x29_add<F>(run, x29_load(&B[k]));
+        acc = x29_add<F>(acc, run);
     }
     // k0 * run, MSB-first double-and-add (k0 < 2^15)
-    xyzz_t w = xyzz_identity();
     if (k0) {
         int top = 31 - __clz(k0);
-        for (int bit = top; bit >= 0; bit--) {
-            w = xyzz_double<F>(w);
-            if ((k0 >> bit) & 1) w = xyzz_add<F>(w, run);
+        xyzz29 w = run;
+        for (int bit = top - 1; bit >= 0; bit--) {
+            w = x29_double<F>(w);
+            if ((k0 >> bit) & 1) w = x29_add<F>(w, run);
         }
+        acc = x29_add<F>(acc, w);
     }
-    xyzz_store(&contrib[gid], xyzz_add<F>(acc, w));
+    x29_store(&contrib[gid], acc);
 }
 
 // tree sum: in[groups][cnt] -> out[groups][ceil(cnt / (2 * MSM_TREE_THREADS))]
 template <class CV>
-__global__ __launch_bounds__(MSM_TREE_THREADS) void k_msm_tree_sum(const xyzz_t* in, u32 cnt, xyzz_t* out, u32 out_cnt) {
-    typedef typename CV::Base F;
-    __shared__ xyzz_t sh[MSM_TREE_THREADS];
+__global__ __launch_bounds__(MSM_TREE_THREADS) void k_msm_tree_sum(const xyzz29_rec* in, u32 cnt, xyzz29_rec* out, u32 out_cnt) {
+    typedef typename f29_of<typename CV::Base>::type F;
+    __shared__ xyzz29_rec sh[MSM_TREE_THREADS];
     u32 grp = blockIdx.y;
-    const xyzz_t* src = in + (u64)grp * cnt;
+    const xyzz29_rec* src = in + (u64)grp * cnt;
     u32 i0 = blockIdx.x * (2 * MSM_TREE_THREADS) + threadIdx.x;
-    xyzz_t a = i0 < cnt ? xyzz_load(&src[i0]) : xyzz_identity();
+    xyzz29 a = i0 < cnt ? x29_load(&src[i0]) : x29_identity();
     u32 i1 = i0 + MSM_TREE_THREADS;
-    if (i1 < cnt) a = xyzz_add<F>(a, xyzz_load(&src[i1]));
-    sh[threadIdx.x] = a;
+    if (i1 < cnt) a = x29_add<F>(a, x29_load(&src[i1]));
+    x29_store(&sh[threadIdx.x], a);
     __syncthreads();
     for (u32 d = MSM_TREE_THREADS / 2; d > 0; d >>= 1) {
         if (threadIdx.x < d) {
-            xyzz_t x = xyzz_add<F>(sh[threadIdx.x], sh[threadIdx.x + d]);
-            sh[threadIdx.x] = x;
+            xyzz29 x = x29_add<F>(x29_load(&sh[threadIdx.x]), x29_load(&sh[threadIdx.x + d]));
+            x29_store(&sh[threadIdx.x], x);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) xyzz_store(&out[(u64)grp * out_cnt + blockIdx.x], sh[0]);
+    if (threadIdx.x == 0) out[(u64)grp * out_cnt + blockIdx.x] = sh[0];
 }
 
 // ---- final: window sums -> one Jacobian point per MSM -------------------------------------
 // G == 1: convert.  G == W: result = sum_w 2^(c*w) S_w; lane w doubles S_w c*w times, then an
 // LDS tree (the one-shot, unregistered-bases path only).
 template <class CV>
-__global__ __launch_bounds__(64) void k_msm_final(MsmGeom g, const xyzz_t* group_sums, jacobian_t* out) {
-    typedef typename CV::Base F;
-    __shared__ xyzz_t sh[64];
+__global__ __launch_bounds__(64) void k_msm_final(MsmGeom g, const xyzz29_rec* group_sums, jacobian_t* out) {
+    typedef typename f29_of<typename CV::Base>::type F;
+    __shared__ xyzz29_rec sh[64];
     u32 bat = blockIdx.x;
     u32 w = threadIdx.x;
-    xyzz_t s = xyzz_identity();
+    xyzz29 s = x29_identity();
     if (w < g.G) {
-        s = xyzz_load(&group_sums[(u64)bat * g.G + w]);
+        s = x29_load(&group_sums[(u64)bat * g.G + w]);
         if (g.G > 1) {
             u32 nd = g.c * w;
-            for (u32 i = 0; i < nd; i++) s = xyzz_double<F>(s);
+            for (u32 i = 0; i < nd; i++) s = x29_double<F>(s);
         }
     }
-    sh[w] = s;
+    x29_store(&sh[w], s);
     __syncthreads();
     for (u32 d = 32; d > 0; d >>= 1) {
         if (w < d) {
-            xyzz_t x = xyzz_add<F>(sh[w], sh[w + d]);
-            sh[w] = x;
+            xyzz29 x = x29_add<F>(x29_load(&sh[w]), x29_load(&sh[w + d]));
+            x29_store(&sh[w], x);
         }
         __syncthreads();
     }
     if (w == 0) {
-        jacobian_t j = xyzz_to_jacobian<F>(sh[0]);
+        jacobian_t j = x29_to_jacobian_std<F>(x29_load(&sh[0]));
         f_store(&out[bat].x, j.x); f_store(&out[bat].y, j.y); f_store(&out[bat].z, j.z);
     }
 }
 
-// ---- SRS table precomputation: table[w][i] = [2^(c*w)] P_i, affine -------------------------
+// ---- SRS table: table[w][i] = [2^(c*w)] P_i, affine, internal canonical packed form ---------
+// (one-time per SRS; window rows by repeated doubling on the 32-bit reference arithmetic of
+// ec.cuh, one Fermat inversion per row entry)
 template <class CV>
-__global__ __launch_bounds__(128) void k_msm_precompute(affine_t* table, u32 n, u32 c, u32 W) {
+__global__ __launch_bounds__(128) void k_msm_build_table(const affine_t* std_points, affine_t* table, u32 n, u32 c, u32 rows) {
     typedef typename CV::Base F;
+    typedef typename f29_of<typename CV::Base>::type F9;
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    affine_t p = aff_load(&table[i]);
+    affine_t p = aff_load(&std_points[i]);
     xyzz_t cur = xyzz_from_affine<F>(p);
-    for (u32 w = 1; w < W; w++) {
-        for (u32 k = 0; k < c; k++) cur = xyzz_double<F>(cur);
-        affine_t a = xyzz_to_affine<F>(cur);
-        aff_store(&table[(u64)w * n + i], a);
+    for (u32 w = 0; w < rows; w++) {
+        affine_t a = p;
+        if (w > 0) {
+            for (u32 k = 0; k < c; k++) cur = xyzz_double<F>(cur);
+            a = xyzz_to_affine<F>(cur);
+        }
+        affine_t o;
+        if (aff_is_identity(a)) { o.x = f_zero(); o.y = f_zero(); }
+        else {
+            o.x = f29_to_packed_canon<F9>(f29_from_std<F9>(a.x));
+            o.y = f29_to_packed_canon<F9>(f29_from_std<F9>(a.y));
+        }
+        aff_store(&table[(u64)w * n + i], o);
     }
 }
 
-// Jacobian -> affine for MSM outputs (dehalo_to_affine)
+// Jacobian -> affine for MSM outputs (dehalo_to_affine), standard form in and out
 template <class CV>
 __global__ void k_jac_to_affine(const jacobian_t* in, affine_t* out, u32 count) {
     typedef typename CV::Base F;
@@ -381,3 +410,151 @@ __global__ void k_jac_to_affine(const jacobian_t* in, affine_t* out, u32 count) 
     }
     aff_store(&out[i], a);
 }
+
+// ==========================================================================================
+// host driver (instantiated once per curve in msm_<curve>.hip)
+// ==========================================================================================
+static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32 L, u32* off, u32* toff, hipStream_t s) {
+    u32 nblocks = (total + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)nblocks * 2 * sizeof(u32)));
+    u32* bs_i = (u32*)ctx->ws_bsum.p;
+    u32* bs_t = bs_i + nblocks;
+    k_scan_block_sums<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, L, bs_i, bs_t);
+    k_scan_top<<<1, SCAN_THREADS, 0, s>>>(bs_i, bs_t, nblocks);
+    k_scan_apply<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, L, bs_i, bs_t, off, toff);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class CV>
+int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, size_t len, size_t batch, jacobian_t* d_out, hipStream_t s) {
+    typedef typename CV::Scalar FS;
+    if (batch == 0) return 0;
+    if (len == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_out, 0, batch * sizeof(jacobian_t), s));
+        return 0;
+    }
+    MsmGeom g;
+    g.n = (u32)len; g.table_n = (u32)bases->n; g.c = bases->c; g.W = bases->W; g.nb = 1u << (g.c - 1);
+    g.G = bases->precomp ? 1 : g.W;
+    g.batch = (u32)batch;
+    g.slices = (u32)std::min<size_t>(256, std::max<size_t>(1, len / 2048));
+    const uint64_t total_groups = (uint64_t)batch * g.G;
+    const uint64_t total_buckets = total_groups * g.nb;
+    const uint64_t Mmax = (uint64_t)batch * len * g.W;
+    if (Mmax >= (1ull << 32) || total_buckets >= (1ull << 31))
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "batch * len * windows too large for one launch");
+    {   // task length: enough tasks to fill 256 CUs, short enough to balance
+        uint64_t l0 = Mmax / (256 * 1024);
+        u32 L0 = 4;
+        while (L0 < 64 && L0 < l0) L0 <<= 1;
+        g.L0 = L0;
+    }
+    const uint64_t nt0_max = Mmax / g.L0 + total_buckets;
+    const uint64_t nt1_max = nt0_max / MSM_L1 + total_buckets;
+    const u32 per_group = (g.nb + MSM_RED_M - 1) / MSM_RED_M;
+    const size_t REC = sizeof(xyzz29_rec);
+
+    TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
+    TRY(dh_ensure(ctx, ctx->ws_cursor, total_buckets * 4));
+    TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
+    TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4));
+    TRY(dh_ensure(ctx, ctx->ws_cnt1, total_buckets * 4));
+    TRY(dh_ensure(ctx, ctx->ws_off1, (total_buckets + 1) * 4));
+    TRY(dh_ensure(ctx, ctx->ws_toff1, (total_buckets + 1) * 4));
+    TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
+    TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
+    TRY(dh_ensure(ctx, ctx->ws_partial1, nt1_max * REC));
+    TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
+    TRY(dh_ensure(ctx, ctx->ws_contrib, total_groups * per_group * REC));
+    TRY(dh_ensure(ctx, ctx->ws_tree, total_groups * ((per_group + 2 * MSM_TREE_THREADS - 1) / (2 * MSM_TREE_THREADS)) * REC));
+    TRY(dh_ensure(ctx, ctx->ws_gsums, total_groups * REC));
+    u32* count = (u32*)ctx->ws_count.p;
+    u32* cursor = (u32*)ctx->ws_cursor.p;
+    u32* off = (u32*)ctx->ws_off.p;
+    u32* toff0 = (u32*)ctx->ws_toff0.p;
+    u32* cnt1 = (u32*)ctx->ws_cnt1.p;
+    u32* off1 = (u32*)ctx->ws_off1.p;
+    u32* toff1 = (u32*)ctx->ws_toff1.p;
+    u32* idx = (u32*)ctx->ws_idx.p;
+    xyzz29_rec* partial0 = (xyzz29_rec*)ctx->ws_partial0.p;
+    xyzz29_rec* partial1 = (xyzz29_rec*)ctx->ws_partial1.p;
+    xyzz29_rec* buckets = (xyzz29_rec*)ctx->ws_buckets.p;
+    xyzz29_rec* contrib = (xyzz29_rec*)ctx->ws_contrib.p;
+    xyzz29_rec* tree = (xyzz29_rec*)ctx->ws_tree.p;
+    xyzz29_rec* gsums = (xyzz29_rec*)ctx->ws_gsums.p;
+
+    const size_t lds_hist = (size_t)g.nb * 4;
+    if (lds_hist > 48 * 1024) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_hist<FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_scatter<FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
+    }
+    const u32 tb = (u32)total_buckets;
+    {
+        ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
+        HIP_TRY(ctx, hipMemsetAsync(count, 0, total_buckets * 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(cursor, 0, total_buckets * 4, s));
+        dim3 grid(g.slices, g.G, (u32)batch);
+        k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, count);
+        TRY(run_scan(ctx, count, tb, g.L0, off, toff0, s));
+        k_msm_scatter<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, off, cursor, idx);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    {
+        ScopedTimer t(ctx, s, DEHALO_K_MSM_ACCUMULATE);
+        u32 blocks = (u32)((nt0_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
+        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, 0, s>>>(g, tb, idx, off, toff0, bases->table, partial0);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    {
+        ScopedTimer t(ctx, s, DEHALO_K_MSM_REDUCE);
+        // level 1: merge partials in chunks of MSM_L1
+        k_diff<<<(tb + 255) / 256, 256, 0, s>>>(toff0, tb, cnt1);
+        TRY(run_scan(ctx, cnt1, tb, MSM_L1, off1, toff1, s));
+        u32 blocks1 = (u32)((nt1_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
+        k_msm_merge<CV><<<blocks1, MSM_ACC_THREADS, 0, s>>>(tb, MSM_L1, toff0, toff1, partial0, partial1, 0);
+        // level 2: whatever is left per bucket
+        k_msm_merge<CV><<<(tb + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, MSM_ACC_THREADS, 0, s>>>(tb, 0xffffffffu, toff1, nullptr, partial1, buckets, 1);
+        // bucket reduction
+        u32 nthreads = per_group * (u32)total_groups;
+        k_msm_reduce_local<CV><<<(nthreads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+        const xyzz29_rec* cur = contrib;
+        u32 cnt = per_group;
+        xyzz29_rec* bufs[2] = {tree, contrib};  // ping-pong: contrib is free once consumed
+        int which = 0;
+        while (cnt > 1) {
+            u32 out_cnt = (cnt + 2 * MSM_TREE_THREADS - 1) / (2 * MSM_TREE_THREADS);
+            xyzz29_rec* o = out_cnt == 1 ? gsums : bufs[which];
+            dim3 grid(out_cnt, (u32)total_groups);
+            k_msm_tree_sum<CV><<<grid, MSM_TREE_THREADS, 0, s>>>(cur, cnt, o, out_cnt);
+            cur = o; cnt = out_cnt; which ^= 1;
+        }
+        if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));
+        k_msm_final<CV><<<(u32)batch, 64, 0, s>>>(g, gsums, d_out);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+template <class CV>
+int build_table_t(dehalo_ctx* ctx, dehalo_bases* b, const affine_t* d_std_points, hipStream_t s) {
+    u32 rows = b->precomp ? b->W : 1;
+    k_msm_build_table<CV><<<(u32)((b->n + 127) / 128), 128, 0, s>>>(d_std_points, b->table, (u32)b->n, b->c, rows);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class CV>
+int to_affine_t(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32_t count, hipStream_t s) {
+    k_jac_to_affine<CV><<<(count + 63) / 64, 64, 0, s>>>(d_in, d_out, count);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+#define DEFINE_MSM_ENTRY(NAME, CV)                                                                                                        \
+    int run_msm_##NAME(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, size_t len, size_t batch, jacobian_t* d_out,      \
+                       hipStream_t s) { return run_msm_t<CV>(ctx, bases, d_scalars, len, batch, d_out, s); }                              \
+    int build_table_##NAME(dehalo_ctx* ctx, dehalo_bases* b, const affine_t* d_std_points, hipStream_t s) {                               \
+        return build_table_t<CV>(ctx, b, d_std_points, s); }                                                                              \
+    int to_affine_##NAME(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32_t count, hipStream_t s) {                       \
+        return to_affine_t<CV>(ctx, d_in, d_out, count, s); }

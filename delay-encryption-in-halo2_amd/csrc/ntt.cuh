@@ -23,7 +23,10 @@
 // load and the last store.  HBM-bound by design (64 B/element algorithmic); measured
 // bound on gfx950 is the VALU (v_mad_u64_u32) -- see DESIGN.md.
 #pragma once
-#include "fp.cuh"
+#include <algorithm>
+
+#include "fp29.cuh"
+#include "internal.hpp"
 
 #define NTT_TILE_LOG 11
 #define NTT_TILE (1 << NTT_TILE_LOG)
@@ -238,7 +241,122 @@ __global__ void k_field_op(int op, const fe* a, const fe* b, fe* out, u64 n) {
         case 2: r = f_mul<F>(x, y); break;
         case 3: r = f_is_zero(x) ? f_zero() : f_inv<F>(x); break;
         case 4: r = f_to_mont<F>(x); break;
-        default: r = f_from_mont<F>(x); break;
+        case 5: r = f_from_mont<F>(x); break;
+        default: {  // 6: the same product through the carry-free 9 x 29-bit path (fp29.cuh)
+            typedef typename f29_of<F>::type F9;
+            r = f29_to_std<F9>(f29_mul<F9>(f29_from_std<F9>(x), f29_from_std<F9>(y)));
+        } break;
     }
     f_store(&out[i], r);
 }
+
+// ==========================================================================================
+// host driver (instantiated once per field in ntt_<field>.hip)
+// ==========================================================================================
+template <class F>
+int get_twiddles(dehalo_ctx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t s, const fe** out) {
+    for (auto& t : ctx->twiddles)
+        if (t.field == F::ID && t.log_n == log_n && t.form == 0 && !memcmp(t.omega, omega, 32)) {
+            *out = t.tw;
+            return 0;
+        }
+    uint64_t half = log_n ? (1ull << (log_n - 1)) : 1;
+    fe* tw = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&tw, half * sizeof(fe)));
+    uint64_t threads = (half + 63) / 64;
+    uint32_t blocks = (uint32_t)((threads + 127) / 128);
+    k_twiddle_gen<F><<<blocks, 128, 0, s>>>(tw, fe_from_u64(omega), half);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->twiddles.size() >= 16) {  // bounded cache: drop the oldest
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipFree(ctx->twiddles.front().tw));
+        ctx->twiddles.erase(ctx->twiddles.begin());
+    }
+    TwiddleEntry e;
+    e.field = F::ID; e.log_n = log_n; e.form = 0; memcpy(e.omega, omega, 32); e.tw = tw;
+    ctx->twiddles.push_back(e);
+    *out = tw;
+    return 0;
+}
+
+// Transforms `batch` polynomials: src (src_len valid elements each, zero-extended to 2^log_n,
+// src_stride apart) -> dst (dst_stride apart).  src == dst allowed.
+template <class F>
+int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_stride, fe* dst, uint64_t dst_stride, uint32_t log_n,
+              const uint64_t omega[4], size_t batch, const NttScale& sc, hipStream_t s) {
+    if (log_n > (uint32_t)F::TWO_ADICITY) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "log_n exceeds the field's two-adicity");
+    if (log_n > 30) return dh_fail(ctx, DEHALO_ERR_INVALID, "log_n > 30");
+    if (batch == 0) return 0;
+    const fe* tw = nullptr;
+    TRY(get_twiddles<F>(ctx, log_n, omega, s, &tw));
+    ScopedTimer timer(ctx, s, DEHALO_K_NTT_PASS);
+
+    // plan: radices
+    uint32_t L, rad[NTT_MAX_PASSES];
+    if (log_n <= NTT_TILE_LOG) { L = 1; rad[0] = log_n; }
+    else {
+        L = (log_n + 7) / 8;
+        if (L > NTT_MAX_PASSES) return dh_fail(ctx, DEHALO_ERR_INVALID, "log_n too large");
+        uint32_t base = log_n / L, extra = log_n % L;
+        for (uint32_t i = 0; i < L; i++) rad[i] = base + (i < extra ? 1 : 0);
+    }
+    const uint64_t N = 1ull << log_n;
+    fe* scratch = nullptr;
+    if (L > 1) {
+        TRY(dh_ensure(ctx, ctx->ws_ntt_scratch, batch * N * sizeof(fe)));
+        scratch = (fe*)ctx->ws_ntt_scratch.p;
+    }
+    static bool attr_set = false;  // one process drives one GPU
+    const size_t lds_max = 2 * NTT_TILE * 16 + (NTT_TILE / 2) * sizeof(fe);
+    if (!attr_set) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr_set = true;
+    }
+    uint32_t log_m = log_n;
+    for (uint32_t p = 0; p < L; p++) {
+        NttPassParams P;
+        memset(&P, 0, sizeof(P));
+        bool first = p == 0, last = p == L - 1;
+        P.tw = tw;
+        P.log_n = log_n; P.log_m = log_m; P.r = rad[p];
+        P.is_final = last ? 1 : 0;
+        P.r1 = L > 1 ? rad[0] : 0;
+        if (first) { P.src = src; P.src_len = src_len; P.src_stride = src_stride; }
+        else { P.src = scratch; P.src_len = N; P.src_stride = N; }
+        if (last) { P.dst = dst; P.dst_stride = dst_stride; }
+        else { P.dst = scratch; P.dst_stride = N; }
+        if (first && sc.pre_mode) { P.pre_mode = sc.pre_mode; P.pre_z = sc.pre_z; }
+        if (last && sc.post_mode) { P.post_mode = sc.post_mode; P.post0 = sc.post0; P.post_z = sc.post_z; }
+        uint32_t log_c;
+        if (!last) {
+            uint32_t log_cols = log_m - rad[p];
+            log_c = std::min<uint32_t>(NTT_TILE_LOG - rad[p], log_cols);
+        } else {
+            log_c = std::min<uint32_t>(NTT_TILE_LOG - rad[p], P.r1);
+            P.nrev = L > 2 ? L - 2 : 0;
+            for (uint32_t i = 0; i < P.nrev; i++) P.rev_r[i] = rad[1 + i];
+        }
+        P.log_c = log_c;
+        uint64_t tiles = N >> (rad[p] + log_c);
+        size_t lds = 2 * NTT_TILE * 16 + ((size_t)1 << rad[p]) / 2 * sizeof(fe);
+        dim3 grid((uint32_t)tiles, (uint32_t)batch);
+        k_ntt_pass<F><<<grid, NTT_THREADS, lds, s>>>(P);
+        HIP_TRY(ctx, hipGetLastError());
+        log_m -= rad[p];
+    }
+    return 0;
+}
+
+template <class F>
+int field_op_t(dehalo_ctx* ctx, int op, const fe* a, const fe* b, fe* out, uint64_t n, hipStream_t s) {
+    k_field_op<F><<<(u32)((n + 127) / 128), 128, 0, s>>>(op, a, b, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+#define DEFINE_NTT_ENTRY(NAME, F)                                                                                                            \
+    int run_ntt_##NAME(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_stride, fe* dst, uint64_t dst_stride, uint32_t log_n, \
+                       const uint64_t omega[4], size_t batch, const NttScale& sc, hipStream_t s) {                                           \
+        return run_ntt_t<F>(ctx, src, src_len, src_stride, dst, dst_stride, log_n, omega, batch, sc, s); }                                   \
+    int field_op_##NAME(dehalo_ctx* ctx, int op, const fe* a, const fe* b, fe* out, uint64_t n, hipStream_t s) {                             \
+        return field_op_t<F>(ctx, op, a, b, out, n, s); }

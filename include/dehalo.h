@@ -126,7 +126,8 @@ int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t
 /* ---- element-wise field ops (halo2curves Fr/Fq/Fp::{add,sub,mul,invert,to_repr,from_repr})
  * Used by the parity tests to pin the device field arithmetic directly (e.g. against the
  * reference's Poseidon known-answer vectors).  Host buffers, n elements each.
- * op: 0 add, 1 sub, 2 mul, 3 invert, 4 canonical->Montgomery, 5 Montgomery->canonical.     */
+ * op: 0 add, 1 sub, 2 mul, 3 invert, 4 canonical->Montgomery, 5 Montgomery->canonical,
+ *     6 mul evaluated through the kernels' internal carry-free 29-bit-limb representation.     */
 int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
 /* ---- measurement ---------------------------------------------------------------------------

@@ -33,6 +33,9 @@ def test_field_ops_vs_python(pkg, po, ctx, fname):
     assert spec.decode_many(ctx.field_op(spec.id, "sub", a, b)) == [(x - y) % p for x, y in zip(vals, vb)]
     assert spec.decode_many(ctx.field_op(spec.id, "mul", a, b)) == [(x * y) % p for x, y in zip(vals, vb)]
     assert spec.decode_many(ctx.field_op(spec.id, "mul", a, a)) == [(x * x) % p for x in vals]
+    # the kernels' internal carry-free 9 x 29-bit representation (fp29.cuh), round-tripped through from_std / to_std
+    assert np.array_equal(ctx.field_op(spec.id, "mul29", a, b), ctx.field_op(spec.id, "mul", a, b))
+    assert np.array_equal(ctx.field_op(spec.id, "mul29", a, a), ctx.field_op(spec.id, "mul", a, a))
     nz = [x for x in vals if x][:200]
     assert spec.decode_many(ctx.field_op(spec.id, "inv", spec.encode_many(nz))) == [pow(x, -1, p) for x in nz]
     canon = np.stack([np.array([(x >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64) for x in vals])
@@ -46,6 +49,7 @@ def test_field_mul_vs_c_oracle_large(pkg, co, ctx):
         b = co.fill_scalars(fid, "uniform", 1 << 16, 22)
         for op in ("mul", "add", "sub"):
             assert np.array_equal(ctx.field_op(fid, op, a, b), co.field_op(fid, op, a, b)), (fid, op)
+        assert np.array_equal(ctx.field_op(fid, "mul29", a, b), co.field_op(fid, "mul", a, b)), (fid, "mul29")
 
 
 def test_poseidon_kats_through_gpu_field_ops(pkg, po, ctx):
