@@ -24,6 +24,7 @@
 // lock-step.  Integer-only (v_mad_u64_u32); no MFMA (nothing here is a contraction).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 
 #include "ec29.cuh"
 #include "internal.hpp"
@@ -343,6 +344,13 @@ __global__ __launch_bounds__(64) void k_msm_final(MsmGeom g, const xyzz29_rec* g
     __shared__ xyzz29_rec sh[64];
     u32 bat = blockIdx.x;
     u32 w = threadIdx.x;
+    if (g.G == 1) {  // precomputed tables: nothing to combine
+        if (w == 0) {
+            jacobian_t j = x29_to_jacobian_std<F>(x29_load(&group_sums[bat]));
+            f_store(&out[bat].x, j.x); f_store(&out[bat].y, j.y); f_store(&out[bat].z, j.z);
+        }
+        return;
+    }
     xyzz29 s = x29_identity();
     if (w < g.G) {
         s = x29_load(&group_sums[(u64)bat * g.G + w]);
@@ -445,9 +453,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     if (Mmax >= (1ull << 32) || total_buckets >= (1ull << 31))
         return dh_fail(ctx, DEHALO_ERR_INVALID, "batch * len * windows too large for one launch");
     {   // task length: enough tasks to fill 256 CUs, short enough to balance
-        uint64_t l0 = Mmax / (256 * 1024);
+        uint64_t l0 = Mmax / (512 * 1024);
         u32 L0 = 4;
-        while (L0 < 64 && L0 < l0) L0 <<= 1;
+        while (L0 < 32 && L0 < l0) L0 <<= 1;
+        if (const char* e = getenv("DEHALO_L0")) L0 = (u32)std::max(1, atoi(e));  // tuning override
         g.L0 = L0;
     }
     const uint64_t nt0_max = Mmax / g.L0 + total_buckets;

@@ -30,7 +30,7 @@
 
 #define NTT_TILE_LOG 11
 #define NTT_TILE (1 << NTT_TILE_LOG)
-#define NTT_THREADS 256
+#define NTT_THREADS 512
 #define NTT_MAX_PASSES 4
 
 struct NttPassParams {
@@ -53,6 +53,14 @@ struct NttPassParams {
     fe pre_z;
     fe post0, post_z;
 };
+
+// a (standard form, canonical) times w (w * 2^261 as limbs, < 2p) -> standard form, canonical
+template <class F>
+FP_DEV fe mul_std_w29(const fe& a, const f29& w) {
+    typedef typename f29_of<F>::type F9;
+    f29 t = f29_mul<F9>(f29_unpack(a), w);   // < a*w/2^261 + p < 2p
+    return f29_pack(f29_cond_sub(t, F9::P));
+}
 
 FP_DEV u32 bitrev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
@@ -101,8 +109,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     }
     const u32 log_q_per_k1 = P.log_n - r - P.r1;  // final: Q / R1
 
-    fe pre2 = f_zero();
-    if (P.pre_mode) pre2 = f_sqr<F>(P.pre_z);
+    typedef typename f29_of<F>::type F9;
+    f29 pre1 = f29_zero(), pre2 = f29_zero();
+    if (P.pre_mode) {
+        pre1 = f29_from_std<F9>(P.pre_z);          // z   * 2^261
+        pre2 = f29_mul<F9>(pre1, pre1);            // z^2 * 2^261
+    }
 
     // ---- load ----
     for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
@@ -122,8 +134,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             v = f_load(&src[g]);
             if (P.pre_mode) {
                 u32 m3 = (u32)(g % 3);
-                if (m3 == 1) v = f_mul<F>(v, P.pre_z);
-                else if (m3 == 2) v = f_mul<F>(v, pre2);
+                if (m3 == 1) v = mul_std_w29<F>(v, pre1);
+                else if (m3 == 2) v = mul_std_w29<F>(v, pre2);
             }
         } else {
             v = f_zero();
@@ -150,9 +162,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             u.v[4] = a1.x; u.v[5] = a1.y; u.v[6] = a1.z; u.v[7] = a1.w;
             v.v[0] = b0.x; v.v[1] = b0.y; v.v[2] = b0.z; v.v[3] = b0.w;
             v.v[4] = b1.x; v.v[5] = b1.y; v.v[6] = b1.z; v.v[7] = b1.w;
-            fe w = f_load(&ltw[pos << s]);
             fe sum = f_add<F>(u, v);
-            fe dif = f_mul<F>(f_sub<F>(u, v), w);
+            fe dif = f_sub<F>(u, v);
+            if (half > 1) dif = mul_std_w29<F>(dif, f29_unpack(f_load(&ltw[pos << s])));   // last stage: all twiddles are 1
             lo[i0] = make_uint4(sum.v[0], sum.v[1], sum.v[2], sum.v[3]);
             hi[i0] = make_uint4(sum.v[4], sum.v[5], sum.v[6], sum.v[7]);
             lo[i1] = make_uint4(dif.v[0], dif.v[1], dif.v[2], dif.v[3]);
@@ -162,10 +174,14 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     }
 
     // ---- store (LDS row j holds output digit k = bitrev_r(j)) ----
-    fe post1m, post2m;
-    if (P.is_final && P.post_mode == 2) {
-        post2m = f_mul<F>(P.post0, P.post_z);
-        post1m = f_mul<F>(post2m, P.post_z);
+    f29 post0m = f29_zero(), post1m = f29_zero(), post2m = f29_zero();
+    if (P.is_final && P.post_mode) {
+        post0m = f29_from_std<F9>(P.post0);
+        if (P.post_mode == 2) {
+            f29 z = f29_from_std<F9>(P.post_z);
+            post2m = f29_mul<F9>(post0m, z);
+            post1m = f29_mul<F9>(post2m, z);
+        }
     }
     u64 revrest = 0;
     if (P.is_final) {
@@ -192,14 +208,14 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         if (!P.is_final) {
             u64 np = np0 + c;
             u64 e = (np * k) << (P.log_n - P.log_m);
-            if (e) v = f_mul<F>(v, tw_lookup<F>(P.tw, e, P.log_n));
+            if (e) v = mul_std_w29<F>(v, f29_unpack(tw_lookup<F>(P.tw, e, P.log_n)));
             o = (q << P.log_m) + ((u64)k << log_cols) + np;
         } else {
             o = (((u64)k1blk << log_c) + c) + (revrest << P.r1) + ((u64)k << (P.log_n - r));
-            if (P.post_mode == 1) v = f_mul<F>(v, P.post0);
+            if (P.post_mode == 1) v = mul_std_w29<F>(v, post0m);
             else if (P.post_mode == 2) {
                 u32 m3 = (u32)(o % 3);
-                v = f_mul<F>(v, m3 == 0 ? P.post0 : (m3 == 1 ? post1m : post2m));
+                v = mul_std_w29<F>(v, m3 == 0 ? post0m : (m3 == 1 ? post1m : post2m));
             }
         }
         f_store(&dst[o], v);
@@ -207,7 +223,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     (void)N;
 }
 
-// tw[j] = omega^j, j < half.  Thread t fills a run of 64 starting from omega^(64 t).
+// tw[j] = omega^j * 2^261 mod p (canonical, packed), j < half.  Thread t fills a run of 64
+// starting from omega^(64 t); the running power is kept in standard form.
 template <class F>
 __global__ void k_twiddle_gen(fe* tw, fe omega, u64 half) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,9 +237,11 @@ __global__ void k_twiddle_gen(fe* tw, fe omega, u64 half) {
         if (e & 1) acc = f_mul<F>(acc, base);
         base = f_sqr<F>(base);
     }
+    typedef typename f29_of<F>::type F9;
+    const fe c261 = f29_pack(f29_const<F9>(F9::ONE));   // 2^261 mod p as a plain integer
     u64 end = start + 64 < half ? start + 64 : half;
     for (u64 j = start; j < end; j++) {
-        f_store(&tw[j], acc);
+        f_store(&tw[j], f_mul<F>(acc, c261));               // (w 2^256)(2^261) 2^-256 = w 2^261
         acc = f_mul<F>(acc, omega);
     }
 }

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "ec.cuh"
+#include "ec29.cuh"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -25,6 +25,17 @@ __global__ void NAME(u32* out, u32 seed) {                                      
 #define ADD32(r) { u32 t = (u32)r; asm volatile("v_add_u32 %0, %0, %1" : "+v"(t) : "v"(b)); r = t; }
 #define ADD64(r) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(r) : "v"((u64)b));
 #define ADDC(r) { u32 lo = (u32)r, hi = (u32)(r >> 32); asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc"); r = ((u64)hi << 32) | lo; }
+#define SHR64(r) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(r));
+#define SHL64(r) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(r));
+#define ALIGNB(r) { u32 t = (u32)r; asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(t) : "v"(b)); r = t; }
+#define AND32(r) { u32 t = (u32)r; asm volatile("v_and_b32 %0, %0, %1" : "+v"(t) : "v"(b)); r = t; }
+#define MOV32(r) { u32 t = (u32)r; asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(b)); r = t; }
+#define LSHLADD64S(r) asm volatile("v_lshl_add_u64 %0, %1, 3, %0" : "+v"(r) : "v"((u64)b));
+DEF_INT_BENCH(k_shr64, SHR64)
+DEF_INT_BENCH(k_shl64, SHL64)
+DEF_INT_BENCH(k_alignb, ALIGNB)
+DEF_INT_BENCH(k_and32, AND32)
+DEF_INT_BENCH(k_lshladd3, LSHLADD64S)
 DEF_INT_BENCH(k_mad64, MAD64)
 DEF_INT_BENCH(k_mullo, MULLO)
 DEF_INT_BENCH(k_mulhi, MULHI)
@@ -58,6 +69,32 @@ __global__ void k_fmul(fe* out, const fe* in, int iters) {
 #pragma unroll
     for (int c = 1; c < CH; c++) r = f_add<F>(r, x[c]);
     f_store(&out[gid], r);
+}
+
+template <class F9, int CH>
+__global__ void k_fmul29(f29* out, const fe* in, int iters) {
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    f29 x[CH];
+    f29 m = f29_unpack(f_load(&in[gid]));
+    m.v[8] &= 0xffff;
+#pragma unroll
+    for (int c = 0; c < CH; c++) { x[c] = m; x[c].v[0] ^= c; }
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) x[c] = f29_mul<F9>(x[c], m);
+    }
+    f29 r = x[0];
+#pragma unroll
+    for (int c = 1; c < CH; c++) r = f29_add(r, x[c]);
+    out[gid] = r;
+}
+template <class F9>
+__global__ void k_fsqr29(f29* out, const fe* in, int iters) {
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    f29 x = f29_unpack(f_load(&in[gid]));
+    x.v[8] &= 0xffff;
+    for (int i = 0; i < iters; i++) x = f29_sqr<F9>(x);
+    out[gid] = x;
 }
 
 template <class F>
@@ -101,6 +138,11 @@ int main() {
         {"v_lshl_add_u64", time_kernel(k_add64, dim3(blocks), dim3(threads), d, 7u)},
         {"add_co+addc (pair)", time_kernel(k_addc, dim3(blocks), dim3(threads), d, 7u)},
         {"v_fma_f64", time_kernel(k_fma64, dim3(blocks), dim3(threads), (double*)d, 1.5)},
+        {"v_lshrrev_b64", time_kernel(k_shr64, dim3(blocks), dim3(threads), d, 7u)},
+        {"v_lshlrev_b64", time_kernel(k_shl64, dim3(blocks), dim3(threads), d, 7u)},
+        {"v_alignbit_b32", time_kernel(k_alignb, dim3(blocks), dim3(threads), d, 7u)},
+        {"v_and_b32", time_kernel(k_and32, dim3(blocks), dim3(threads), d, 7u)},
+        {"v_lshl_add_u64 (<<3)", time_kernel(k_lshladd3, dim3(blocks), dim3(threads), d, 7u)},
     };
     for (auto& r : rows) {
         double rate = ops / (r.ms * 1e-3);
@@ -125,6 +167,15 @@ int main() {
     printf("f_mul<Bn254Fr> chain1  %8.3f ms  %8.2f Gmul/s\n", ms, (double)nel * fit / ms / 1e6);
     ms = time_kernel(k_fmul<Bn254Fq, 2>, dim3(fblocks), dim3(fthreads), fout, fin, fit);
     printf("f_mul<Bn254Fq> chain2  %8.3f ms  %8.2f Gmul/s\n", ms, (double)nel * fit * 2 / ms / 1e6);
+    f29* f29out; CHECK(hipMalloc(&f29out, nel * sizeof(f29)));
+    ms = time_kernel(k_fmul29<PastaFp29, 1>, dim3(fblocks), dim3(fthreads), f29out, fin, fit);
+    printf("f29_mul<PastaFp29> ch1 %8.3f ms  %8.2f Gmul/s\n", ms, (double)nel * fit / ms / 1e6);
+    ms = time_kernel(k_fmul29<PastaFp29, 2>, dim3(fblocks), dim3(fthreads), f29out, fin, fit);
+    printf("f29_mul<PastaFp29> ch2 %8.3f ms  %8.2f Gmul/s\n", ms, (double)nel * fit * 2 / ms / 1e6);
+    ms = time_kernel(k_fmul29<Bn254Fq29, 1>, dim3(fblocks), dim3(fthreads), f29out, fin, fit);
+    printf("f29_mul<Bn254Fq29> ch1 %8.3f ms  %8.2f Gmul/s\n", ms, (double)nel * fit / ms / 1e6);
+    ms = time_kernel(k_fsqr29<PastaFp29>, dim3(fblocks), dim3(fthreads), f29out, fin, fit);
+    printf("f29_sqr<PastaFp29>     %8.3f ms  %8.2f Gsqr/s\n", ms, (double)nel * fit / ms / 1e6);
     // mixed-add throughput with random gathers from a 64 MB table
     u32 npts = 1 << 20;
     affine_t* pts; CHECK(hipMalloc(&pts, (size_t)npts * 64));
