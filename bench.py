@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "witness", "lookup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--prover-k", type=int, default=17, help="also time the delay_enc-shaped MSM/NTT schedule at this k (0 = skip)")
+    ap.add_argument("--prover-curve", default="bn254")
     ap.add_argument("--inflight", type=int, default=2, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
 
@@ -69,6 +71,45 @@ def cpu_baseline(co, po, curve, field, log_n, dist):
         "sample": "%d x (2^%d-term MSM + 2^%d-point NTT), oracle/oracle.c best_multiexp+best_fft, %d threads" % (reps, log_n, log_n, cores),
         "msm_ms": round(1e3 * t_msm / reps, 2), "ntt_ms": round(1e3 * t_ntt / reps, 2),
     }
+
+
+def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu):
+    """The k~17 half of the metric: the MSM/NTT schedule of one delay_enc create_proof
+    (31 MSM(n) + 24 iNTT(n) + 23 coset NTT(n -> 4n) + 1 iNTT(4n), phases separated by host
+    syncs), synthetic device-resident columns; CPU = the same calls through oracle/oracle.c."""
+    import numpy as np
+    from dehalo2_amd import prover_shape as ps
+    curve = pkg.fields.CURVES[curve_name]
+    n = 1 << k
+    g = co.synth_bases(curve.id, n)
+    gl = g[::-1].copy()
+    cols = ps.synthetic_columns(lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed), curve.scalar.id, k, 7)
+    bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, gl, 0, True)
+    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
+    shape.run()                                   # warm-up (twiddle tables, workspace)
+    runs = [shape.run() for _ in range(5)]
+    best = min(runs, key=lambda r: r.ms_total)
+    out = {"k": k, "curve": curve_name, "gpu_ms": round(best.ms_total, 3), "gpu_msm_ms": round(best.ms_msm, 3), "gpu_ntt_ms": round(best.ms_ntt, 3),
+           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + 1 iNTT(4n); 7 host syncs; columns resident in HBM"}
+    if with_cpu:
+        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+        f = curve.scalar
+        d = shape.domain
+        e = f.encode
+        t0 = time.time()
+        for name, cnt, _ in ps.MSM_PHASES:
+            basis = gl if name in ("advice", "lookup_permuted", "grand_products") else g
+            for i in range(cnt):
+                co.best_multiexp(curve.id, cols[name][i], basis, cores)
+        t1 = time.time()
+        coeffs = [co.lagrange_to_coeff(f.id, cols["polys"][i], k, e(d.omega_inv), e(d.ifft_divisor), cores) for i in range(ps.N_INTT)]
+        exts = [co.coeff_to_extended(f.id, coeffs[i], k, d.extended_k, e(d.extended_omega), e(d.g_coset), cores) for i in range(ps.N_COSET)]
+        co.extended_to_coeff(f.id, exts[0], d.extended_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), cores)
+        t2 = time.time()
+        out.update({"cpu_ms": round(1e3 * (t2 - t0), 1), "cpu_msm_ms": round(1e3 * (t1 - t0), 1), "cpu_ntt_ms": round(1e3 * (t2 - t1), 1), "cpu_cores": cores,
+                    "cpu_kind": "port (oracle/oracle.c)"})
+    bg.release(); bgl.release()
+    return out
 
 
 def main():
@@ -205,6 +246,8 @@ def main():
         out["ntt_roofline"]["frac"] = round(out["ntt_roofline"]["achieved"] / HBM_PEAK_GBS, 5)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(co, po, curve, field, log_n, args.dist)
+        if world == 1 and args.prover_k > 0:
+            out["prover_shape"] = prover_shape_numbers(pkg, co, po, ctx, args.prover_k, args.prover_curve, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
 
     bases.release()

@@ -274,3 +274,66 @@ def test_msm_full_size_2_20(pkg, co, ctx, cname):
     pa, pb = ctx.to_affine(spec.id, ja)[0], ctx.to_affine(spec.id, jb)[0]
     s = co.to_affine(spec.id, co.best_multiexp(spec.id, np.stack([one, one]), np.stack([pa, pb]), 1))
     assert np.array_equal(ctx.to_affine(spec.id, jab)[0], s)
+
+
+# ---------------------------------------------------------------- prover-shaped schedule (device-resident, batched)
+@pytest.mark.parametrize("cname,k", [("bn254", 8), ("pallas", 9)])
+def test_prover_shape_vs_oracle(pkg, po, co, ctx, cname, k):
+    """The 31 MSMs + 48 NTTs of one delay_enc-shaped create_proof through the batched device entry
+    points, every output checked against the oracle."""
+    import torch
+    from dehalo2_amd import prover_shape as ps
+    curve = pkg.fields.CURVES[cname]
+    f = curve.scalar
+    n = 1 << k
+    g = co.synth_bases(curve.id, n)
+    gl = g[::-1].copy()
+    cols = ps.synthetic_columns(lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed), f.id, k, 3)
+    bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, gl, 0, False)
+    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
+    polys_before = cols["polys"].copy()
+    res = shape.run()
+    assert res.commitments.shape == (31, 12)
+    got = ctx.to_affine(curve.id, res.commitments)
+    row = 0
+    for name, cnt, _ in ps.MSM_PHASES:
+        basis = gl if name in ("advice", "lookup_permuted", "grand_products") else g
+        for i in range(cnt):
+            want = co.to_affine(curve.id, co.best_multiexp(curve.id, cols[name][i], basis, 2))
+            assert np.array_equal(got[row], want), (name, i)
+            row += 1
+    d, e = shape.domain, f.encode
+    coeffs_dev = shape.polys.cpu().numpy().view(np.uint64)
+    ext_dev = shape.ext.cpu().numpy().view(np.uint64)
+    for i in range(ps.N_INTT):
+        want = co.lagrange_to_coeff(f.id, polys_before[i], k, e(d.omega_inv), e(d.ifft_divisor), 2)
+        assert np.array_equal(coeffs_dev[i], want), i
+    for i in range(ps.N_COSET):
+        want = co.coeff_to_extended(f.id, coeffs_dev[i], k, d.extended_k, e(d.extended_omega), e(d.g_coset), 2)
+        if i == 0:  # the schedule takes extended vector 0 back through extended_to_coeff
+            want = co.extended_to_coeff(f.id, want, d.extended_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), 2)
+        assert np.array_equal(ext_dev[i], want), i
+    bg.release(); bgl.release()
+
+
+def test_two_contexts_concurrently(pkg, co, ctx):
+    """bench.py keeps several steps in flight, one context (stream + workspace) each, sharing one SRS."""
+    import torch
+    spec = pkg.fields.PALLAS
+    n = 1 << 13
+    bases = co.synth_bases(spec.id, n)
+    h = ctx.register_bases(spec.id, bases, 0, True)
+    other = pkg.Context(0)
+    cols = [co.fill_scalars(spec.scalar.id, "uniform", n, 70 + i) for i in range(4)]
+    d_cols = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+    d_outs = [torch.zeros((1, 12), dtype=torch.int64, device="cuda") for _ in cols]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, (dc, do) in enumerate(zip(d_cols, d_outs)):
+            (ctx if i % 2 == 0 else other).msm_device(h, dc.data_ptr(), n, 1, do.data_ptr(), 0)
+    torch.cuda.synchronize()
+    for c, do in zip(cols, d_outs):
+        want = co.to_affine(spec.id, co.best_multiexp(spec.id, c, bases, 2))
+        assert np.array_equal(ctx.to_affine(spec.id, do.cpu().numpy().view(np.uint64))[0], want)
+    other.close()
+    h.release()
