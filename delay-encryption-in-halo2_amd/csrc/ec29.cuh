@@ -168,3 +168,29 @@ FP_DEV jacobian_t x29_to_jacobian_std(const xyzz29& p) {
     r.z = f29_to_std<F>(p.zz);
     return r;
 }
+
+// ---- wave-level reduction (64 lanes -> lane 0) through register shuffles; every lane runs the
+// additions (a wave executes them in lock-step anyway), only lane 0's result is meaningful.
+template <int W>
+FP_DEV xyzz29 x29_shfl_down(const xyzz29& v, int d) {
+    xyzz29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.x.v[i] = __shfl_down(v.x.v[i], d, W);
+        r.y.v[i] = __shfl_down(v.y.v[i], d, W);
+        r.zz.v[i] = __shfl_down(v.zz.v[i], d, W);
+        r.zzz.v[i] = __shfl_down(v.zzz.v[i], d, W);
+    }
+    return r;
+}
+// sum over groups of W consecutive lanes (W a power of two <= 64); lane 0 of each group gets it
+template <class F, int W>
+FP_DEV xyzz29 x29_group_reduce(xyzz29 v) {
+    const int gl = threadIdx.x & (W - 1);
+    for (int d = W >> 1; d > 0; d >>= 1) {
+        xyzz29 o = x29_shfl_down<W>(v, d);
+        if (gl + d >= W) o = x29_identity();   // lanes past the fold add nothing (and never see P + P)
+        v = x29_add<F>(v, o);
+    }
+    return v;
+}

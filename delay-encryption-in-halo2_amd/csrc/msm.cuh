@@ -16,7 +16,8 @@
 //  * Bucket accumulation split into fixed-length tasks of <= L points regardless of bucket
 //    size (a bucket that receives 300 k points of a 0/1 column costs the same per lane as a
 //    uniform one), one lane per task, XYZZ mixed additions on the carry-free 9 x 29-bit field
-//    (fp29.cuh / ec29.cuh); partial sums are merged by two further levels of the same scheme.
+//    (fp29.cuh / ec29.cuh); a bucket's partial sums are merged by a lane group sized to their
+//    number (1 / 8 / 64 / 1024 lanes).
 //  * Bucket reduction sum_k k*B_k: lanes take 4 consecutive buckets (local running sums),
 //    weight their run by the block offset with double-and-add, then a tree of group additions.
 //
@@ -31,7 +32,6 @@
 
 #define MSM_SORT_THREADS 1024
 #define MSM_ACC_THREADS 128
-#define MSM_L1 32          // chunk of the first merge level
 #define MSM_RED_M 4        // buckets per lane in the bucket reduction
 #define MSM_TREE_THREADS 128
 
@@ -257,29 +257,96 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_accum0(MsmGeom g, u32 t
     x29_store(&partial[t], acc);
 }
 
-// ---- merge levels: segments of XYZZ partials --------------------------------------------
-// level 1: task = <= L consecutive partials of one bucket; level 2 (per_bucket): whole segment
+// ---- merging the partial sums of each bucket ---------------------------------------------
+// Signed-digit carries of small witness values pile thousands of points into bucket 0 (digit
+// +-1) and 0/1 columns put half the column into one bucket, so the number S of partial sums per
+// bucket spans 0 .. 10^5.  Buckets are classed by S and merged by a lane group sized to it:
+//   S <= 16: one lane | S <= 128: 8 lanes | S <= 2048: one wave | larger: a 1024-thread block;
+// chain length <= S/g + log2 g group additions instead of S.
+#define MSM_C0_MAX 16
+#define MSM_C1_MAX 128
+#define MSM_C2_MAX 2048
+#define MSM_HEAVY_THREADS 1024
+#define MSM_MERGE_BLOCKS 1024
+
+// lists: [class 1 | class 2 | class 3], each with `cap` slots; counters[3]
 template <class CV>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge(u32 total_buckets, u32 L, const u32* seg_off, const u32* toff, const xyzz29_rec* in,
-                                                              xyzz29_rec* out, u32 per_bucket) {
+__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge_light(u32 total_buckets, const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
+                                                                    u32* counters, u32* lists, u32 cap) {
     typedef typename f29_of<typename CV::Base>::type F;
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 b, beg, end;
-    if (per_bucket) {
-        if (t >= total_buckets) return;
-        b = t; beg = seg_off[b]; end = seg_off[b + 1];
-    } else {
-        u32 ntasks = toff[total_buckets];
-        if (t >= ntasks) return;
-        b = find_segment(toff, total_buckets, t);
-        u32 j = t - toff[b];
-        beg = seg_off[b] + j * L;
-        end = min(beg + L, seg_off[b + 1]);
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= total_buckets) return;
+    u32 beg = toff[b], end = toff[b + 1];
+    u32 S = end - beg;
+    // queue the heavier classes: one atomic per wave and class (a single hot counter serialises)
+    const u32 cls = S <= MSM_C0_MAX ? 3u : (S <= MSM_C1_MAX ? 0u : (S <= MSM_C2_MAX ? 1u : 2u));
+    const u32 lane = threadIdx.x & 63;
+    for (u32 c = 0; c < 3; c++) {
+        unsigned long long mask = __ballot(cls == c);
+        if (mask == 0) continue;
+        u32 leader = (u32)__ffsll((long long)mask) - 1;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
+        base = __shfl(base, (int)leader);
+        if (cls == c) lists[c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
     }
+    if (cls != 3u) return;
     xyzz29 acc = x29_identity();
-    if (beg < end) acc = x29_load(&in[beg]);
-    for (u32 p = beg + 1; p < end; p++) acc = x29_add<F>(acc, x29_load(&in[p]));
-    x29_store(&out[t], acc);
+    if (beg < end) acc = x29_load(&partial[beg]);
+    for (u32 p = beg + 1; p < end; p++) acc = x29_add<F>(acc, x29_load(&partial[p]));
+    x29_store(&buckets[b], acc);
+}
+
+// groups of G lanes (8 or 64) walk a class list: strided lane sums, then a shuffle reduction
+template <class CV, int G>
+__global__ __launch_bounds__(256) void k_msm_merge_group(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter,
+                                                        const u32* list) {
+    typedef typename f29_of<typename CV::Base>::type F;
+    const u32 count = *counter;
+    const u32 groups_per_block = 256 / G;
+    const u32 gl = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    for (u32 i = blockIdx.x * groups_per_block + grp; i < count; i += gridDim.x * groups_per_block) {
+        u32 b = list[i];
+        u32 beg = toff[b], end = toff[b + 1];
+        xyzz29 acc = x29_identity();
+        u32 p = beg + gl;
+        if (p < end) {
+            acc = x29_load(&partial[p]);
+            for (p += G; p < end; p += G) acc = x29_add<F>(acc, x29_load(&partial[p]));
+        }
+        acc = x29_group_reduce<F, G>(acc);
+        if (gl == 0) x29_store(&buckets[b], acc);
+    }
+}
+
+// 1024-thread blocks walk the heaviest class: strided lane sums, shuffle reduction per wave,
+// 16 wave results through LDS, shuffle reduction again.  Chain: ceil(S / 1024) + 10 adds.
+template <class CV>
+__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
+                                                                     const u32* counter, const u32* list) {
+    typedef typename f29_of<typename CV::Base>::type F;
+    __shared__ xyzz29_rec sh[MSM_HEAVY_THREADS / 64];
+    const u32 count = *counter;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
+        u32 b = list[i];
+        u32 beg = toff[b], end = toff[b + 1];
+        xyzz29 acc = x29_identity();
+        u32 p = beg + threadIdx.x;
+        if (p < end) {
+            acc = x29_load(&partial[p]);
+            for (p += MSM_HEAVY_THREADS; p < end; p += MSM_HEAVY_THREADS) acc = x29_add<F>(acc, x29_load(&partial[p]));
+        }
+        acc = x29_group_reduce<F, 64>(acc);
+        if (lane == 0) x29_store(&sh[wave], acc);
+        __syncthreads();
+        if (wave == 0) {
+            xyzz29 v = lane < MSM_HEAVY_THREADS / 64 ? x29_load(&sh[lane]) : x29_identity();
+            v = x29_group_reduce<F, MSM_HEAVY_THREADS / 64>(v);
+            if (lane == 0) x29_store(&buckets[b], v);
+        }
+        __syncthreads();
+    }
 }
 
 // ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
@@ -460,20 +527,17 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         g.L0 = L0;
     }
     const uint64_t nt0_max = Mmax / g.L0 + total_buckets;
-    const uint64_t nt1_max = nt0_max / MSM_L1 + total_buckets;
     const u32 per_group = (g.nb + MSM_RED_M - 1) / MSM_RED_M;
     const size_t REC = sizeof(xyzz29_rec);
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
-    TRY(dh_ensure(ctx, ctx->ws_cursor, total_buckets * 4));
+    TRY(dh_ensure(ctx, ctx->ws_cursor, (total_buckets + 4) * 4));   // + 3 merge-class counters
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
     TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4));
-    TRY(dh_ensure(ctx, ctx->ws_cnt1, total_buckets * 4));
-    TRY(dh_ensure(ctx, ctx->ws_off1, (total_buckets + 1) * 4));
-    TRY(dh_ensure(ctx, ctx->ws_toff1, (total_buckets + 1) * 4));
+    const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / (MSM_C0_MAX + 1) + 1);
+    TRY(dh_ensure(ctx, ctx->ws_cnt1, (size_t)merge_cap * 3 * 4));   // merge-class lists
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
-    TRY(dh_ensure(ctx, ctx->ws_partial1, nt1_max * REC));
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
     TRY(dh_ensure(ctx, ctx->ws_contrib, total_groups * per_group * REC));
     TRY(dh_ensure(ctx, ctx->ws_tree, total_groups * ((per_group + 2 * MSM_TREE_THREADS - 1) / (2 * MSM_TREE_THREADS)) * REC));
@@ -482,12 +546,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     u32* cursor = (u32*)ctx->ws_cursor.p;
     u32* off = (u32*)ctx->ws_off.p;
     u32* toff0 = (u32*)ctx->ws_toff0.p;
-    u32* cnt1 = (u32*)ctx->ws_cnt1.p;
-    u32* off1 = (u32*)ctx->ws_off1.p;
-    u32* toff1 = (u32*)ctx->ws_toff1.p;
+    u32* merge_lists = (u32*)ctx->ws_cnt1.p;
+    u32* merge_counters = cursor + total_buckets;
     u32* idx = (u32*)ctx->ws_idx.p;
     xyzz29_rec* partial0 = (xyzz29_rec*)ctx->ws_partial0.p;
-    xyzz29_rec* partial1 = (xyzz29_rec*)ctx->ws_partial1.p;
     xyzz29_rec* buckets = (xyzz29_rec*)ctx->ws_buckets.p;
     xyzz29_rec* contrib = (xyzz29_rec*)ctx->ws_contrib.p;
     xyzz29_rec* tree = (xyzz29_rec*)ctx->ws_tree.p;
@@ -502,7 +564,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
         HIP_TRY(ctx, hipMemsetAsync(count, 0, total_buckets * 4, s));
-        HIP_TRY(ctx, hipMemsetAsync(cursor, 0, total_buckets * 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(cursor, 0, (total_buckets + 4) * 4, s));
         dim3 grid(g.slices, g.G, (u32)batch);
         k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, count);
         TRY(run_scan(ctx, count, tb, g.L0, off, toff0, s));
@@ -517,13 +579,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     }
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_REDUCE);
-        // level 1: merge partials in chunks of MSM_L1
-        k_diff<<<(tb + 255) / 256, 256, 0, s>>>(toff0, tb, cnt1);
-        TRY(run_scan(ctx, cnt1, tb, MSM_L1, off1, toff1, s));
-        u32 blocks1 = (u32)((nt1_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
-        k_msm_merge<CV><<<blocks1, MSM_ACC_THREADS, 0, s>>>(tb, MSM_L1, toff0, toff1, partial0, partial1, 0);
-        // level 2: whatever is left per bucket
-        k_msm_merge<CV><<<(tb + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, MSM_ACC_THREADS, 0, s>>>(tb, 0xffffffffu, toff1, nullptr, partial1, buckets, 1);
+        // partial sums -> one point per bucket (by size class)
+        k_msm_merge_light<CV><<<(tb + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, MSM_ACC_THREADS, 0, s>>>(tb, toff0, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        k_msm_merge_group<CV, 8><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
+        k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
+        k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 2, MSM_HEAVY_THREADS, 0, s>>>(toff0, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
         // bucket reduction
         u32 nthreads = per_group * (u32)total_groups;
         k_msm_reduce_local<CV><<<(nthreads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
