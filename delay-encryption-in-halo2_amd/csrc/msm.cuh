@@ -32,6 +32,9 @@
 
 #define MSM_SORT_THREADS 1024
 #define MSM_ACC_THREADS 128
+// (measured: 2 and 3 resident waves per SIMD give the same k_msm_accum0 time -- the loop is
+// VALU-issue-bound -- and capping residency at 2 did not improve multi-stream overlap)
+#define MSM_ACC_WAVES_ATTR
 #define MSM_RED_M 4        // buckets per lane in the bucket reduction
 #define MSM_TREE_THREADS 128
 
@@ -236,7 +239,7 @@ FP_DEV aff29 load_point(const affine_t* table, u32 e, bool& is_id) {
 
 // ---- level 0: one lane = one task of <= L0 points of one bucket ---------------------------
 template <class CV>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* toff,
+__global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* toff,
                                                                const affine_t* table, xyzz29_rec* partial) {
     typedef typename f29_of<typename CV::Base>::type F;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,12 +249,23 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_accum0(MsmGeom g, u32 t
     u32 j = t - toff[b];
     u32 beg = off[b] + j * g.L0;
     u32 end = min(beg + g.L0, off[b + 1]);
-    bool is_id;
-    aff29 q = load_point<F>(table, idx[beg], is_id);
+    // the next point's index is fetched one iteration ahead (dependent idx -> table[idx] chain);
+    // measured: prefetching the 64-B point too changes nothing -- the loop is VALU-issue-bound
+    affine_t pk = aff_load(&table[idx[beg] & 0x7fffffffu]);
+    u32 e = idx[beg];
+    bool is_id = aff_is_identity(pk);
+    aff29 q = a29_from_packed(pk);
+    if (e >> 31) q.y = f29_sub(f29_zero(), q.y, F::KN);
     xyzz29 acc = x29_from_affine<F>(q, is_id);
     if (!is_id) acc.y = f29_norm(acc.y);
+    u32 e_next = beg + 1 < end ? idx[beg + 1] : 0;
     for (u32 p = beg + 1; p < end; p++) {
-        q = load_point<F>(table, idx[p], is_id);
+        e = e_next;
+        pk = aff_load(&table[e & 0x7fffffffu]);
+        e_next = p + 1 < end ? idx[p + 1] : 0;
+        is_id = aff_is_identity(pk);
+        q = a29_from_packed(pk);
+        if (e >> 31) q.y = f29_sub(f29_zero(), q.y, F::KN);   // 2p - y, limbs < 2^30
         if (!is_id) acc = x29_add_mixed<F>(acc, q);
     }
     x29_store(&partial[t], acc);

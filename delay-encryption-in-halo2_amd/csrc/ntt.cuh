@@ -24,6 +24,7 @@
 // bound on gfx950 is the VALU (v_mad_u64_u32) -- see DESIGN.md.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 
 #include "fp29.cuh"
 #include "internal.hpp"
@@ -223,6 +224,199 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     (void)N;
 }
 
+// ---- pass kernel, version 2 -----------------------------------------------------------------
+// Same tiling / passes / fused scaling as k_ntt_pass, but the tile lives in LDS as lazily reduced
+// 9 x 29-bit limbs (five planes: four u64 limb pairs + one u32, 36 B per element, conflict-free
+// ds_read/write_b64) and the butterflies are decimation-in-time:
+//     t = w * v (carry-free multiplier, < 2p);  u' = u + t;  v' = u - t + 4p
+// so values grow ADDITIVELY (< p + 4p per stage, < 30p after 7 stages, far inside 2^261) and no
+// stage needs a modular reduction -- only a carry normalisation every second stage.  Two stages
+// run in registers per LDS round trip (radix 4).  The element is the plain integer of upstream's
+// standard form (x * 2^256); twiddles are w * 2^261, so products stay in that form, and the
+// multiplication every element needs on the way out (inter-pass twiddle, post-scale, or 1)
+// brings it back below 2p for one conditional subtraction.
+#define NTT2_THREADS 512
+
+struct Lds29 {
+    u64* p01; u64* p23; u64* p45; u64* p67; u32* p8;
+};
+FP_DEV f29 lds29_load(const Lds29& L, u32 i) {
+    f29 r;
+    u64 a = L.p01[i], b = L.p23[i], c = L.p45[i], d = L.p67[i];
+    r.v[0] = (u32)a; r.v[1] = (u32)(a >> 32); r.v[2] = (u32)b; r.v[3] = (u32)(b >> 32);
+    r.v[4] = (u32)c; r.v[5] = (u32)(c >> 32); r.v[6] = (u32)d; r.v[7] = (u32)(d >> 32);
+    r.v[8] = L.p8[i];
+    return r;
+}
+FP_DEV void lds29_store(const Lds29& L, u32 i, const f29& v) {
+    L.p01[i] = (u64)v.v[0] | ((u64)v.v[1] << 32);
+    L.p23[i] = (u64)v.v[2] | ((u64)v.v[3] << 32);
+    L.p45[i] = (u64)v.v[4] | ((u64)v.v[5] << 32);
+    L.p67[i] = (u64)v.v[6] | ((u64)v.v[7] << 32);
+    L.p8[i] = v.v[8];
+}
+
+// DIT butterfly on lazily reduced limbs; v may carry limbs < 2^31, w is normalized
+template <class F9>
+FP_DEV void bfly29(f29& u, f29& v, const f29& w, bool mul) {
+    f29 t = mul ? f29_mul<F9>(v, w) : f29_norm(v);
+    f29 nu = f29_add(u, t);
+    v = f29_sub(u, t, F9::KM);
+    u = nu;
+}
+
+template <class F>
+__global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
+    typedef typename f29_of<F>::type F9;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Lds29 L;
+    L.p01 = reinterpret_cast<u64*>(smem_raw);
+    L.p23 = L.p01 + NTT_TILE; L.p45 = L.p23 + NTT_TILE; L.p67 = L.p45 + NTT_TILE;
+    L.p8 = reinterpret_cast<u32*>(L.p67 + NTT_TILE);
+    fe* ltw = reinterpret_cast<fe*>(L.p8 + NTT_TILE);  // R/2 sub-transform roots (w * 2^261, packed)
+
+    const u32 tid = threadIdx.x;
+    const u32 r = P.r, log_c = P.log_c;
+    const u32 R = 1u << r, Cc = 1u << log_c;
+    const u32 tile = R << log_c;
+    const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
+    fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
+
+    for (u32 j = tid; j < (R >> 1); j += NTT2_THREADS) f_store(&ltw[j], f_load(&P.tw[(u64)j << (P.log_n - r)]));
+
+    // ---- tile coordinates (as in k_ntt_pass) ----
+    u64 q = 0, np0 = 0;
+    u32 k1blk = 0; u64 rest = 0;
+    const u32 log_cols = P.log_m - r;
+    if (!P.is_final) {
+        u32 tiles_per_sub_log = log_cols - log_c;
+        q = (u64)blockIdx.x >> tiles_per_sub_log;
+        np0 = ((u64)blockIdx.x & ((1ull << tiles_per_sub_log) - 1)) << log_c;
+    } else {
+        u32 kb_log = P.r1 - log_c;
+        k1blk = blockIdx.x & ((1u << kb_log) - 1);
+        rest = (u64)blockIdx.x >> kb_log;
+    }
+    const u32 log_q_per_k1 = P.log_n - r - P.r1;
+
+    f29 pre1 = f29_zero(), pre2 = f29_zero();
+    if (P.pre_mode) {
+        pre1 = f29_from_std<F9>(P.pre_z);
+        pre2 = f29_mul<F9>(pre1, pre1);
+    }
+
+    // ---- load: global (standard form, canonical) -> limbs, into row bitrev(j) (DIT input order) ----
+    for (u32 idx = tid; idx < tile; idx += NTT2_THREADS) {
+        u32 j, c;
+        u64 g;
+        if (!P.is_final) {
+            j = idx >> log_c; c = idx & (Cc - 1);
+            g = (q << P.log_m) + ((u64)j << log_cols) + np0 + c;
+        } else {
+            c = idx >> r; j = idx & (R - 1);
+            u64 qq = (((u64)k1blk << log_c) + c) << log_q_per_k1;
+            qq += rest;
+            g = (qq << r) + j;
+        }
+        f29 v = f29_zero();
+        if (g < P.src_len) {
+            v = f29_unpack(f_load(&src[g]));
+            if (P.pre_mode) {
+                u32 m3 = (u32)(g % 3);
+                if (m3 == 1) v = f29_mul<F9>(v, pre1);
+                else if (m3 == 2) v = f29_mul<F9>(v, pre2);
+            }
+        }
+        lds29_store(L, (bitrev32(j, r) << log_c) + c, v);
+    }
+    __syncthreads();
+
+    // ---- DIT stages, two per round ----
+    u32 s = 0;
+    for (; s + 1 < r; s += 2) {
+        const u32 h = 1u << s;
+        const u32 ngroups = tile >> 2;   // radix-4 groups in the tile
+        for (u32 gidx = tid; gidx < ngroups; gidx += NTT2_THREADS) {
+            u32 c = gidx & (Cc - 1), gq = gidx >> log_c;          // gq in [0, R/4)
+            u32 pos = gq & (h - 1);
+            u32 i0 = ((gq >> s) << (s + 2)) | pos;
+            u32 a0 = (i0 << log_c) + c, a1 = a0 + (h << log_c), a2 = a1 + (h << log_c), a3 = a2 + (h << log_c);
+            f29 e0 = lds29_load(L, a0), e1 = lds29_load(L, a1), e2 = lds29_load(L, a2), e3 = lds29_load(L, a3);
+            // stage s: (e0, e1) and (e2, e3), twiddle w_R^(pos * R / 2h)
+            f29 w = f29_unpack(f_load(&ltw[pos << (r - 1 - s)]));
+            bfly29<F9>(e0, e1, w, s != 0);
+            bfly29<F9>(e2, e3, w, s != 0);
+            // stage s + 1: (e0, e2) with pos, (e1, e3) with pos + h, twiddle w_R^(pos' * R / 4h)
+            f29 w0 = f29_unpack(f_load(&ltw[pos << (r - 2 - s)]));
+            f29 w1 = f29_unpack(f_load(&ltw[(pos + h) << (r - 2 - s)]));
+            bfly29<F9>(e0, e2, w0, true);
+            bfly29<F9>(e1, e3, w1, true);
+            lds29_store(L, a0, f29_norm(e0)); lds29_store(L, a1, f29_norm(e1));
+            lds29_store(L, a2, f29_norm(e2)); lds29_store(L, a3, f29_norm(e3));
+        }
+        __syncthreads();
+    }
+    if (s < r) {   // odd r: one last radix-2 stage
+        const u32 h = 1u << s;
+        const u32 nbf = tile >> 1;
+        for (u32 bidx = tid; bidx < nbf; bidx += NTT2_THREADS) {
+            u32 c = bidx & (Cc - 1), b = bidx >> log_c;
+            u32 pos = b & (h - 1);
+            u32 i0 = ((b >> s) << (s + 1)) | pos;
+            u32 a0 = (i0 << log_c) + c, a1 = a0 + (h << log_c);
+            f29 e0 = lds29_load(L, a0), e1 = lds29_load(L, a1);
+            f29 w = f29_unpack(f_load(&ltw[pos << (r - 1 - s)]));
+            bfly29<F9>(e0, e1, w, s != 0);
+            lds29_store(L, a0, f29_norm(e0)); lds29_store(L, a1, f29_norm(e1));
+        }
+        __syncthreads();
+    }
+
+    // ---- store: row k holds output digit k; one multiplication brings every element below 2p ----
+    f29 post0m = f29_one<F9>(), post1m = f29_zero(), post2m = f29_zero();
+    if (P.is_final && P.post_mode) {
+        post0m = f29_from_std<F9>(P.post0);
+        if (P.post_mode == 2) {
+            f29 z = f29_from_std<F9>(P.post_z);
+            post2m = f29_mul<F9>(post0m, z);
+            post1m = f29_mul<F9>(post2m, z);
+        }
+    }
+    u64 revrest = 0;
+    if (P.is_final) {
+        u64 rem = rest;
+        u32 bits_left = log_q_per_k1, mult = 0;
+        for (u32 i = 0; i < P.nrev; i++) {
+            bits_left -= P.rev_r[i];
+            u64 d = rem >> bits_left;
+            rem -= d << bits_left;
+            revrest += d << mult;
+            mult += P.rev_r[i];
+        }
+    }
+    for (u32 idx = tid; idx < tile; idx += NTT2_THREADS) {
+        u32 k = idx >> log_c, c = idx & (Cc - 1);
+        f29 v = lds29_load(L, (k << log_c) + c);
+        u64 o;
+        f29 w;
+        if (!P.is_final) {
+            u64 np = np0 + c;
+            u64 e = (np * k) << (P.log_n - P.log_m);
+            w = f29_unpack(tw_lookup<F>(P.tw, e, P.log_n));
+            o = (q << P.log_m) + ((u64)k << log_cols) + np;
+        } else {
+            o = (((u64)k1blk << log_c) + c) + (revrest << P.r1) + ((u64)k << (P.log_n - r));
+            w = post0m;
+            if (P.post_mode == 2) {
+                u32 m3 = (u32)(o % 3);
+                w = m3 == 0 ? post0m : (m3 == 1 ? post1m : post2m);
+            }
+        }
+        f29 t = f29_mul<F9>(v, w);   // < 30p * p / 2^261 + p < 2p
+        f_store(&dst[o], f29_pack(f29_cond_sub(t, F9::P)));
+    }
+}
+
 // tw[j] = omega^j * 2^261 mod p (canonical, packed), j < half.  Thread t fills a run of 64
 // starting from omega^(64 t); the running power is kept in standard form.
 template <class F>
@@ -326,9 +520,13 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         scratch = (fe*)ctx->ws_ntt_scratch.p;
     }
     static bool attr_set = false;  // one process drives one GPU
+    static bool use_v2 = true;
     const size_t lds_max = 2 * NTT_TILE * 16 + (NTT_TILE / 2) * sizeof(fe);
+    const size_t lds_max2 = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(fe);
     if (!attr_set) {
+        if (const char* e = getenv("DEHALO_NTT_V1")) use_v2 = atoi(e) == 0;   // A/B switch (the older LDS-32-byte kernel)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max2));
         attr_set = true;
     }
     uint32_t log_m = log_n;
@@ -357,9 +555,14 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         }
         P.log_c = log_c;
         uint64_t tiles = N >> (rad[p] + log_c);
-        size_t lds = 2 * NTT_TILE * 16 + ((size_t)1 << rad[p]) / 2 * sizeof(fe);
         dim3 grid((uint32_t)tiles, (uint32_t)batch);
-        k_ntt_pass<F><<<grid, NTT_THREADS, lds, s>>>(P);
+        if (use_v2) {
+            size_t lds = (size_t)NTT_TILE * 36 + ((size_t)1 << rad[p]) / 2 * sizeof(fe);
+            k_ntt_pass2<F><<<grid, NTT2_THREADS, lds, s>>>(P);
+        } else {
+            size_t lds = 2 * NTT_TILE * 16 + ((size_t)1 << rad[p]) / 2 * sizeof(fe);
+            k_ntt_pass<F><<<grid, NTT_THREADS, lds, s>>>(P);
+        }
         HIP_TRY(ctx, hipGetLastError());
         log_m -= rad[p];
     }
