@@ -194,3 +194,90 @@ FP_DEV xyzz29 x29_group_reduce(xyzz29 v) {
     }
     return v;
 }
+
+// ---- quad-cooperative group operations -----------------------------------------------------
+// The bucket-reduction tail is a chain of ~45 dependent group additions executed by a handful of
+// waves: latency-bound, and a lone wave issues one VALU instruction per ~4 cycles whatever the
+// instruction-level parallelism.  Here FOUR adjacent lanes (a DPP quad) hold the same operands
+// and share one addition: the 14 multiplications of add-2008-s fall into 4 dependency levels of
+// <= 4 independent products, so each lane computes one product per level and the quad exchanges
+// results with quad_perm broadcasts (v_mov_b32_dpp, no LDS).  4 multiplication rounds instead
+// of 14, at 4x the lanes -- free while the chip is otherwise idle.  All four lanes of a quad
+// must be active and return the same (replicated) result.
+template <int K>
+FP_DEV f29 f29_quad_bcast(const f29& a) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 t = (u32)__builtin_amdgcn_update_dpp(0, (int)a.v[i], K * 0x55, 0xf, 0xf, false);
+        // keep the broadcast a plain v_mov_b32_dpp: hipcc (ROCm 7.2) otherwise folds some of them into
+        // v_sub(rev)_u32_dpp consumers and x29_double_quad then returns a wrong y (tools/test_quad2.hip)
+        asm volatile("" : "+v"(t));
+        r.v[i] = t;
+    }
+    return r;
+}
+FP_DEV f29 f29_sel4(const f29& a, const f29& b, const f29& c, const f29& d, u32 role) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 lo = (role & 1) ? b.v[i] : a.v[i];
+        u32 hi = (role & 1) ? d.v[i] : c.v[i];
+        r.v[i] = (role & 2) ? hi : lo;
+    }
+    return r;
+}
+
+template <class F>
+FP_DEV xyzz29 x29_add_quad(const xyzz29& a, const xyzz29& b) {
+    const u32 role = threadIdx.x & 3;
+    // level 1: u1 = X1 ZZ2 | u2 = X2 ZZ1 | s1 = Y1 ZZZ2 | s2 = Y2 ZZZ1
+    f29 m = f29_mul<F>(f29_sel4(a.x, b.x, a.y, b.y, role), f29_sel4(b.zz, a.zz, b.zzz, a.zzz, role));
+    f29 u1 = f29_quad_bcast<0>(m), u2 = f29_quad_bcast<1>(m), s1 = f29_quad_bcast<2>(m), s2 = f29_quad_bcast<3>(m);
+    f29 p = f29_norm(f29_sub(u2, u1, F::KM));
+    f29 rr = f29_norm(f29_sub(s2, s1, F::KM));
+    // level 2: pp = P^2 | r2 = R^2 | zz12 = ZZ1 ZZ2 | zzz12 = ZZZ1 ZZZ2
+    m = f29_mul<F>(f29_sel4(p, rr, a.zz, a.zzz, role), f29_sel4(p, rr, b.zz, b.zzz, role));
+    f29 pp = f29_quad_bcast<0>(m), r2 = f29_quad_bcast<1>(m);
+    f29 keep = m;                                   // lanes 2 / 3 keep zz12 / zzz12
+    // level 3: ppp = P PP | qq = U1 PP | zz3 = zz12 PP | (lane 3: spare)
+    m = f29_mul<F>(f29_sel4(p, u1, keep, p, role), pp);
+    f29 ppp = f29_quad_bcast<0>(m), qq = f29_quad_bcast<1>(m);
+    xyzz29 r;
+    r.zz = f29_quad_bcast<2>(m);
+    r.x = f29_norm(f29_sub(r2, f29_add(ppp, f29_dbl(qq)), F::KB));
+    f29 t = f29_sub(qq, r.x, F::KA);
+    // level 4: R T | S1 PPP | (lane 2: spare) | zzz3 = zzz12 PPP
+    m = f29_mul<F>(f29_sel4(rr, s1, rr, keep, role), f29_sel4(t, ppp, t, ppp, role));
+    f29 rt = f29_quad_bcast<0>(m), sp = f29_quad_bcast<1>(m);
+    r.zzz = f29_quad_bcast<3>(m);
+    r.y = f29_norm(f29_sub(rt, sp, F::KM));
+    if (__builtin_expect(f29_maybe_zero_lt2p<F>(r.zz), 0)) {
+        if (f29_is_zero_lt2p<F>(r.zz)) r = x29_add<F>(a, b);   // exceptional cases: every lane resolves them alone (identically)
+    }
+    return r;
+}
+
+template <class F>
+FP_DEV xyzz29 x29_double_quad(const xyzz29& a) {
+    const u32 role = threadIdx.x & 3;
+    f29 u = f29_dbl(a.y);
+    // level 1: v = U^2 | xx = X^2
+    f29 op = f29_sel4(u, a.x, u, a.x, role);
+    f29 m = f29_mul<F>(op, op);
+    f29 v = f29_quad_bcast<0>(m), xx = f29_quad_bcast<1>(m);
+    f29 mm_in = f29_norm(f29_add(f29_dbl(xx), xx));
+    // level 2: w = U V | s = X V | mm = M^2 | zz3 = V ZZ
+    m = f29_mul<F>(f29_sel4(u, a.x, mm_in, v, role), f29_sel4(v, v, mm_in, a.zz, role));
+    f29 w = f29_quad_bcast<0>(m), s = f29_quad_bcast<1>(m), mm = f29_quad_bcast<2>(m);
+    xyzz29 r;
+    r.zz = f29_quad_bcast<3>(m);
+    r.x = f29_norm(f29_sub(mm, f29_dbl(s), F::KB));
+    f29 t = f29_sub(s, r.x, F::KA);
+    // level 3: M T | W Y | zzz3 = W ZZZ | (lane 3: spare)
+    m = f29_mul<F>(f29_sel4(mm_in, w, w, w, role), f29_sel4(t, a.y, a.zzz, a.y, role));
+    f29 mt = f29_quad_bcast<0>(m), wy = f29_quad_bcast<1>(m);
+    r.zzz = f29_quad_bcast<2>(m);
+    r.y = f29_norm(f29_sub(mt, wy, F::KM));
+    return r;
+}

@@ -36,7 +36,6 @@
 // VALU-issue-bound -- and capping residency at 2 did not improve multi-stream overlap)
 #define MSM_ACC_WAVES_ATTR
 #define MSM_RED_M 4        // buckets per lane in the bucket reduction
-#define MSM_TREE_THREADS 128
 
 struct MsmGeom {
     u32 n;          // scalars per MSM
@@ -283,12 +282,14 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 #define MSM_HEAVY_THREADS 1024
 #define MSM_MERGE_BLOCKS 1024
 
-// lists: [class 1 | class 2 | class 3], each with `cap` slots; counters[3]
+// lists: [class 1 | class 2 | class 3], each with `cap` slots; counters[3].  One QUAD per bucket
+// (x29_add_quad): the <= 16 sequential additions of a light bucket run 4 lanes wide.
 template <class CV>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge_light(u32 total_buckets, const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
                                                                     u32* counters, u32* lists, u32 cap) {
     typedef typename f29_of<typename CV::Base>::type F;
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const u32 role = threadIdx.x & 3;
     if (b >= total_buckets) return;
     u32 beg = toff[b], end = toff[b + 1];
     u32 S = end - beg;
@@ -296,19 +297,19 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge_light(u32 total_b
     const u32 cls = S <= MSM_C0_MAX ? 3u : (S <= MSM_C1_MAX ? 0u : (S <= MSM_C2_MAX ? 1u : 2u));
     const u32 lane = threadIdx.x & 63;
     for (u32 c = 0; c < 3; c++) {
-        unsigned long long mask = __ballot(cls == c);
+        unsigned long long mask = __ballot(cls == c && role == 0);
         if (mask == 0) continue;
         u32 leader = (u32)__ffsll((long long)mask) - 1;
         u32 base = 0;
         if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
         base = __shfl(base, (int)leader);
-        if (cls == c) lists[c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
+        if (cls == c && role == 0) lists[c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
     }
     if (cls != 3u) return;
     xyzz29 acc = x29_identity();
     if (beg < end) acc = x29_load(&partial[beg]);
-    for (u32 p = beg + 1; p < end; p++) acc = x29_add<F>(acc, x29_load(&partial[p]));
-    x29_store(&buckets[b], acc);
+    for (u32 p = beg + 1; p < end; p++) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
+    if (role == 0) x29_store(&buckets[b], acc);
 }
 
 // groups of G lanes (8 or 64) walk a class list: strided lane sums, then a shuffle reduction
@@ -364,12 +365,14 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32
 }
 
 // ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
-// lane (group, t) takes buckets [t*M, t*M + M): contribution = sum (k - k0 + 1) B_k + k0 * sum B_k
+// quad (group, t) takes buckets [t*M, t*M + M): contribution = sum (k - k0 + 1) B_k + k0 * sum B_k.
+// Every group operation is quad-cooperative (ec29.cuh): this kernel and the tree below are pure
+// latency (a chain of ~45 dependent additions / doublings on an otherwise idle chip).
 template <class CV>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
     typedef typename f29_of<typename CV::Base>::type F;
     const u32 per_group = (nb + MSM_RED_M - 1) / MSM_RED_M;
-    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     if (gid >= per_group * total_groups) return;
     u32 grp = gid / per_group, t = gid % per_group;
     u32 k0 = t * MSM_RED_M, k1 = min(k0 + MSM_RED_M, nb);
@@ -377,39 +380,41 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u3
     xyzz29 run = x29_load(&B[k1 - 1]);
     xyzz29 acc = run;
     for (u32 k = k1 - 1; k-- > k0;) {
-        run = x29_add<F>(run, x29_load(&B[k]));
-        acc = x29_add<F>(acc, run);
+        run = x29_add_quad<F>(run, x29_load(&B[k]));
+        acc = x29_add_quad<F>(acc, run);
     }
     // k0 * run, MSB-first double-and-add (k0 < 2^15)
     if (k0) {
         int top = 31 - __clz(k0);
         xyzz29 w = run;
         for (int bit = top - 1; bit >= 0; bit--) {
-            w = x29_double<F>(w);
-            if ((k0 >> bit) & 1) w = x29_add<F>(w, run);
+            w = x29_double_quad<F>(w);
+            if ((k0 >> bit) & 1) w = x29_add_quad<F>(w, run);
         }
-        acc = x29_add<F>(acc, w);
+        acc = x29_add_quad<F>(acc, w);
     }
-    x29_store(&contrib[gid], acc);
+    if ((threadIdx.x & 3) == 0) x29_store(&contrib[gid], acc);
 }
 
-// tree sum: in[groups][cnt] -> out[groups][ceil(cnt / (2 * MSM_TREE_THREADS))]
+// tree sum: in[groups][cnt] -> out[groups][ceil(cnt / MSM_TREE_ITEMS)]; 64 quads per block
+#define MSM_TREE_ITEMS 128
 template <class CV>
-__global__ __launch_bounds__(MSM_TREE_THREADS) void k_msm_tree_sum(const xyzz29_rec* in, u32 cnt, xyzz29_rec* out, u32 out_cnt) {
+__global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 cnt, xyzz29_rec* out, u32 out_cnt) {
     typedef typename f29_of<typename CV::Base>::type F;
-    __shared__ xyzz29_rec sh[MSM_TREE_THREADS];
+    __shared__ xyzz29_rec sh[64];
+    const u32 qd = threadIdx.x >> 2, role = threadIdx.x & 3;
     u32 grp = blockIdx.y;
     const xyzz29_rec* src = in + (u64)grp * cnt;
-    u32 i0 = blockIdx.x * (2 * MSM_TREE_THREADS) + threadIdx.x;
+    u32 i0 = blockIdx.x * MSM_TREE_ITEMS + qd;
     xyzz29 a = i0 < cnt ? x29_load(&src[i0]) : x29_identity();
-    u32 i1 = i0 + MSM_TREE_THREADS;
-    if (i1 < cnt) a = x29_add<F>(a, x29_load(&src[i1]));
-    x29_store(&sh[threadIdx.x], a);
+    u32 i1 = i0 + 64;
+    if (i1 < cnt) a = x29_add_quad<F>(a, x29_load(&src[i1]));
+    if (role == 0) x29_store(&sh[qd], a);
     __syncthreads();
-    for (u32 d = MSM_TREE_THREADS / 2; d > 0; d >>= 1) {
-        if (threadIdx.x < d) {
-            xyzz29 x = x29_add<F>(x29_load(&sh[threadIdx.x]), x29_load(&sh[threadIdx.x + d]));
-            x29_store(&sh[threadIdx.x], x);
+    for (u32 d = 32; d > 0; d >>= 1) {
+        if (qd < d) {
+            xyzz29 x = x29_add_quad<F>(x29_load(&sh[qd]), x29_load(&sh[qd + d]));
+            if (role == 0) x29_store(&sh[qd], x);
         }
         __syncthreads();
     }
@@ -554,7 +559,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
     TRY(dh_ensure(ctx, ctx->ws_contrib, total_groups * per_group * REC));
-    TRY(dh_ensure(ctx, ctx->ws_tree, total_groups * ((per_group + 2 * MSM_TREE_THREADS - 1) / (2 * MSM_TREE_THREADS)) * REC));
+    TRY(dh_ensure(ctx, ctx->ws_tree, total_groups * ((per_group + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS) * REC));
     TRY(dh_ensure(ctx, ctx->ws_gsums, total_groups * REC));
     u32* count = (u32*)ctx->ws_count.p;
     u32* cursor = (u32*)ctx->ws_cursor.p;
@@ -594,22 +599,22 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_REDUCE);
         // partial sums -> one point per bucket (by size class)
-        k_msm_merge_light<CV><<<(tb + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, MSM_ACC_THREADS, 0, s>>>(tb, toff0, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        k_msm_merge_light<CV><<<(u32)(((uint64_t)tb * 4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(tb, toff0, partial0, buckets, merge_counters, merge_lists, merge_cap);
         k_msm_merge_group<CV, 8><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
         k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
         k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 2, MSM_HEAVY_THREADS, 0, s>>>(toff0, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
         // bucket reduction
-        u32 nthreads = per_group * (u32)total_groups;
-        k_msm_reduce_local<CV><<<(nthreads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+        uint64_t nthreads = (uint64_t)per_group * total_groups * 4;   // one quad per 4-bucket block
+        k_msm_reduce_local<CV><<<(u32)((nthreads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
         const xyzz29_rec* cur = contrib;
         u32 cnt = per_group;
         xyzz29_rec* bufs[2] = {tree, contrib};  // ping-pong: contrib is free once consumed
         int which = 0;
         while (cnt > 1) {
-            u32 out_cnt = (cnt + 2 * MSM_TREE_THREADS - 1) / (2 * MSM_TREE_THREADS);
+            u32 out_cnt = (cnt + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS;
             xyzz29_rec* o = out_cnt == 1 ? gsums : bufs[which];
             dim3 grid(out_cnt, (u32)total_groups);
-            k_msm_tree_sum<CV><<<grid, MSM_TREE_THREADS, 0, s>>>(cur, cnt, o, out_cnt);
+            k_msm_tree_sum<CV><<<grid, 256, 0, s>>>(cur, cnt, o, out_cnt);
             cur = o; cnt = out_cnt; which ^= 1;
         }
         if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));
