@@ -128,6 +128,8 @@ FP_DEV xyzz29 x29_add_mixed(const xyzz29& a, const aff29& q) {
 // A + B
 template <class F>
 FP_DEV xyzz29 x29_add(const xyzz29& a, const xyzz29& b) {
+    if (f29_all_zero(a.zz)) return b;   // literal identities: cheap exit (the general ZZ = 0 mod p case is below)
+    if (f29_all_zero(b.zz)) return a;
     f29 u1 = f29_mul<F>(a.x, b.zz);
     f29 u2 = f29_mul<F>(b.x, a.zz);
     f29 s1 = f29_mul<F>(a.y, b.zzz);
@@ -230,6 +232,9 @@ FP_DEV f29 f29_sel4(const f29& a, const f29& b, const f29& c, const f29& d, u32 
 
 template <class F>
 FP_DEV xyzz29 x29_add_quad(const xyzz29& a, const xyzz29& b) {
+    // literal identities (empty buckets, x29_identity()) are the common case in sparse columns
+    if (f29_all_zero(a.zz)) return b;
+    if (f29_all_zero(b.zz)) return a;
     const u32 role = threadIdx.x & 3;
     // level 1: u1 = X1 ZZ2 | u2 = X2 ZZ1 | s1 = Y1 ZZZ2 | s2 = Y2 ZZZ1
     f29 m = f29_mul<F>(f29_sel4(a.x, b.x, a.y, b.y, role), f29_sel4(b.zz, a.zz, b.zzz, a.zzz, role));
@@ -260,6 +265,7 @@ FP_DEV xyzz29 x29_add_quad(const xyzz29& a, const xyzz29& b) {
 
 template <class F>
 FP_DEV xyzz29 x29_double_quad(const xyzz29& a) {
+    if (f29_all_zero(a.zz)) return a;
     const u32 role = threadIdx.x & 3;
     f29 u = f29_dbl(a.y);
     // level 1: v = U^2 | xx = X^2

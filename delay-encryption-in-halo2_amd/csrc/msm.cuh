@@ -282,34 +282,50 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 #define MSM_HEAVY_THREADS 1024
 #define MSM_MERGE_BLOCKS 1024
 
-// lists: [class 1 | class 2 | class 3], each with `cap` slots; counters[3].  One QUAD per bucket
-// (x29_add_quad): the <= 16 sequential additions of a light bucket run 4 lanes wide.
+// classification: one lane per bucket.  S = 0 -> identity, S = 1 -> copy; otherwise the bucket is
+// queued in the list of its class (one atomic per wave and class: a single hot counter serialises).
+// lists: [light | class 1 | class 2 | class 3], each with `cap` slots; counters[4].
 template <class CV>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_merge_light(u32 total_buckets, const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
-                                                                    u32* counters, u32* lists, u32 cap) {
-    typedef typename f29_of<typename CV::Base>::type F;
-    u32 b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const u32 role = threadIdx.x & 3;
+__global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
+                                                           u32* counters, u32* lists, u32 cap) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total_buckets) return;
     u32 beg = toff[b], end = toff[b + 1];
     u32 S = end - beg;
-    // queue the heavier classes: one atomic per wave and class (a single hot counter serialises)
-    const u32 cls = S <= MSM_C0_MAX ? 3u : (S <= MSM_C1_MAX ? 0u : (S <= MSM_C2_MAX ? 1u : 2u));
+    const u32 cls = S <= 1 ? 4u : (S <= MSM_C0_MAX ? 0u : (S <= MSM_C1_MAX ? 1u : (S <= MSM_C2_MAX ? 2u : 3u)));
     const u32 lane = threadIdx.x & 63;
-    for (u32 c = 0; c < 3; c++) {
-        unsigned long long mask = __ballot(cls == c && role == 0);
+    for (u32 c = 0; c < 4; c++) {
+        unsigned long long mask = __ballot(cls == c);
         if (mask == 0) continue;
         u32 leader = (u32)__ffsll((long long)mask) - 1;
         u32 base = 0;
         if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
         base = __shfl(base, (int)leader);
-        if (cls == c && role == 0) lists[c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
+        if (cls == c) lists[c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
     }
-    if (cls != 3u) return;
-    xyzz29 acc = x29_identity();
-    if (beg < end) acc = x29_load(&partial[beg]);
-    for (u32 p = beg + 1; p < end; p++) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
-    if (role == 0) x29_store(&buckets[b], acc);
+    if (cls != 4u) return;
+    xyzz29_rec rec;
+    if (S == 1) rec = partial[beg];
+    else {
+#pragma unroll
+        for (int i = 0; i < 36; i++) rec.w[i] = 0;
+    }
+    buckets[b] = rec;
+}
+
+// light class (2 .. 16 partials): one QUAD per listed bucket, quad-cooperative sequential additions
+template <class CV>
+__global__ __launch_bounds__(256) void k_msm_merge_light(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter, const u32* list) {
+    typedef typename f29_of<typename CV::Base>::type F;
+    const u32 count = *counter;
+    const u32 role = threadIdx.x & 3;
+    for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < count; i += (gridDim.x * blockDim.x) >> 2) {
+        u32 b = list[i];
+        u32 beg = toff[b], end = toff[b + 1];
+        xyzz29 acc = x29_load(&partial[beg]);
+        for (u32 p = beg + 1; p < end; p++) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
+        if (role == 0) x29_store(&buckets[b], acc);
+    }
 }
 
 // groups of G lanes (8 or 64) walk a class list: strided lane sums, then a shuffle reduction
@@ -383,8 +399,8 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u3
         run = x29_add_quad<F>(run, x29_load(&B[k]));
         acc = x29_add_quad<F>(acc, run);
     }
-    // k0 * run, MSB-first double-and-add (k0 < 2^15)
-    if (k0) {
+    // k0 * run, MSB-first double-and-add (k0 < 2^15); nothing to weight when the block is empty
+    if (k0 && !f29_all_zero(run.zz)) {
         int top = 31 - __clz(k0);
         xyzz29 w = run;
         for (int bit = top - 1; bit >= 0; bit--) {
@@ -550,11 +566,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const size_t REC = sizeof(xyzz29_rec);
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
-    TRY(dh_ensure(ctx, ctx->ws_cursor, (total_buckets + 4) * 4));   // + 3 merge-class counters
+    TRY(dh_ensure(ctx, ctx->ws_cursor, (total_buckets + 4) * 4));   // + 4 merge-class counters
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
     TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4));
-    const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / (MSM_C0_MAX + 1) + 1);
-    TRY(dh_ensure(ctx, ctx->ws_cnt1, (size_t)merge_cap * 3 * 4));   // merge-class lists
+    const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / 2 + 1);
+    TRY(dh_ensure(ctx, ctx->ws_cnt1, (size_t)merge_cap * 4 * 4));   // merge-class lists
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
@@ -599,10 +615,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_REDUCE);
         // partial sums -> one point per bucket (by size class)
-        k_msm_merge_light<CV><<<(u32)(((uint64_t)tb * 4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(tb, toff0, partial0, buckets, merge_counters, merge_lists, merge_cap);
-        k_msm_merge_group<CV, 8><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
-        k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
-        k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 2, MSM_HEAVY_THREADS, 0, s>>>(toff0, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
+        k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, toff0, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        k_msm_merge_light<CV><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
+        k_msm_merge_group<CV, 8><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
+        k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
+        k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 4, MSM_HEAVY_THREADS, 0, s>>>(toff0, partial0, buckets, merge_counters + 3, merge_lists + 3 * (size_t)merge_cap);
         // bucket reduction
         uint64_t nthreads = (uint64_t)per_group * total_groups * 4;   // one quad per 4-bucket block
         k_msm_reduce_local<CV><<<(u32)((nthreads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
