@@ -382,34 +382,38 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32
 
 // ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
 // quad (group, t) takes buckets [t*M, t*M + M): contribution = sum (k - k0 + 1) B_k + k0 * sum B_k.
-// Every group operation is quad-cooperative (ec29.cuh): this kernel and the tree below are pure
-// latency (a chain of ~45 dependent additions / doublings on an otherwise idle chip).
-template <class CV>
+// With few groups in flight this kernel and the tree below are pure latency (a chain of ~45
+// dependent additions / doublings on an otherwise idle chip): then every group operation is
+// quad-cooperative (ec29.cuh).  With many groups (large batches) the lanes are better spent one
+// per block (QUAD = false): quads trade 1.6x the work for 2.4x less latency.
+template <class CV, bool QUAD>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
     typedef typename f29_of<typename CV::Base>::type F;
     const u32 per_group = (nb + MSM_RED_M - 1) / MSM_RED_M;
-    u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
     if (gid >= per_group * total_groups) return;
     u32 grp = gid / per_group, t = gid % per_group;
     u32 k0 = t * MSM_RED_M, k1 = min(k0 + MSM_RED_M, nb);
     const xyzz29_rec* B = buckets + (u64)grp * nb;
+    auto add = [](const xyzz29& a, const xyzz29& b) { return QUAD ? x29_add_quad<F>(a, b) : x29_add<F>(a, b); };
+    auto dbl = [](const xyzz29& a) { return QUAD ? x29_double_quad<F>(a) : x29_double<F>(a); };
     xyzz29 run = x29_load(&B[k1 - 1]);
     xyzz29 acc = run;
     for (u32 k = k1 - 1; k-- > k0;) {
-        run = x29_add_quad<F>(run, x29_load(&B[k]));
-        acc = x29_add_quad<F>(acc, run);
+        run = add(run, x29_load(&B[k]));
+        acc = add(acc, run);
     }
     // k0 * run, MSB-first double-and-add (k0 < 2^15); nothing to weight when the block is empty
     if (k0 && !f29_all_zero(run.zz)) {
         int top = 31 - __clz(k0);
         xyzz29 w = run;
         for (int bit = top - 1; bit >= 0; bit--) {
-            w = x29_double_quad<F>(w);
-            if ((k0 >> bit) & 1) w = x29_add_quad<F>(w, run);
+            w = dbl(w);
+            if ((k0 >> bit) & 1) w = add(w, run);
         }
-        acc = x29_add_quad<F>(acc, w);
+        acc = add(acc, w);
     }
-    if ((threadIdx.x & 3) == 0) x29_store(&contrib[gid], acc);
+    if (!QUAD || (threadIdx.x & 3) == 0) x29_store(&contrib[gid], acc);
 }
 
 // tree sum: in[groups][cnt] -> out[groups][ceil(cnt / MSM_TREE_ITEMS)]; 64 quads per block
@@ -621,8 +625,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
         k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 4, MSM_HEAVY_THREADS, 0, s>>>(toff0, partial0, buckets, merge_counters + 3, merge_lists + 3 * (size_t)merge_cap);
         // bucket reduction
-        uint64_t nthreads = (uint64_t)per_group * total_groups * 4;   // one quad per 4-bucket block
-        k_msm_reduce_local<CV><<<(u32)((nthreads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+        uint64_t nblocks4 = (uint64_t)per_group * total_groups;       // 4-bucket blocks
+        if (nblocks4 * 4 <= 96 * 1024) {   // <= ~1.5 waves per SIMD even at 4 lanes per block: latency-bound
+            k_msm_reduce_local<CV, true><<<(u32)((nblocks4 * 4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+        } else {
+            k_msm_reduce_local<CV, false><<<(u32)((nblocks4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+        }
         const xyzz29_rec* cur = contrib;
         u32 cnt = per_group;
         xyzz29_rec* bufs[2] = {tree, contrib};  // ping-pong: contrib is free once consumed
