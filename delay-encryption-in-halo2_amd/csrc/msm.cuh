@@ -274,9 +274,9 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 // Signed-digit carries of small witness values pile thousands of points into bucket 0 (digit
 // +-1) and 0/1 columns put half the column into one bucket, so the number S of partial sums per
 // bucket spans 0 .. 10^5.  Buckets are classed by S and merged by a lane group sized to it:
-//   S <= 16: one lane | S <= 128: 8 lanes | S <= 2048: one wave | larger: a 1024-thread block;
+//   S <= 24: one lane or quad | S <= 128: 8 lanes | S <= 2048: one wave | larger: a 1024-thread block;
 // chain length <= S/g + log2 g group additions instead of S.
-#define MSM_C0_MAX 16
+#define MSM_C0_MAX 24
 #define MSM_C1_MAX 128
 #define MSM_C2_MAX 2048
 #define MSM_HEAVY_THREADS 1024
@@ -313,18 +313,30 @@ __global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, c
     buckets[b] = rec;
 }
 
-// light class (2 .. 16 partials): one QUAD per listed bucket, quad-cooperative sequential additions
+// light class (2 .. MSM_C0_MAX partials).  Few listed buckets (latency-bound): one QUAD per bucket,
+// quad-cooperative additions; many (throughput-bound, e.g. every bucket of a large uniform MSM):
+// one lane per bucket.  The choice is made on the device from the list length.
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter, const u32* list) {
     typedef typename f29_of<typename CV::Base>::type F;
     const u32 count = *counter;
-    const u32 role = threadIdx.x & 3;
-    for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < count; i += (gridDim.x * blockDim.x) >> 2) {
-        u32 b = list[i];
-        u32 beg = toff[b], end = toff[b + 1];
-        xyzz29 acc = x29_load(&partial[beg]);
-        for (u32 p = beg + 1; p < end; p++) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
-        if (role == 0) x29_store(&buckets[b], acc);
+    if (count <= 16384) {
+        const u32 role = threadIdx.x & 3;
+        for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < count; i += (gridDim.x * blockDim.x) >> 2) {
+            u32 b = list[i];
+            u32 beg = toff[b], end = toff[b + 1];
+            xyzz29 acc = x29_load(&partial[beg]);
+            for (u32 p = beg + 1; p < end; p++) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
+            if (role == 0) x29_store(&buckets[b], acc);
+        }
+    } else {
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+            u32 b = list[i];
+            u32 beg = toff[b], end = toff[b + 1];
+            xyzz29 acc = x29_load(&partial[beg]);
+            for (u32 p = beg + 1; p < end; p++) acc = x29_add<F>(acc, x29_load(&partial[p]));
+            x29_store(&buckets[b], acc);
+        }
     }
 }
 
