@@ -39,9 +39,11 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "witness", "lookup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --force-device rehearse N > 1 on a one-GPU box")
+    ap.add_argument("--force-device", type=int, default=-1)
     ap.add_argument("--prover-k", type=int, default=17, help="also time the delay_enc-shaped MSM/NTT schedule at this k (0 = skip)")
     ap.add_argument("--prover-curve", default="bn254")
-    ap.add_argument("--inflight", type=int, default=2, help="independent steps in flight, each on its own HIP stream / workspace")
+    ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
 
 
@@ -128,10 +130,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the measured path)")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group(args.dist_backend)  # "nccl" = RCCL over xGMI
 
     pkg = entry.load_package()
     po, co = entry.load_oracle()  # synthetic-input generators + the cpu_baseline leg only
@@ -154,22 +158,32 @@ def main():
     bases = ctx.register_bases(curve.id, bases_h, args.window_bits, True)  # resident SRS tables
     d_scalars = torch.from_numpy(scalars_h.view(np.int64)).cuda()
     d_polys = [torch.from_numpy(poly_h.view(np.int64)).cuda() for _ in range(inflight)]
-    d_outs = [torch.zeros((1, 12), dtype=torch.int64, device="cuda") for _ in range(inflight)]
-    d_out = d_outs[0]
+    # one output row per step: the commitment vector of this rank (gathered once, at the end)
+    d_out_all = torch.zeros((args.warmup + args.steps + 1, 12), dtype=torch.int64, device="cuda")
+    d_out = d_out_all[0:1]
     omega = field.encode(po.FIELDS[field.name].omega(log_n))
     torch.cuda.synchronize()
     counter = [0]
 
     def step():
-        k = counter[0] % inflight
+        i = counter[0]
+        k = i % inflight
         counter[0] += 1
         c = ctxs[k]
-        c.msm_device(bases, d_scalars.data_ptr(), n, 1, d_outs[k].data_ptr(), 0)   # the context's own stream
+        c.msm_device(bases, d_scalars.data_ptr(), n, 1, d_out_all[i].data_ptr(), 0)   # the context's own stream
         c.ntt_device(field.id, d_polys[k].data_ptr(), log_n, omega, 1, 0)
-        if world > 1:
-            c.synchronize()   # the collective runs on torch's stream: order it after this step's MSM
-            return sharding.all_gather_commitments(d_outs[k], world, rank, world)
-        return d_outs[k]
+
+    def gather_commitments(first, count):
+        """RCCL all-gather of this job's commitment vector (north star: 'all-gather over xGMI for the
+        final commitment vector'): every rank ends with all world x count commitments, in unit order."""
+        for c in ctxs:
+            c.synchronize()   # the collective runs on torch's stream: order it after the MSMs
+        local = d_out_all[first:first + count]
+        if world == 1:
+            return local
+        if args.dist_backend != "nccl":
+            local = local.cpu()
+        return sharding.all_gather_commitments(local, world * count, rank, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -179,10 +193,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    gather_commitments(0, max(args.warmup, 1))
     # parity spot-check of the measured configuration, outside the timed region (rank 0, once)
     fence()
     if rank == 0 and log_n <= 14:
-        got = ctx.to_affine(curve.id, d_out.cpu().numpy().view(np.uint64))[0]
+        got = ctx.to_affine(curve.id, d_out.cpu().numpy().view(np.uint64).reshape(1, 12))[0]
         want = co.to_affine(curve.id, co.best_multiexp(curve.id, scalars_h, bases_h, 4))
         assert np.array_equal(got, want), "bench MSM result differs from the oracle"
 
@@ -193,8 +208,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    commitments = gather_commitments(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    assert commitments.shape == (world * args.steps, 12)
     elapsed = sharding.max_over_ranks(elapsed)
     for c in ctxs:
         c.timing_enable(False)
@@ -229,7 +246,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)",
+            "dtype": "u256 Montgomery (9 x 29-bit limbs in u32, 64-bit v_mad_u64_u32 accumulators)",
             "data": "synthetic",
             "config": {"workload": "1 x MSM(2^%d, %s) + 1 x NTT(2^%d, %s) per step per GPU, %s scalars, SRS tables resident" % (log_n, args.curve, log_n, args.ntt_field, args.dist),
                        "configs_index": 1, "steps_in_flight": inflight,
