@@ -337,3 +337,46 @@ def test_two_contexts_concurrently(pkg, co, ctx):
         assert np.array_equal(ctx.to_affine(spec.id, do.cpu().numpy().view(np.uint64))[0], want)
     other.close()
     h.release()
+
+
+def test_msm_randomised_configurations(pkg, co, ctx):
+    """Seeded sweep over (curve, n, window bits, table mode, batch, scalar distribution): every
+    combination goes through sort -> accumulate -> size-classed merge -> reduction and must match
+    the oracle bit for bit."""
+    rng = np.random.default_rng(20261003)
+    curves = [pkg.fields.BN254, pkg.fields.PALLAS, pkg.fields.VESTA]
+    dists = ["uniform", "witness", "lookup"]
+    for trial in range(24):
+        spec = curves[trial % 3]
+        n = int(rng.integers(1, 6000)) if trial % 4 else int(rng.integers(6000, 40000))
+        c = int(rng.choice([0, 4, 6, 9, 12, 14, 16]))
+        precompute = bool(rng.integers(0, 2))
+        batch = int(rng.choice([1, 1, 2, 5]))
+        bases = co.synth_bases(spec.id, n)
+        h = ctx.register_bases(spec.id, bases, c, precompute)
+        cols = [co.fill_scalars(spec.scalar.id, dists[int(rng.integers(0, 3))], n, 7000 + 10 * trial + j) for j in range(batch)]
+        m = int(rng.integers(1, n + 1))          # commit() over a prefix of the SRS
+        got = ctx.to_affine(spec.id, ctx.msm_batch(h, [col[:m] for col in cols]))
+        h.release()
+        for j, col in enumerate(cols):
+            want = co.to_affine(spec.id, co.best_multiexp(spec.id, col[:m], bases[:m], 4))
+            assert np.array_equal(got[j], want), (trial, spec.name, n, m, c, precompute, batch, j)
+
+
+def test_ntt_batched_device_entry_points(pkg, po, co, ctx):
+    """ntt_device / intt_scaled_device with batch > 1 (the prover runs its columns batched)."""
+    import torch
+    f = pkg.fields.BN254_FR
+    of = po.FIELDS[f.name]
+    for k, batch in ((5, 3), (11, 4), (13, 7), (16, 2)):
+        polys = np.stack([co.fill_scalars(f.id, "uniform", 1 << k, 900 + 7 * k + b) for b in range(batch)])
+        d = torch.from_numpy(polys.view(np.int64)).cuda()
+        omega = f.encode(of.omega(k))
+        ctx.ntt_device(f.id, d.data_ptr(), k, omega, batch, 0)
+        ctx.synchronize()
+        got = d.cpu().numpy().view(np.uint64)
+        for b in range(batch):
+            assert np.array_equal(got[b], co.best_fft(f.id, polys[b], omega, k, 2)), (k, b)
+        ctx.intt_scaled_device(f.id, d.data_ptr(), k, f.encode(of.inv(of.omega(k))), f.encode(of.inv(1 << k)), batch, 0)
+        ctx.synchronize()
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), polys)

@@ -97,6 +97,22 @@ __global__ void k_fsqr29(f29* out, const fe* in, int iters) {
     out[gid] = x;
 }
 
+template <class F9>
+__global__ void k_madd29(xyzz29_rec* out, const affine_t* pts, int iters, u32 npts) {
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 idx = gid % npts;
+    affine_t pk = aff_load(&pts[idx]);
+    aff29 q = a29_from_packed(pk);
+    xyzz29 acc; acc.x = q.x; acc.y = q.y; acc.zz = f29_one<F9>(); acc.zzz = f29_one<F9>();
+    for (int i = 0; i < iters; i++) {
+        idx = (idx * 1664525u + 1013904223u) % npts;
+        pk = aff_load(&pts[idx]);
+        q = a29_from_packed(pk);
+        acc = x29_add_mixed<F9>(acc, q);
+    }
+    x29_store(&out[gid], acc);
+}
+
 template <class F>
 __global__ void k_madd(xyzz_t* out, const affine_t* pts, int iters, u32 npts) {
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,6 +200,16 @@ int main() {
     CHECK(hipMemcpy(pts, hp.data(), (size_t)npts * 64, hipMemcpyHostToDevice));
     xyzz_t* xo; CHECK(hipMalloc(&xo, nel * 128));
     const int ait = 256;
+    {
+        // canonical-looking table entries (top word < 2^30) so that unpacked limbs are in range
+        xyzz29_rec* xo29; CHECK(hipMalloc(&xo29, nel * sizeof(xyzz29_rec)));
+        for (u32 np : {1u << 10, 1u << 20}) {
+            ms = time_kernel(k_madd29<PastaFp29>, dim3(fblocks), dim3(fthreads), xo29, pts, ait, np);
+            printf("x29_add_mixed<PastaFp29> table %7u pts %8.3f ms  %8.2f Gadd/s\n", np, ms, (double)nel * ait / ms / 1e6);
+        }
+        ms = time_kernel(k_madd29<Bn254Fq29>, dim3(fblocks), dim3(fthreads), xo29, pts, ait, 1u << 20);
+        printf("x29_add_mixed<Bn254Fq29>                    %8.3f ms  %8.2f Gadd/s\n", ms, (double)nel * ait / ms / 1e6);
+    }
     ms = time_kernel(k_madd<PastaFp>, dim3(fblocks), dim3(fthreads), xo, pts, ait, npts);
     printf("xyzz_add_mixed<PastaFp> %8.3f ms  %8.2f Gadd/s (garbage points: exercises the generic path)\n", ms, (double)nel * ait / ms / 1e6);
     ms = time_kernel(k_madd<Bn254Fq>, dim3(fblocks), dim3(fthreads), xo, pts, ait, npts);
