@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
     L.p01 = reinterpret_cast<u64*>(smem_raw);
     L.p23 = L.p01 + NTT_TILE; L.p45 = L.p23 + NTT_TILE; L.p67 = L.p45 + NTT_TILE;
     L.p8 = reinterpret_cast<u32*>(L.p67 + NTT_TILE);
-    fe* ltw = reinterpret_cast<fe*>(L.p8 + NTT_TILE);  // R/2 sub-transform roots (w * 2^261, packed)
+    f29* ltw = reinterpret_cast<f29*>(L.p8 + NTT_TILE);  // R/2 sub-transform roots (w * 2^261), unpacked limbs
 
     const u32 tid = threadIdx.x;
     const u32 r = P.r, log_c = P.log_c;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
     const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
     fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
 
-    for (u32 j = tid; j < (R >> 1); j += NTT2_THREADS) f_store(&ltw[j], f_load(&P.tw[(u64)j << (P.log_n - r)]));
+    for (u32 j = tid; j < (R >> 1); j += NTT2_THREADS) ltw[j] = f29_unpack(f_load(&P.tw[(u64)j << (P.log_n - r)]));
 
     // ---- tile coordinates (as in k_ntt_pass) ----
     u64 q = 0, np0 = 0;
@@ -343,13 +343,14 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
             u32 a0 = (i0 << log_c) + c, a1 = a0 + (h << log_c), a2 = a1 + (h << log_c), a3 = a2 + (h << log_c);
             f29 e0 = lds29_load(L, a0), e1 = lds29_load(L, a1), e2 = lds29_load(L, a2), e3 = lds29_load(L, a3);
             // stage s: (e0, e1) and (e2, e3), twiddle w_R^(pos * R / 2h)
-            f29 w = f29_unpack(f_load(&ltw[pos << (r - 1 - s)]));
+            f29 w = ltw[pos << (r - 1 - s)];
             bfly29<F9>(e0, e1, w, s != 0);
             bfly29<F9>(e2, e3, w, s != 0);
-            // stage s + 1: (e0, e2) with pos, (e1, e3) with pos + h, twiddle w_R^(pos' * R / 4h)
-            f29 w0 = f29_unpack(f_load(&ltw[pos << (r - 2 - s)]));
-            f29 w1 = f29_unpack(f_load(&ltw[(pos + h) << (r - 2 - s)]));
-            bfly29<F9>(e0, e2, w0, true);
+            // stage s + 1: (e0, e2) with pos, (e1, e3) with pos + h, twiddle w_R^(pos' * R / 4h);
+            // in the first round pos = 0, so the (e0, e2) twiddle is 1
+            f29 w0 = ltw[pos << (r - 2 - s)];
+            f29 w1 = ltw[(pos + h) << (r - 2 - s)];
+            bfly29<F9>(e0, e2, w0, s != 0);
             bfly29<F9>(e1, e3, w1, true);
             lds29_store(L, a0, f29_norm(e0)); lds29_store(L, a1, f29_norm(e1));
             lds29_store(L, a2, f29_norm(e2)); lds29_store(L, a3, f29_norm(e3));
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
             u32 i0 = ((b >> s) << (s + 1)) | pos;
             u32 a0 = (i0 << log_c) + c, a1 = a0 + (h << log_c);
             f29 e0 = lds29_load(L, a0), e1 = lds29_load(L, a1);
-            f29 w = f29_unpack(f_load(&ltw[pos << (r - 1 - s)]));
+            f29 w = ltw[pos << (r - 1 - s)];
             bfly29<F9>(e0, e1, w, s != 0);
             lds29_store(L, a0, f29_norm(e0)); lds29_store(L, a1, f29_norm(e1));
         }
@@ -522,7 +523,7 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
     static bool attr_set = false;  // one process drives one GPU
     static bool use_v2 = true;
     const size_t lds_max = 2 * NTT_TILE * 16 + (NTT_TILE / 2) * sizeof(fe);
-    const size_t lds_max2 = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(fe);
+    const size_t lds_max2 = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(f29);
     if (!attr_set) {
         if (const char* e = getenv("DEHALO_NTT_V1")) use_v2 = atoi(e) == 0;   // A/B switch (the older LDS-32-byte kernel)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -557,7 +558,7 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         uint64_t tiles = N >> (rad[p] + log_c);
         dim3 grid((uint32_t)tiles, (uint32_t)batch);
         if (use_v2) {
-            size_t lds = (size_t)NTT_TILE * 36 + ((size_t)1 << rad[p]) / 2 * sizeof(fe);
+            size_t lds = (size_t)NTT_TILE * 36 + ((size_t)1 << rad[p]) / 2 * sizeof(f29);
             k_ntt_pass2<F><<<grid, NTT2_THREADS, lds, s>>>(P);
         } else {
             size_t lds = 2 * NTT_TILE * 16 + ((size_t)1 << rad[p]) / 2 * sizeof(fe);
