@@ -10,9 +10,10 @@
 //    (x * 2^261 mod p, canonical, packed in 32 B) so the hot loop never converts.
 //  * Signed c-bit digits (buckets halve), digit = 0 skipped (witness columns are mostly
 //    small values: SURVEY.md 8(d)).
-//  * Counting sort of (bucket, point) pairs with a whole-bucket-range histogram in LDS
-//    (2^15 x 4 B = 128 KiB of the CU's 160 KiB): histogram -> scan -> scatter, no digit
-//    array in HBM (digits are recomputed from the scalar, ~1 % of the group-add work).
+//  * Stable counting sort of (bucket, point) pairs with a whole-bucket-range histogram in LDS
+//    (2^15 x 4 B = 128 KiB of the CU's 160 KiB): per-block histograms -> column scan -> bucket
+//    scan -> single-pass scatter; no global atomics, no digit array in HBM (digits are
+//    recomputed from the scalar, ~1 % of the group-add work).
 //  * Bucket accumulation split into fixed-length tasks of <= L points regardless of bucket
 //    size (a bucket that receives 300 k points of a 0/1 column costs the same per lane as a
 //    uniform one), one lane per task, XYZZ mixed additions on the carry-free 9 x 29-bit field
@@ -70,10 +71,12 @@ FP_DEV void for_each_digit(const fe& mont_scalar, u32 c, u32 w_lo, u32 w_hi, Fn 
     }
 }
 
-// ---- sort step 1: per-bucket counts ------------------------------------------------------
-// grid (slices, G, batch); dynamic LDS nb * 4 B
+// ---- sort step 1: per-block histograms ----------------------------------------------------
+// grid (slices, G, batch); dynamic LDS nb * 4 B.  Each block stores its whole local histogram
+// (plain coalesced stores): bh[group][slice][bucket].  No global atomics anywhere in the sort:
+// 256 blocks claiming runs in the same 2^15 counters with returning atomics cost 0.2 ms.
 template <class FS>
-__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_hist(MsmGeom g, const fe* scalars, u32* count) {
+__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_hist(MsmGeom g, const fe* scalars, u32* bh) {
     extern __shared__ u32 lhist[];
     for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) lhist[b] = 0;
     __syncthreads();
@@ -87,11 +90,34 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_hist(MsmGeom g, const 
         for_each_digit<FS>(s, g.c, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
     }
     __syncthreads();
-    u32* gc = count + ((u64)bat * g.G + grp) * g.nb;
-    for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) {
-        u32 v = lhist[b];
-        if (v) atomicAdd(&gc[b], v);
+    u32* out = bh + (((u64)bat * g.G + grp) * g.slices + blockIdx.x) * g.nb;
+    for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) out[b] = lhist[b];
+}
+
+// column scan: for every bucket, exclusive prefix over the slices (in place) and the total count
+static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count) {
+    u32 gb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gb >= total_buckets) return;
+    u32 grp = gb / nb, b = gb - grp * nb;
+    u32* col = bh + (u64)grp * slices * nb + b;
+    u32 run = 0;
+    u32 k = 0;
+    for (; k + 16 <= slices; k += 16) {   // 16 independent loads in flight per lane, then the prefix
+        u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = col[(u64)(k + j) * nb];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            col[(u64)(k + j) * nb] = run;
+            run += v[j];
+        }
     }
+    for (; k < slices; k++) {
+        u32 v = col[(u64)k * nb];
+        col[(u64)k * nb] = run;
+        run += v;
+    }
+    count[gb] = run;
 }
 
 // ---- scans (3 kernels): item offsets and task offsets ------------------------------------
@@ -184,28 +210,22 @@ static __global__ void k_diff(const u32* toff, u32 total, u32* cnt_out) {
 }
 
 // ---- sort step 2: scatter point references into bucket order -----------------------------
-// entry = table index | sign << 31.  Same grid / LDS as k_msm_hist.
+// entry = table index | sign << 31.  Same grid / LDS as k_msm_hist.  The block's first position in
+// every bucket is known (bucket offset + prefix over earlier slices), so one pass suffices and the
+// sort is stable across blocks.
 template <class FS>
-__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_scatter(MsmGeom g, const fe* scalars, const u32* off, u32* cursor, u32* idx_out) {
+__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_scatter(MsmGeom g, const fe* scalars, const u32* off, const u32* bh, u32* idx_out) {
     extern __shared__ u32 lhist[];
-    for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) lhist[b] = 0;
-    __syncthreads();
     const u32 grp = blockIdx.y, bat = blockIdx.z;
+    const u64 gidx = (u64)bat * g.G + grp;
+    const u32* rel = bh + (gidx * g.slices + blockIdx.x) * g.nb;
+    const u32* goff = off + gidx * g.nb;
+    for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) lhist[b] = goff[b] + rel[b];
+    __syncthreads();
     const u32 w_lo = g.G == 1 ? 0 : grp, w_hi = g.G == 1 ? g.W : grp + 1;
     const fe* sc = scalars + (u64)bat * g.n;
     const u32 per = (g.n + g.slices - 1) / g.slices;
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
-    for (u32 i = beg + threadIdx.x; i < end; i += blockDim.x) {
-        fe s = f_load(&sc[i]);
-        for_each_digit<FS>(s, g.c, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
-    }
-    __syncthreads();
-    const u64 gb = ((u64)bat * g.G + grp) * g.nb;
-    for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) {
-        u32 v = lhist[b];
-        if (v) lhist[b] = off[gb + b] + atomicAdd(&cursor[gb + b], v);  // claim a run inside the bucket
-    }
-    __syncthreads();
     for (u32 i = beg + threadIdx.x; i < end; i += blockDim.x) {
         fe s = f_load(&sc[i]);
         for_each_digit<FS>(s, g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool neg) {
@@ -582,7 +602,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const size_t REC = sizeof(xyzz29_rec);
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
-    TRY(dh_ensure(ctx, ctx->ws_cursor, (total_buckets + 4) * 4));   // + 4 merge-class counters
+    TRY(dh_ensure(ctx, ctx->ws_cursor, 16));                                   // 4 merge-class counters
+    TRY(dh_ensure(ctx, ctx->ws_off1, total_buckets * (size_t)g.slices * 4));   // per-block histograms
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
     TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4));
     const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / 2 + 1);
@@ -598,7 +619,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     u32* off = (u32*)ctx->ws_off.p;
     u32* toff0 = (u32*)ctx->ws_toff0.p;
     u32* merge_lists = (u32*)ctx->ws_cnt1.p;
-    u32* merge_counters = cursor + total_buckets;
+    u32* merge_counters = cursor;
+    u32* bh = (u32*)ctx->ws_off1.p;
     u32* idx = (u32*)ctx->ws_idx.p;
     xyzz29_rec* partial0 = (xyzz29_rec*)ctx->ws_partial0.p;
     xyzz29_rec* buckets = (xyzz29_rec*)ctx->ws_buckets.p;
@@ -614,12 +636,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const u32 tb = (u32)total_buckets;
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
-        HIP_TRY(ctx, hipMemsetAsync(count, 0, total_buckets * 4, s));
-        HIP_TRY(ctx, hipMemsetAsync(cursor, 0, (total_buckets + 4) * 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(merge_counters, 0, 16, s));
         dim3 grid(g.slices, g.G, (u32)batch);
-        k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, count);
+        k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, bh);
+        k_msm_colscan<<<(tb + 255) / 256, 256, 0, s>>>(g.nb, g.slices, tb, bh, count);
         TRY(run_scan(ctx, count, tb, g.L0, off, toff0, s));
-        k_msm_scatter<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, off, cursor, idx);
+        k_msm_scatter<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, off, bh, idx);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
