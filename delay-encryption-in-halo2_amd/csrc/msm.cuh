@@ -294,12 +294,12 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 // Signed-digit carries of small witness values pile thousands of points into bucket 0 (digit
 // +-1) and 0/1 columns put half the column into one bucket, so the number S of partial sums per
 // bucket spans 0 .. 10^5.  Buckets are classed by S and merged by a lane group sized to it:
-//   S <= 24: one lane or quad | S <= 128: 8 lanes | S <= 2048: one wave | larger: a 1024-thread block;
+//   S <= 24: one lane or quad | S <= 128: 8 lanes | S <= 2048: one wave | larger: a 512-thread block;
 // chain length <= S/g + log2 g group additions instead of S.
 #define MSM_C0_MAX 24
 #define MSM_C1_MAX 128
 #define MSM_C2_MAX 2048
-#define MSM_HEAVY_THREADS 1024
+#define MSM_HEAVY_THREADS 512    // 2 waves per SIMD: room for the ~170 VGPRs of a group addition (1024 threads would spill)
 #define MSM_MERGE_BLOCKS 1024
 
 // classification: one lane per bucket.  S = 0 -> identity, S = 1 -> copy; otherwise the bucket is
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_group(const u32* toff, const 
     }
 }
 
-// 1024-thread blocks walk the heaviest class: strided lane sums, shuffle reduction per wave,
+// 512-thread blocks walk the heaviest class: strided lane sums, shuffle reduction per wave,
 // 16 wave results through LDS, shuffle reduction again.  Chain: ceil(S / 1024) + 10 adds.
 template <class CV>
 __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
