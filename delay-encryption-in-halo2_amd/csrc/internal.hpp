@@ -35,8 +35,8 @@ struct dehalo_ctx {
     std::string err;
     std::mutex mu;
     // workspace (grow-only)
-    DevBuf ws_scalars, ws_out, ws_count, ws_cursor, ws_off, ws_toff0, ws_cnt1, ws_off1, ws_toff1, ws_bsum, ws_idx, ws_partial0, ws_partial1,
-        ws_buckets, ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases;
+    DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_toff0, ws_merge_lists, ws_bhist, ws_bsum, ws_idx, ws_partial0, ws_buckets,
+        ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases;
     std::vector<TwiddleEntry> twiddles;
     bool timing = false;
     std::vector<TimedRegion> regions;

@@ -203,12 +203,6 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* c
     }
 }
 
-// cnt_out[b] = toff[b + 1] - toff[b]   (number of partials per bucket = next level's item count)
-static __global__ void k_diff(const u32* toff, u32 total, u32* cnt_out) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) cnt_out[i] = toff[i + 1] - toff[i];
-}
-
 // ---- sort step 2: scatter point references into bucket order -----------------------------
 // entry = table index | sign << 31.  Same grid / LDS as k_msm_hist.  The block's first position in
 // every bucket is known (bucket offset + prefix over earlier slices), so one pass suffices and the
@@ -602,12 +596,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const size_t REC = sizeof(xyzz29_rec);
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
-    TRY(dh_ensure(ctx, ctx->ws_cursor, 16));                                   // 4 merge-class counters
-    TRY(dh_ensure(ctx, ctx->ws_off1, total_buckets * (size_t)g.slices * 4));   // per-block histograms
+    TRY(dh_ensure(ctx, ctx->ws_counters, 16));                                   // 4 merge-class counters
+    TRY(dh_ensure(ctx, ctx->ws_bhist, total_buckets * (size_t)g.slices * 4));   // per-block histograms
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
     TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4));
     const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / 2 + 1);
-    TRY(dh_ensure(ctx, ctx->ws_cnt1, (size_t)merge_cap * 4 * 4));   // merge-class lists
+    TRY(dh_ensure(ctx, ctx->ws_merge_lists, (size_t)merge_cap * 4 * 4));   // merge-class lists
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
@@ -615,12 +609,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_tree, total_groups * ((per_group + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS) * REC));
     TRY(dh_ensure(ctx, ctx->ws_gsums, total_groups * REC));
     u32* count = (u32*)ctx->ws_count.p;
-    u32* cursor = (u32*)ctx->ws_cursor.p;
+    u32* cursor = (u32*)ctx->ws_counters.p;
     u32* off = (u32*)ctx->ws_off.p;
     u32* toff0 = (u32*)ctx->ws_toff0.p;
-    u32* merge_lists = (u32*)ctx->ws_cnt1.p;
+    u32* merge_lists = (u32*)ctx->ws_merge_lists.p;
     u32* merge_counters = cursor;
-    u32* bh = (u32*)ctx->ws_off1.p;
+    u32* bh = (u32*)ctx->ws_bhist.p;
     u32* idx = (u32*)ctx->ws_idx.p;
     xyzz29_rec* partial0 = (xyzz29_rec*)ctx->ws_partial0.p;
     xyzz29_rec* buckets = (xyzz29_rec*)ctx->ws_buckets.p;

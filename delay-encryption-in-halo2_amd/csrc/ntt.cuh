@@ -7,21 +7,20 @@
 // over the whole array; here the transform is factored N = R_1 * R_2 * ... * R_L
 // (Cooley-Tukey, L <= 4) so each pass moves every element through HBM once:
 //
-//   pass p < L : for every sub-problem of size M and every column n', an R_p-point DIF
+//   pass p < L : for every sub-problem of size M and every column n', an R_p-point DIT
 //                transform along the stride-M/R_p axis inside LDS, times the inter-pass
 //                twiddle omega_M^(n' * k), stored back at the same positions;
 //   pass L     : R_L-point transforms of contiguous rows; the store performs the digit
 //                reversal (k = k_1 + R_1 k_2 + ...), so no separate bit-reverse pass.
 //
-// A workgroup owns a tile of R x C elements (R*C <= 2048, 64 KiB of the CU's 160 KiB
-// LDS, two workgroups per CU), kept as two 16-byte planes so that consecutive lanes
-// touch consecutive LDS slots (conflict-free ds_read/write_b128).  Global accesses are
-// C*32-byte contiguous segments.  Twiddles omega^j (j < N/2) live in an HBM/L2-resident
-// table built once per (field, omega, log_n); the R/2 roots of the sub-transform are
-// staged in LDS.  Pre-/post-scaling of lagrange_to_coeff / coeff_to_extended /
-// extended_to_coeff (x n^-1, x zeta^(i mod 3), zero padding) is fused into the first
-// load and the last store.  HBM-bound by design (64 B/element algorithmic); measured
-// bound on gfx950 is the VALU (v_mad_u64_u32) -- see DESIGN.md.
+// A workgroup owns a tile of R x C elements (R*C <= 2048) kept in LDS as lazily reduced 9 x 29-bit
+// limbs (72 KiB of the CU's 160 KiB, two workgroups per CU).  Global accesses are C*32-byte
+// contiguous segments.  Twiddles omega^j * 2^261 (j < N/2) live in an HBM/L2-resident table built
+// once per (field, omega, log_n); the R/2 roots of the sub-transform are staged in LDS.  Every
+// multiplication runs on the carry-free multiplier of fp29.cuh.  Pre-/post-scaling of
+// lagrange_to_coeff / coeff_to_extended / extended_to_coeff (x n^-1, x zeta^(i mod 3), zero
+// padding) is fused into the first load and the last store.  HBM-bound by design (64 B/element
+// algorithmic); the measured bound on gfx950 is the VALU (v_mad_u64_u32) -- see DESIGN.md.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -31,13 +30,12 @@
 
 #define NTT_TILE_LOG 11
 #define NTT_TILE (1 << NTT_TILE_LOG)
-#define NTT_THREADS 512
 #define NTT_MAX_PASSES 4
 
 struct NttPassParams {
     const fe* src;
     fe* dst;
-    const fe* tw;        // omega^j, j < N/2
+    const fe* tw;        // omega^j * 2^261 (canonical, packed), j < N/2
     u32 log_n;           // N
     u32 log_m;           // sub-problem size at this pass
     u32 r;               // log2 of this pass's radix
@@ -55,14 +53,6 @@ struct NttPassParams {
     fe post0, post_z;
 };
 
-// a (standard form, canonical) times w (w * 2^261 as limbs, < 2p) -> standard form, canonical
-template <class F>
-FP_DEV fe mul_std_w29(const fe& a, const f29& w) {
-    typedef typename f29_of<F>::type F9;
-    f29 t = f29_mul<F9>(f29_unpack(a), w);   // < a*w/2^261 + p < 2p
-    return f29_pack(f29_cond_sub(t, F9::P));
-}
-
 FP_DEV u32 bitrev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
 // omega^e for e < N from the half table (omega^(N/2) = -1)
@@ -74,158 +64,8 @@ FP_DEV fe tw_lookup(const fe* tw, u64 e, u32 log_n) {
     return neg ? f_neg<F>(w) : w;
 }
 
-template <class F>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint4* lo = reinterpret_cast<uint4*>(smem_raw);
-    uint4* hi = lo + NTT_TILE;
-    fe* ltw = reinterpret_cast<fe*>(hi + NTT_TILE);  // R/2 sub-transform roots
-
-    const u32 tid = threadIdx.x;
-    const u32 r = P.r, log_c = P.log_c;
-    const u32 R = 1u << r, Cc = 1u << log_c;
-    const u32 tile = R << log_c;
-    const u64 N = 1ull << P.log_n;
-    const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
-    fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
-
-    // stage omega_R^j = omega_N^(j * N/R), j < R/2
-    for (u32 j = tid; j < (R >> 1); j += NTT_THREADS) {
-        fe w = f_load(&P.tw[(u64)j << (P.log_n - r)]);
-        f_store(&ltw[j], w);
-    }
-
-    // ---- tile coordinates ----
-    u64 q = 0, np0 = 0;          // non-final: sub-problem index, first column
-    u32 k1blk = 0; u64 rest = 0; // final
-    const u32 log_cols = P.log_m - r;  // log2(M/R) columns per sub-problem
-    if (!P.is_final) {
-        u32 tiles_per_sub_log = log_cols - log_c;
-        q = (u64)blockIdx.x >> tiles_per_sub_log;
-        np0 = ((u64)blockIdx.x & ((1ull << tiles_per_sub_log) - 1)) << log_c;
-    } else {
-        u32 kb_log = P.r1 - log_c;  // k1 blocks
-        k1blk = blockIdx.x & ((1u << kb_log) - 1);
-        rest = (u64)blockIdx.x >> kb_log;
-    }
-    const u32 log_q_per_k1 = P.log_n - r - P.r1;  // final: Q / R1
-
-    typedef typename f29_of<F>::type F9;
-    f29 pre1 = f29_zero(), pre2 = f29_zero();
-    if (P.pre_mode) {
-        pre1 = f29_from_std<F9>(P.pre_z);          // z   * 2^261
-        pre2 = f29_mul<F9>(pre1, pre1);            // z^2 * 2^261
-    }
-
-    // ---- load ----
-    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
-        u32 j, c;
-        u64 g;
-        if (!P.is_final) {
-            j = idx >> log_c; c = idx & (Cc - 1);
-            g = (q << P.log_m) + ((u64)j << log_cols) + np0 + c;
-        } else {
-            c = idx >> r; j = idx & (R - 1);
-            u64 qq = (((u64)k1blk << log_c) + c) << log_q_per_k1;
-            qq += rest;
-            g = (qq << r) + j;
-        }
-        fe v;
-        if (g < P.src_len) {
-            v = f_load(&src[g]);
-            if (P.pre_mode) {
-                u32 m3 = (u32)(g % 3);
-                if (m3 == 1) v = mul_std_w29<F>(v, pre1);
-                else if (m3 == 2) v = mul_std_w29<F>(v, pre2);
-            }
-        } else {
-            v = f_zero();
-        }
-        u32 li = (j << log_c) + c;
-        lo[li] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-        hi[li] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
-    }
-    __syncthreads();
-
-    // ---- r DIF stages in LDS: (u, v) -> (u + v, (u - v) * w) ----
-    const u32 nbf = tile >> 1;
-    for (u32 s = 0; s < r; s++) {
-        const u32 log_half = r - s - 1;
-        const u32 half = 1u << log_half;
-        for (u32 bidx = tid; bidx < nbf; bidx += NTT_THREADS) {
-            u32 c = bidx & (Cc - 1), b = bidx >> log_c;
-            u32 pos = b & (half - 1), grp = b >> log_half;
-            u32 i0 = (((grp << (log_half + 1)) + pos) << log_c) + c;
-            u32 i1 = i0 + (half << log_c);
-            uint4 a0 = lo[i0], a1 = hi[i0], b0 = lo[i1], b1 = hi[i1];
-            fe u, v;
-            u.v[0] = a0.x; u.v[1] = a0.y; u.v[2] = a0.z; u.v[3] = a0.w;
-            u.v[4] = a1.x; u.v[5] = a1.y; u.v[6] = a1.z; u.v[7] = a1.w;
-            v.v[0] = b0.x; v.v[1] = b0.y; v.v[2] = b0.z; v.v[3] = b0.w;
-            v.v[4] = b1.x; v.v[5] = b1.y; v.v[6] = b1.z; v.v[7] = b1.w;
-            fe sum = f_add<F>(u, v);
-            fe dif = f_sub<F>(u, v);
-            if (half > 1) dif = mul_std_w29<F>(dif, f29_unpack(f_load(&ltw[pos << s])));   // last stage: all twiddles are 1
-            lo[i0] = make_uint4(sum.v[0], sum.v[1], sum.v[2], sum.v[3]);
-            hi[i0] = make_uint4(sum.v[4], sum.v[5], sum.v[6], sum.v[7]);
-            lo[i1] = make_uint4(dif.v[0], dif.v[1], dif.v[2], dif.v[3]);
-            hi[i1] = make_uint4(dif.v[4], dif.v[5], dif.v[6], dif.v[7]);
-        }
-        __syncthreads();
-    }
-
-    // ---- store (LDS row j holds output digit k = bitrev_r(j)) ----
-    f29 post0m = f29_zero(), post1m = f29_zero(), post2m = f29_zero();
-    if (P.is_final && P.post_mode) {
-        post0m = f29_from_std<F9>(P.post0);
-        if (P.post_mode == 2) {
-            f29 z = f29_from_std<F9>(P.post_z);
-            post2m = f29_mul<F9>(post0m, z);
-            post1m = f29_mul<F9>(post2m, z);
-        }
-    }
-    u64 revrest = 0;
-    if (P.is_final) {
-        // rest holds the middle digits (k_2 .. k_{L-1}), k_2 most significant; reverse them
-        u64 rem = rest;
-        u32 bits_left = log_q_per_k1, mult = 0;
-        for (u32 i = 0; i < P.nrev; i++) {
-            bits_left -= P.rev_r[i];
-            u64 d = rem >> bits_left;
-            rem -= d << bits_left;
-            revrest += d << mult;
-            mult += P.rev_r[i];
-        }
-    }
-    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
-        u32 k = idx >> log_c, c = idx & (Cc - 1);
-        u32 j = bitrev32(k, r);
-        u32 li = (j << log_c) + c;
-        uint4 a0 = lo[li], a1 = hi[li];
-        fe v;
-        v.v[0] = a0.x; v.v[1] = a0.y; v.v[2] = a0.z; v.v[3] = a0.w;
-        v.v[4] = a1.x; v.v[5] = a1.y; v.v[6] = a1.z; v.v[7] = a1.w;
-        u64 o;
-        if (!P.is_final) {
-            u64 np = np0 + c;
-            u64 e = (np * k) << (P.log_n - P.log_m);
-            if (e) v = mul_std_w29<F>(v, f29_unpack(tw_lookup<F>(P.tw, e, P.log_n)));
-            o = (q << P.log_m) + ((u64)k << log_cols) + np;
-        } else {
-            o = (((u64)k1blk << log_c) + c) + (revrest << P.r1) + ((u64)k << (P.log_n - r));
-            if (P.post_mode == 1) v = mul_std_w29<F>(v, post0m);
-            else if (P.post_mode == 2) {
-                u32 m3 = (u32)(o % 3);
-                v = mul_std_w29<F>(v, m3 == 0 ? post0m : (m3 == 1 ? post1m : post2m));
-            }
-        }
-        f_store(&dst[o], v);
-    }
-    (void)N;
-}
-
-// ---- pass kernel, version 2 -----------------------------------------------------------------
-// Same tiling / passes / fused scaling as k_ntt_pass, but the tile lives in LDS as lazily reduced
+// ---- pass kernel ----------------------------------------------------------------------------
+// The tile lives in LDS as lazily reduced
 // 9 x 29-bit limbs (five planes: four u64 limb pairs + one u32, 36 B per element, conflict-free
 // ds_read/write_b64) and the butterflies are decimation-in-time:
 //     t = w * v (carry-free multiplier, < 2p);  u' = u + t;  v' = u - t + 4p
@@ -235,7 +75,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
 // standard form (x * 2^256); twiddles are w * 2^261, so products stay in that form, and the
 // multiplication every element needs on the way out (inter-pass twiddle, post-scale, or 1)
 // brings it back below 2p for one conditional subtraction.
-#define NTT2_THREADS 512
+#define NTT_THREADS 512
 
 struct Lds29 {
     u64* p01; u64* p23; u64* p45; u64* p67; u32* p8;
@@ -266,7 +106,7 @@ FP_DEV void bfly29(f29& u, f29& v, const f29& w, bool mul) {
 }
 
 template <class F>
-__global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     typedef typename f29_of<F>::type F9;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Lds29 L;
@@ -282,9 +122,9 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
     const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
     fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
 
-    for (u32 j = tid; j < (R >> 1); j += NTT2_THREADS) ltw[j] = f29_unpack(f_load(&P.tw[(u64)j << (P.log_n - r)]));
+    for (u32 j = tid; j < (R >> 1); j += NTT_THREADS) ltw[j] = f29_unpack(f_load(&P.tw[(u64)j << (P.log_n - r)]));
 
-    // ---- tile coordinates (as in k_ntt_pass) ----
+    // ---- tile coordinates ----
     u64 q = 0, np0 = 0;
     u32 k1blk = 0; u64 rest = 0;
     const u32 log_cols = P.log_m - r;
@@ -306,7 +146,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
     }
 
     // ---- load: global (standard form, canonical) -> limbs, into row bitrev(j) (DIT input order) ----
-    for (u32 idx = tid; idx < tile; idx += NTT2_THREADS) {
+    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
         u32 j, c;
         u64 g;
         if (!P.is_final) {
@@ -336,7 +176,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
     for (; s + 1 < r; s += 2) {
         const u32 h = 1u << s;
         const u32 ngroups = tile >> 2;   // radix-4 groups in the tile
-        for (u32 gidx = tid; gidx < ngroups; gidx += NTT2_THREADS) {
+        for (u32 gidx = tid; gidx < ngroups; gidx += NTT_THREADS) {
             u32 c = gidx & (Cc - 1), gq = gidx >> log_c;          // gq in [0, R/4)
             u32 pos = gq & (h - 1);
             u32 i0 = ((gq >> s) << (s + 2)) | pos;
@@ -360,7 +200,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
     if (s < r) {   // odd r: one last radix-2 stage
         const u32 h = 1u << s;
         const u32 nbf = tile >> 1;
-        for (u32 bidx = tid; bidx < nbf; bidx += NTT2_THREADS) {
+        for (u32 bidx = tid; bidx < nbf; bidx += NTT_THREADS) {
             u32 c = bidx & (Cc - 1), b = bidx >> log_c;
             u32 pos = b & (h - 1);
             u32 i0 = ((b >> s) << (s + 1)) | pos;
@@ -395,7 +235,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void k_ntt_pass2(NttPassParams P) {
             mult += P.rev_r[i];
         }
     }
-    for (u32 idx = tid; idx < tile; idx += NTT2_THREADS) {
+    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
         u32 k = idx >> log_c, c = idx & (Cc - 1);
         f29 v = lds29_load(L, (k << log_c) + c);
         u64 o;
@@ -521,13 +361,9 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         scratch = (fe*)ctx->ws_ntt_scratch.p;
     }
     static bool attr_set = false;  // one process drives one GPU
-    static bool use_v2 = true;
-    const size_t lds_max = 2 * NTT_TILE * 16 + (NTT_TILE / 2) * sizeof(fe);
-    const size_t lds_max2 = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(f29);
+    const size_t lds_max = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(f29);
     if (!attr_set) {
-        if (const char* e = getenv("DEHALO_NTT_V1")) use_v2 = atoi(e) == 0;   // A/B switch (the older LDS-32-byte kernel)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max2));
         attr_set = true;
     }
     uint32_t log_m = log_n;
@@ -557,13 +393,8 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         P.log_c = log_c;
         uint64_t tiles = N >> (rad[p] + log_c);
         dim3 grid((uint32_t)tiles, (uint32_t)batch);
-        if (use_v2) {
-            size_t lds = (size_t)NTT_TILE * 36 + ((size_t)1 << rad[p]) / 2 * sizeof(f29);
-            k_ntt_pass2<F><<<grid, NTT2_THREADS, lds, s>>>(P);
-        } else {
-            size_t lds = 2 * NTT_TILE * 16 + ((size_t)1 << rad[p]) / 2 * sizeof(fe);
-            k_ntt_pass<F><<<grid, NTT_THREADS, lds, s>>>(P);
-        }
+        size_t lds = (size_t)NTT_TILE * 36 + ((size_t)1 << rad[p]) / 2 * sizeof(f29);
+        k_ntt_pass<F><<<grid, NTT_THREADS, lds, s>>>(P);
         HIP_TRY(ctx, hipGetLastError());
         log_m -= rad[p];
     }

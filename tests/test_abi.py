@@ -63,4 +63,4 @@ def test_product_does_not_touch_the_oracle():
         for fn in files:
             if fn.endswith((".py", ".hip", ".cuh", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, fn)).read()
-                assert "oracle" not in txt.lower() or fn == "__init__.py" and False, (fn, "mentions the oracle")
+                assert "oracle" not in txt.lower(), (fn, "mentions the oracle")
