@@ -116,7 +116,7 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_out, &ctx->ws_count, &ctx->ws_counters, &ctx->ws_off, &ctx->ws_toff0, &ctx->ws_merge_lists,
-                      &ctx->ws_bhist, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree,
+                      &ctx->ws_bhist, &ctx->ws_pcount, &ctx->ws_pairs, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree,
                       &ctx->ws_gsums, &ctx->ws_ntt_scratch, &ctx->ws_ntt_io, &ctx->ws_ntt_io2, &ctx->ws_fop[0], &ctx->ws_fop[1], &ctx->ws_fop[2],
                       &ctx->ws_tmp_bases};
     for (DevBuf* b : bufs)
