@@ -26,6 +26,10 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy ceiling
 MSM_BYTES_PER_TERM = 96  # 64 B affine base + 32 B scalar
 NTT_BYTES_PER_ELEM = 64  # read once + write once
+# v_mad_u64_u32 per XYZZ mixed addition in k_msm_accum0's loop (ISA count) and the measured issue
+# peak of that instruction on MI355X (profiles/r01_ubench_instruction_rates.txt)
+MADS_PER_MIXED_ADD = {"pallas": 1099, "vesta": 1099, "bn254": 1549}
+VMAD_PEAK_TMADS = 30.5
 
 
 def parse():
@@ -225,6 +229,7 @@ def main():
         red_ms, red_cnt = tsum(_lib.K_MSM_REDUCE)
         ntt_ms, ntt_cnt = tsum(_lib.K_NTT_PASS)
         acc_avg_ms = acc_ms / max(acc_cnt, 1)
+        n_windows = 16 if log_n >= 16 else -(-256 // max(6, log_n - 1))   # ceil(256 / c), c as dehalo_bases_register chooses it
         achieved = MSM_BYTES_PER_TERM * n / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
@@ -254,7 +259,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_msm_accum0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": MSM_BYTES_PER_TERM * n, "avg_kernel_ms": round(acc_avg_ms, 4),
-                         "note": "MSM is integer-VALU-bound (group adds), not HBM-bound: a low HBM fraction is expected (SURVEY.md 8d)"},
+                         "note": "MSM is integer-VALU-bound (group adds), not HBM-bound: a low HBM fraction is expected (SURVEY.md 8d)",
+                         # the honest ceiling of this kernel: wide integer multiplies issued vs the measured v_mad_u64_u32 peak
+                         "valu": {"mads_per_launch": MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows, "peak_tmad_per_s": VMAD_PEAK_TMADS,
+                                  "achieved_tmad_per_s": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (acc_avg_ms * 1e-3) / 1e12, 2) if acc_avg_ms > 0 else 0.0,
+                                  "frac": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (acc_avg_ms * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4) if acc_avg_ms > 0 else 0.0}},
             "breakdown_ms_per_step": {"msm_sort": round(sort_ms / max(sort_cnt, 1), 4), "msm_accumulate": round(acc_avg_ms, 4),
                                       "msm_reduce": round(red_ms / max(red_cnt, 1), 4), "ntt": round(ntt_ms / max(ntt_cnt, 1), 4)},
             "ntt_roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEM * n / (ntt_ms / max(ntt_cnt, 1) * 1e-3) / 1e9, 2) if ntt_ms > 0 else 0.0,
