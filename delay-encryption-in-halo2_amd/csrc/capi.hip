@@ -10,10 +10,14 @@ namespace {
 
 hipStream_t pick_stream(dehalo_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+// Window bits by measurement on MI355X (tools/sweep_c.py): below 2^20 points the bucket reduction
+// (cost ~ 2^(c-1)) outweighs one or two extra windows, so c = 15; tiny problems want fewer buckets.
 uint32_t choose_window(size_t n) {
     uint32_t l = log2_ceil(n ? n : 1);
-    if (l >= 16) return 16;
-    return std::max<uint32_t>(6, l > 1 ? l - 1 : 1);
+    if (l >= 20) return 16;
+    if (l >= 13) return 15;
+    if (l >= 10) return 13;
+    return std::max<uint32_t>(6, l + 1);
 }
 
 int do_msm(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, size_t len, size_t batch, jacobian_t* d_out, hipStream_t s) {

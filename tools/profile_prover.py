@@ -12,7 +12,8 @@ ctx = pkg.Context(0)
 n = 1 << k
 g = co.synth_bases(curve.id, n); gl = g[::-1].copy()
 cols = ps.synthetic_columns(lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed), curve.scalar.id, k, 7)
-bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, gl, 0, True)
+wb = int(os.environ.get('WINDOW_BITS', '0'))
+bg, bgl = ctx.register_bases(curve.id, g, wb, True), ctx.register_bases(curve.id, gl, wb, True)
 shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
 shape.run()
 for _ in range(3):
