@@ -274,6 +274,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(co, po, curve, field, log_n, args.dist)
         if world == 1 and args.prover_k > 0:
             out["prover_shape"] = prover_shape_numbers(pkg, co, po, ctx, args.prover_k, args.prover_curve, not args.no_cpu_baseline)
+            # the other two sizes the north star names (GPU only: the CPU port takes ~1 min at k = 20)
+            out["prover_shape_other_k"] = [prover_shape_numbers(pkg, co, po, ctx, k, args.prover_curve, False) for k in (14, 20) if k != args.prover_k]
         print(json.dumps(out), flush=True)
 
     bases.release()
