@@ -115,73 +115,77 @@ FP_DEV f29 f29_sub(const f29& a, const f29& b, const u32 (&K)[9]) {
 
 FP_DEV u64 mad_wide(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
 
+// One multiply-add step of a column.  The empty asm pins the association order: without it LLVM
+// reassociates the 64-bit sums and the carry of the previous column comes back as a separate
+// v_lshl_add_u64 (4.4 cycles) instead of being the addend of the column's first v_mad_u64_u32.
+FP_DEV void f29_col_mad(u64& acc, u32 a, u32 b) {
+    acc = mad_wide(a, b, acc);
+    asm("" : "+v"(acc));
+}
+// the modulus limbs as opaque scalar registers: keeps hipcc from strength-reducing m * P[j] for
+// the sparse Pasta limbs (1, 2^22) into 64-bit shift/add sequences that issue slower than the mad
+template <class F>
+FP_DEV void f29_load_p(u32 (&P)[9]) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        P[j] = F::P[j];
+        if (F::P[j] != 0) asm("" : "+s"(P[j]));
+    }
+}
+// Montgomery reduction interleaved column by column (product scanning).  Column k of
+// a*b + sum_i m_i p 2^(29 i) is accumulated in ONE 64-bit register that starts as the carry of
+// column k-1, so the only non-multiply work per column is m_k (k < 9) or the 29-bit mask
+// (k >= 9) and one 64-bit shift.  Same values as operand scanning; measured on MI355X
+// (tools/ubench_mul.hip): Pasta 172 -> 200 Gmul/s, BN254 172 -> 175.
+// Column bound: <= 9 products of <= 2^60 + 9 reduction terms of <= 2^58 + carry < 2^64.
+template <class F, class PROD>
+FP_DEV f29 f29_montgomery_columns(const PROD& products) {
+    u32 m[9], P[9];
+    f29_load_p<F>(P);
+    f29 r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        products(k, acc);
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (i < k && k - i < 9 && F::P[k - i] != 0) f29_col_mad(acc, m[i], P[k - i]);
+        if (k < 9) {
+            if (F::INV == F29_MASK) m[k] = (0u - (u32)acc) & F29_MASK;   // p = 1 mod 2^29 (Pasta)
+            else m[k] = ((u32)acc * F::INV) & F29_MASK;
+            f29_col_mad(acc, m[k], P[0]);
+        } else {
+            r.v[k - 9] = (u32)acc & F29_MASK;
+        }
+        acc >>= F29_BITS;
+    }
+    r.v[8] = (u32)acc;
+    return r;
+}
+
 // a * b * 2^-261 mod p, lazily reduced: result limbs normalized, value < a*b/2^261 + p.
 // Limb-size contract: bits(max a limb) + bits(max b limb) <= 60.
 template <class F>
 FP_DEV f29 f29_mul(const f29& a, const f29& b) {
-    u64 acc[18];
+    return f29_montgomery_columns<F>([&](int k, u64& acc) {
 #pragma unroll
-    for (int i = 0; i < 18; i++) acc[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-#pragma unroll
-        for (int j = 0; j < 9; j++) acc[i + j] = mad_wide(a.v[i], b.v[j], acc[i + j]);
-        u32 m;
-        if (F::INV == F29_MASK) m = (0u - (u32)acc[i]) & F29_MASK;   // p = 1 mod 2^29 (Pasta)
-        else m = ((u32)acc[i] * F::INV) & F29_MASK;
-#pragma unroll
-        for (int j = 0; j < 9; j++)
-            if (F::P[j] != 0) acc[i + j] = mad_wide(m, F::P[j], acc[i + j]);
-        acc[i + 1] += acc[i] >> F29_BITS;
-    }
-    f29 r;
-    u64 c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        u64 t = acc[9 + j] + c;
-        r.v[j] = (u32)t & F29_MASK;
-        c = t >> F29_BITS;
-    }
-    r.v[8] = (u32)(acc[17] + c);
-    return r;
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 9) f29_col_mad(acc, a.v[i], b.v[k - i]);
+    });
 }
 
 // a^2 * 2^-261: cross products once, against the doubled operand (limbs < 2^30 for a normalized a)
 template <class F>
 FP_DEV f29 f29_sqr(const f29& a) {
-    u64 acc[18];
-#pragma unroll
-    for (int i = 0; i < 18; i++) acc[i] = 0;
     u32 d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+    return f29_montgomery_columns<F>([&](int k, u64& acc) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        // column contributions whose smaller index is i: a_i^2 and 2 a_i a_j (j > i)
-        acc[2 * i] = mad_wide(a.v[i], a.v[i], acc[2 * i]);
-#pragma unroll
-        for (int j = i + 1; j < 9; j++) acc[i + j] = mad_wide(d[i], a.v[j], acc[i + j]);
-    }
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        u32 m;
-        if (F::INV == F29_MASK) m = (0u - (u32)acc[i]) & F29_MASK;
-        else m = ((u32)acc[i] * F::INV) & F29_MASK;
-#pragma unroll
-        for (int j = 0; j < 9; j++)
-            if (F::P[j] != 0) acc[i + j] = mad_wide(m, F::P[j], acc[i + j]);
-        acc[i + 1] += acc[i] >> F29_BITS;
-    }
-    f29 r;
-    u64 c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        u64 t = acc[9 + j] + c;
-        r.v[j] = (u32)t & F29_MASK;
-        c = t >> F29_BITS;
-    }
-    r.v[8] = (u32)(acc[17] + c);
-    return r;
+        for (int i = 0; i < 9; i++)
+            if (k - i > i && k - i < 9) f29_col_mad(acc, d[i], a.v[k - i]);
+        if ((k & 1) == 0 && k / 2 < 9) f29_col_mad(acc, a.v[k / 2], a.v[k / 2]);
+    });
 }
 
 // v >= c ? v - c : v   on normalized limbs (c a normalized constant)

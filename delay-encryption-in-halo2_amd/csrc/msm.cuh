@@ -374,7 +374,8 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
     u32 beg = off[b] + j * g.L0;
     u32 end = min(beg + g.L0, off[b + 1]);
     // the next point's index is fetched one iteration ahead (dependent idx -> table[idx] chain);
-    // measured: prefetching the 64-B point too changes nothing -- the loop is VALU-issue-bound
+    // measured twice (also after the product-scanning multiplication): prefetching the 64-B point
+    // one iteration ahead too changes nothing, although SQ_WAIT_ANY is 24 % of the wave cycles
     affine_t pk = aff_load(&table[idx[beg] & 0x7fffffffu]);
     u32 e = idx[beg];
     bool is_id = aff_is_identity(pk);

@@ -35,7 +35,8 @@ t = sharding.max_over_ranks(float(rank + 1))
 assert t == float(world)
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok")
+sys.stdout.write("rank %d ok\n" % rank)   # one write: two ranks share the pipe
+sys.stdout.flush()
 '''
 
 
