@@ -13,9 +13,9 @@ The directory name has a hyphen, so load it with ``__graft_entry__.load_package(
 """
 from . import fields  # noqa: F401
 from ._lib import Context, DehaloError, Bases, library_path, load_library  # noqa: F401
-from .arithmetic import best_fft, best_multiexp  # noqa: F401
+from .arithmetic import batch_invert, best_fft, best_multiexp, eval_polynomial, grand_product  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
 from .commitment import Params  # noqa: F401
 
-__all__ = ["Context", "DehaloError", "Bases", "best_multiexp", "best_fft", "EvaluationDomain", "Params", "fields",
+__all__ = ["Context", "DehaloError", "Bases", "best_multiexp", "best_fft", "eval_polynomial", "batch_invert", "grand_product", "EvaluationDomain", "Params", "fields",
            "library_path", "load_library"]

@@ -18,9 +18,11 @@ SYMBOLS = [
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
+    "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
+    "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device",
 ]
 
-K_MSM_ACCUMULATE, K_MSM_SORT, K_MSM_REDUCE, K_NTT_PASS = 0, 1, 2, 3
+K_MSM_ACCUMULATE, K_MSM_SORT, K_MSM_REDUCE, K_NTT_PASS, K_POLY = 0, 1, 2, 3, 4
 
 
 class DehaloError(RuntimeError):
@@ -73,6 +75,13 @@ def load_library():
     lib.dehalo_coset_ntt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p, sz, P]
     lib.dehalo_coset_intt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p, sz, P]
     lib.dehalo_field_op.argtypes = [P, C.c_int, C.c_int, u64p, u64p, u64p, sz]
+    lib.dehalo_eval_polynomial.argtypes = [P, C.c_int, u64p, sz, u64p, u64p]
+    lib.dehalo_eval_polynomial_device.argtypes = [P, C.c_int, u64p, sz, sz, sz, u64p, u64p, P]
+    lib.dehalo_batch_invert.argtypes = [P, C.c_int, u64p, sz]
+    lib.dehalo_batch_invert_device.argtypes = [P, C.c_int, u64p, sz, P]
+    lib.dehalo_prefix_product_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
+    lib.dehalo_grand_product.argtypes = [P, C.c_int, u64p, u64p, sz, u64p]
+    lib.dehalo_grand_product_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, P]
     lib.dehalo_timing_enable.argtypes = [P, C.c_int]
     lib.dehalo_timing_reset.argtypes = [P]
     lib.dehalo_timing_get.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -226,6 +235,39 @@ class Context:
         bp = _ptr(_u64(b, 4)) if b is not None else None
         self._check(self.lib.dehalo_field_op(self.handle, field, self.OPS[op], _ptr(a), bp, _ptr(out), a.shape[0]))
         return out
+
+    # ---- field-vector primitives around the path ----
+    def eval_polynomial(self, field: int, coeffs, point) -> np.ndarray:
+        c = _u64(coeffs, 4)
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.dehalo_eval_polynomial(self.handle, field, _ptr(c) if c.shape[0] else None, c.shape[0], _ptr(_u64(point, 4)), _ptr(out)))
+        return out
+
+    def eval_polynomial_device(self, field: int, d_coeffs: int, length: int, stride: int, batch: int, point, d_out: int, stream: int = 0):
+        self._check(self.lib.dehalo_eval_polynomial_device(self.handle, field, d_coeffs, length, stride, batch, _ptr(_u64(point, 4)), d_out, stream or None))
+
+    def batch_invert(self, field: int, values) -> np.ndarray:
+        v = np.array(values, dtype=np.uint64).reshape(-1, 4)
+        self._check(self.lib.dehalo_batch_invert(self.handle, field, _ptr(v) if v.shape[0] else None, v.shape[0]))
+        return v
+
+    def batch_invert_device(self, field: int, d_values: int, length: int, stream: int = 0):
+        self._check(self.lib.dehalo_batch_invert_device(self.handle, field, d_values, length, stream or None))
+
+    def prefix_product_device(self, field: int, d_in: int, length: int, d_out: int, stream: int = 0):
+        self._check(self.lib.dehalo_prefix_product_device(self.handle, field, d_in, length, d_out, stream or None))
+
+    def grand_product(self, field: int, num, den) -> np.ndarray:
+        a, b = _u64(num, 4), _u64(den, 4)
+        if a.shape[0] != b.shape[0]:
+            raise ValueError("grand_product: num.len() != den.len()")
+        z = np.zeros_like(a)
+        if a.shape[0]:
+            self._check(self.lib.dehalo_grand_product(self.handle, field, _ptr(a), _ptr(b), a.shape[0], _ptr(z)))
+        return z
+
+    def grand_product_device(self, field: int, d_num: int, d_den: int, length: int, d_z: int, stream: int = 0):
+        self._check(self.lib.dehalo_grand_product_device(self.handle, field, d_num, d_den, length, d_z, stream or None))
 
     # ---- measurement ----
     def timing_enable(self, on: bool = True):

@@ -64,6 +64,35 @@ int do_field_op(dehalo_ctx* ctx, int field, int op, const fe* a, const fe* b, fe
     }
 }
 
+#define FIELD_SWITCH(ctx, field, CALL)                                                  \
+    switch (field) {                                                                    \
+        case DEHALO_FIELD_BN254_FR: return CALL(bn254_fr);                              \
+        case DEHALO_FIELD_BN254_FQ: return CALL(bn254_fq);                              \
+        case DEHALO_FIELD_PASTA_FP: return CALL(pasta_fp);                              \
+        case DEHALO_FIELD_PASTA_FQ: return CALL(pasta_fq);                              \
+        default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");           \
+    }
+int do_eval_poly(dehalo_ctx* ctx, int field, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s) {
+#define CALL(N) eval_poly_##N(ctx, c, len, stride, batch, pt, out, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_batch_invert(dehalo_ctx* ctx, int field, fe* v, uint64_t len, hipStream_t s) {
+#define CALL(N) batch_invert_##N(ctx, v, len, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_prefix_product(dehalo_ctx* ctx, int field, const fe* in, uint64_t len, fe* out, hipStream_t s) {
+#define CALL(N) prefix_product_##N(ctx, in, len, out, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_grand_product(dehalo_ctx* ctx, int field, const fe* num, const fe* den, uint64_t len, fe* z, hipStream_t s) {
+#define CALL(N) grand_product_##N(ctx, num, den, len, z, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+
 int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes, int window_bits, int precompute,
                   dehalo_bases** out) {
     if (!affine_xy || !out || n == 0 || stride_bytes < 64 || n >= (1ull << 30)) return dh_fail(ctx, DEHALO_ERR_INVALID, "bases_register: bad argument");
@@ -122,7 +151,8 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_out, &ctx->ws_count, &ctx->ws_counters, &ctx->ws_off, &ctx->ws_toff0, &ctx->ws_merge_lists,
                       &ctx->ws_bhist, &ctx->ws_pcount, &ctx->ws_pairs, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree,
                       &ctx->ws_gsums, &ctx->ws_ntt_scratch, &ctx->ws_ntt_io, &ctx->ws_ntt_io2, &ctx->ws_fop[0], &ctx->ws_fop[1], &ctx->ws_fop[2],
-                      &ctx->ws_tmp_bases};
+                      &ctx->ws_tmp_bases, &ctx->ws_poly[0], &ctx->ws_poly[1], &ctx->ws_poly[2], &ctx->ws_poly[3], &ctx->ws_poly_io[0], &ctx->ws_poly_io[1],
+                      &ctx->ws_poly_io[2]};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->twiddles) (void)hipFree(t.tw);
@@ -348,6 +378,95 @@ int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const
     if (b) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_fop[1].p, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
     TRY(do_field_op(ctx, field, op, (const fe*)ctx->ws_fop[0].p, b ? (const fe*)ctx->ws_fop[1].p : nullptr, (fe*)ctx->ws_fop[2].p, n, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->ws_fop[2].p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- field-vector primitives (poly.cuh) ---------------------------------------------------------
+int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
+                                  const uint64_t point[4], uint64_t* d_out, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_coeffs && len) || !point || !d_out) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: null argument");
+    if (batch > 1 && stride_elems < len) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: stride shorter than the polynomial");
+    if (batch >= 65536) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: batch too large");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_eval_poly(ctx, field, (const fe*)d_coeffs, len, stride_elems, batch, point, (fe*)d_out, pick_stream(ctx, stream));
+}
+
+int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!coeffs && len) || !point || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: null argument");
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        TRY(dh_ensure(ctx, ctx->ws_poly_io[0], std::max<size_t>(32, len * 32)));
+        TRY(dh_ensure(ctx, ctx->ws_poly_io[1], 32));
+        if (len) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, coeffs, len * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    TRY(dehalo_eval_polynomial_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, len, len, 1, point, (uint64_t*)ctx->ws_poly_io[1].p, nullptr));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->ws_poly_io[1].p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dehalo_batch_invert_device(dehalo_ctx* ctx, int field, uint64_t* d_values, size_t len, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!d_values && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "batch_invert: null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_batch_invert(ctx, field, (fe*)d_values, len, pick_stream(ctx, stream));
+}
+
+int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!values && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "batch_invert: null argument");
+    if (len == 0) return 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        TRY(dh_ensure(ctx, ctx->ws_poly_io[0], len * 32));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, values, len * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    TRY(dehalo_batch_invert_device(ctx, field, (uint64_t*)ctx->ws_poly_io[0].p, len, nullptr));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipMemcpyAsync(values, ctx->ws_poly_io[0].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, size_t len, uint64_t* d_out, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_in || !d_out) && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "prefix_product: null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_prefix_product(ctx, field, (const fe*)d_in, len, (fe*)d_out, pick_stream(ctx, stream));
+}
+
+int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, uint64_t* d_z, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_num || !d_den || !d_z) && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_grand_product(ctx, field, (const fe*)d_num, (const fe*)d_den, len, (fe*)d_z, pick_stream(ctx, stream));
+}
+
+int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const uint64_t* den, size_t len, uint64_t* z) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!num || !den || !z) && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: null argument");
+    if (len == 0) return 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        for (int i = 0; i < 3; i++) TRY(dh_ensure(ctx, ctx->ws_poly_io[i], len * 32));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, num, len * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[1].p, den, len * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    TRY(dehalo_grand_product_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, (const uint64_t*)ctx->ws_poly_io[1].p, len,
+                                    (uint64_t*)ctx->ws_poly_io[2].p, nullptr));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipMemcpyAsync(z, ctx->ws_poly_io[2].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -36,12 +36,12 @@ struct dehalo_ctx {
     std::mutex mu;
     // workspace (grow-only)
     DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_toff0, ws_merge_lists, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
-        ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases;
+        ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[4], ws_poly_io[3];
     std::vector<TwiddleEntry> twiddles;
     bool timing = false;
     std::vector<TimedRegion> regions;
-    double timing_ms[DEHALO_K_COUNT] = {0, 0, 0, 0};
-    uint64_t timing_cnt[DEHALO_K_COUNT] = {0, 0, 0, 0};
+    double timing_ms[DEHALO_K_COUNT] = {};
+    uint64_t timing_cnt[DEHALO_K_COUNT] = {};
 };
 
 struct dehalo_bases {
@@ -149,3 +149,15 @@ DECL_NTT(bn254_fq)
 DECL_NTT(pasta_fp)
 DECL_NTT(pasta_fq)
 #undef DECL_NTT
+
+// field-vector primitives (poly.cuh), instantiated in the same per-field translation units
+#define DECL_POLY(NAME)                                                                                                                     \
+    int eval_poly_##NAME(dehalo_ctx* ctx, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s); \
+    int batch_invert_##NAME(dehalo_ctx* ctx, fe* v, uint64_t len, hipStream_t s);                                                           \
+    int prefix_product_##NAME(dehalo_ctx* ctx, const fe* in, uint64_t len, fe* out, hipStream_t s);                                         \
+    int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, fe* z, hipStream_t s);
+DECL_POLY(bn254_fr)
+DECL_POLY(bn254_fq)
+DECL_POLY(pasta_fp)
+DECL_POLY(pasta_fq)
+#undef DECL_POLY

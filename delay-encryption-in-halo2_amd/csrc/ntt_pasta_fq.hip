@@ -1,3 +1,5 @@
-// NTT / field-op kernels + driver instantiated for PastaFq.
+// NTT / field-op / field-vector kernels + drivers instantiated for PastaFq.
 #include "ntt.cuh"
+#include "poly.cuh"
 DEFINE_NTT_ENTRY(pasta_fq, PastaFq)
+DEFINE_POLY_ENTRY(pasta_fq, PastaFq)

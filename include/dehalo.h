@@ -130,6 +130,33 @@ int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t
  *     6 mul evaluated through the kernels' internal carry-free 29-bit-limb representation.     */
 int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
+/* ---- field-vector primitives around the path ---------------------------
+ * Everything create_proof does between two commitments that is a scan over a column of field
+ * elements, so that columns can stay in HBM from one MSM / NTT to the next.  Elements are
+ * upstream's in-memory form (4 x u64 Montgomery limbs, canonical).
+ *
+ * dehalo_eval_polynomial: out = sum_i coeffs[i] * point^i; 0 for len == 0.  Replaces
+ *   halo2_proofs::arithmetic::eval_polynomial (halo2_proofs/src/arithmetic.rs @ v2023_04_20;
+ *   called for every opened polynomial in plonk/prover.rs after the challenge x is squeezed).
+ *   The device form evaluates `batch` polynomials (stride_elems apart) at the same point into
+ *   d_out[batch][4].
+ * dehalo_batch_invert: values[i] <- values[i]^-1 in place, zero elements left zero.  Replaces
+ *   ff::BatchInvert::batch_invert as used on the denominators of the permutation and lookup
+ *   grand products (plonk/permutation/prover.rs, plonk/lookup/prover.rs).
+ * dehalo_prefix_product_device: out[0] = 1, out[i] = in[0] * ... * in[i-1]  (in == out allowed).
+ * dehalo_grand_product: z[0] = 1, z[i] = prod_{j<i} num[j] / den[j] -- the running product
+ *   upstream builds after its batch_invert ("z.push(one); for row in 1..n { tmp *= product[row-1] }");
+ *   the caller appends upstream's blinding rows.  A zero denominator behaves like upstream's
+ *   batch_invert (left zero), so the product is zero from that row on.                          */
+int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]);
+int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
+                                  const uint64_t point[4], uint64_t* d_out, void* stream);
+int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len);
+int dehalo_batch_invert_device(dehalo_ctx* ctx, int field, uint64_t* d_values, size_t len, void* stream);
+int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, size_t len, uint64_t* d_out, void* stream);
+int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const uint64_t* den, size_t len, uint64_t* z);
+int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, uint64_t* d_z, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-kernel device time measured with HIP events on the launching stream (bench.py's
  * roofline leg).  kernel ids: see dehalo_kernel_id.                                          */
@@ -138,7 +165,8 @@ typedef enum {
     DEHALO_K_MSM_SORT = 1,       /* digit histogram + scatter                       */
     DEHALO_K_MSM_REDUCE = 2,     /* partial merge + bucket reduction                */
     DEHALO_K_NTT_PASS = 3,       /* all NTT passes of one transform                 */
-    DEHALO_K_COUNT = 4
+    DEHALO_K_POLY = 4,           /* eval_polynomial / batch_invert / prefix product */
+    DEHALO_K_COUNT = 5
 } dehalo_kernel_id;
 int dehalo_timing_enable(dehalo_ctx* ctx, int on);
 int dehalo_timing_reset(dehalo_ctx* ctx);

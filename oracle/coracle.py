@@ -35,6 +35,9 @@ def lib():
         _LIB.orc_field_info.argtypes = [C.c_int, P, P, P, P]
         _LIB.orc_fill_scalars.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_size_t, P]
         _LIB.orc_synth_bases.argtypes = [C.c_int, C.c_size_t, P]
+        _LIB.orc_eval_polynomial.argtypes = [C.c_int, P, C.c_size_t, P, C.c_int, P]
+        _LIB.orc_batch_invert.argtypes = [C.c_int, P, C.c_size_t]
+        _LIB.orc_grand_product.argtypes = [C.c_int, P, P, C.c_size_t, P]
     return _LIB
 
 
@@ -116,3 +119,24 @@ def synth_bases(curve: int, n: int) -> np.ndarray:
     out = np.zeros((n, 8), dtype=np.uint64)
     assert lib().orc_synth_bases(curve, n, _p(out)) == 0
     return out
+
+
+def eval_polynomial(field: int, coeffs: np.ndarray, point: np.ndarray, threads: int = 1) -> np.ndarray:
+    c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    assert lib().orc_eval_polynomial(field, _p(c), c.shape[0], _p(np.ascontiguousarray(point, dtype=np.uint64)), threads, _p(out)) == 0
+    return out
+
+
+def batch_invert(field: int, values: np.ndarray) -> np.ndarray:
+    v = np.array(values, dtype=np.uint64).reshape(-1, 4)
+    assert lib().orc_batch_invert(field, _p(v), v.shape[0]) == 0
+    return v
+
+
+def grand_product(field: int, num: np.ndarray, den: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(num, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(den, dtype=np.uint64).reshape(-1, 4)
+    z = np.zeros_like(a)
+    assert lib().orc_grand_product(field, _p(a), _p(b), a.shape[0], _p(z)) == 0
+    return z

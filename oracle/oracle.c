@@ -440,6 +440,84 @@ int orc_extended_to_coeff(int field, u64* a, uint32_t ext_k, const u64 ext_omega
     return 0;
 }
 
+/* ---------- field-vector primitives around the path (Montgomery in/out) ----------
+ * eval_polynomial: [UPSTREAM halo2_proofs/src/arithmetic.rs] serial Horner below 2^? terms, else one
+ * Horner per thread chunk, scaled by point^(chunk start) and summed. */
+typedef struct { const field_t* F; const fe* c; size_t n; fe point; fe res; } evp_job;
+static void* evp_worker(void* arg) {
+    evp_job* j = arg;
+    fe acc; memset(&acc, 0, sizeof(acc));
+    for (size_t i = j->n; i-- > 0;) { f_mul(j->F, &acc, &acc, &j->point); f_add(j->F, &acc, &acc, &j->c[i]); }
+    j->res = acc;
+    return NULL;
+}
+int orc_eval_polynomial(int field, const u64* coeffs, size_t n, const u64 point[4], int threads, u64 out[4]) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if (n < (size_t)threads || threads == 1) {
+        evp_job j = {F, (const fe*)coeffs, n, *(const fe*)point, {{0}}};
+        evp_worker(&j);
+        memcpy(out, &j.res, 32);
+        return 0;
+    }
+    size_t chunk = (n + threads - 1) / threads;
+    evp_job jobs[256]; pthread_t th[256];
+    int used = 0;
+    for (size_t st = 0; st < n; st += chunk, used++) {
+        jobs[used].F = F; jobs[used].c = (const fe*)coeffs + st; jobs[used].n = st + chunk <= n ? chunk : n - st;
+        jobs[used].point = *(const fe*)point;
+        pthread_create(&th[used], NULL, evp_worker, &jobs[used]);
+    }
+    fe step = F->r, sum, pw = F->r;               /* point^chunk, running power */
+    { u64 e[4] = {chunk, 0, 0, 0}; f_pow(F, &step, (const fe*)point, e); }
+    memset(&sum, 0, sizeof(sum));
+    for (int i = 0; i < used; i++) {
+        pthread_join(th[i], NULL);
+        fe t; f_mul(F, &t, &jobs[i].res, &pw); f_add(F, &sum, &sum, &t);
+        f_mul(F, &pw, &pw, &step);
+    }
+    memcpy(out, &sum, 32);
+    return 0;
+}
+/* batch_invert: [UPSTREAM ff::BatchInvert] one inversion, zeros skipped.  scratch = n elements. */
+int orc_batch_invert(int field, u64* v_, size_t n) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    fe* v = (fe*)v_;
+    fe* prefix = malloc((n ? n : 1) * sizeof(fe));
+    if (!prefix) return -3;
+    fe acc = F->r;
+    for (size_t i = 0; i < n; i++) { prefix[i] = acc; if (!f_is_zero(&v[i])) f_mul(F, &acc, &acc, &v[i]); }
+    fe inv; f_inv(F, &inv, &acc);
+    for (size_t i = n; i-- > 0;) {
+        if (f_is_zero(&v[i])) continue;
+        fe t = v[i];
+        f_mul(F, &v[i], &inv, &prefix[i]);
+        f_mul(F, &inv, &inv, &t);
+    }
+    free(prefix);
+    return 0;
+}
+/* grand product: [UPSTREAM plonk/permutation/prover.rs, plonk/lookup/prover.rs] z[0] = 1, z[i] = z[i-1] num[i-1] / den[i-1] */
+int orc_grand_product(int field, const u64* num_, const u64* den_, size_t n, u64* z_) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    fe* dinv = malloc((n ? n : 1) * sizeof(fe));
+    if (!dinv) return -3;
+    memcpy(dinv, den_, n * sizeof(fe));
+    orc_batch_invert(field, (u64*)dinv, n);
+    const fe* num = (const fe*)num_; fe* z = (fe*)z_;
+    fe acc = F->r;
+    for (size_t i = 0; i < n; i++) { z[i] = acc; fe t; f_mul(F, &t, &num[i], &dinv[i]); f_mul(F, &acc, &acc, &t); }
+    free(dinv);
+    return 0;
+}
+
 /* ---------- field ops exposed for the KAT pin (Montgomery in/out) ---------- */
 int orc_field_op(int field, int op, const u64* a, const u64* b, u64* out, size_t n) {
     if (field < 0 || field > 3) return -1;

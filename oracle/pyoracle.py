@@ -318,6 +318,48 @@ def synth_bases(c: Curve, n: int) -> List[Affine]:
 
 
 # ----------------------------------------------------------------------------
+# Field-vector primitives around the path (SURVEY.md 8(f) row 2).  Canonical ints in and out.
+# ----------------------------------------------------------------------------
+def eval_polynomial(f: Field, poly: Sequence[int], point: int) -> int:
+    """[UPSTREAM halo2_proofs/src/arithmetic.rs eval_polynomial] Horner: sum_i poly[i] point^i."""
+    acc = 0
+    for c in reversed(poly):
+        acc = (acc * point + c) % f.p
+    return acc
+
+
+def batch_invert(f: Field, values: Sequence[int]) -> List[int]:
+    """[UPSTREAM ff::BatchInvert] Montgomery's trick; zero elements are skipped and stay zero."""
+    p = f.p
+    acc, prefix = 1, []
+    for v in values:
+        prefix.append(acc)
+        if v % p:
+            acc = acc * v % p
+    inv = pow(acc, p - 2, p)
+    out = [0] * len(values)
+    for i in range(len(values) - 1, -1, -1):
+        v = values[i] % p
+        if v:
+            out[i] = inv * prefix[i] % p
+            inv = inv * v % p
+    return out
+
+
+def grand_product(f: Field, num: Sequence[int], den: Sequence[int]) -> List[int]:
+    """[UPSTREAM plonk/permutation/prover.rs, plonk/lookup/prover.rs] z[0] = 1,
+    z[i] = z[i-1] * num[i-1] * den[i-1]^-1, denominators inverted with batch_invert (a zero
+    denominator stays zero and zeroes the product from there on); blinding rows not included."""
+    assert len(num) == len(den)
+    dinv = batch_invert(f, den)
+    z, acc = [], 1
+    for a, d in zip(num, dinv):
+        z.append(acc)
+        acc = acc * a % f.p * d % f.p
+    return z
+
+
+# ----------------------------------------------------------------------------
 # NTT (best_fft) and EvaluationDomain wrappers
 # ----------------------------------------------------------------------------
 def dft_naive(f: Field, a: Sequence[int], omega: int) -> List[int]:

@@ -86,9 +86,28 @@ def msm_vectors():
 def bases_vectors():
     return {cname: [[hx(P[0]), hx(P[1])] for P in po.synth_bases(po.CURVES[cname], 256)] for cname in ("bn254", "pallas", "vesta")}
 
+def poly_vectors():
+    """eval_polynomial / batch_invert / grand_product, canonical hex."""
+    out = []
+    for fname in ("bn254_fr", "pasta_fp", "pasta_fq"):
+        f = po.FIELDS[fname]
+        rng = po.Xoshiro(0xF2 + po.FIELD_IDS[fname])
+        for n in (0, 1, 5, 64, 300):
+            poly = [rng.below(f.p) for _ in range(n)]
+            for x in (0, 1, f.p - 1, rng.below(f.p)):
+                out.append({"op": "eval_polynomial", "field": fname, "poly": [hx(c) for c in poly], "point": hx(x), "result": hx(po.eval_polynomial(f, poly, x))})
+        vals = [0, 1, f.p - 1, 2, 0, 0] + [rng.below(f.p) for _ in range(120)] + [0]
+        out.append({"op": "batch_invert", "field": fname, "values": [hx(v) for v in vals], "result": [hx(v) for v in po.batch_invert(f, vals)]})
+        num = [rng.below(f.p) for _ in range(130)]
+        den = [rng.below(f.p - 1) + 1 for _ in range(130)]
+        out.append({"op": "grand_product", "field": fname, "num": [hx(v) for v in num], "den": [hx(v) for v in den], "result": [hx(v) for v in po.grand_product(f, num, den)]})
+        den[40] = 0   # upstream's batch_invert leaves a zero denominator zero
+        out.append({"op": "grand_product", "field": fname, "num": [hx(v) for v in num], "den": [hx(v) for v in den], "result": [hx(v) for v in po.grand_product(f, num, den)]})
+    return out
+
 if __name__ == "__main__":
     po.self_check()
-    for name, fn in (("ntt", ntt_vectors), ("domain", domain_vectors), ("msm", msm_vectors), ("bases", bases_vectors)):
+    for name, fn in (("ntt", ntt_vectors), ("domain", domain_vectors), ("msm", msm_vectors), ("bases", bases_vectors), ("poly", poly_vectors)):
         with open(os.path.join(HERE, name + ".json"), "w") as fh:
             json.dump(fn(), fh, separators=(",", ":"))
         print("wrote", name)

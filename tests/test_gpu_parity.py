@@ -380,3 +380,100 @@ def test_ntt_batched_device_entry_points(pkg, po, co, ctx):
         ctx.intt_scaled_device(f.id, d.data_ptr(), k, f.encode(of.inv(of.omega(k))), f.encode(of.inv(1 << k)), batch, 0)
         ctx.synchronize()
         assert np.array_equal(d.cpu().numpy().view(np.uint64), polys)
+
+
+# ---------------------------------------------------------------- field-vector primitives
+def test_poly_golden(pkg, ctx):
+    for v in golden("poly"):
+        spec = pkg.fields.FIELDS[v["field"]]
+        if v["op"] == "eval_polynomial":
+            poly = spec.encode_many([int(c, 16) for c in v["poly"]]) if v["poly"] else np.zeros((0, 4), dtype=np.uint64)
+            got = pkg.eval_polynomial(ctx, spec, poly, spec.encode(int(v["point"], 16)))
+            assert spec.decode(got) == int(v["result"], 16), (v["field"], len(v["poly"]), v["point"])
+        elif v["op"] == "batch_invert":
+            got = pkg.batch_invert(ctx, spec, spec.encode_many([int(c, 16) for c in v["values"]]))
+            assert spec.decode_many(got) == [int(c, 16) for c in v["result"]]
+        else:
+            got = pkg.grand_product(ctx, spec, spec.encode_many([int(c, 16) for c in v["num"]]), spec.encode_many([int(c, 16) for c in v["den"]]))
+            assert spec.decode_many(got) == [int(c, 16) for c in v["result"]]
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_eval_polynomial_vs_c_oracle(pkg, co, ctx, fid):
+    x = co.fill_scalars(fid, "uniform", 1, 900 + fid)[0]
+    # tile edges (2048 coefficients per block), two and three tree levels
+    for n in (1, 7, 8, 9, 2047, 2048, 2049, 5000, (1 << 16) + 3, 1 << 20, (1 << 22) + 5):
+        c = co.fill_scalars(fid, "uniform", n, 901 + n % 97)
+        assert np.array_equal(ctx.eval_polynomial(fid, c, x), co.eval_polynomial(fid, c, x, 16)), (fid, n)
+    zero = np.zeros(4, dtype=np.uint64)
+    c = co.fill_scalars(fid, "uniform", 3000, 5)
+    assert np.array_equal(ctx.eval_polynomial(fid, c, zero), c[0])                 # p(0) = c_0
+    assert not ctx.eval_polynomial(fid, np.zeros((0, 4), dtype=np.uint64), x).any()  # empty polynomial -> 0
+
+
+def test_eval_polynomial_device_batch(pkg, co, ctx):
+    import torch
+    fid, n, stride, batch = 0, 70000, 70016, 5
+    cols = np.zeros((batch, stride, 4), dtype=np.uint64)
+    for b in range(batch):
+        cols[b, :n] = co.fill_scalars(fid, "uniform", n, 40 + b)
+        cols[b, n:] = co.fill_scalars(fid, "uniform", stride - n, 50 + b)      # must be ignored
+    x = co.fill_scalars(fid, "uniform", 1, 60)[0]
+    d = torch.from_numpy(cols.view(np.int64)).cuda()
+    out = torch.zeros((batch, 4), dtype=torch.int64, device="cuda")
+    ctx.eval_polynomial_device(fid, d.data_ptr(), n, stride, batch, x, out.data_ptr(), 0)
+    ctx.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        assert np.array_equal(got[b], co.eval_polynomial(fid, cols[b, :n], x, 8)), b
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_batch_invert_vs_c_oracle(pkg, co, ctx, fid):
+    for n in (1, 3, 1023, 1024, 1025, 4096, (1 << 16) + 7):
+        v = co.fill_scalars(fid, "uniform", n, 300 + n % 89)
+        v[:: 5] = 0 if n > 3 else v[:: 5]                                       # zeros stay zero
+        if n > 2000:
+            v[1024:2048] = 0                                                     # a whole block of zeros
+        assert np.array_equal(ctx.batch_invert(fid, v), co.batch_invert(fid, v)), (fid, n)
+    assert ctx.batch_invert(fid, np.zeros((0, 4), dtype=np.uint64)).shape == (0, 4)
+
+
+def test_batch_invert_full_size_property(pkg, co, ctx):
+    """2^20 elements: v * v^-1 = 1 through the element-wise kernel, and spot rows against the oracle."""
+    fid, n = 0, 1 << 20
+    v = co.fill_scalars(fid, "uniform", n, 31337)
+    inv = ctx.batch_invert(fid, v)
+    prod = ctx.field_op(fid, "mul", v, inv)
+    one = ctx.field_op(fid, "to_mont", np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+    assert (prod == one).all()
+    assert np.array_equal(inv[:4096], co.field_op(fid, "inv", v[:4096]))
+
+
+@pytest.mark.parametrize("fid", [0, 2, 3])
+def test_grand_product_vs_c_oracle(pkg, co, ctx, fid):
+    for n in (1, 4, 1023, 1024, 1025, 5000, (1 << 18) + 11, 1 << 20):
+        num = co.fill_scalars(fid, "uniform", n, 400 + n % 83)
+        den = co.fill_scalars(fid, "uniform", n, 500 + n % 83)
+        assert np.array_equal(ctx.grand_product(fid, num, den), co.grand_product(fid, num, den)), (fid, n)
+    # a permutation-argument-shaped case: num is a permutation of den -> the product telescopes back to 1
+    n = 1 << 16
+    den = co.fill_scalars(fid, "uniform", n, 7)
+    num = den[np.random.default_rng(5).permutation(n)]
+    z = ctx.grand_product(fid, num, den)
+    last = ctx.field_op(fid, "mul", ctx.field_op(fid, "mul", z[-1:], num[-1:]), ctx.field_op(fid, "inv", den[-1:]))
+    one = ctx.field_op(fid, "to_mont", np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    assert np.array_equal(z[0], one[0]) and np.array_equal(last, one)
+    with pytest.raises(ValueError):
+        pkg.grand_product(ctx, pkg.fields.FIELDS["bn254_fr"], num[:5], den[:4])
+
+
+def test_prefix_product_device_in_place(pkg, co, ctx):
+    import torch
+    fid, n = 2, 100003
+    v = co.fill_scalars(fid, "uniform", n, 8)
+    d = torch.from_numpy(v.view(np.int64).copy()).cuda()
+    ctx.prefix_product_device(fid, d.data_ptr(), n, d.data_ptr(), 0)
+    ctx.synchronize()
+    ones = ctx.field_op(fid, "to_mont", np.tile(np.array([[1, 0, 0, 0]], dtype=np.uint64), (n, 1)))
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), co.grand_product(fid, v, ones))

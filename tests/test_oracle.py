@@ -162,3 +162,43 @@ def test_c_fft_roundtrip_and_threads(po, co):
     ninv = co.limbs(f.to_mont(f.inv(1 << k)))
     back = co.field_op(fid, "mul", back, np.tile(ninv, (1 << k, 1)))
     assert np.array_equal(back, a)
+
+
+# ---------------------------------------------------------------- field-vector primitives
+def _enc(po, f, vals):
+    return np.array([[(f.to_mont(v) >> (64 * i)) & (2**64 - 1) for i in range(4)] for v in vals], dtype=np.uint64).reshape(-1, 4)
+
+
+def _dec(po, f, arr):
+    return [f.from_mont(po.from_limbs64(r)) for r in np.asarray(arr).reshape(-1, 4)]
+
+
+def test_poly_golden_vs_both_oracles(po, co, golden_loader):
+    for v in golden_loader("poly"):
+        f = po.FIELDS[v["field"]]
+        fid = po.FIELD_IDS[v["field"]]
+        if v["op"] == "eval_polynomial":
+            poly, x, want = [int(c, 16) for c in v["poly"]], int(v["point"], 16), int(v["result"], 16)
+            assert po.eval_polynomial(f, poly, x) == want
+            assert want == sum(c * pow(x, i, f.p) for i, c in enumerate(poly)) % f.p       # the definition
+            for threads in (1, 3):
+                assert _dec(po, f, co.eval_polynomial(fid, _enc(po, f, poly), _enc(po, f, [x])[0], threads)) == [want]
+        elif v["op"] == "batch_invert":
+            vals, want = [int(c, 16) for c in v["values"]], [int(c, 16) for c in v["result"]]
+            assert po.batch_invert(f, vals) == want
+            assert all((a * b) % f.p == (1 if a else 0) for a, b in zip(vals, want))
+            assert _dec(po, f, co.batch_invert(fid, _enc(po, f, vals))) == want
+        else:
+            num, den, want = ([int(c, 16) for c in v[k]] for k in ("num", "den", "result"))
+            assert po.grand_product(f, num, den) == want
+            assert _dec(po, f, co.grand_product(fid, _enc(po, f, num), _enc(po, f, den))) == want
+
+
+def test_c_eval_polynomial_threads_agree(po, co):
+    f = po.PASTA_FP
+    fid = po.FIELD_IDS[f.name]
+    c = co.fill_scalars(fid, "uniform", 5000, 77)
+    x = co.fill_scalars(fid, "uniform", 1, 78)[0]
+    one = co.eval_polynomial(fid, c, x, 1)
+    for t in (2, 7, 64):
+        assert np.array_equal(co.eval_polynomial(fid, c, x, t), one)
