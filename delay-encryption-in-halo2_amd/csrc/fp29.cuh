@@ -115,6 +115,85 @@ FP_DEV f29 f29_sub(const f29& a, const f29& b, const u32 (&K)[9]) {
 
 FP_DEV u64 mad_wide(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
 
+// Operand scanning (18 independent column accumulators).  More instructions
+// than product scanning (a carry add per column) but no dependent multiply-add chain, hence none
+// of the s_nop wait states hipcc must put between dependent v_mad_u64_u32 (about 130 per
+// multiplication, 4 cycles each when a wave runs alone).  Same values.
+template <class F>
+FP_DEV f29 f29_mul_os(const f29& a, const f29& b) {
+    u64 acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) acc[i + j] = mad_wide(a.v[i], b.v[j], acc[i + j]);
+        u32 m;
+        if (F::INV == F29_MASK) m = (0u - (u32)acc[i]) & F29_MASK;   // p = 1 mod 2^29 (Pasta)
+        else m = ((u32)acc[i] * F::INV) & F29_MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (F::P[j] != 0) acc[i + j] = mad_wide(m, F::P[j], acc[i + j]);
+        acc[i + 1] += acc[i] >> F29_BITS;
+    }
+    f29 r;
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u64 t = acc[9 + j] + c;
+        r.v[j] = (u32)t & F29_MASK;
+        c = t >> F29_BITS;
+    }
+    r.v[8] = (u32)(acc[17] + c);
+    return r;
+}
+
+// a^2, latency schedule
+template <class F>
+FP_DEV f29 f29_sqr_os(const f29& a) {
+    u64 acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) acc[i] = 0;
+    u32 d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        // column contributions whose smaller index is i: a_i^2 and 2 a_i a_j (j > i)
+        acc[2 * i] = mad_wide(a.v[i], a.v[i], acc[2 * i]);
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) acc[i + j] = mad_wide(d[i], a.v[j], acc[i + j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 m;
+        if (F::INV == F29_MASK) m = (0u - (u32)acc[i]) & F29_MASK;
+        else m = ((u32)acc[i] * F::INV) & F29_MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (F::P[j] != 0) acc[i + j] = mad_wide(m, F::P[j], acc[i + j]);
+        acc[i + 1] += acc[i] >> F29_BITS;
+    }
+    f29 r;
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u64 t = acc[9 + j] + c;
+        r.v[j] = (u32)t & F29_MASK;
+        c = t >> F29_BITS;
+    }
+    r.v[8] = (u32)(acc[17] + c);
+    return r;
+}
+
+// Schedule selection: f29_lat<F> marks a field whose multiplications use the operand-scanning
+// schedule.  Chosen per kernel by measurement: the MSM's merge / bucket-reduction kernels (group
+// additions on ~170 live registers at 2-3 waves per SIMD) run 8 % faster with it; the bucket
+// accumulation, the NTT and even the lone-wave Fermat inversion are faster with product scanning.
+template <class F9> struct f29_lat : F9 { static constexpr bool LATENCY = true; };
+template <class F, class = void> struct f29_is_lat { static constexpr bool value = false; };
+template <class F> struct f29_is_lat<F, decltype((void)F::LATENCY)> { static constexpr bool value = true; };
+
 // One multiply-add step of a column.  The empty asm pins the association order: without it LLVM
 // reassociates the 64-bit sums and the carry of the previous column comes back as a separate
 // v_lshl_add_u64 (4.4 cycles) instead of being the addend of the column's first v_mad_u64_u32.
@@ -167,7 +246,8 @@ FP_DEV f29 f29_montgomery_columns(const PROD& products) {
 // Limb-size contract: bits(max a limb) + bits(max b limb) <= 60.
 template <class F>
 FP_DEV f29 f29_mul(const f29& a, const f29& b) {
-    return f29_montgomery_columns<F>([&](int k, u64& acc) {
+    if constexpr (f29_is_lat<F>::value) return f29_mul_os<F>(a, b);
+    else return f29_montgomery_columns<F>([&](int k, u64& acc) {
 #pragma unroll
         for (int i = 0; i < 9; i++)
             if (k - i >= 0 && k - i < 9) f29_col_mad(acc, a.v[i], b.v[k - i]);
@@ -177,6 +257,7 @@ FP_DEV f29 f29_mul(const f29& a, const f29& b) {
 // a^2 * 2^-261: cross products once, against the doubled operand (limbs < 2^30 for a normalized a)
 template <class F>
 FP_DEV f29 f29_sqr(const f29& a) {
+    if constexpr (f29_is_lat<F>::value) return f29_sqr_os<F>(a);
     u32 d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, c
 // one lane per bucket.  The choice is made on the device from the list length.
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter, const u32* list) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     const u32 count = *counter;
     if (count <= 16384) {
         const u32 role = threadIdx.x & 3;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* toff, const 
 template <class CV, int G>
 __global__ __launch_bounds__(256) void k_msm_merge_group(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter,
                                                         const u32* list) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     const u32 count = *counter;
     const u32 groups_per_block = 256 / G;
     const u32 gl = threadIdx.x & (G - 1), grp = threadIdx.x / G;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_group(const u32* toff, const 
 template <class CV>
 __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
                                                                      const u32* counter, const u32* list) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[MSM_HEAVY_THREADS / 64];
     const u32 count = *counter;
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32
 // per block (QUAD = false): quads trade 1.6x the work for 2.4x less latency.
 template <class CV, bool QUAD>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     const u32 per_group = (nb + MSM_RED_M - 1) / MSM_RED_M;
     u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
     if (gid >= per_group * total_groups) return;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u3
 #define MSM_TREE_ITEMS 128
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 cnt, xyzz29_rec* out, u32 out_cnt) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[64];
     const u32 qd = threadIdx.x >> 2, role = threadIdx.x & 3;
     u32 grp = blockIdx.y;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 
 // LDS tree (the one-shot, unregistered-bases path only).
 template <class CV>
 __global__ __launch_bounds__(64) void k_msm_final(MsmGeom g, const xyzz29_rec* group_sums, jacobian_t* out) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[64];
     u32 bat = blockIdx.x;
     u32 w = threadIdx.x;

@@ -37,6 +37,8 @@ FP_DEV f29 poly_load_packed(const fe* p) { return f29_unpack(f_load(p)); }
 template <class F9>
 FP_DEV f29 f29_inv(const f29& a) {
     typedef typename F9::Std F;
+    // (measured: the operand-scanning schedule is 1.5x SLOWER here -- a lone wave pays per instruction,
+    // and product scanning has fewer of them even counting its wait states)
     u32 e[8];
     u64 br = 2;
 #pragma unroll
@@ -119,19 +121,17 @@ __global__ __launch_bounds__(POLY_THREADS) void k_poly_eval(const fe* coeffs, u6
 }
 
 // ---- batch inversion -----------------------------------------------------------------------------
-// One block inverts 1024 elements with ONE exponentiation: four per thread (strided, so the loads
-// coalesce -- Montgomery's trick does not care about order), thread products, block-wide prefix
-// and suffix products in LDS, the block total inverted by wave 0, then
-//   inv(T_t) = inv(total) * prefix_excl(t) * suffix_excl(t)   and the usual back-substitution.
-template <class F>
-__global__ __launch_bounds__(POLY_THREADS) void k_batch_invert(fe* v, u64 len) {
+// A block owns 1024 elements, four per thread (strided, so the loads coalesce -- Montgomery's
+// trick does not care about order): thread products, block-wide prefix and suffix products in
+// LDS, then  inv(T_t) = inv(block total) * prefix_excl(t) * suffix_excl(t)  and the usual
+// back-substitution.  The block totals are themselves batch-inverted one level up (same kernels
+// on the packed totals), so a call of any size runs exactly ONE Fermat exponentiation -- the
+// ~0.2 ms latency floor of the whole operation -- in the single block at the top of the recursion:
+//   k_bi_reduce (per level, going up)  ->  k_batch_invert<.., TOP> (1 block)  ->  k_batch_invert (going down).
+// PACKED: elements are internal-form packed words (the totals), never zero.
+template <class F, bool PACKED>
+FP_DEV void bi_load(const fe* v, u64 len, u64 base, f29 (&a)[POLY_K], bool (&live)[POLY_K]) {
     typedef typename f29_of<F>::type F9;
-    __shared__ f29 pre[POLY_THREADS], suf[POLY_THREADS];
-    __shared__ f29 inv_total;
-    const u32 t = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * POLY_PTILE + t;
-    f29 a[POLY_K];
-    bool live[POLY_K];
 #pragma unroll
     for (int j = 0; j < POLY_K; j++) {
         u64 i = base + (u64)j * POLY_THREADS;
@@ -139,19 +139,56 @@ __global__ __launch_bounds__(POLY_THREADS) void k_batch_invert(fe* v, u64 len) {
         a[j] = f29_one<F9>();
         if (i < len) {
             fe raw = f_load(&v[i]);
-            if (!f_is_zero(raw)) { live[j] = true; a[j] = f29_from_std<F9>(raw); }
+            if (PACKED) { live[j] = true; a[j] = f29_unpack(raw); }
+            else if (!f_is_zero(raw)) { live[j] = true; a[j] = f29_from_std<F9>(raw); }
         }
     }
+}
+
+// totals[block] = product of the block's non-zero elements (packed internal form)
+template <class F, bool PACKED>
+__global__ __launch_bounds__(POLY_THREADS) void k_bi_reduce(const fe* v, u64 len, fe* totals) {
+    typedef typename f29_of<F>::type F9;
+    __shared__ f29 sh[POLY_THREADS];
+    const u32 t = threadIdx.x;
+    f29 a[POLY_K];
+    bool live[POLY_K];
+    bi_load<F, PACKED>(v, len, (u64)blockIdx.x * POLY_PTILE + t, a, live);
+    sh[t] = f29_mul<F9>(f29_mul<F9>(a[0], a[1]), f29_mul<F9>(a[2], a[3]));
+    __syncthreads();
+    for (u32 d = POLY_THREADS / 2; d >= 1; d >>= 1) {
+        if (t < d) sh[t] = f29_mul<F9>(sh[t], sh[t + d]);
+        __syncthreads();
+    }
+    if (t == 0) poly_store_packed<F9>(&totals[blockIdx.x], sh[0]);
+}
+
+// TOP: the block inverts its own total (grid of one block); otherwise inv_totals[block] holds it.
+template <class F, bool PACKED, bool TOP>
+__global__ __launch_bounds__(POLY_THREADS) void k_batch_invert(fe* v, u64 len, const fe* inv_totals) {
+    typedef typename f29_of<F>::type F9;
+    __shared__ f29 pre[POLY_THREADS], suf[POLY_THREADS];
+    __shared__ f29 inv_total;
+    const u32 t = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * POLY_PTILE + t;
+    f29 a[POLY_K];
+    bool live[POLY_K];
+    bi_load<F, PACKED>(v, len, base, a, live);
     const f29 p2 = f29_mul<F9>(a[0], a[1]);
     const f29 p3 = f29_mul<F9>(p2, a[2]);
     const f29 T = f29_mul<F9>(p3, a[3]);
     block_scan_mul<F9, true>(pre, suf, T);
-    if (t < 64) {                                            // one wave, every lane the same value
-        f29 inv = f29_inv<F9>(pre[POLY_THREADS - 1]);
-        if (t == 0) inv_total = inv;
+    f29 u;
+    if (TOP) {
+        if (t < 64) {                                        // one wave, every lane the same value
+            f29 inv = f29_inv<F9>(pre[POLY_THREADS - 1]);
+            if (t == 0) inv_total = inv;
+        }
+        __syncthreads();
+        u = inv_total;
+    } else {
+        u = poly_load_packed(&inv_totals[blockIdx.x]);
     }
-    __syncthreads();
-    f29 u = inv_total;
     if (t > 0) u = f29_mul<F9>(u, pre[t - 1]);
     if (t + 1 < POLY_THREADS) u = f29_mul<F9>(u, suf[t + 1]);
     // u = 1 / (a0 a1 a2 a3)
@@ -163,7 +200,10 @@ __global__ __launch_bounds__(POLY_THREADS) void k_batch_invert(fe* v, u64 len) {
 #pragma unroll
     for (int j = 0; j < POLY_K; j++) {
         u64 i = base + (u64)j * POLY_THREADS;
-        if (i < len && live[j]) poly_store<F9>(&v[i], r[j]);
+        if (i < len && live[j]) {
+            if (PACKED) poly_store_packed<F9>(&v[i], r[j]);
+            else poly_store<F9>(&v[i], r[j]);
+        }
     }
 }
 
@@ -270,11 +310,26 @@ int eval_poly_t(dehalo_ctx* ctx, const fe* d_coeffs, uint64_t len, uint64_t stri
     return 0;
 }
 
+template <class F, bool PACKED>
+int batch_invert_level(dehalo_ctx* ctx, fe* d_v, uint64_t len, fe* scratch, hipStream_t s) {
+    const uint64_t nb = (len + POLY_PTILE - 1) / POLY_PTILE;
+    if (nb == 1) {
+        k_batch_invert<F, PACKED, true><<<1, POLY_THREADS, 0, s>>>(d_v, len, nullptr);
+        return 0;
+    }
+    k_bi_reduce<F, PACKED><<<(u32)nb, POLY_THREADS, 0, s>>>(d_v, len, scratch);
+    TRY((batch_invert_level<F, true>(ctx, scratch, nb, scratch + nb, s)));
+    k_batch_invert<F, PACKED, false><<<(u32)nb, POLY_THREADS, 0, s>>>(d_v, len, scratch);
+    return 0;
+}
+
 template <class F>
 int batch_invert_t(dehalo_ctx* ctx, fe* d_v, uint64_t len, hipStream_t s) {
     if (len == 0) return 0;
     ScopedTimer timer(ctx, s, DEHALO_K_POLY);
-    k_batch_invert<F><<<(u32)((len + POLY_PTILE - 1) / POLY_PTILE), POLY_THREADS, 0, s>>>(d_v, len);
+    const uint64_t nb = (len + POLY_PTILE - 1) / POLY_PTILE;
+    TRY(dh_ensure(ctx, ctx->ws_poly[4], (nb + nb / 512 + 8) * sizeof(fe)));     // totals of every level
+    TRY((batch_invert_level<F, false>(ctx, d_v, len, (fe*)ctx->ws_poly[4].p, s)));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
