@@ -19,8 +19,12 @@
 // once per (field, omega, log_n); the R/2 roots of the sub-transform are staged in LDS.  Every
 // multiplication runs on the carry-free multiplier of fp29.cuh.  Pre-/post-scaling of
 // lagrange_to_coeff / coeff_to_extended / extended_to_coeff (x n^-1, x zeta^(i mod 3), zero
-// padding) is fused into the first load and the last store.  HBM-bound by design (64 B/element
-// algorithmic); the measured bound on gfx950 is the VALU (v_mad_u64_u32) -- see DESIGN.md.
+// padding) is fused into the first load and the last store.  64 B/element algorithmic, but on
+// gfx950 the bound is the VALU: log2(N)/2 + L multiplications per element at ~200 Gmul/s is 6x
+// the HBM time.  Measured by elimination (23 x 2^19, bn256::Fr, 1.37 ms): butterfly stages 0.63,
+// global load + store 0.26, everything else (index math, LDS fill, the per-pass output
+// multiplication) 0.39; multiplication floor 0.86 ms.  Two-pass plans (radix 2^10) were measured
+// slower than three (1.60 vs 1.34 ms): their 64/128-byte segments cost more than the pass saved.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
