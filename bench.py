@@ -30,6 +30,7 @@ NTT_BYTES_PER_ELEM = 64  # read once + write once
 # peak of that instruction on MI355X (profiles/r01_ubench_instruction_rates.txt)
 MADS_PER_MIXED_ADD = {"pallas": 1278, "vesta": 1278, "bn254": 1548}
 VMAD_PEAK_TMADS = 30.5
+MADS_PER_FIELD_MUL = {"pasta_fp": 135, "pasta_fq": 135, "bn254_fr": 162, "bn254_fq": 162}   # f29_mul, ISA count
 
 
 def parse():
@@ -270,6 +271,15 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s"},
         }
         out["ntt_roofline"]["frac"] = round(out["ntt_roofline"]["achieved"] / HBM_PEAK_GBS, 5)
+        # like the MSM, a 255-bit NTT on gfx950 is bound by wide-multiply issue, not by HBM: N/2 log2 N butterfly
+        # multiplications + one output multiplication per element per pass (3 passes from 2^12 up to 2^24)
+        ntt_avg_ms = ntt_ms / max(ntt_cnt, 1)
+        passes = 1 if log_n <= 11 else (log_n + 7) // 8
+        ntt_muls = n * log_n // 2 + n * passes
+        mads_per_mul = MADS_PER_FIELD_MUL.get(args.ntt_field, 0)
+        out["ntt_roofline"]["valu"] = {"muls_per_launch": ntt_muls, "mads_per_mul": mads_per_mul, "peak_tmad_per_s": VMAD_PEAK_TMADS,
+                                       "achieved_tmad_per_s": round(ntt_muls * mads_per_mul / (ntt_avg_ms * 1e-3) / 1e12, 2) if ntt_avg_ms > 0 else 0.0}
+        out["ntt_roofline"]["valu"]["frac"] = round(out["ntt_roofline"]["valu"]["achieved_tmad_per_s"] / VMAD_PEAK_TMADS, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(co, po, curve, field, log_n, args.dist)
         if world == 1 and args.prover_k > 0:
