@@ -20,9 +20,36 @@ SYMBOLS = [
     "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device",
+    "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
-K_MSM_ACCUMULATE, K_MSM_SORT, K_MSM_REDUCE, K_NTT_PASS, K_POLY = 0, 1, 2, 3, 4
+K_MSM_ACCUMULATE, K_MSM_SORT, K_MSM_REDUCE, K_NTT_PASS, K_POLY, K_EVAL_H = 0, 1, 2, 3, 4, 5
+
+
+class CSource(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("rotation", C.c_uint32)]
+
+
+class CCalculation(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", CSource), ("b", CSource), ("parts_begin", C.c_uint32), ("parts_len", C.c_uint32), ("target", C.c_uint32)]
+
+
+class CEvalInputs(C.Structure):
+    _fields_ = [("fixed", C.POINTER(C.c_void_p)), ("num_fixed", C.c_uint32), ("advice", C.POINTER(C.c_void_p)), ("num_advice", C.c_uint32),
+                ("instance", C.POINTER(C.c_void_p)), ("num_instance", C.c_uint32), ("challenges", C.c_void_p), ("num_challenges", C.c_uint32),
+                ("beta", C.c_void_p), ("gamma", C.c_void_p), ("theta", C.c_void_p), ("y", C.c_void_p)]
+
+
+class CPermInputs(C.Structure):
+    _fields_ = [("z", C.POINTER(C.c_void_p)), ("num_sets", C.c_uint32), ("columns", C.POINTER(C.c_void_p)), ("sigma", C.POINTER(C.c_void_p)),
+                ("num_columns", C.c_uint32), ("chunk_len", C.c_uint32), ("last_rotation", C.c_int32),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
+                ("beta", C.c_void_p), ("gamma", C.c_void_p), ("y", C.c_void_p), ("delta", C.c_void_p), ("beta_zeta", C.c_void_p), ("extended_omega", C.c_void_p)]
+
+
+class CLookupInputs(C.Structure):
+    _fields_ = [("product_coset", C.c_void_p), ("permuted_input_coset", C.c_void_p), ("permuted_table_coset", C.c_void_p), ("table_value", C.c_void_p),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p), ("beta", C.c_void_p), ("gamma", C.c_void_p), ("y", C.c_void_p)]
 
 
 class DehaloError(RuntimeError):
@@ -82,6 +109,11 @@ def load_library():
     lib.dehalo_prefix_product_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
     lib.dehalo_grand_product.argtypes = [P, C.c_int, u64p, u64p, sz, u64p]
     lib.dehalo_grand_product_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, P]
+    lib.dehalo_graph_create.argtypes = [P, C.c_int, u64p, u32, C.POINTER(C.c_int32), u32, C.POINTER(CCalculation), u32, C.POINTER(CSource), u32, u32, C.POINTER(P)]
+    lib.dehalo_graph_release.argtypes = [P, P]
+    lib.dehalo_graph_evaluate_device.argtypes = [P, P, C.POINTER(CEvalInputs), u32, u32, u64p, u64p, P]
+    lib.dehalo_permutation_h_device.argtypes = [P, C.c_int, C.POINTER(CPermInputs), u32, u32, u64p, P]
+    lib.dehalo_lookup_h_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u64p, P]
     lib.dehalo_timing_enable.argtypes = [P, C.c_int]
     lib.dehalo_timing_reset.argtypes = [P]
     lib.dehalo_timing_get.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -268,6 +300,50 @@ class Context:
 
     def grand_product_device(self, field: int, d_num: int, d_den: int, length: int, d_z: int, stream: int = 0):
         self._check(self.lib.dehalo_grand_product_device(self.handle, field, d_num, d_den, length, d_z, stream or None))
+
+    # ---- quotient numerator; see evaluation.py for the upstream-shaped wrapper ----
+    def graph_create(self, field: int, constants, rotations, calcs, parts, num_intermediates: int):
+        """calcs: [(op, (kind, index, rot), (kind, index, rot), parts_begin, parts_len, target)]; parts: [(kind, index, rot)]."""
+        cst = _u64(constants, 4) if len(constants) else np.zeros((0, 4), dtype=np.uint64)
+        rot = (C.c_int32 * max(1, len(rotations)))(*rotations)
+        cc = (CCalculation * max(1, len(calcs)))()
+        for i, (op, a, b, pb, pl, tgt) in enumerate(calcs):
+            cc[i] = CCalculation(op, CSource(*a), CSource(*b), pb, pl, tgt)
+        pp = (CSource * max(1, len(parts)))(*[CSource(*p) for p in parts])
+        h = C.c_void_p()
+        self._check(self.lib.dehalo_graph_create(self.handle, field, _ptr(cst) if cst.shape[0] else None, cst.shape[0], rot, len(rotations), cc, len(calcs), pp,
+                                                 len(parts), num_intermediates, C.byref(h)))
+        return h
+
+    def graph_release(self, graph):
+        self._check(self.lib.dehalo_graph_release(self.handle, graph))
+
+    @staticmethod
+    def _ptr_table(ptrs):
+        return (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+
+    def graph_evaluate_device(self, graph, fixed, advice, instance, challenges, beta, gamma, theta, y, log_rows: int, rot_scale: int, d_previous: int,
+                              d_out: int, stream: int = 0):
+        """fixed / advice / instance: lists of device pointers; challenges: k x 4 u64; beta..y: 4 u64 or None."""
+        keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) if v is not None else None for v in (beta, gamma, theta, y)]
+        ch = _u64(challenges, 4) if challenges is not None and len(challenges) else np.zeros((0, 4), dtype=np.uint64)
+        tf, ta, ti = self._ptr_table(fixed), self._ptr_table(advice), self._ptr_table(instance)
+        inp = CEvalInputs(tf, len(fixed), ta, len(advice), ti, len(instance), ch.ctypes.data if ch.shape[0] else None, ch.shape[0],
+                          *[k.ctypes.data if k is not None else None for k in keep])
+        self._check(self.lib.dehalo_graph_evaluate_device(self.handle, graph, C.byref(inp), log_rows, rot_scale, d_previous or None, d_out, stream or None))
+
+    def permutation_h_device(self, field: int, z, columns, sigma, chunk_len: int, last_rotation: int, l0: int, l_last: int, l_active: int, beta, gamma, y,
+                             delta, beta_zeta, extended_omega, log_rows: int, rot_scale: int, d_values: int, stream: int = 0):
+        keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y, delta, beta_zeta, extended_omega)]
+        tz, tc, ts = self._ptr_table(z), self._ptr_table(columns), self._ptr_table(sigma)
+        inp = CPermInputs(tz, len(z), tc, ts, len(columns), chunk_len, last_rotation, l0, l_last, l_active, *[k.ctypes.data for k in keep])
+        self._check(self.lib.dehalo_permutation_h_device(self.handle, field, C.byref(inp), log_rows, rot_scale, d_values, stream or None))
+
+    def lookup_h_device(self, field: int, product: int, permuted_input: int, permuted_table: int, table_value: int, l0: int, l_last: int, l_active: int,
+                        beta, gamma, y, log_rows: int, rot_scale: int, d_values: int, stream: int = 0):
+        keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y)]
+        inp = CLookupInputs(product, permuted_input, permuted_table, table_value, l0, l_last, l_active, *[k.ctypes.data for k in keep])
+        self._check(self.lib.dehalo_lookup_h_device(self.handle, field, C.byref(inp), log_rows, rot_scale, d_values, stream or None))
 
     # ---- measurement ----
     def timing_enable(self, on: bool = True):

@@ -4,6 +4,9 @@
 // or group operation runs on the device, and context creation fails without one.
 #include <algorithm>
 
+#include <map>
+
+#include "evalh_types.hpp"
 #include "internal.hpp"
 
 namespace {
@@ -93,6 +96,131 @@ int do_grand_product(dehalo_ctx* ctx, int field, const fe* num, const fe* den, u
 #undef CALL
 }
 
+int do_graph_upload(dehalo_ctx* ctx, int field, dehalo_graph* g, const uint64_t* constants, hipStream_t s) {
+#define CALL(N) graph_upload_##N(ctx, g, constants, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_graph_evaluate(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale, const fe* prev, fe* out,
+                      hipStream_t s) {
+#define CALL(N) graph_evaluate_##N(ctx, g, in, log_rows, rot_scale, prev, out, s)
+    FIELD_SWITCH(ctx, g->field, CALL)
+#undef CALL
+}
+int do_perm_h(dehalo_ctx* ctx, int field, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {
+#define CALL(N) perm_h_##N(ctx, in, log_rows, rot_scale, v, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_lookup_h(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {
+#define CALL(N) lookup_h_##N(ctx, in, log_rows, rot_scale, v, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+
+// Host-side compilation of upstream's GraphEvaluator into the device program: sources are
+// resolved to table indices, and every intermediate gets a slot from a liveness scan (a slot is
+// reused as soon as its value has been read for the last time; the first EVH_MAX_LDS_SLOTS slots
+// live in LDS, the rest in an HBM scratch column).
+int compile_graph(dehalo_ctx* ctx, dehalo_graph* g, const int32_t* rotations, uint32_t num_rotations, const dehalo_calculation* calcs, uint32_t num_calcs,
+                  const dehalo_source* parts, uint32_t num_parts, uint32_t num_intermediates, std::vector<DevCalc>& out_calcs, std::vector<DevSrc>& out_parts) {
+    const uint32_t NEVER = 0xffffffffu;
+    std::vector<uint32_t> last_use(num_intermediates, NEVER), first_def(num_intermediates, NEVER);
+    auto check_src = [&](const dehalo_source& src, uint32_t at) -> int {
+        switch (src.kind) {
+            case DEHALO_SRC_CONSTANT: if (src.index >= g->num_constants) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: constant index out of range"); break;
+            case DEHALO_SRC_INTERMEDIATE:
+                if (src.index >= num_intermediates) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: intermediate index out of range");
+                if (first_def[src.index] == NEVER || first_def[src.index] >= at) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: intermediate read before it is written");
+                last_use[src.index] = at;
+                break;
+            case DEHALO_SRC_FIXED: case DEHALO_SRC_ADVICE: case DEHALO_SRC_INSTANCE:
+                if (src.rotation >= num_rotations) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: rotation index out of range");
+                break;
+            case DEHALO_SRC_CHALLENGE: case DEHALO_SRC_BETA: case DEHALO_SRC_GAMMA: case DEHALO_SRC_THETA: case DEHALO_SRC_Y: case DEHALO_SRC_PREVIOUS: break;
+            default: return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: unknown value source kind");
+        }
+        return 0;
+    };
+    auto binary = [](uint32_t op) { return op == DEHALO_CALC_ADD || op == DEHALO_CALC_SUB || op == DEHALO_CALC_MUL || op == DEHALO_CALC_HORNER; };
+    // pass 1: validation, definitions and last uses
+    for (uint32_t i = 0; i < num_calcs; i++) {
+        const dehalo_calculation& c = calcs[i];
+        if (c.op > DEHALO_CALC_STORE) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: unknown calculation");
+        if (c.target >= num_intermediates) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: target out of range");
+        TRY(check_src(c.a, i));
+        if (binary(c.op)) TRY(check_src(c.b, i));
+        if (c.op == DEHALO_CALC_HORNER) {
+            if ((uint64_t)c.parts_begin + c.parts_len > num_parts) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph: horner parts out of range");
+            for (uint32_t k = 0; k < c.parts_len; k++) TRY(check_src(parts[c.parts_begin + k], i));
+        }
+        if (first_def[c.target] == NEVER) first_def[c.target] = i;
+    }
+    if (num_calcs) last_use[calcs[num_calcs - 1].target] = num_calcs;   // the result stays live to the end
+    // pass 2: slots
+    std::vector<uint32_t> slot_of(num_intermediates, NEVER), free_slots;
+    uint32_t next_slot = 0;
+    auto conv = [&](const dehalo_source& src) {
+        DevSrc d{EVS_SCALAR, 0, 0};
+        switch (src.kind) {
+            case DEHALO_SRC_BETA: d.index = 0; break;
+            case DEHALO_SRC_GAMMA: d.index = 1; break;
+            case DEHALO_SRC_THETA: d.index = 2; break;
+            case DEHALO_SRC_Y: d.index = 3; break;
+            case DEHALO_SRC_CONSTANT: d.index = 4 + src.index; break;
+            case DEHALO_SRC_CHALLENGE: d.index = 4 + g->num_constants + src.index; g->max_challenge = std::max(g->max_challenge, src.index + 1); break;
+            case DEHALO_SRC_INTERMEDIATE: {
+                uint32_t sl = slot_of[src.index];
+                d.kind = sl < EVH_MAX_LDS_SLOTS ? EVS_SLOT_LDS : EVS_SLOT_HBM;
+                d.index = sl < EVH_MAX_LDS_SLOTS ? sl : sl - EVH_MAX_LDS_SLOTS;
+            } break;
+            case DEHALO_SRC_FIXED: d.kind = EVS_FIXED; d.index = src.index; d.rot = rotations[src.rotation]; g->max_fixed = std::max(g->max_fixed, src.index + 1); break;
+            case DEHALO_SRC_ADVICE: d.kind = EVS_ADVICE; d.index = src.index; d.rot = rotations[src.rotation]; g->max_advice = std::max(g->max_advice, src.index + 1); break;
+            case DEHALO_SRC_INSTANCE: d.kind = EVS_INSTANCE; d.index = src.index; d.rot = rotations[src.rotation]; g->max_instance = std::max(g->max_instance, src.index + 1); break;
+            default: d.kind = EVS_PREVIOUS; g->uses_previous = true; break;
+        }
+        return d;
+    };
+    std::vector<std::vector<uint32_t>> dying(num_calcs + 1);
+    for (uint32_t v = 0; v < num_intermediates; v++)
+        if (last_use[v] != NEVER) dying[last_use[v]].push_back(v);
+    out_calcs.resize(num_calcs);
+    out_parts.resize(num_parts ? num_parts : 1);
+    for (uint32_t i = 0; i < num_calcs; i++) {
+        const dehalo_calculation& c = calcs[i];
+        DevCalc d{};
+        d.op = c.op;
+        d.a = conv(c.a);
+        if (binary(c.op)) d.b = conv(c.b);
+        d.parts_begin = c.parts_begin; d.parts_len = c.op == DEHALO_CALC_HORNER ? c.parts_len : 0;
+        for (uint32_t k = 0; k < d.parts_len; k++) out_parts[c.parts_begin + k] = conv(parts[c.parts_begin + k]);
+        // operands are all read before the result is written: slots whose last use is this calculation are free for its target
+        for (uint32_t v : dying[i])
+            if (slot_of[v] != NEVER && v != c.target) { free_slots.push_back(slot_of[v]); slot_of[v] = NEVER; }
+        if (slot_of[c.target] == NEVER) {
+            if (!free_slots.empty()) {
+                auto it = std::min_element(free_slots.begin(), free_slots.end());   // lowest slot first: LDS before HBM
+                slot_of[c.target] = *it;
+                free_slots.erase(it);
+            } else slot_of[c.target] = next_slot++;
+        }
+        uint32_t sl = slot_of[c.target];
+        d.target_kind = sl < EVH_MAX_LDS_SLOTS ? EVS_SLOT_LDS : EVS_SLOT_HBM;
+        d.target_slot = sl < EVH_MAX_LDS_SLOTS ? sl : sl - EVH_MAX_LDS_SLOTS;
+        if (last_use[c.target] == NEVER || last_use[c.target] <= i) { /* dead value: its slot is released at once */
+            if (!(i + 1 == num_calcs)) { free_slots.push_back(sl); slot_of[c.target] = NEVER; }
+        }
+        out_calcs[i] = d;
+    }
+    g->lds_slots = std::min<uint32_t>(next_slot, EVH_MAX_LDS_SLOTS);
+    g->hbm_slots = next_slot > EVH_MAX_LDS_SLOTS ? next_slot - EVH_MAX_LDS_SLOTS : 0;
+    if (num_calcs) {
+        dehalo_source r{DEHALO_SRC_INTERMEDIATE, calcs[num_calcs - 1].target, 0};
+        g->result = conv(r);
+    }
+    return 0;
+}
+
 int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes, int window_bits, int precompute,
                   dehalo_bases** out) {
     if (!affine_xy || !out || n == 0 || stride_bytes < 64 || n >= (1ull << 30)) return dh_fail(ctx, DEHALO_ERR_INVALID, "bases_register: bad argument");
@@ -152,7 +280,7 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
                       &ctx->ws_bhist, &ctx->ws_pcount, &ctx->ws_pairs, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree,
                       &ctx->ws_gsums, &ctx->ws_ntt_scratch, &ctx->ws_ntt_io, &ctx->ws_ntt_io2, &ctx->ws_fop[0], &ctx->ws_fop[1], &ctx->ws_fop[2],
                       &ctx->ws_tmp_bases, &ctx->ws_poly[0], &ctx->ws_poly[1], &ctx->ws_poly[2], &ctx->ws_poly[3], &ctx->ws_poly[4], &ctx->ws_poly_io[0], &ctx->ws_poly_io[1],
-                      &ctx->ws_poly_io[2]};
+                      &ctx->ws_poly_io[2], &ctx->ws_evh[0], &ctx->ws_evh[1], &ctx->ws_evh[2], &ctx->ws_evh[3]};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->twiddles) (void)hipFree(t.tw);
@@ -469,6 +597,88 @@ int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const 
     HIP_TRY(ctx, hipMemcpyAsync(z, ctx->ws_poly_io[2].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+// ---- quotient numerator (evalh.cuh) -----------------------------------------------------------------
+int dehalo_graph_create(dehalo_ctx* ctx, int field, const uint64_t* constants, uint32_t num_constants, const int32_t* rotations, uint32_t num_rotations,
+                        const dehalo_calculation* calcs, uint32_t num_calcs, const dehalo_source* horner_parts, uint32_t num_horner_parts,
+                        uint32_t num_intermediates, dehalo_graph** out) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!out || (num_constants && !constants) || (num_rotations && !rotations) || (num_calcs && !calcs) || (num_horner_parts && !horner_parts))
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_create: null argument");
+    if (field < 0 || field > 3) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
+    if (num_calcs > (1u << 20) || num_intermediates > (1u << 20)) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_create: program too large");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    dehalo_graph* g = new dehalo_graph();
+    memset(g, 0, sizeof(*g));
+    g->field = field; g->num_calcs = num_calcs; g->num_parts = num_horner_parts; g->num_constants = num_constants;
+    std::vector<DevCalc> dc;
+    std::vector<DevSrc> dp;
+    int rc = compile_graph(ctx, g, rotations, num_rotations, calcs, num_calcs, horner_parts, num_horner_parts, num_intermediates, dc, dp);
+    hipError_t e = hipSuccess;
+    if (rc == 0) e = hipMalloc((void**)&g->d_calcs, std::max<size_t>(1, dc.size()) * sizeof(DevCalc));
+    if (rc == 0 && e == hipSuccess) e = hipMalloc((void**)&g->d_parts, dp.size() * sizeof(DevSrc));
+    if (rc == 0 && e == hipSuccess) e = hipMalloc((void**)&g->d_constants, std::max<size_t>(1, num_constants) * sizeof(fe));
+    if (rc == 0 && e == hipSuccess && !dc.empty()) e = hipMemcpy(g->d_calcs, dc.data(), dc.size() * sizeof(DevCalc), hipMemcpyHostToDevice);
+    if (rc == 0 && e == hipSuccess) e = hipMemcpy(g->d_parts, dp.data(), dp.size() * sizeof(DevSrc), hipMemcpyHostToDevice);
+    if (rc == 0 && e == hipSuccess) rc = do_graph_upload(ctx, field, g, constants, ctx->stream);
+    if (rc != 0 || e != hipSuccess) {
+        (void)hipFree(g->d_calcs); (void)hipFree(g->d_parts); (void)hipFree(g->d_constants);
+        delete g;
+        return rc ? rc : dh_fail(ctx, e == hipErrorOutOfMemory ? DEHALO_ERR_OOM : DEHALO_ERR_HIP, std::string("graph_create: ") + hipGetErrorString(e));
+    }
+    *out = g;
+    return 0;
+}
+
+int dehalo_graph_release(dehalo_ctx* ctx, dehalo_graph* g) {
+    if (!ctx || !g) return DEHALO_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g->d_calcs); (void)hipFree(g->d_parts); (void)hipFree(g->d_constants);
+    delete g;
+    return 0;
+}
+
+int dehalo_graph_evaluate_device(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,
+                                 const uint64_t* d_previous, uint64_t* d_out, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!g || !in || !d_out) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate: null argument");
+    if (log_rows > 30) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate: log_rows > 30");
+    if (in->num_fixed < g->max_fixed || in->num_advice < g->max_advice || in->num_instance < g->max_instance || in->num_challenges < g->max_challenge)
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate: the program reads a column or challenge that was not supplied");
+    if ((in->num_fixed && !in->fixed) || (in->num_advice && !in->advice) || (in->num_instance && !in->instance) || (in->num_challenges && !in->challenges))
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate: null column table");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_graph_evaluate(ctx, g, in, log_rows, rot_scale, (const fe*)d_previous, (fe*)d_out, pick_stream(ctx, stream));
+}
+
+int dehalo_permutation_h_device(dehalo_ctx* ctx, int field, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
+                                void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!in || !d_values || !in->l0 || !in->l_last || !in->l_active_row || !in->beta || !in->gamma || !in->y || !in->delta || !in->beta_zeta || !in->extended_omega)
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "permutation_h: null argument");
+    if ((in->num_sets && !in->z) || (in->num_columns && (!in->columns || !in->sigma))) return dh_fail(ctx, DEHALO_ERR_INVALID, "permutation_h: null column table");
+    if (log_rows == 0 || log_rows > 30 || in->chunk_len == 0 || (uint64_t)in->num_sets * in->chunk_len < in->num_columns)
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "permutation_h: sets * chunk_len must cover the columns");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_perm_h(ctx, field, in, log_rows, rot_scale, (fe*)d_values, pick_stream(ctx, stream));
+}
+
+int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
+                           void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!in || !d_values || !in->product_coset || !in->permuted_input_coset || !in->permuted_table_coset || !in->table_value || !in->l0 || !in->l_last ||
+        !in->l_active_row || !in->beta || !in->gamma || !in->y)
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h: null argument");
+    if (log_rows > 30) return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h: log_rows > 30");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_lookup_h(ctx, field, in, log_rows, rot_scale, (fe*)d_values, pick_stream(ctx, stream));
 }
 
 // ---- measurement ------------------------------------------------------------------------------

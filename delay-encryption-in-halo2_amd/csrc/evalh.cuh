@@ -1,0 +1,376 @@
+// evalh.cuh -- the quotient numerator of create_proof on the device.
+//
+// Replaces the row loops of [UPSTREAM halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20]:
+//   GraphEvaluator::evaluate      custom gates and the lookups' compressed (input, table) product:
+//                                 a straight-line program of Calculation{Add, Sub, Mul, Square,
+//                                 Double, Negate, Horner, Store} over ValueSource{Constant,
+//                                 Intermediate, Fixed, Advice, Instance, Challenge, Beta, Gamma,
+//                                 Theta, Y, PreviousValue}, run once per extended-domain row;
+//   Evaluator::evaluate_h         the hard-coded permutation and lookup argument terms folded into
+//                                 the same accumulator with  value = value * y + term.
+// Upstream runs them with `parallelize` over row chunks on the CPU; here one lane owns one row,
+// every lane executes the same instruction stream (the program is uniform), intermediates live in
+// LDS slots assigned by a liveness pass on the host (spilling to HBM beyond the LDS budget), and
+// columns are read with the rotation folded into the index:  (row + rot * rot_scale) mod rows.
+//
+// Values in a slot: x * 2^261, < 2p, limbs normalized.
+#pragma once
+#include <vector>
+
+#include "fp29.cuh"
+#include "internal.hpp"
+
+#include "evalh_types.hpp"
+
+struct EvhArgs {
+    const DevCalc* calcs;
+    const DevSrc* parts;
+    const fe* scalars;            // [beta, gamma, theta, y, constants..., challenges...] internal packed
+    const fe* const* columns;     // [fixed..., advice..., instance...] device pointers
+    u32 num_calcs, fixed_base, advice_base, instance_base;
+    u32 rows_mask, rot_scale;
+    const fe* previous;
+    fe* out;
+    fe* spill;                    // [hbm slot][row], internal packed
+    u64 rows;
+    DevSrc result;
+};
+
+// ---- lazily reduced helpers: every stored value is < 2p with normalized limbs ----------------
+template <class F9> FP_DEV f29 evh_reduce_lt4p(const f29& a) { return f29_cond_sub(f29_norm(a), F9::P2); }
+template <class F9> FP_DEV f29 evh_add(const f29& a, const f29& b) { return evh_reduce_lt4p<F9>(f29_add(a, b)); }
+template <class F9> FP_DEV f29 evh_sub(const f29& a, const f29& b) {                  // a - b + 4p < 6p
+    f29 t = f29_norm(f29_sub(a, b, F9::KM));
+    return f29_cond_sub(f29_cond_sub(t, F9::P4), F9::P2);
+}
+template <class F9> FP_DEV f29 evh_neg(const f29& a) { return evh_reduce_lt4p<F9>(f29_sub(f29_zero(), a, F9::KM)); }
+
+struct EvhLds {
+    u32* base;
+    FP_DEV f29 load(u32 slot) const {
+        f29 r;
+#pragma unroll
+        for (int l = 0; l < 9; l++) r.v[l] = base[(slot * 9 + l) * EVH_THREADS + threadIdx.x];
+        return r;
+    }
+    FP_DEV void store(u32 slot, const f29& v) const {
+#pragma unroll
+        for (int l = 0; l < 9; l++) base[(slot * 9 + l) * EVH_THREADS + threadIdx.x] = v.v[l];
+    }
+};
+
+template <class F9>
+FP_DEV f29 evh_fetch(const EvhArgs& A, const EvhLds& L, const DevSrc& s, u64 row) {
+    switch (s.kind) {
+        case EVS_SCALAR: return f29_unpack(f_load(&A.scalars[s.index]));
+        case EVS_SLOT_LDS: return L.load(s.index);
+        case EVS_SLOT_HBM: return f29_unpack(f_load(&A.spill[(u64)s.index * A.rows + row]));
+        case EVS_PREVIOUS: return A.previous ? f29_from_std<F9>(f_load(&A.previous[row])) : f29_zero();
+        default: {
+            u32 base = s.kind == EVS_FIXED ? A.fixed_base : (s.kind == EVS_ADVICE ? A.advice_base : A.instance_base);
+            const fe* col = A.columns[base + s.index];
+            u32 r = ((u32)row + (u32)(s.rot * (int32_t)A.rot_scale)) & A.rows_mask;    // rem_euclid for a power of two
+            return f29_from_std<F9>(f_load(&col[r]));
+        }
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(EVH_THREADS) void k_graph_eval(EvhArgs A) {
+    typedef typename f29_of<F>::type F9;
+    extern __shared__ u32 evh_lds[];
+    EvhLds L{evh_lds};
+    const u64 row = (u64)blockIdx.x * EVH_THREADS + threadIdx.x;
+    if (row >= A.rows) return;                  // no barriers below: a lane only touches its own LDS column
+    for (u32 ci = 0; ci < A.num_calcs; ci++) {
+        const DevCalc c = A.calcs[ci];
+        f29 a = evh_fetch<F9>(A, L, c.a, row);
+        f29 r;
+        switch (c.op) {
+            case DEHALO_CALC_ADD: r = evh_add<F9>(a, evh_fetch<F9>(A, L, c.b, row)); break;
+            case DEHALO_CALC_SUB: r = evh_sub<F9>(a, evh_fetch<F9>(A, L, c.b, row)); break;
+            case DEHALO_CALC_MUL: r = f29_mul<F9>(a, evh_fetch<F9>(A, L, c.b, row)); break;
+            case DEHALO_CALC_SQUARE: r = f29_sqr<F9>(a); break;
+            case DEHALO_CALC_DOUBLE: r = evh_add<F9>(a, a); break;
+            case DEHALO_CALC_NEGATE: r = evh_neg<F9>(a); break;
+            case DEHALO_CALC_HORNER: {
+                const f29 factor = evh_fetch<F9>(A, L, c.b, row);
+                r = a;
+                for (u32 k = 0; k < c.parts_len; k++)
+                    r = evh_add<F9>(f29_mul<F9>(r, factor), evh_fetch<F9>(A, L, A.parts[c.parts_begin + k], row));
+            } break;
+            default: r = a; break;              // STORE
+        }
+        if (c.target_kind == EVS_SLOT_LDS) L.store(c.target_slot, r);
+        else f_store(&A.spill[(u64)c.target_slot * A.rows + row], f29_to_packed_canon<F9>(r));
+    }
+    f29 res = A.num_calcs ? evh_fetch<F9>(A, L, A.result, row) : f29_zero();
+    f_store(&A.out[row], f29_to_std<F9>(res));
+}
+
+// standard-form scalars -> the internal packed table.  Per-call values (challenges, beta, ...)
+// travel as kernel arguments, eight at a time: no pageable host buffer has to outlive the call.
+template <class F>
+__global__ void k_evh_scalars(const fe* std_in, fe* out, u32 n) {
+    typedef typename f29_of<F>::type F9;
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f_store(&out[i], f29_to_packed_canon<F9>(f29_from_std<F9>(f_load(&std_in[i]))));
+}
+struct FeBatch { fe v[8]; };
+template <class F>
+__global__ void k_evh_scalars_val(FeBatch b, fe* out, u32 n) {
+    typedef typename f29_of<F>::type F9;
+    u32 i = threadIdx.x;
+    if (i < n) f_store(&out[i], f29_to_packed_canon<F9>(f29_from_std<F9>(b.v[i])));
+}
+struct PtrBatch { const void* p[32]; };
+static __global__ void k_evh_ptrs(PtrBatch b, const void** out, u32 n) {
+    u32 i = threadIdx.x;
+    if (i < n) out[i] = b.p[i];
+}
+
+// ---- permutation argument terms (Evaluator::evaluate_h, "Permutation constraints") ------------
+// sets: the grand-product cosets z_0 .. z_{S-1}; cols: the permuted columns' cosets in order,
+// chunk_len per set; sigma: pk.permutation.cosets in the same order.  Per row (X = zeta w^row):
+//   v = v y + l0 (1 - z_0)
+//   v = v y + l_last (z_last^2 - z_last)
+//   for s >= 1:  v = v y + l0 (z_s - z_{s-1}(w^last X))
+//   for each set: v = v y + l_active ( z_s(wX) prod_j (col_j + beta sigma_j + gamma)
+//                                   - z_s(X)  prod_j (col_j + delta^j beta X + gamma) )      delta^j running across sets
+struct PermArgs {
+    const fe* const* z;        // S set cosets
+    const fe* const* cols;     // ncols column cosets
+    const fe* const* sigma;    // ncols permutation cosets
+    const fe* l0; const fe* l_last; const fe* l_active;
+    const fe* scalars;         // internal packed: [beta, gamma, y, delta, beta*zeta]
+    const fe* tw;              // omega_ext^j * 2^261 (canonical, packed), j < rows / 2: the NTT's table
+    u32 nsets, ncols, chunk_len;
+    u32 rows_mask, rot_scale;
+    int32_t last_rotation;     // -(blinding_factors + 1)
+    fe* values;                // in/out, standard form
+    u64 rows;
+};
+
+template <class F>
+__global__ __launch_bounds__(EVH_THREADS) void k_perm_h(PermArgs A) {
+    typedef typename f29_of<F>::type F9;
+    const u64 row = (u64)blockIdx.x * EVH_THREADS + threadIdx.x;
+    if (row >= A.rows) return;
+    const f29 beta = f29_unpack(f_load(&A.scalars[0])), gamma = f29_unpack(f_load(&A.scalars[1])), y = f29_unpack(f_load(&A.scalars[2]));
+    const f29 delta = f29_unpack(f_load(&A.scalars[3])), beta_zeta = f29_unpack(f_load(&A.scalars[4]));
+    const f29 one = f29_one<F9>();
+    const u32 r_next = ((u32)row + A.rot_scale) & A.rows_mask;
+    const u32 r_last = ((u32)row + (u32)(A.last_rotation * (int32_t)A.rot_scale)) & A.rows_mask;
+    auto ld = [&](const fe* p, u64 i) { return f29_from_std<F9>(f_load(&p[i])); };
+    f29 v = ld(A.values, row);
+    const f29 l0 = ld(A.l0, row), l_last = ld(A.l_last, row), l_active = ld(A.l_active, row);
+    if (A.nsets) {
+        f29 z0 = ld(A.z[0], row);
+        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(one, z0), l0));
+        f29 zl = ld(A.z[A.nsets - 1], row);
+        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(f29_sqr<F9>(zl), zl), l_last));
+        for (u32 s = 1; s < A.nsets; s++) {
+            f29 t = evh_sub<F9>(ld(A.z[s], row), ld(A.z[s - 1], r_last));
+            v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(t, l0));
+        }
+        // beta * zeta * omega_ext^row, omega_ext^row from the NTT twiddle table (omega^(rows/2) = -1)
+        const u64 half = A.rows >> 1;
+        f29 w = f29_unpack(f_load(&A.tw[row >= half ? row - half : row]));
+        if (row >= half) w = evh_neg<F9>(w);
+        f29 current_delta = f29_mul<F9>(beta_zeta, w);
+        for (u32 s = 0; s < A.nsets; s++) {
+            const u32 c0 = s * A.chunk_len, c1 = min(c0 + A.chunk_len, A.ncols);
+            f29 left = ld(A.z[s], r_next), right = ld(A.z[s], row);
+            for (u32 j = c0; j < c1; j++) {
+                f29 col = ld(A.cols[j], row);
+                f29 t = evh_add<F9>(evh_add<F9>(col, f29_mul<F9>(beta, ld(A.sigma[j], row))), gamma);
+                left = f29_mul<F9>(left, t);
+                f29 u = evh_add<F9>(evh_add<F9>(col, current_delta), gamma);
+                right = f29_mul<F9>(right, u);
+                current_delta = f29_mul<F9>(current_delta, delta);
+            }
+            v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(left, right), l_active));
+        }
+    }
+    f_store(&A.values[row], f29_to_std<F9>(v));
+}
+
+// ---- lookup argument terms (Evaluator::evaluate_h, "Lookup constraints") ----------------------
+// table_value[row] = (compressed input + beta)(compressed table + gamma) comes from the lookup's
+// GraphEvaluator (k_graph_eval into a scratch column).  Per row:
+//   v = v y + l0 (1 - z)
+//   v = v y + l_last (z^2 - z)
+//   v = v y + l_active ( z(wX) (a' + beta)(s' + gamma) - z(X) table_value )
+//   v = v y + l0 (a' - s')
+//   v = v y + l_active (a' - s')(a' - a'(w^-1 X))
+struct LookupArgs {
+    const fe* z; const fe* a_perm; const fe* s_perm; const fe* table_value;
+    const fe* l0; const fe* l_last; const fe* l_active;
+    const fe* scalars;         // internal packed: [beta, gamma, y]
+    u32 rows_mask, rot_scale;
+    fe* values;
+    u64 rows;
+};
+
+template <class F>
+__global__ __launch_bounds__(EVH_THREADS) void k_lookup_h(LookupArgs A) {
+    typedef typename f29_of<F>::type F9;
+    const u64 row = (u64)blockIdx.x * EVH_THREADS + threadIdx.x;
+    if (row >= A.rows) return;
+    const f29 beta = f29_unpack(f_load(&A.scalars[0])), gamma = f29_unpack(f_load(&A.scalars[1])), y = f29_unpack(f_load(&A.scalars[2]));
+    const f29 one = f29_one<F9>();
+    const u32 r_next = ((u32)row + A.rot_scale) & A.rows_mask;
+    const u32 r_prev = ((u32)row - A.rot_scale) & A.rows_mask;
+    auto ld = [&](const fe* p, u64 i) { return f29_from_std<F9>(f_load(&p[i])); };
+    f29 v = ld(A.values, row);
+    const f29 l0 = ld(A.l0, row), l_last = ld(A.l_last, row), l_active = ld(A.l_active, row);
+    const f29 z = ld(A.z, row), a = ld(A.a_perm, row), s = ld(A.s_perm, row);
+    const f29 a_minus_s = evh_sub<F9>(a, s);
+    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(one, z), l0));
+    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(f29_sqr<F9>(z), z), l_last));
+    f29 lhs = f29_mul<F9>(f29_mul<F9>(ld(A.z, r_next), evh_add<F9>(a, beta)), evh_add<F9>(s, gamma));
+    f29 rhs = f29_mul<F9>(z, ld(A.table_value, row));
+    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(lhs, rhs), l_active));
+    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(a_minus_s, l0));
+    f29 t = f29_mul<F9>(a_minus_s, evh_sub<F9>(a, ld(A.a_perm, r_prev)));
+    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(t, l_active));
+    f_store(&A.values[row], f29_to_std<F9>(v));
+}
+
+// ==========================================================================================
+// host drivers
+// ==========================================================================================
+template <class F>
+int graph_upload_t(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, hipStream_t s) {
+    // constants: standard form on the host -> internal packed on the device, once
+    if (g->num_constants) {
+        fe* tmp = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&tmp, (size_t)g->num_constants * sizeof(fe)));
+        hipError_t e = hipMemcpyAsync(tmp, constants, (size_t)g->num_constants * sizeof(fe), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            k_evh_scalars<F><<<(g->num_constants + 127) / 128, 128, 0, s>>>(tmp, g->d_constants, g->num_constants);
+            e = hipStreamSynchronize(s);
+        }
+        (void)hipFree(tmp);
+        HIP_TRY(ctx, e);
+    }
+    return 0;
+}
+
+template <class F>
+int evh_stage_scalars(dehalo_ctx* ctx, const std::vector<fe>& host_std, fe* d_table, hipStream_t s) {
+    for (size_t o = 0; o < host_std.size(); o += 8) {
+        FeBatch b;
+        u32 n = (u32)std::min<size_t>(8, host_std.size() - o);
+        for (u32 i = 0; i < n; i++) b.v[i] = host_std[o + i];
+        k_evh_scalars_val<F><<<1, 8, 0, s>>>(b, d_table + o, n);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+inline int evh_stage_ptrs(dehalo_ctx* ctx, const std::vector<const fe*>& ptrs, const void** d_table, hipStream_t s) {
+    for (size_t o = 0; o < ptrs.size(); o += 32) {
+        PtrBatch b;
+        u32 n = (u32)std::min<size_t>(32, ptrs.size() - o);
+        for (u32 i = 0; i < n; i++) b.p[i] = ptrs[o + i];
+        k_evh_ptrs<<<1, 32, 0, s>>>(b, d_table + o, n);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class F>
+int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale, const fe* d_previous,
+                     fe* d_out, hipStream_t s) {
+    const u64 rows = 1ull << log_rows;
+    ScopedTimer timer(ctx, s, DEHALO_K_EVAL_H);
+    // scalar table: [beta, gamma, theta, y, constants..., challenges...]
+    const u32 nsc = 4 + g->num_constants + in->num_challenges;
+    TRY(dh_ensure(ctx, ctx->ws_evh[0], (size_t)(nsc + 8) * sizeof(fe)));
+    fe* table = (fe*)ctx->ws_evh[0].p;
+    std::vector<fe> head(4), chal(in->num_challenges);
+    const uint64_t* four[4] = {in->beta, in->gamma, in->theta, in->y};
+    for (int i = 0; i < 4; i++) head[i] = four[i] ? fe_from_u64(four[i]) : fe{};
+    for (u32 i = 0; i < in->num_challenges; i++) chal[i] = fe_from_u64(in->challenges + 4 * (size_t)i);
+    TRY(evh_stage_scalars<F>(ctx, head, table, s));
+    if (g->num_constants) HIP_TRY(ctx, hipMemcpyAsync(table + 4, g->d_constants, (size_t)g->num_constants * sizeof(fe), hipMemcpyDeviceToDevice, s));
+    TRY(evh_stage_scalars<F>(ctx, chal, table + 4 + g->num_constants, s));
+    // column pointer table
+    const u32 ncol = in->num_fixed + in->num_advice + in->num_instance;
+    std::vector<const fe*> cols(ncol, nullptr);
+    for (u32 i = 0; i < in->num_fixed; i++) cols[i] = (const fe*)in->fixed[i];
+    for (u32 i = 0; i < in->num_advice; i++) cols[in->num_fixed + i] = (const fe*)in->advice[i];
+    for (u32 i = 0; i < in->num_instance; i++) cols[in->num_fixed + in->num_advice + i] = (const fe*)in->instance[i];
+    TRY(dh_ensure(ctx, ctx->ws_evh[2], (cols.size() + 1) * sizeof(void*)));
+    TRY(evh_stage_ptrs(ctx, cols, (const void**)ctx->ws_evh[2].p, s));
+    if (g->hbm_slots) TRY(dh_ensure(ctx, ctx->ws_evh[3], (size_t)g->hbm_slots * rows * sizeof(fe)));
+    EvhArgs A;
+    A.calcs = g->d_calcs; A.parts = g->d_parts; A.scalars = table; A.columns = (const fe* const*)ctx->ws_evh[2].p;
+    A.num_calcs = g->num_calcs; A.fixed_base = 0; A.advice_base = in->num_fixed; A.instance_base = in->num_fixed + in->num_advice;
+    A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale;
+    A.previous = d_previous; A.out = d_out; A.spill = (fe*)ctx->ws_evh[3].p; A.rows = rows; A.result = g->result;
+    const size_t lds = (size_t)std::max<u32>(1, g->lds_slots) * EVH_SLOT_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_graph_eval<F>, hipFuncAttributeMaxDynamicSharedMemorySize, EVH_LDS_BYTES));
+        attr_set = true;
+    }
+    k_graph_eval<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, lds, s>>>(A);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class F>
+int perm_h_t(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* d_values, hipStream_t s) {
+    const u64 rows = 1ull << log_rows;
+    ScopedTimer timer(ctx, s, DEHALO_K_EVAL_H);
+    std::vector<fe> sc = {fe_from_u64(in->beta), fe_from_u64(in->gamma), fe_from_u64(in->y), fe_from_u64(in->delta), fe_from_u64(in->beta_zeta)};
+    TRY(dh_ensure(ctx, ctx->ws_evh[0], 16 * sizeof(fe)));
+    TRY(evh_stage_scalars<F>(ctx, sc, (fe*)ctx->ws_evh[0].p, s));
+    std::vector<const fe*> ptrs;
+    for (u32 i = 0; i < in->num_sets; i++) ptrs.push_back((const fe*)in->z[i]);
+    for (u32 i = 0; i < in->num_columns; i++) ptrs.push_back((const fe*)in->columns[i]);
+    for (u32 i = 0; i < in->num_columns; i++) ptrs.push_back((const fe*)in->sigma[i]);
+    TRY(dh_ensure(ctx, ctx->ws_evh[2], (ptrs.size() + 1) * sizeof(void*)));
+    TRY(evh_stage_ptrs(ctx, ptrs, (const void**)ctx->ws_evh[2].p, s));
+    const fe* tw = nullptr;                                   // omega_ext^j * 2^261, j < rows / 2 (shared with the NTT)
+    TRY(get_twiddles<F>(ctx, log_rows, in->extended_omega, s, &tw));
+    PermArgs A;
+    const fe* const* base = (const fe* const*)ctx->ws_evh[2].p;
+    A.z = base; A.cols = base + in->num_sets; A.sigma = base + in->num_sets + in->num_columns;
+    A.l0 = (const fe*)in->l0; A.l_last = (const fe*)in->l_last; A.l_active = (const fe*)in->l_active_row;
+    A.scalars = (const fe*)ctx->ws_evh[0].p;
+    A.nsets = in->num_sets; A.ncols = in->num_columns; A.chunk_len = in->chunk_len;
+    A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale; A.last_rotation = in->last_rotation;
+    A.values = d_values; A.rows = rows; A.tw = tw;
+    k_perm_h<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, 0, s>>>(A);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class F>
+int lookup_h_t(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* d_values, hipStream_t s) {
+    const u64 rows = 1ull << log_rows;
+    ScopedTimer timer(ctx, s, DEHALO_K_EVAL_H);
+    std::vector<fe> sc = {fe_from_u64(in->beta), fe_from_u64(in->gamma), fe_from_u64(in->y)};
+    TRY(dh_ensure(ctx, ctx->ws_evh[0], 16 * sizeof(fe)));
+    TRY(evh_stage_scalars<F>(ctx, sc, (fe*)ctx->ws_evh[0].p, s));
+    LookupArgs A;
+    A.z = (const fe*)in->product_coset; A.a_perm = (const fe*)in->permuted_input_coset; A.s_perm = (const fe*)in->permuted_table_coset;
+    A.table_value = (const fe*)in->table_value;
+    A.l0 = (const fe*)in->l0; A.l_last = (const fe*)in->l_last; A.l_active = (const fe*)in->l_active_row;
+    A.scalars = (const fe*)ctx->ws_evh[0].p;
+    A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale; A.values = d_values; A.rows = rows;
+    k_lookup_h<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, 0, s>>>(A);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+#define DEFINE_EVALH_ENTRY(NAME, F)                                                                                                              \
+    int graph_upload_##NAME(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, hipStream_t s) { return graph_upload_t<F>(ctx, g, constants, s); } \
+    int graph_evaluate_##NAME(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,      \
+                              const fe* prev, fe* out, hipStream_t s) { return graph_evaluate_t<F>(ctx, g, in, log_rows, rot_scale, prev, out, s); } \
+    int perm_h_##NAME(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {             \
+        return perm_h_t<F>(ctx, in, log_rows, rot_scale, v, s); }                                                                                \
+    int lookup_h_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {         \
+        return lookup_h_t<F>(ctx, in, log_rows, rot_scale, v, s); }

@@ -36,7 +36,7 @@ struct dehalo_ctx {
     std::mutex mu;
     // workspace (grow-only)
     DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_toff0, ws_merge_lists, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
-        ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[5], ws_poly_io[3];
+        ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[5], ws_poly_io[3], ws_evh[4];
     std::vector<TwiddleEntry> twiddles;
     bool timing = false;
     std::vector<TimedRegion> regions;
@@ -161,3 +161,17 @@ DECL_POLY(bn254_fq)
 DECL_POLY(pasta_fp)
 DECL_POLY(pasta_fq)
 #undef DECL_POLY
+
+// quotient-numerator kernels (evalh.cuh)
+struct dehalo_graph;
+#define DECL_EVALH(NAME)                                                                                                                    \
+    int graph_upload_##NAME(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, hipStream_t s);                                   \
+    int graph_evaluate_##NAME(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale, \
+                              const fe* prev, fe* out, hipStream_t s);                                                                     \
+    int perm_h_##NAME(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s);         \
+    int lookup_h_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s);
+DECL_EVALH(bn254_fr)
+DECL_EVALH(bn254_fq)
+DECL_EVALH(pasta_fp)
+DECL_EVALH(pasta_fq)
+#undef DECL_EVALH

@@ -157,6 +157,77 @@ int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_i
 int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const uint64_t* den, size_t len, uint64_t* z);
 int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, uint64_t* d_z, void* stream);
 
+/* ---- quotient numerator: evaluate_h --------------------------------------
+ * The row loops of halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20 on device-resident
+ * extended-domain columns (each `rows = 1 << log_rows` elements, standard Montgomery form), so the
+ * cosets produced by dehalo_coset_ntt_device never leave HBM before dehalo_coset_intt_device.
+ *
+ * A dehalo_graph is upstream's GraphEvaluator { constants, rotations, calculations,
+ * num_intermediates } handed over verbatim: ValueSource -> dehalo_source (kind, index, rotation
+ * = index into rotations[]), Calculation -> dehalo_calculation (Horner(start, parts, factor):
+ * a = start, b = factor, parts = horner_parts[parts_begin .. parts_begin + parts_len]),
+ * CalculationInfo.target -> target.  dehalo_graph_evaluate_device computes, for every row idx,
+ *   out[idx] = GraphEvaluator::evaluate(.., previous_value = previous[idx] (0 if NULL), idx, rot_scale, isize = rows)
+ * i.e. the value of the LAST calculation (0 for an empty graph); a column source reads
+ * column[(idx + rotations[rotation] * rot_scale) mod rows].  previous == out is allowed (custom
+ * gates: values[idx] = evaluate(.., values[idx], ..)).
+ *
+ * dehalo_permutation_h_device / dehalo_lookup_h_device fold upstream's hard-coded argument terms
+ * into `values` in place (value = value * y + term, in upstream's order):
+ *   permutation: l0 (1 - z_0); l_last (z_last^2 - z_last); for sets s >= 1: l0 (z_s - z_{s-1}(w^last X));
+ *                for every set: l_active (z_s(wX) prod_j (col_j + beta sigma_j + gamma)
+ *                                         - z_s(X) prod_j (col_j + delta^j beta X + gamma)),
+ *                X = zeta * extended_omega^idx, delta^j running across the sets' column chunks;
+ *   lookup:      l0 (1 - z); l_last (z^2 - z); l_active (z(wX)(a' + beta)(s' + gamma) - z(X) table_value);
+ *                l0 (a' - s'); l_active (a' - s')(a' - a'(w^-1 X)),
+ *                table_value = the lookup's GraphEvaluator output for the row.                    */
+typedef enum {
+    DEHALO_SRC_CONSTANT = 0, DEHALO_SRC_INTERMEDIATE = 1, DEHALO_SRC_FIXED = 2, DEHALO_SRC_ADVICE = 3, DEHALO_SRC_INSTANCE = 4,
+    DEHALO_SRC_CHALLENGE = 5, DEHALO_SRC_BETA = 6, DEHALO_SRC_GAMMA = 7, DEHALO_SRC_THETA = 8, DEHALO_SRC_Y = 9, DEHALO_SRC_PREVIOUS = 10
+} dehalo_source_kind;
+typedef struct { uint32_t kind, index, rotation; } dehalo_source;
+typedef enum {
+    DEHALO_CALC_ADD = 0, DEHALO_CALC_SUB = 1, DEHALO_CALC_MUL = 2, DEHALO_CALC_SQUARE = 3, DEHALO_CALC_DOUBLE = 4, DEHALO_CALC_NEGATE = 5,
+    DEHALO_CALC_HORNER = 6, DEHALO_CALC_STORE = 7
+} dehalo_calc_op;
+typedef struct {
+    uint32_t op;
+    dehalo_source a, b;
+    uint32_t parts_begin, parts_len;
+    uint32_t target;
+} dehalo_calculation;
+typedef struct dehalo_graph dehalo_graph;
+int dehalo_graph_create(dehalo_ctx* ctx, int field, const uint64_t* constants, uint32_t num_constants, const int32_t* rotations, uint32_t num_rotations,
+                        const dehalo_calculation* calcs, uint32_t num_calcs, const dehalo_source* horner_parts, uint32_t num_horner_parts,
+                        uint32_t num_intermediates, dehalo_graph** out);
+int dehalo_graph_release(dehalo_ctx* ctx, dehalo_graph* graph);
+typedef struct {
+    const uint64_t* const* fixed; uint32_t num_fixed;        /* host arrays of DEVICE column pointers */
+    const uint64_t* const* advice; uint32_t num_advice;
+    const uint64_t* const* instance; uint32_t num_instance;
+    const uint64_t* challenges; uint32_t num_challenges;     /* host, 4 u64 each */
+    const uint64_t *beta, *gamma, *theta, *y;                /* host, 4 u64 each; NULL = 0 */
+} dehalo_eval_inputs;
+int dehalo_graph_evaluate_device(dehalo_ctx* ctx, const dehalo_graph* graph, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,
+                                 const uint64_t* d_previous, uint64_t* d_out, void* stream);
+typedef struct {
+    const uint64_t* const* z; uint32_t num_sets;             /* permutation_product_coset per set (device pointers) */
+    const uint64_t* const* columns; const uint64_t* const* sigma; uint32_t num_columns;   /* column cosets / pk.permutation.cosets */
+    uint32_t chunk_len;                                      /* cs.degree() - 2 */
+    int32_t last_rotation;                                   /* -(blinding_factors + 1) */
+    const uint64_t *l0, *l_last, *l_active_row;              /* device */
+    const uint64_t *beta, *gamma, *y, *delta, *beta_zeta, *extended_omega;   /* host, 4 u64 each */
+} dehalo_perm_inputs;
+int dehalo_permutation_h_device(dehalo_ctx* ctx, int field, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
+                                void* stream);
+typedef struct {
+    const uint64_t *product_coset, *permuted_input_coset, *permuted_table_coset, *table_value;   /* device */
+    const uint64_t *l0, *l_last, *l_active_row;              /* device */
+    const uint64_t *beta, *gamma, *y;                        /* host */
+} dehalo_lookup_inputs;
+int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
+                           void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-kernel device time measured with HIP events on the launching stream (bench.py's
  * roofline leg).  kernel ids: see dehalo_kernel_id.                                          */
@@ -166,7 +237,8 @@ typedef enum {
     DEHALO_K_MSM_REDUCE = 2,     /* partial merge + bucket reduction                */
     DEHALO_K_NTT_PASS = 3,       /* all NTT passes of one transform                 */
     DEHALO_K_POLY = 4,           /* eval_polynomial / batch_invert / prefix product */
-    DEHALO_K_COUNT = 5
+    DEHALO_K_EVAL_H = 5,         /* quotient-numerator kernels (graph, permutation, lookup) */
+    DEHALO_K_COUNT = 6
 } dehalo_kernel_id;
 int dehalo_timing_enable(dehalo_ctx* ctx, int on);
 int dehalo_timing_reset(dehalo_ctx* ctx);

@@ -360,6 +360,116 @@ def grand_product(f: Field, num: Sequence[int], den: Sequence[int]) -> List[int]
 
 
 # ----------------------------------------------------------------------------
+# Quotient numerator (SURVEY.md 8(f) row 1): [UPSTREAM halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20].
+# Canonical ints.  A graph is a dict {constants, rotations, calcs, num_intermediates}; a source is
+# (kind, index, rotation_index) with kinds SRC_*; a calculation is (op, a, b, parts, target).
+# ----------------------------------------------------------------------------
+SRC_CONSTANT, SRC_INTERMEDIATE, SRC_FIXED, SRC_ADVICE, SRC_INSTANCE, SRC_CHALLENGE, SRC_BETA, SRC_GAMMA, SRC_THETA, SRC_Y, SRC_PREVIOUS = range(11)
+CALC_ADD, CALC_SUB, CALC_MUL, CALC_SQUARE, CALC_DOUBLE, CALC_NEGATE, CALC_HORNER, CALC_STORE = range(8)
+
+
+def get_rotation_idx(idx: int, rot: int, rot_scale: int, isize: int) -> int:
+    """[UPSTREAM evaluation.rs get_rotation_idx] (idx + rot * rot_scale).rem_euclid(isize)."""
+    return (idx + rot * rot_scale) % isize
+
+
+def graph_evaluate_row(f: Field, g: dict, env: dict, idx: int, rot_scale: int, isize: int, previous: int) -> int:
+    """[UPSTREAM GraphEvaluator::evaluate] value of the last calculation at row idx (0 for an empty graph)."""
+    p = f.p
+    rots = [get_rotation_idx(idx, r, rot_scale, isize) for r in g["rotations"]]
+    inter = [0] * g["num_intermediates"]
+
+    def get(src):
+        kind, index, rot = src
+        if kind == SRC_CONSTANT: return g["constants"][index]
+        if kind == SRC_INTERMEDIATE: return inter[index]
+        if kind == SRC_FIXED: return env["fixed"][index][rots[rot]]
+        if kind == SRC_ADVICE: return env["advice"][index][rots[rot]]
+        if kind == SRC_INSTANCE: return env["instance"][index][rots[rot]]
+        if kind == SRC_CHALLENGE: return env["challenges"][index]
+        if kind == SRC_BETA: return env["beta"]
+        if kind == SRC_GAMMA: return env["gamma"]
+        if kind == SRC_THETA: return env["theta"]
+        if kind == SRC_Y: return env["y"]
+        return previous
+
+    for op, a, b, parts, target in g["calcs"]:
+        if op == CALC_ADD: v = (get(a) + get(b)) % p
+        elif op == CALC_SUB: v = (get(a) - get(b)) % p
+        elif op == CALC_MUL: v = get(a) * get(b) % p
+        elif op == CALC_SQUARE: v = get(a) * get(a) % p
+        elif op == CALC_DOUBLE: v = 2 * get(a) % p
+        elif op == CALC_NEGATE: v = (-get(a)) % p
+        elif op == CALC_HORNER:
+            v, factor = get(a), get(b)
+            for part in parts:
+                v = (v * factor + get(part)) % p
+        else: v = get(a)
+        inter[target] = v
+    return inter[g["calcs"][-1][4]] if g["calcs"] else 0
+
+
+def graph_evaluate(f: Field, g: dict, env: dict, rows: int, rot_scale: int, previous: Optional[Sequence[int]] = None) -> List[int]:
+    return [graph_evaluate_row(f, g, env, i, rot_scale, rows, previous[i] if previous is not None else 0) for i in range(rows)]
+
+
+def permutation_h(f: Field, values: Sequence[int], z: Sequence[Sequence[int]], columns: Sequence[Sequence[int]], sigma: Sequence[Sequence[int]], chunk_len: int,
+                  last_rotation: int, l0, l_last, l_active, beta: int, gamma: int, y: int, delta: int, zeta_: int, extended_omega: int, rot_scale: int) -> List[int]:
+    """[UPSTREAM Evaluator::evaluate_h, "Permutation constraints"] folds the permutation argument's terms into values."""
+    p = f.p
+    rows = len(values)
+    out = list(values)
+    if not z:
+        return out
+    delta_start = beta * zeta_ % p
+    beta_term = 1
+    for idx in range(rows):
+        v = out[idx]
+        r_next = get_rotation_idx(idx, 1, rot_scale, rows)
+        r_last = get_rotation_idx(idx, last_rotation, rot_scale, rows)
+        v = (v * y + (1 - z[0][idx]) * l0[idx]) % p
+        zl = z[-1][idx]
+        v = (v * y + (zl * zl - zl) * l_last[idx]) % p
+        for s in range(1, len(z)):
+            v = (v * y + (z[s][idx] - z[s - 1][r_last]) * l0[idx]) % p
+        current_delta = delta_start * beta_term % p
+        for s in range(len(z)):
+            cols = range(s * chunk_len, min((s + 1) * chunk_len, len(columns)))
+            left = z[s][r_next]
+            for j in cols:
+                left = left * (columns[j][idx] + beta * sigma[j][idx] + gamma) % p
+            right = z[s][idx]
+            for j in cols:
+                right = right * (columns[j][idx] + current_delta + gamma) % p
+                current_delta = current_delta * delta % p
+            v = (v * y + (left - right) * l_active[idx]) % p
+        beta_term = beta_term * extended_omega % p
+        out[idx] = v
+    return out
+
+
+def lookup_h(f: Field, values: Sequence[int], product, permuted_input, permuted_table, table_value, l0, l_last, l_active, beta: int, gamma: int, y: int,
+             rot_scale: int) -> List[int]:
+    """[UPSTREAM Evaluator::evaluate_h, "Lookup constraints"] one lookup argument's five terms."""
+    p = f.p
+    rows = len(values)
+    out = list(values)
+    for idx in range(rows):
+        v = out[idx]
+        r_next = get_rotation_idx(idx, 1, rot_scale, rows)
+        r_prev = get_rotation_idx(idx, -1, rot_scale, rows)
+        a_minus_s = permuted_input[idx] - permuted_table[idx]
+        zc = product[idx]
+        v = (v * y + (1 - zc) * l0[idx]) % p
+        v = (v * y + (zc * zc - zc) * l_last[idx]) % p
+        v = (v * y + (product[r_next] * (permuted_input[idx] + beta) * (permuted_table[idx] + gamma) - zc * table_value[idx]) * l_active[idx]) % p
+        v = (v * y + a_minus_s * l0[idx]) % p
+        v = (v * y + a_minus_s * (permuted_input[idx] - permuted_input[r_prev]) * l_active[idx]) % p
+        out[idx] = v
+    return out
+
+
+# ----------------------------------------------------------------------------
 # NTT (best_fft) and EvaluationDomain wrappers
 # ----------------------------------------------------------------------------
 def dft_naive(f: Field, a: Sequence[int], omega: int) -> List[int]:

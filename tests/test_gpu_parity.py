@@ -477,3 +477,180 @@ def test_prefix_product_device_in_place(pkg, co, ctx):
     ctx.synchronize()
     ones = ctx.field_op(fid, "to_mont", np.tile(np.array([[1, 0, 0, 0]], dtype=np.uint64), (n, 1)))
     assert np.array_equal(d.cpu().numpy().view(np.uint64), co.grand_product(fid, v, ones))
+
+
+# ---------------------------------------------------------------- quotient numerator
+def _dev(spec, vals):
+    import torch
+    return torch.from_numpy(spec.encode_many(list(vals)).view(np.int64).copy()).cuda()
+
+
+def _host(spec, t):
+    return spec.decode_many(t.cpu().numpy().view(np.uint64))
+
+
+def _random_graph(po, f, rng, n_calcs, n_fixed, n_advice, n_instance, n_chal, long_lived):
+    """A random straight-line program over every source kind and operation.  long_lived > 0 keeps
+    that many early intermediates alive to the end, forcing slots beyond the LDS budget into HBM."""
+    consts = [0, 1, 2] + [rng.below(f.p) for _ in range(4)]
+    rotations = [0, 1, -1, 2, -3, 5]
+    calcs, n_int = [], 0
+
+    def src():
+        kinds = [po.SRC_CONSTANT, po.SRC_FIXED, po.SRC_ADVICE, po.SRC_ADVICE, po.SRC_CHALLENGE, po.SRC_BETA, po.SRC_GAMMA, po.SRC_THETA, po.SRC_Y, po.SRC_PREVIOUS]
+        if n_instance: kinds.append(po.SRC_INSTANCE)
+        if n_int: kinds += [po.SRC_INTERMEDIATE] * 8
+        k = kinds[rng.below(len(kinds))]
+        if k == po.SRC_CONSTANT: return (k, rng.below(len(consts)), 0)
+        if k == po.SRC_INTERMEDIATE: return (k, rng.below(n_int), 0)
+        if k == po.SRC_FIXED: return (k, rng.below(n_fixed), rng.below(len(rotations)))
+        if k == po.SRC_ADVICE: return (k, rng.below(n_advice), rng.below(len(rotations)))
+        if k == po.SRC_INSTANCE: return (k, rng.below(n_instance), rng.below(len(rotations)))
+        if k == po.SRC_CHALLENGE: return (k, rng.below(n_chal), 0)
+        return (k, 0, 0)
+
+    for _ in range(n_calcs):
+        op = rng.below(8)
+        parts = tuple(src() for _ in range(1 + rng.below(4))) if op == po.CALC_HORNER else ()
+        calcs.append((op, src(), src(), parts, n_int))
+        n_int += 1
+    if long_lived:   # a final Horner over the first `long_lived` intermediates keeps all of them live
+        calcs.append((po.CALC_HORNER, (po.SRC_INTERMEDIATE, n_int - 1, 0), (po.SRC_Y, 0, 0), tuple((po.SRC_INTERMEDIATE, i, 0) for i in range(long_lived)), n_int))
+        n_int += 1
+    return {"constants": consts, "rotations": rotations, "calcs": calcs, "num_intermediates": n_int}
+
+
+def _run_graph(pkg, ctx, spec, g, env, log_rows, rot_scale, previous):
+    import torch
+    ev = pkg.evaluation
+    ge = ev.GraphEvaluator(constants=list(g["constants"]), rotations=list(g["rotations"]), calculations=list(g["calcs"]), num_intermediates=g["num_intermediates"])
+    cg = ge.compile(ctx, spec)
+    cols = {k: [_dev(spec, c) for c in env[k]] for k in ("fixed", "advice", "instance")}
+    prev = _dev(spec, previous) if previous is not None else None
+    out = torch.zeros((1 << log_rows, 4), dtype=torch.int64, device="cuda")
+    cg.evaluate_device([t.data_ptr() for t in cols["fixed"]], [t.data_ptr() for t in cols["advice"]], [t.data_ptr() for t in cols["instance"]], env["challenges"],
+                       env["beta"], env["gamma"], env["theta"], env["y"], log_rows, rot_scale, prev.data_ptr() if prev is not None else 0, out.data_ptr())
+    ctx.synchronize()
+    res = _host(spec, out)
+    if prev is not None:   # in place: previous == out (custom gates accumulate into `values`)
+        cg.evaluate_device([t.data_ptr() for t in cols["fixed"]], [t.data_ptr() for t in cols["advice"]], [t.data_ptr() for t in cols["instance"]], env["challenges"],
+                           env["beta"], env["gamma"], env["theta"], env["y"], log_rows, rot_scale, prev.data_ptr(), prev.data_ptr())
+        ctx.synchronize()
+        assert _host(spec, prev) == res
+    cg.release()
+    return res
+
+
+@pytest.mark.parametrize("fname,seed,n_calcs,long_lived", [("bn254_fr", 1, 12, 0), ("bn254_fr", 2, 60, 0), ("pasta_fp", 3, 40, 30), ("pasta_fq", 4, 150, 20),
+                                                           ("bn254_fq", 5, 25, 14)])
+def test_graph_evaluate_random_programs(pkg, po, ctx, fname, seed, n_calcs, long_lived):
+    f, spec = po.FIELDS[fname], pkg.fields.FIELDS[fname]
+    rng = po.Xoshiro(0xE7A1 + seed)
+    log_rows, rot_scale = 7, 4
+    rows = 1 << log_rows
+    nf, na, ni, nc = 3, 4, 1, 2
+    col = lambda: [rng.below(f.p) for _ in range(rows)]
+    env = {"fixed": [col() for _ in range(nf)], "advice": [col() for _ in range(na)], "instance": [col() for _ in range(ni)],
+           "challenges": [rng.below(f.p) for _ in range(nc)], "beta": rng.below(f.p), "gamma": rng.below(f.p), "theta": rng.below(f.p), "y": rng.below(f.p)}
+    g = _random_graph(po, f, rng, n_calcs, nf, na, ni, nc, long_lived)
+    previous = col()
+    assert _run_graph(pkg, ctx, spec, g, env, log_rows, rot_scale, previous) == po.graph_evaluate(f, g, env, rows, rot_scale, previous)
+    assert _run_graph(pkg, ctx, spec, g, env, log_rows, rot_scale, None) == po.graph_evaluate(f, g, env, rows, rot_scale, None)
+
+
+def test_graph_evaluate_maingate_shape(pkg, po, ctx):
+    """The delay-encryption circuit's gate shape (5 advice a..e, selectors
+    sa..se, s_mul_ab, s_mul_cd, s_next_e, s_constant, public input), built with upstream's
+    de-duplicating builder and folded with y like Evaluator::new does for the gate polynomials."""
+    ev = pkg.evaluation
+    f, spec = po.BN254_FR, pkg.fields.BN254_FR
+    rng = po.Xoshiro(77)
+    g = ev.GraphEvaluator()
+    adv = [g.column(ev.ADVICE, i) for i in range(5)]
+    e_next = g.column(ev.ADVICE, 4, 1)
+    fx = [g.column(ev.FIXED, i) for i in range(9)]
+    inst = g.column(ev.INSTANCE, 0)
+    terms = [g.add_calculation(ev.MUL, adv[i], fx[i]) for i in range(5)]
+    terms.append(g.add_calculation(ev.MUL, g.add_calculation(ev.MUL, adv[0], adv[1]), fx[5]))
+    terms.append(g.add_calculation(ev.MUL, g.add_calculation(ev.MUL, adv[2], adv[3]), fx[6]))
+    terms.append(g.add_calculation(ev.MUL, e_next, fx[7]))
+    terms.append(fx[8])
+    terms.append(inst)
+    acc = terms[0]
+    for t in terms[1:]:
+        acc = g.add_calculation(ev.ADD, acc, t)
+    assert g.add_calculation(ev.MUL, adv[0], fx[0]) == terms[0]                  # de-duplicated like upstream
+    g.add_calculation(ev.HORNER, (ev.PREVIOUS, 0, 0), (ev.Y, 0, 0), (acc,))      # values * y + gate
+    log_rows, rot_scale = 10, 4
+    rows = 1 << log_rows
+    col = lambda: [rng.below(f.p) for _ in range(rows)]
+    env = {"fixed": [col() for _ in range(9)], "advice": [col() for _ in range(5)], "instance": [col()], "challenges": [], "beta": None, "gamma": None,
+           "theta": None, "y": rng.below(f.p)}
+    og = {"constants": g.constants, "rotations": g.rotations, "calcs": g.calculations, "num_intermediates": g.num_intermediates}
+    previous = col()
+    oenv = dict(env, beta=0, gamma=0, theta=0)
+    assert _run_graph(pkg, ctx, spec, og, env, log_rows, rot_scale, previous) == po.graph_evaluate(f, og, oenv, rows, rot_scale, previous)
+
+
+def test_graph_create_rejects_bad_programs(pkg, po, ctx):
+    ev = pkg.evaluation
+    spec = pkg.fields.BN254_FR
+    bad = [
+        [(ev.ADD, (ev.CONSTANT, 9, 0), (ev.CONSTANT, 0, 0), (), 0)],               # constant out of range
+        [(ev.ADD, (ev.INTERMEDIATE, 0, 0), (ev.CONSTANT, 0, 0), (), 0)],           # read before write
+        [(ev.ADD, (ev.ADVICE, 0, 3), (ev.CONSTANT, 0, 0), (), 0)],                 # rotation index out of range
+        [(9, (ev.CONSTANT, 0, 0), (ev.CONSTANT, 0, 0), (), 0)],                    # unknown op
+        [(ev.STORE, (ev.CONSTANT, 0, 0), (ev.CONSTANT, 0, 0), (), 5)],             # target out of range
+    ]
+    for calcs in bad:
+        g = ev.GraphEvaluator(calculations=calcs, num_intermediates=1, rotations=[0])
+        with pytest.raises(pkg.DehaloError):
+            g.compile(ctx, spec)
+    # a program that reads advice column 2 cannot run with only one advice column supplied
+    import torch
+    g = ev.GraphEvaluator(calculations=[(ev.STORE, (ev.ADVICE, 2, 0), (ev.CONSTANT, 0, 0), (), 0)], num_intermediates=1, rotations=[0])
+    cg = g.compile(ctx, spec)
+    out = torch.zeros((16, 4), dtype=torch.int64, device="cuda")
+    with pytest.raises(pkg.DehaloError):
+        cg.evaluate_device([], [out.data_ptr()], [], [], None, None, None, None, 4, 1, 0, out.data_ptr())
+    cg.release()
+
+
+@pytest.mark.parametrize("fname,ncols,chunk_len", [("bn254_fr", 6, 3), ("pasta_fp", 5, 3), ("pasta_fq", 4, 4), ("bn254_fr", 1, 2)])
+def test_permutation_h_vs_oracle(pkg, po, ctx, fname, ncols, chunk_len):
+    f, spec = po.FIELDS[fname], pkg.fields.FIELDS[fname]
+    rng = po.Xoshiro(0x9E21 + ncols)
+    k, ext_k = 6, 8
+    rows, rot_scale = 1 << ext_k, 1 << (ext_k - k)
+    nsets = (ncols + chunk_len - 1) // chunk_len
+    col = lambda: [rng.below(f.p) for _ in range(rows)]
+    z, cols, sigma = [col() for _ in range(nsets)], [col() for _ in range(ncols)], [col() for _ in range(ncols)]
+    l0, l_last, l_active, values = col(), col(), col(), col()
+    beta, gamma, y, delta = (rng.below(f.p) for _ in range(4))
+    zeta, w = po.zeta(f), f.omega(ext_k)
+    want = po.permutation_h(f, values, z, cols, sigma, chunk_len, -6, l0, l_last, l_active, beta, gamma, y, delta, zeta, w, rot_scale)
+    d = {n: _dev(spec, v) for n, v in (("l0", l0), ("l_last", l_last), ("l_active", l_active), ("values", values))}
+    dz, dc, ds = [_dev(spec, c) for c in z], [_dev(spec, c) for c in cols], [_dev(spec, c) for c in sigma]
+    pkg.evaluation.permutation_h_device(ctx, spec, [t.data_ptr() for t in dz], [t.data_ptr() for t in dc], [t.data_ptr() for t in ds], chunk_len, -6,
+                                        d["l0"].data_ptr(), d["l_last"].data_ptr(), d["l_active"].data_ptr(), beta, gamma, y, delta, zeta, w, ext_k, rot_scale,
+                                        d["values"].data_ptr())
+    ctx.synchronize()
+    assert _host(spec, d["values"]) == want
+
+
+@pytest.mark.parametrize("fname", ["bn254_fr", "pasta_fp"])
+def test_lookup_h_vs_oracle(pkg, po, ctx, fname):
+    f, spec = po.FIELDS[fname], pkg.fields.FIELDS[fname]
+    rng = po.Xoshiro(0x100C)
+    k, ext_k = 5, 7
+    rows, rot_scale = 1 << ext_k, 1 << (ext_k - k)
+    col = lambda: [rng.below(f.p) for _ in range(rows)]
+    names = ("product", "a", "s", "tv", "l0", "l_last", "l_active", "values")
+    h = {n: col() for n in names}
+    beta, gamma, y = (rng.below(f.p) for _ in range(3))
+    want = po.lookup_h(f, h["values"], h["product"], h["a"], h["s"], h["tv"], h["l0"], h["l_last"], h["l_active"], beta, gamma, y, rot_scale)
+    d = {n: _dev(spec, h[n]) for n in names}
+    pkg.evaluation.lookup_h_device(ctx, spec, d["product"].data_ptr(), d["a"].data_ptr(), d["s"].data_ptr(), d["tv"].data_ptr(), d["l0"].data_ptr(),
+                                   d["l_last"].data_ptr(), d["l_active"].data_ptr(), beta, gamma, y, ext_k, rot_scale, d["values"].data_ptr())
+    ctx.synchronize()
+    assert _host(spec, d["values"]) == want
