@@ -80,7 +80,7 @@ def cpu_baseline(co, po, curve, field, log_n, dist):
     }
 
 
-def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu):
+def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu, with_quotient=True):
     """The k~17 half of the metric: the MSM/NTT schedule of one delay_enc create_proof
     (31 MSM(n) + 24 iNTT(n) + 23 coset NTT(n -> 4n) + 1 iNTT(4n), phases separated by host
     syncs), synthetic device-resident columns; CPU = the same calls through oracle/oracle.c."""
@@ -92,12 +92,17 @@ def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu):
     gl = g[::-1].copy()
     cols = ps.synthetic_columns(lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed), curve.scalar.id, k, 7)
     bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, gl, 0, True)
-    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
+    fill = lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed)
+    if with_quotient:
+        cols.update(ps.synthetic_proving_key(fill, curve.scalar, k, k + 2, 55))
+    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols, with_quotient=with_quotient)
     shape.run()                                   # warm-up (twiddle tables, workspace)
     runs = [shape.run() for _ in range(5)]
     best = min(runs, key=lambda r: r.ms_total)
     out = {"k": k, "curve": curve_name, "gpu_ms": round(best.ms_total, 3), "gpu_msm_ms": round(best.ms_msm, 3), "gpu_ntt_ms": round(best.ms_ntt, 3),
-           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + 1 iNTT(4n); 7 host syncs; columns resident in HBM"}
+           "gpu_eval_h_ms": round(best.ms_eval_h, 3) if with_quotient else None,
+           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + evaluate_h(4n: gates, 2 permutation sets, 5 lookups)%s + 1 iNTT(4n); host syncs between "
+                       "phases; columns resident in HBM" % ("" if with_quotient else " [skipped]")}
     if with_cpu:
         cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
         f = curve.scalar
@@ -111,10 +116,28 @@ def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu):
         t1 = time.time()
         coeffs = [co.lagrange_to_coeff(f.id, cols["polys"][i], k, e(d.omega_inv), e(d.ifft_divisor), cores) for i in range(ps.N_INTT)]
         exts = [co.coeff_to_extended(f.id, coeffs[i], k, d.extended_k, e(d.extended_omega), e(d.g_coset), cores) for i in range(ps.N_COSET)]
-        co.extended_to_coeff(f.id, exts[0], d.extended_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), cores)
+        th = 0.0
+        h = exts[0]
+        if with_quotient:
+            th0 = time.time()
+            ch, ext_k, rs = cols["challenges"], d.extended_k, 1 << (d.extended_k - k)
+            fixed, advice, L = [cols["pk_fixed"][i] for i in range(ps.N_FIXED)], exts[:5], cols["pk_l"]
+            mg = ps.maingate_graph()
+            h = co.graph_evaluate(f.id, f.encode_many(mg.constants), mg.rotations, mg.calculations, mg.num_intermediates, fixed, advice,
+                                  [np.zeros((1 << ext_k, 4), dtype=np.uint64)], None, None, None, None, e(ch["y"]), ext_k, rs, None, cores)
+            h = co.permutation_h(f.id, h, [exts[15], exts[16]], advice + [fixed[14]], [cols["pk_sigma"][i] for i in range(ps.N_SIGMA)], ps.PERM_CHUNK, ps.LAST_ROTATION,
+                                 L[0], L[1], L[2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]), e(ch["delta"]), e(ch["beta"] * d.g_coset % f.p), e(d.extended_omega),
+                                 ext_k, rs, cores)
+            for i in range(ps.N_LOOKUPS):
+                lg = ps.lookup_graph(i)
+                tv = co.graph_evaluate(f.id, f.encode_many(lg.constants), lg.rotations, lg.calculations, lg.num_intermediates, fixed, advice, [], None, e(ch["beta"]),
+                                       e(ch["gamma"]), e(ch["theta"]), None, ext_k, rs, None, cores)
+                h = co.lookup_h(f.id, h, exts[17 + i], exts[5 + 2 * i], exts[6 + 2 * i], tv, L[0], L[1], L[2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]), ext_k, rs, cores)
+            th = time.time() - th0
+        co.extended_to_coeff(f.id, h, d.extended_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), cores)
         t2 = time.time()
-        out.update({"cpu_ms": round(1e3 * (t2 - t0), 1), "cpu_msm_ms": round(1e3 * (t1 - t0), 1), "cpu_ntt_ms": round(1e3 * (t2 - t1), 1), "cpu_cores": cores,
-                    "cpu_kind": "port (oracle/oracle.c)"})
+        out.update({"cpu_ms": round(1e3 * (t2 - t0), 1), "cpu_msm_ms": round(1e3 * (t1 - t0), 1), "cpu_ntt_ms": round(1e3 * (t2 - t1 - th), 1),
+                    "cpu_eval_h_ms": round(1e3 * th, 1) if with_quotient else None, "cpu_cores": cores, "cpu_kind": "port (oracle/oracle.c)"})
     bg.release(); bgl.release()
     return out
 
@@ -221,16 +244,34 @@ def main():
     for c in ctxs:
         c.timing_enable(False)
 
+    # Not part of the metric: the same step with nothing else in flight, so that the per-kernel device
+    # times are free of the overlap with the neighbouring steps' kernels (reported as single_stream).
+    def collect(cs):
+        return {kid: (sum(c.timing_get(kid)[0] for c in cs), sum(c.timing_get(kid)[1] for c in cs))
+                for kid in (_lib.K_MSM_ACCUMULATE, _lib.K_MSM_SORT, _lib.K_MSM_REDUCE, _lib.K_NTT_PASS)}
+    overlapped = collect(ctxs) if rank == 0 else None
+    ss_steps = min(10, args.steps)
+    ctx.timing_reset(); ctx.timing_enable(True)
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    for i in range(ss_steps):
+        ctx.msm_device(bases, d_scalars.data_ptr(), n, 1, d_out_all[0].data_ptr(), 0)
+        ctx.ntt_device(field.id, d_polys[0].data_ptr(), log_n, omega, 1, 0)
+    ctx.synchronize()
+    ss_ms = (time.perf_counter() - ts) * 1e3 / max(ss_steps, 1)
+    ctx.timing_enable(False)
+    single = collect([ctx]) if rank == 0 else None
+
     if rank == 0:
         def tsum(kid):
-            pairs = [c.timing_get(kid) for c in ctxs]
-            return sum(p[0] for p in pairs), sum(p[1] for p in pairs)
+            return overlapped[kid]
         acc_ms, acc_cnt = tsum(_lib.K_MSM_ACCUMULATE)
         sort_ms, sort_cnt = tsum(_lib.K_MSM_SORT)
         red_ms, red_cnt = tsum(_lib.K_MSM_REDUCE)
         ntt_ms, ntt_cnt = tsum(_lib.K_NTT_PASS)
         acc_avg_ms = acc_ms / max(acc_cnt, 1)
-        n_windows = 16 if log_n >= 16 else -(-256 // max(6, log_n - 1))   # ceil(256 / c), c as dehalo_bases_register chooses it
+        c_bits = args.window_bits or (16 if log_n >= 20 else 15 if log_n >= 13 else 13 if log_n >= 10 else max(6, log_n + 1))   # as dehalo_bases_register chooses it
+        n_windows = -(-256 // c_bits)
         achieved = MSM_BYTES_PER_TERM * n / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
@@ -267,6 +308,10 @@ def main():
                                   "frac": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (acc_avg_ms * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4) if acc_avg_ms > 0 else 0.0}},
             "breakdown_ms_per_step": {"msm_sort": round(sort_ms / max(sort_cnt, 1), 4), "msm_accumulate": round(acc_avg_ms, 4),
                                       "msm_reduce": round(red_ms / max(red_cnt, 1), 4), "ntt": round(ntt_ms / max(ntt_cnt, 1), 4)},
+            "single_stream": {"ms_per_step": round(ss_ms, 4), "steps": ss_steps,
+                              "kernel_ms": {name: round(single[kid][0] / max(single[kid][1], 1), 4) for name, kid in
+                                            (("msm_sort", _lib.K_MSM_SORT), ("msm_accumulate", _lib.K_MSM_ACCUMULATE), ("msm_reduce", _lib.K_MSM_REDUCE), ("ntt", _lib.K_NTT_PASS))},
+                              "note": "same step, one at a time (not the metric): kernel times without overlap from the %d steps in flight" % inflight},
             "ntt_roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEM * n / (ntt_ms / max(ntt_cnt, 1) * 1e-3) / 1e9, 2) if ntt_ms > 0 else 0.0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s"},
         }
@@ -280,12 +325,17 @@ def main():
         out["ntt_roofline"]["valu"] = {"muls_per_launch": ntt_muls, "mads_per_mul": mads_per_mul, "peak_tmad_per_s": VMAD_PEAK_TMADS,
                                        "achieved_tmad_per_s": round(ntt_muls * mads_per_mul / (ntt_avg_ms * 1e-3) / 1e12, 2) if ntt_avg_ms > 0 else 0.0}
         out["ntt_roofline"]["valu"]["frac"] = round(out["ntt_roofline"]["valu"]["achieved_tmad_per_s"] / VMAD_PEAK_TMADS, 4)
+        ss = out["single_stream"]["kernel_ms"]
+        if ss["msm_accumulate"] > 0 and ss["ntt"] > 0:
+            out["single_stream"]["valu_frac"] = {"k_msm_accum0": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (ss["msm_accumulate"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4),
+                                                 "k_ntt_pass": round(ntt_muls * mads_per_mul / (ss["ntt"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(co, po, curve, field, log_n, args.dist)
         if world == 1 and args.prover_k > 0:
             out["prover_shape"] = prover_shape_numbers(pkg, co, po, ctx, args.prover_k, args.prover_curve, not args.no_cpu_baseline)
             # the other two sizes the north star names (GPU only: the CPU port takes ~1 min at k = 20)
-            out["prover_shape_other_k"] = [prover_shape_numbers(pkg, co, po, ctx, k, args.prover_curve, False) for k in (14, 20) if k != args.prover_k]
+            out["prover_shape_other_k"] = [prover_shape_numbers(pkg, co, po, ctx, k, args.prover_curve, False, with_quotient=(k < 20))
+                                           for k in (14, 20) if k != args.prover_k]
         print(json.dumps(out), flush=True)
 
     bases.release()

@@ -9,7 +9,8 @@ Per proof (KZG/GWC over BN254, or the Pasta variant):
   phase 3   7 x commit_lagrange(grand products)         uniform
   phase 4   1 x commit(random poly)                     uniform
   phase 5  24 x lagrange_to_coeff (iNTT n), 23 x coeff_to_extended (coset NTT n -> 4n),
-            [evaluate_h: field-only, not on this path], 1 x extended_to_coeff (iNTT 4n),
+            evaluate_h over 4n rows (with_quotient=True: custom gates, 2 permutation sets, 5 lookups on
+            the device; otherwise skipped), 1 x extended_to_coeff (iNTT 4n),
             4 x commit(h pieces)
   phase 6   4 x commit(opening quotients)
 Phases are separated by a host synchronisation (the transcript squeeze happens on the host);
@@ -25,13 +26,18 @@ from typing import List
 
 import numpy as np
 
+from . import evaluation as ev
 from ._lib import Bases, Context
 from .domain import EvaluationDomain
-from .fields import CurveSpec
+from .fields import CurveSpec, FieldSpec  # noqa: F401
 
 MSM_PHASES = [("advice", 5, "witness"), ("lookup_permuted", 10, "lookup"), ("grand_products", 7, "uniform"),
               ("random", 1, "uniform"), ("h_pieces", 4, "uniform"), ("openings", 4, "uniform")]
 N_INTT, N_COSET, N_EXT_INTT = 24, 23, 1
+
+
+N_FIXED, N_SIGMA, N_LOOKUPS, PERM_CHUNK = 15, 6, 5, 3      # 15 fixed, 6 permutation columns, 5 lookups, degree 5
+LAST_ROTATION = -6                                         # -(blinding_factors + 1), blinding_factors = 5
 
 
 @dataclass
@@ -40,12 +46,41 @@ class ProverShapeResult:
     ms_total: float
     ms_msm: float
     ms_ntt: float
+    ms_eval_h: float = 0.0
+
+
+def maingate_graph() -> ev.GraphEvaluator:
+    """The custom-gate program of the circuit shape: sum_i q_i a_i + q_ab a b + q_cd c d + q_e' e(wX)
+    + q_const + instance, folded into the running value with y (values * y + gate)."""
+    g = ev.GraphEvaluator()
+    adv = [g.column(ev.ADVICE, i) for i in range(5)]
+    fx = [g.column(ev.FIXED, i) for i in range(9)]
+    terms = [g.add_calculation(ev.MUL, adv[i], fx[i]) for i in range(5)]
+    terms.append(g.add_calculation(ev.MUL, g.add_calculation(ev.MUL, adv[0], adv[1]), fx[5]))
+    terms.append(g.add_calculation(ev.MUL, g.add_calculation(ev.MUL, adv[2], adv[3]), fx[6]))
+    terms.append(g.add_calculation(ev.MUL, g.column(ev.ADVICE, 4, 1), fx[7]))
+    terms += [fx[8], g.column(ev.INSTANCE, 0)]
+    acc = terms[0]
+    for t in terms[1:]:
+        acc = g.add_calculation(ev.ADD, acc, t)
+    g.add_calculation(ev.HORNER, (ev.PREVIOUS, 0, 0), (ev.Y, 0, 0), (acc,))
+    return g
+
+
+def lookup_graph(i: int) -> ev.GraphEvaluator:
+    """table_value of range lookup i: (q_i * a_i + beta) * (table + gamma)."""
+    g = ev.GraphEvaluator()
+    inp = g.add_calculation(ev.MUL, g.column(ev.ADVICE, i), g.column(ev.FIXED, 9 + i))
+    lhs = g.add_calculation(ev.ADD, inp, (ev.BETA, 0, 0))
+    rhs = g.add_calculation(ev.ADD, g.column(ev.FIXED, 14), (ev.GAMMA, 0, 0))
+    g.add_calculation(ev.MUL, lhs, rhs)
+    return g
 
 
 class ProverShape:
     """Owns the device buffers of one proof's columns (torch tensors) and replays the schedule."""
 
-    def __init__(self, ctx: Context, curve: CurveSpec, k: int, g_lagrange: Bases, g: Bases, columns: dict, j: int = 5):
+    def __init__(self, ctx: Context, curve: CurveSpec, k: int, g_lagrange: Bases, g: Bases, columns: dict, j: int = 5, with_quotient: bool = False):
         import torch
 
         self.torch = torch
@@ -62,6 +97,34 @@ class ProverShape:
         d, e = self.domain, curve.scalar.encode
         self._c = dict(omega_inv=e(d.omega_inv), ifft=e(d.ifft_divisor), ext_omega=e(d.extended_omega), ext_omega_inv=e(d.extended_omega_inv),
                        ext_ifft=e(d.extended_ifft_divisor), zeta=e(d.g_coset))
+        self.with_quotient = with_quotient
+        if with_quotient:
+            # proving-key columns in the extended domain (resident for the life of the key) and the challenges
+            self.pk = {name: to_dev(columns["pk_" + name]) for name in ("fixed", "sigma", "l")}          # (15 | 6 | 3, 4n, 4)
+            self.instance = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")               # the circuit has no public inputs
+            self.h = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")
+            self.table_value = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")
+            self.challenges = dict(columns["challenges"])                                                  # theta, beta, gamma, y, delta: canonical ints
+            self.gate_graph = maingate_graph().compile(ctx, curve.scalar)
+            self.lookup_graphs = [lookup_graph(i).compile(ctx, curve.scalar) for i in range(N_LOOKUPS)]
+
+    def evaluate_h(self):
+        """Evaluator::evaluate_h on the device: advice = ext[0:5], (a', s') of lookup i = ext[5+2i], ext[6+2i],
+        permutation z = ext[15:17], lookup z = ext[17:22]; result (the numerator, not yet divided by the
+        vanishing polynomial -- that is one more element-wise product upstream) in self.h."""
+        f, ch, rot_scale, log_rows = self.curve.scalar, self.challenges, self.ext_n // self.n, self.domain.extended_k
+        col = lambda t, i: t[i].data_ptr()
+        fixed = [col(self.pk["fixed"], i) for i in range(N_FIXED)]
+        advice = [col(self.ext, i) for i in range(5)]
+        l0, l_last, l_active = (col(self.pk["l"], i) for i in range(3))
+        self.gate_graph.evaluate_device(fixed, advice, [self.instance.data_ptr()], [], None, None, None, ch["y"], log_rows, rot_scale, 0, self.h.data_ptr())
+        ev.permutation_h_device(self.ctx, f, [col(self.ext, 15), col(self.ext, 16)], advice + [fixed[14]], [col(self.pk["sigma"], i) for i in range(N_SIGMA)],
+                                PERM_CHUNK, LAST_ROTATION, l0, l_last, l_active, ch["beta"], ch["gamma"], ch["y"], ch["delta"], self.domain.g_coset,
+                                self.domain.extended_omega, log_rows, rot_scale, self.h.data_ptr())
+        for i in range(N_LOOKUPS):
+            self.lookup_graphs[i].evaluate_device(fixed, advice, [], [], ch["beta"], ch["gamma"], ch["theta"], None, log_rows, rot_scale, 0, self.table_value.data_ptr())
+            ev.lookup_h_device(self.ctx, f, col(self.ext, 17 + i), col(self.ext, 5 + 2 * i), col(self.ext, 6 + 2 * i), self.table_value.data_ptr(), l0, l_last,
+                               l_active, ch["beta"], ch["gamma"], ch["y"], log_rows, rot_scale, self.h.data_ptr())
 
     def _commit(self, name: str, lagrange: bool):
         t = self.cols[name]
@@ -80,14 +143,21 @@ class ProverShape:
         t1 = time.perf_counter(); t_msm += t1 - t0
         ctx.intt_scaled_device(f.id, self.polys.data_ptr(), self.k, c["omega_inv"], c["ifft"], N_INTT, 0)
         ctx.coset_ntt_device(f.id, self.polys.data_ptr(), self.k, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega"], c["zeta"], N_COSET, 0)
-        ctx.coset_intt_device(f.id, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], N_EXT_INTT, 0)
+        t_h = 0.0
+        if self.with_quotient:
+            sync(); th0 = time.perf_counter()
+            self.evaluate_h()
+            sync(); t_h = time.perf_counter() - th0
+            ctx.coset_intt_device(f.id, self.h.data_ptr(), self.domain.extended_k, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], N_EXT_INTT, 0)
+        else:
+            ctx.coset_intt_device(f.id, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], N_EXT_INTT, 0)
         sync()
-        t2 = time.perf_counter(); t_ntt += t2 - t1
+        t2 = time.perf_counter(); t_ntt += t2 - t1 - t_h
         self._commit("h_pieces", False); sync()
         self._commit("openings", False); sync()
         t3 = time.perf_counter(); t_msm += t3 - t2
         outs = np.concatenate([self.out[name].cpu().numpy().view(np.uint64) for name, _, _ in MSM_PHASES])
-        return ProverShapeResult(outs, 1e3 * (t3 - t0), 1e3 * t_msm, 1e3 * t_ntt)
+        return ProverShapeResult(outs, 1e3 * (t3 - t0), 1e3 * t_msm, 1e3 * t_ntt, 1e3 * t_h)
 
 
 def synthetic_columns(fill_scalars, scalar_field_id: int, k: int, seed: int = 1) -> dict:
@@ -100,3 +170,16 @@ def synthetic_columns(fill_scalars, scalar_field_id: int, k: int, seed: int = 1)
         s += cnt
     cols["polys"] = np.stack([fill_scalars(scalar_field_id, "uniform", n, s + i) for i in range(N_INTT)])
     return cols
+
+
+def synthetic_proving_key(fill_scalars, field, k: int, extended_k: int, seed: int = 101) -> dict:
+    """Extended-domain proving-key columns (fixed cosets, permutation cosets, l0 / l_last / l_active_row) and
+    the five challenges, to be merged into synthetic_columns' dict for ProverShape(with_quotient=True)."""
+    m = 1 << extended_k
+    scalar_field_id = field.id
+    out = {"pk_fixed": np.stack([fill_scalars(scalar_field_id, "uniform", m, seed + i) for i in range(N_FIXED)]),
+           "pk_sigma": np.stack([fill_scalars(scalar_field_id, "uniform", m, seed + 20 + i) for i in range(N_SIGMA)]),
+           "pk_l": np.stack([fill_scalars(scalar_field_id, "uniform", m, seed + 30 + i) for i in range(3)])}
+    ch = field.decode_many(fill_scalars(scalar_field_id, "uniform", 5, seed + 40))
+    out["challenges"] = dict(zip(("theta", "beta", "gamma", "y", "delta"), ch))
+    return out

@@ -35,6 +35,9 @@ def lib():
         _LIB.orc_field_info.argtypes = [C.c_int, P, P, P, P]
         _LIB.orc_fill_scalars.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_size_t, P]
         _LIB.orc_synth_bases.argtypes = [C.c_int, C.c_size_t, P]
+        _LIB.orc_graph_evaluate.argtypes = [C.c_int, P, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, P, P, C.c_uint32, C.c_uint32, P, P, C.c_int]
+        _LIB.orc_permutation_h.argtypes = [C.c_int, P, C.c_uint32, P, P, C.c_uint32, C.c_uint32, C.c_int32, P, P, P, P, C.c_uint32, C.c_uint32, P, C.c_int]
+        _LIB.orc_lookup_h.argtypes = [C.c_int, P, P, P, P, P, P, P, P, C.c_uint32, C.c_uint32, P, C.c_int]
         _LIB.orc_eval_polynomial.argtypes = [C.c_int, P, C.c_size_t, P, C.c_int, P]
         _LIB.orc_batch_invert.argtypes = [C.c_int, P, C.c_size_t]
         _LIB.orc_grand_product.argtypes = [C.c_int, P, P, C.c_size_t, P]
@@ -140,3 +143,63 @@ def grand_product(field: int, num: np.ndarray, den: np.ndarray) -> np.ndarray:
     z = np.zeros_like(a)
     assert lib().orc_grand_product(field, _p(a), _p(b), a.shape[0], _p(z)) == 0
     return z
+
+
+# ---- quotient numerator (Montgomery n x 4 u64 columns) ----
+class _Src(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("rotation", C.c_uint32)]
+
+
+class _Calc(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", _Src), ("b", _Src), ("parts_begin", C.c_uint32), ("parts_len", C.c_uint32), ("target", C.c_uint32)]
+
+
+def _cols(cols):
+    keep = [np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 4) for c in cols]
+    return keep, (C.c_void_p * max(1, len(keep)))(*[k.ctypes.data for k in keep])
+
+
+def graph_evaluate(field: int, constants, rotations, calcs, num_intermediates, fixed, advice, instance, challenges, beta, gamma, theta, y, log_rows: int,
+                   rot_scale: int, previous=None, threads: int = 1) -> np.ndarray:
+    """constants / challenges: k x 4 u64; calcs: [(op, a, b, parts, target)] with sources (kind, index, rot); columns: lists of rows x 4 u64."""
+    cst = np.ascontiguousarray(constants, dtype=np.uint64).reshape(-1, 4) if len(constants) else np.zeros((1, 4), dtype=np.uint64)
+    rot = (C.c_int32 * max(1, len(rotations)))(*rotations)
+    flat = []
+    cc = (_Calc * max(1, len(calcs)))()
+    for i, (op, a, b, parts, target) in enumerate(calcs):
+        cc[i] = _Calc(op, _Src(*a), _Src(*b), len(flat), len(parts), target)
+        flat.extend(parts)
+    pp = (_Src * max(1, len(flat)))(*[_Src(*q) for q in flat])
+    kf, tf = _cols(fixed); ka, ta = _cols(advice); ki, ti = _cols(instance)
+    ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4) if challenges is not None and len(challenges) else np.zeros((1, 4), dtype=np.uint64)
+    bgty = np.zeros((4, 4), dtype=np.uint64)
+    for i, v in enumerate((beta, gamma, theta, y)):
+        if v is not None:
+            bgty[i] = v
+    prev = np.ascontiguousarray(previous, dtype=np.uint64).reshape(-1, 4) if previous is not None else None
+    out = np.zeros((1 << log_rows, 4), dtype=np.uint64)
+    rc = lib().orc_graph_evaluate(field, _p(cst), rot, len(rotations), cc, len(calcs), pp, num_intermediates, tf, ta, ti, _p(ch), _p(bgty), log_rows, rot_scale,
+                                  _p(prev) if prev is not None else None, _p(out), threads)
+    assert rc == 0
+    return out
+
+
+def permutation_h(field: int, values, z, columns, sigma, chunk_len: int, last_rotation: int, l0, l_last, l_active, beta, gamma, y, delta, beta_zeta,
+                  extended_omega, log_rows: int, rot_scale: int, threads: int = 1) -> np.ndarray:
+    kz, tz = _cols(z); kc, tc = _cols(columns); ks, ts = _cols(sigma)
+    sc = np.stack([np.asarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y, delta, beta_zeta, extended_omega)])
+    v = np.array(values, dtype=np.uint64).reshape(-1, 4)
+    a0, a1, a2 = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (l0, l_last, l_active))
+    rc = lib().orc_permutation_h(field, tz, len(kz), tc, ts, len(kc), chunk_len, last_rotation, _p(a0), _p(a1), _p(a2), _p(sc), log_rows, rot_scale, _p(v), threads)
+    assert rc == 0
+    return v
+
+
+def lookup_h(field: int, values, product, permuted_input, permuted_table, table_value, l0, l_last, l_active, beta, gamma, y, log_rows: int, rot_scale: int,
+             threads: int = 1) -> np.ndarray:
+    arrs = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (product, permuted_input, permuted_table, table_value, l0, l_last, l_active)]
+    sc = np.stack([np.asarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y)])
+    v = np.array(values, dtype=np.uint64).reshape(-1, 4)
+    rc = lib().orc_lookup_h(field, *[_p(a) for a in arrs], _p(sc), log_rows, rot_scale, _p(v), threads)
+    assert rc == 0
+    return v

@@ -31,6 +31,7 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 #include <math.h>
 
@@ -515,6 +516,187 @@ int orc_grand_product(int field, const u64* num_, const u64* den_, size_t n, u64
     fe acc = F->r;
     for (size_t i = 0; i < n; i++) { z[i] = acc; fe t; f_mul(F, &t, &num[i], &dinv[i]); f_mul(F, &acc, &acc, &t); }
     free(dinv);
+    return 0;
+}
+
+/* ---------- quotient numerator: [UPSTREAM halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20] ----------
+ * GraphEvaluator::evaluate per row, and the permutation / lookup terms of Evaluator::evaluate_h, with upstream's
+ * `parallelize` (contiguous row chunks, one per thread).  Montgomery in / out. */
+typedef struct { uint32_t kind, index, rotation; } orc_source;
+typedef struct { uint32_t op; orc_source a, b; uint32_t parts_begin, parts_len, target; } orc_calc;
+typedef struct {
+    const field_t* F;
+    const fe* constants; const int32_t* rotations; uint32_t nrot; const orc_calc* calcs; uint32_t ncalcs; const orc_source* parts; uint32_t nint;
+    const fe* const* fixed; const fe* const* advice; const fe* const* instance; const fe* challenges; fe beta, gamma, theta, y;
+    uint32_t rot_scale; size_t rows; const fe* previous; fe* out;
+    size_t start, end;
+} geval_job;
+static inline size_t rot_idx(size_t idx, int32_t rot, uint32_t rot_scale, size_t isize) {
+    int64_t v = ((int64_t)idx + (int64_t)rot * (int64_t)rot_scale) % (int64_t)isize;
+    return (size_t)(v < 0 ? v + (int64_t)isize : v);
+}
+static void* geval_worker(void* arg) {
+    geval_job* j = arg;
+    const field_t* F = j->F;
+    fe* inter = malloc((j->nint ? j->nint : 1) * sizeof(fe));
+    size_t* rots = malloc((j->nrot ? j->nrot : 1) * sizeof(size_t));
+    fe zero; memset(&zero, 0, sizeof(zero));
+    for (size_t idx = j->start; idx < j->end; idx++) {
+        for (uint32_t r = 0; r < j->nrot; r++) rots[r] = rot_idx(idx, j->rotations[r], j->rot_scale, j->rows);
+        const fe prev = j->previous ? j->previous[idx] : zero;
+#define GET(S) ((S).kind == 0 ? j->constants[(S).index] : (S).kind == 1 ? inter[(S).index] : (S).kind == 2 ? j->fixed[(S).index][rots[(S).rotation]] : \
+                (S).kind == 3 ? j->advice[(S).index][rots[(S).rotation]] : (S).kind == 4 ? j->instance[(S).index][rots[(S).rotation]] :                  \
+                (S).kind == 5 ? j->challenges[(S).index] : (S).kind == 6 ? j->beta : (S).kind == 7 ? j->gamma : (S).kind == 8 ? j->theta :                \
+                (S).kind == 9 ? j->y : prev)
+        for (uint32_t c = 0; c < j->ncalcs; c++) {
+            const orc_calc* k = &j->calcs[c];
+            fe a = GET(k->a), b, v;
+            switch (k->op) {
+                case 0: b = GET(k->b); f_add(F, &v, &a, &b); break;
+                case 1: b = GET(k->b); f_sub(F, &v, &a, &b); break;
+                case 2: b = GET(k->b); f_mul(F, &v, &a, &b); break;
+                case 3: f_sqr(F, &v, &a); break;
+                case 4: f_dbl(F, &v, &a); break;
+                case 5: f_neg(F, &v, &a); break;
+                case 6:
+                    b = GET(k->b); v = a;
+                    for (uint32_t q = 0; q < k->parts_len; q++) { fe part = GET(j->parts[k->parts_begin + q]); f_mul(F, &v, &v, &b); f_add(F, &v, &v, &part); }
+                    break;
+                default: v = a; break;
+            }
+            inter[k->target] = v;
+        }
+#undef GET
+        j->out[idx] = j->ncalcs ? inter[j->calcs[j->ncalcs - 1].target] : zero;
+    }
+    free(inter); free(rots);
+    return NULL;
+}
+static void run_chunks(void* (*fn)(void*), void* jobs, size_t job_size, size_t rows, int threads, size_t start_off, size_t end_off) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if ((size_t)threads > rows) threads = (int)(rows ? rows : 1);
+    pthread_t th[256];
+    size_t chunk = (rows + threads - 1) / threads;
+    char* base = jobs;
+    for (int t = 0; t < threads; t++) {
+        char* jt = base + (size_t)t * job_size;
+        if (t) memcpy(jt, base, job_size);
+        size_t st = (size_t)t * chunk, en = st + chunk < rows ? st + chunk : rows;
+        if (st > rows) st = rows;
+        *(size_t*)(jt + start_off) = st; *(size_t*)(jt + end_off) = en;
+    }
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, fn, base + (size_t)t * job_size);
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
+int orc_graph_evaluate(int field, const u64* constants, const int32_t* rotations, uint32_t nrot, const orc_calc* calcs, uint32_t ncalcs, const orc_source* parts,
+                       uint32_t nint, const u64* const* fixed, const u64* const* advice, const u64* const* instance, const u64* challenges,
+                       const u64* bgty /* beta, gamma, theta, y: 16 u64 */, uint32_t log_rows, uint32_t rot_scale, const u64* previous, u64* out, int threads) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    geval_job* jobs = calloc(256, sizeof(geval_job));
+    geval_job* j = &jobs[0];
+    j->F = &FIELDS[field]; j->constants = (const fe*)constants; j->rotations = rotations; j->nrot = nrot; j->calcs = calcs; j->ncalcs = ncalcs; j->parts = parts;
+    j->nint = nint; j->fixed = (const fe* const*)fixed; j->advice = (const fe* const*)advice; j->instance = (const fe* const*)instance;
+    j->challenges = (const fe*)challenges;
+    memcpy(&j->beta, bgty, 32); memcpy(&j->gamma, bgty + 4, 32); memcpy(&j->theta, bgty + 8, 32); memcpy(&j->y, bgty + 12, 32);
+    j->rot_scale = rot_scale; j->rows = (size_t)1 << log_rows; j->previous = (const fe*)previous; j->out = (fe*)out;
+    run_chunks(geval_worker, jobs, sizeof(geval_job), j->rows, threads, offsetof(geval_job, start), offsetof(geval_job, end));
+    free(jobs);
+    return 0;
+}
+
+typedef struct {
+    const field_t* F; const fe* const* z; uint32_t nsets; const fe* const* cols; const fe* const* sigma; uint32_t ncols, chunk_len; int32_t last_rotation;
+    const fe *l0, *l_last, *l_active; fe beta, gamma, y, delta, beta_zeta, omega; uint32_t rot_scale; size_t rows; fe* values;
+    size_t start, end;
+} perm_job;
+static void* perm_worker(void* arg) {
+    perm_job* j = arg;
+    const field_t* F = j->F;
+    if (!j->nsets) return NULL;
+    fe beta_term; { u64 e[4] = {j->start, 0, 0, 0}; f_pow(F, &beta_term, &j->omega, e); }
+    const fe one = F->r;
+    for (size_t idx = j->start; idx < j->end; idx++) {
+        fe v = j->values[idx], t, u;
+        size_t r_next = rot_idx(idx, 1, j->rot_scale, j->rows), r_last = rot_idx(idx, j->last_rotation, j->rot_scale, j->rows);
+        f_mul(F, &v, &v, &j->y); f_sub(F, &t, &one, &j->z[0][idx]); f_mul(F, &t, &t, &j->l0[idx]); f_add(F, &v, &v, &t);
+        const fe* zl = &j->z[j->nsets - 1][idx];
+        f_mul(F, &v, &v, &j->y); f_sqr(F, &t, zl); f_sub(F, &t, &t, zl); f_mul(F, &t, &t, &j->l_last[idx]); f_add(F, &v, &v, &t);
+        for (uint32_t s = 1; s < j->nsets; s++) {
+            f_mul(F, &v, &v, &j->y); f_sub(F, &t, &j->z[s][idx], &j->z[s - 1][r_last]); f_mul(F, &t, &t, &j->l0[idx]); f_add(F, &v, &v, &t);
+        }
+        fe cur; f_mul(F, &cur, &j->beta_zeta, &beta_term);
+        for (uint32_t s = 0; s < j->nsets; s++) {
+            uint32_t c0 = s * j->chunk_len, c1 = c0 + j->chunk_len < j->ncols ? c0 + j->chunk_len : j->ncols;
+            fe left = j->z[s][r_next], right = j->z[s][idx];
+            for (uint32_t c = c0; c < c1; c++) {
+                f_mul(F, &t, &j->beta, &j->sigma[c][idx]); f_add(F, &t, &t, &j->cols[c][idx]); f_add(F, &t, &t, &j->gamma); f_mul(F, &left, &left, &t);
+            }
+            for (uint32_t c = c0; c < c1; c++) {
+                f_add(F, &u, &j->cols[c][idx], &cur); f_add(F, &u, &u, &j->gamma); f_mul(F, &right, &right, &u);
+                f_mul(F, &cur, &cur, &j->delta);
+            }
+            f_mul(F, &v, &v, &j->y); f_sub(F, &t, &left, &right); f_mul(F, &t, &t, &j->l_active[idx]); f_add(F, &v, &v, &t);
+        }
+        f_mul(F, &beta_term, &beta_term, &j->omega);
+        j->values[idx] = v;
+    }
+    return NULL;
+}
+int orc_permutation_h(int field, const u64* const* z, uint32_t nsets, const u64* const* cols, const u64* const* sigma, uint32_t ncols, uint32_t chunk_len,
+                      int32_t last_rotation, const u64* l0, const u64* l_last, const u64* l_active, const u64* scalars /* beta gamma y delta beta_zeta omega */,
+                      uint32_t log_rows, uint32_t rot_scale, u64* values, int threads) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    perm_job* jobs = calloc(256, sizeof(perm_job));
+    perm_job* j = &jobs[0];
+    j->F = &FIELDS[field]; j->z = (const fe* const*)z; j->nsets = nsets; j->cols = (const fe* const*)cols; j->sigma = (const fe* const*)sigma; j->ncols = ncols;
+    j->chunk_len = chunk_len; j->last_rotation = last_rotation; j->l0 = (const fe*)l0; j->l_last = (const fe*)l_last; j->l_active = (const fe*)l_active;
+    memcpy(&j->beta, scalars, 32); memcpy(&j->gamma, scalars + 4, 32); memcpy(&j->y, scalars + 8, 32); memcpy(&j->delta, scalars + 12, 32);
+    memcpy(&j->beta_zeta, scalars + 16, 32); memcpy(&j->omega, scalars + 20, 32);
+    j->rot_scale = rot_scale; j->rows = (size_t)1 << log_rows; j->values = (fe*)values;
+    run_chunks(perm_worker, jobs, sizeof(perm_job), j->rows, threads, offsetof(perm_job, start), offsetof(perm_job, end));
+    free(jobs);
+    return 0;
+}
+
+typedef struct {
+    const field_t* F; const fe *z, *a, *s, *tv, *l0, *l_last, *l_active; fe beta, gamma, y; uint32_t rot_scale; size_t rows; fe* values;
+    size_t start, end;
+} lookup_job;
+static void* lookup_worker(void* arg) {
+    lookup_job* j = arg;
+    const field_t* F = j->F;
+    const fe one = F->r;
+    for (size_t idx = j->start; idx < j->end; idx++) {
+        fe v = j->values[idx], t, u, ams;
+        size_t r_next = rot_idx(idx, 1, j->rot_scale, j->rows), r_prev = rot_idx(idx, -1, j->rot_scale, j->rows);
+        f_sub(F, &ams, &j->a[idx], &j->s[idx]);
+        f_mul(F, &v, &v, &j->y); f_sub(F, &t, &one, &j->z[idx]); f_mul(F, &t, &t, &j->l0[idx]); f_add(F, &v, &v, &t);
+        f_mul(F, &v, &v, &j->y); f_sqr(F, &t, &j->z[idx]); f_sub(F, &t, &t, &j->z[idx]); f_mul(F, &t, &t, &j->l_last[idx]); f_add(F, &v, &v, &t);
+        f_add(F, &t, &j->a[idx], &j->beta); f_mul(F, &t, &t, &j->z[r_next]); f_add(F, &u, &j->s[idx], &j->gamma); f_mul(F, &t, &t, &u);
+        f_mul(F, &u, &j->z[idx], &j->tv[idx]); f_sub(F, &t, &t, &u); f_mul(F, &t, &t, &j->l_active[idx]);
+        f_mul(F, &v, &v, &j->y); f_add(F, &v, &v, &t);
+        f_mul(F, &v, &v, &j->y); f_mul(F, &t, &ams, &j->l0[idx]); f_add(F, &v, &v, &t);
+        f_sub(F, &t, &j->a[idx], &j->a[r_prev]); f_mul(F, &t, &t, &ams); f_mul(F, &t, &t, &j->l_active[idx]);
+        f_mul(F, &v, &v, &j->y); f_add(F, &v, &v, &t);
+        j->values[idx] = v;
+    }
+    return NULL;
+}
+int orc_lookup_h(int field, const u64* z, const u64* a, const u64* s_, const u64* tv, const u64* l0, const u64* l_last, const u64* l_active,
+                 const u64* scalars /* beta gamma y */, uint32_t log_rows, uint32_t rot_scale, u64* values, int threads) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    lookup_job* jobs = calloc(256, sizeof(lookup_job));
+    lookup_job* j = &jobs[0];
+    j->F = &FIELDS[field]; j->z = (const fe*)z; j->a = (const fe*)a; j->s = (const fe*)s_; j->tv = (const fe*)tv; j->l0 = (const fe*)l0; j->l_last = (const fe*)l_last;
+    j->l_active = (const fe*)l_active;
+    memcpy(&j->beta, scalars, 32); memcpy(&j->gamma, scalars + 4, 32); memcpy(&j->y, scalars + 8, 32);
+    j->rot_scale = rot_scale; j->rows = (size_t)1 << log_rows; j->values = (fe*)values;
+    run_chunks(lookup_worker, jobs, sizeof(lookup_job), j->rows, threads, offsetof(lookup_job, start), offsetof(lookup_job, end));
+    free(jobs);
     return 0;
 }
 

@@ -6,7 +6,7 @@ on summation order (as it does upstream with the rayon thread count)."""
 import numpy as np
 import pytest
 
-from conftest import dec_point, enc_points, golden
+from conftest import dec_point, enc_points, golden, random_graph as _random_graph
 
 pytestmark = pytest.mark.gpu
 
@@ -489,37 +489,6 @@ def _host(spec, t):
     return spec.decode_many(t.cpu().numpy().view(np.uint64))
 
 
-def _random_graph(po, f, rng, n_calcs, n_fixed, n_advice, n_instance, n_chal, long_lived):
-    """A random straight-line program over every source kind and operation.  long_lived > 0 keeps
-    that many early intermediates alive to the end, forcing slots beyond the LDS budget into HBM."""
-    consts = [0, 1, 2] + [rng.below(f.p) for _ in range(4)]
-    rotations = [0, 1, -1, 2, -3, 5]
-    calcs, n_int = [], 0
-
-    def src():
-        kinds = [po.SRC_CONSTANT, po.SRC_FIXED, po.SRC_ADVICE, po.SRC_ADVICE, po.SRC_CHALLENGE, po.SRC_BETA, po.SRC_GAMMA, po.SRC_THETA, po.SRC_Y, po.SRC_PREVIOUS]
-        if n_instance: kinds.append(po.SRC_INSTANCE)
-        if n_int: kinds += [po.SRC_INTERMEDIATE] * 8
-        k = kinds[rng.below(len(kinds))]
-        if k == po.SRC_CONSTANT: return (k, rng.below(len(consts)), 0)
-        if k == po.SRC_INTERMEDIATE: return (k, rng.below(n_int), 0)
-        if k == po.SRC_FIXED: return (k, rng.below(n_fixed), rng.below(len(rotations)))
-        if k == po.SRC_ADVICE: return (k, rng.below(n_advice), rng.below(len(rotations)))
-        if k == po.SRC_INSTANCE: return (k, rng.below(n_instance), rng.below(len(rotations)))
-        if k == po.SRC_CHALLENGE: return (k, rng.below(n_chal), 0)
-        return (k, 0, 0)
-
-    for _ in range(n_calcs):
-        op = rng.below(8)
-        parts = tuple(src() for _ in range(1 + rng.below(4))) if op == po.CALC_HORNER else ()
-        calcs.append((op, src(), src(), parts, n_int))
-        n_int += 1
-    if long_lived:   # a final Horner over the first `long_lived` intermediates keeps all of them live
-        calcs.append((po.CALC_HORNER, (po.SRC_INTERMEDIATE, n_int - 1, 0), (po.SRC_Y, 0, 0), tuple((po.SRC_INTERMEDIATE, i, 0) for i in range(long_lived)), n_int))
-        n_int += 1
-    return {"constants": consts, "rotations": rotations, "calcs": calcs, "num_intermediates": n_int}
-
-
 def _run_graph(pkg, ctx, spec, g, env, log_rows, rot_scale, previous):
     import torch
     ev = pkg.evaluation
@@ -654,3 +623,44 @@ def test_lookup_h_vs_oracle(pkg, po, ctx, fname):
                                    d["l_last"].data_ptr(), d["l_active"].data_ptr(), beta, gamma, y, ext_k, rot_scale, d["values"].data_ptr())
     ctx.synchronize()
     assert _host(spec, d["values"]) == want
+
+
+@pytest.mark.parametrize("cname,k", [("bn254", 7), ("pallas", 8)])
+def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k):
+    """The same schedule with evaluate_h on the device: custom gates + 2 permutation sets + 5 lookups over the
+    extended domain, then extended_to_coeff, against the C oracle run on the same cosets."""
+    from dehalo2_amd import prover_shape as ps
+    curve = pkg.fields.CURVES[cname]
+    f = curve.scalar
+    n = 1 << k
+    g = co.synth_bases(curve.id, n)
+    fill = lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed)
+    cols = ps.synthetic_columns(fill, f.id, k, 3)
+    bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, g[::-1].copy(), 0, True)
+    shape0 = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
+    cols.update(ps.synthetic_proving_key(fill, f, k, shape0.domain.extended_k, 55))
+    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols, with_quotient=True)
+    res = shape.run()
+    assert res.ms_eval_h > 0
+    d, e = shape.domain, f.encode
+    ext = shape.ext.cpu().numpy().view(np.uint64)                       # cosets as the device produced them (checked elsewhere)
+    pk = {name: cols["pk_" + name] for name in ("fixed", "sigma", "l")}
+    ch = cols["challenges"]
+    ext_k, rot_scale = d.extended_k, (1 << d.extended_k) // n
+    zero_col = np.zeros((1 << ext_k, 4), dtype=np.uint64)
+    mg = ps.maingate_graph()
+    fixed, advice = [pk["fixed"][i] for i in range(ps.N_FIXED)], [ext[i] for i in range(5)]
+    h = co.graph_evaluate(f.id, f.encode_many(mg.constants), mg.rotations, mg.calculations, mg.num_intermediates, fixed, advice, [zero_col], None, None, None, None,
+                          e(ch["y"]), ext_k, rot_scale, None, 4)
+    h = co.permutation_h(f.id, h, [ext[15], ext[16]], advice + [fixed[14]], [pk["sigma"][i] for i in range(ps.N_SIGMA)], ps.PERM_CHUNK, ps.LAST_ROTATION,
+                         pk["l"][0], pk["l"][1], pk["l"][2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]), e(ch["delta"]), e(ch["beta"] * d.g_coset % f.p),
+                         e(d.extended_omega), ext_k, rot_scale, 4)
+    for i in range(ps.N_LOOKUPS):
+        lg = ps.lookup_graph(i)
+        tv = co.graph_evaluate(f.id, f.encode_many(lg.constants), lg.rotations, lg.calculations, lg.num_intermediates, fixed, advice, [], None, e(ch["beta"]),
+                               e(ch["gamma"]), e(ch["theta"]), None, ext_k, rot_scale, None, 4)
+        h = co.lookup_h(f.id, h, ext[17 + i], ext[5 + 2 * i], ext[6 + 2 * i], tv, pk["l"][0], pk["l"][1], pk["l"][2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]),
+                        ext_k, rot_scale, 4)
+    want = co.extended_to_coeff(f.id, h, ext_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), 2)
+    assert np.array_equal(shape.h.cpu().numpy().view(np.uint64), want)
+    bg.release(); bgl.release()

@@ -202,3 +202,41 @@ def test_c_eval_polynomial_threads_agree(po, co):
     one = co.eval_polynomial(fid, c, x, 1)
     for t in (2, 7, 64):
         assert np.array_equal(co.eval_polynomial(fid, c, x, t), one)
+
+
+# ---------------------------------------------------------------- quotient numerator
+def test_evalh_c_oracle_vs_python(po, co):
+    from conftest import random_graph
+    f = po.BN254_FR
+    fid = po.FIELD_IDS[f.name]
+    rng = po.Xoshiro(0xE0A1)
+    k, ext_k = 4, 6
+    rows, rot_scale = 1 << ext_k, 1 << (ext_k - k)
+    col = lambda: [rng.below(f.p) for _ in range(rows)]
+    enc = lambda vals: _enc(po, f, vals)
+    env = {"fixed": [col() for _ in range(3)], "advice": [col() for _ in range(4)], "instance": [col()], "challenges": [rng.below(f.p) for _ in range(2)],
+           "beta": rng.below(f.p), "gamma": rng.below(f.p), "theta": rng.below(f.p), "y": rng.below(f.p)}
+    previous = col()
+    for n_calcs, long_lived in ((15, 0), (70, 25)):
+        g = random_graph(po, f, rng, n_calcs, 3, 4, 1, 2, long_lived)
+        want = po.graph_evaluate(f, g, env, rows, rot_scale, previous)
+        for threads in (1, 5):
+            got = co.graph_evaluate(fid, enc(g["constants"]), g["rotations"], g["calcs"], g["num_intermediates"], [enc(c) for c in env["fixed"]],
+                                    [enc(c) for c in env["advice"]], [enc(c) for c in env["instance"]], enc(env["challenges"]), enc([env["beta"]])[0],
+                                    enc([env["gamma"]])[0], enc([env["theta"]])[0], enc([env["y"]])[0], ext_k, rot_scale, enc(previous), threads)
+            assert _dec(po, f, got) == want
+    # permutation and lookup terms
+    z, cols, sigma = [col() for _ in range(2)], [col() for _ in range(5)], [col() for _ in range(5)]
+    l0, l_last, l_active, values = col(), col(), col(), col()
+    beta, gamma, y, delta = (rng.below(f.p) for _ in range(4))
+    zeta, w = po.zeta(f), f.omega(ext_k)
+    want = po.permutation_h(f, values, z, cols, sigma, 3, -6, l0, l_last, l_active, beta, gamma, y, delta, zeta, w, rot_scale)
+    e1 = lambda v: enc([v])[0]
+    for threads in (1, 7):
+        got = co.permutation_h(fid, enc(values), [enc(c) for c in z], [enc(c) for c in cols], [enc(c) for c in sigma], 3, -6, enc(l0), enc(l_last), enc(l_active),
+                               e1(beta), e1(gamma), e1(y), e1(delta), e1(beta * zeta % f.p), e1(w), ext_k, rot_scale, threads)
+        assert _dec(po, f, got) == want
+    prod, a, s, tv = col(), col(), col(), col()
+    want = po.lookup_h(f, values, prod, a, s, tv, l0, l_last, l_active, beta, gamma, y, rot_scale)
+    got = co.lookup_h(fid, enc(values), enc(prod), enc(a), enc(s), enc(tv), enc(l0), enc(l_last), enc(l_active), e1(beta), e1(gamma), e1(y), ext_k, rot_scale, 3)
+    assert _dec(po, f, got) == want
