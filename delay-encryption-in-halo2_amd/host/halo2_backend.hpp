@@ -43,6 +43,23 @@ class Backend {
         if (a.size() != (size_t(1) << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
         check(dehalo_ntt(ctx_, field, a[0].data(), log_n, omega.data()));
     }
+    // arithmetic::eval_polynomial(poly, point) -> F
+    Fe eval_polynomial(dehalo_field field, const std::vector<Fe>& poly, const Fe& point) const {
+        Fe out{};
+        check(dehalo_eval_polynomial(ctx_, field, poly.empty() ? nullptr : poly[0].data(), poly.size(), point.data(), out.data()));
+        return out;
+    }
+    // ff::BatchInvert: in place, zeros stay zero
+    void batch_invert(dehalo_field field, std::vector<Fe>& values) const {
+        check(dehalo_batch_invert(ctx_, field, values.empty() ? nullptr : values[0].data(), values.size()));
+    }
+    // z[0] = 1, z[i] = prod_{j<i} num[j] / den[j]  (permutation::commit / lookup::commit_product without the blinding rows)
+    std::vector<Fe> grand_product(dehalo_field field, const std::vector<Fe>& num, const std::vector<Fe>& den) const {
+        if (num.size() != den.size()) throw std::invalid_argument("grand_product: num.len() != den.len()");
+        std::vector<Fe> z(num.size());
+        if (!num.empty()) check(dehalo_grand_product(ctx_, field, num[0].data(), den[0].data(), num.size(), z[0].data()));
+        return z;
+    }
     void check(int rc) const {
         if (rc != 0) throw std::runtime_error(std::string("dehalo error ") + std::to_string(rc) + ": " + dehalo_last_error(ctx_));
     }
