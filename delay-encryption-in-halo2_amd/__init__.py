@@ -16,7 +16,7 @@ from ._lib import Context, DehaloError, Bases, library_path, load_library  # noq
 from .arithmetic import batch_invert, best_fft, best_multiexp, eval_polynomial, grand_product  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
 from .commitment import Params  # noqa: F401
-from . import evaluation  # noqa: F401
+from . import evaluation, lookup  # noqa: F401
 
 __all__ = ["Context", "DehaloError", "Bases", "best_multiexp", "best_fft", "eval_polynomial", "batch_invert", "grand_product", "EvaluationDomain", "Params", "fields",
            "library_path", "load_library"]

@@ -20,6 +20,7 @@ SYMBOLS = [
     "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device",
+    "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
@@ -109,6 +110,8 @@ def load_library():
     lib.dehalo_prefix_product_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
     lib.dehalo_grand_product.argtypes = [P, C.c_int, u64p, u64p, sz, u64p]
     lib.dehalo_grand_product_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, P]
+    lib.dehalo_permute_expression_pair.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p]
+    lib.dehalo_permute_expression_pair_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p, P]
     lib.dehalo_graph_create.argtypes = [P, C.c_int, u64p, u32, C.POINTER(C.c_int32), u32, C.POINTER(CCalculation), u32, C.POINTER(CSource), u32, u32, C.POINTER(P)]
     lib.dehalo_graph_release.argtypes = [P, P]
     lib.dehalo_graph_evaluate_device.argtypes = [P, P, C.POINTER(CEvalInputs), u32, u32, u64p, u64p, P]
@@ -300,6 +303,19 @@ class Context:
 
     def grand_product_device(self, field: int, d_num: int, d_den: int, length: int, d_z: int, stream: int = 0):
         self._check(self.lib.dehalo_grand_product_device(self.handle, field, d_num, d_den, length, d_z, stream or None))
+
+    def permute_expression_pair(self, field: int, input_values, table_values, usable_rows: int):
+        """-> (permuted_input, permuted_table), usable_rows x 4 u64 each; DehaloError(-6) when an input value is not in the table."""
+        a, t = _u64(input_values, 4), _u64(table_values, 4)
+        if a.shape[0] < usable_rows or t.shape[0] < usable_rows:
+            raise ValueError("permute_expression_pair: fewer than usable_rows values")
+        pi, pt = np.zeros((usable_rows, 4), dtype=np.uint64), np.zeros((usable_rows, 4), dtype=np.uint64)
+        if usable_rows:
+            self._check(self.lib.dehalo_permute_expression_pair(self.handle, field, _ptr(a), _ptr(t), usable_rows, _ptr(pi), _ptr(pt)))
+        return pi, pt
+
+    def permute_expression_pair_device(self, field: int, d_input: int, d_table: int, usable_rows: int, d_permuted_input: int, d_permuted_table: int, stream: int = 0):
+        self._check(self.lib.dehalo_permute_expression_pair_device(self.handle, field, d_input, d_table, usable_rows, d_permuted_input, d_permuted_table, stream or None))
 
     # ---- quotient numerator (SURVEY.md 8(f) row 1); see evaluation.py for the upstream-shaped wrapper ----
     def graph_create(self, field: int, constants, rotations, calcs, parts, num_intermediates: int):

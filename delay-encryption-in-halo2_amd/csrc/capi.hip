@@ -280,7 +280,7 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
                       &ctx->ws_bhist, &ctx->ws_pcount, &ctx->ws_pairs, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree,
                       &ctx->ws_gsums, &ctx->ws_ntt_scratch, &ctx->ws_ntt_io, &ctx->ws_ntt_io2, &ctx->ws_fop[0], &ctx->ws_fop[1], &ctx->ws_fop[2],
                       &ctx->ws_tmp_bases, &ctx->ws_poly[0], &ctx->ws_poly[1], &ctx->ws_poly[2], &ctx->ws_poly[3], &ctx->ws_poly[4], &ctx->ws_poly_io[0], &ctx->ws_poly_io[1],
-                      &ctx->ws_poly_io[2], &ctx->ws_evh[0], &ctx->ws_evh[1], &ctx->ws_evh[2], &ctx->ws_evh[3]};
+                      &ctx->ws_poly_io[2], &ctx->ws_evh[0], &ctx->ws_evh[1], &ctx->ws_evh[2], &ctx->ws_evh[3], &ctx->ws_lookup};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->twiddles) (void)hipFree(t.tw);
@@ -595,6 +595,41 @@ int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const 
                                     (uint64_t*)ctx->ws_poly_io[2].p, nullptr));
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipMemcpyAsync(z, ctx->ws_poly_io[2].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,
+                                          uint64_t* d_permuted_input, uint64_t* d_permuted_table, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_input || !d_table || !d_permuted_input || !d_permuted_table) && usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
+    if (d_permuted_input == d_input || d_permuted_table == d_table || d_permuted_input == d_table || d_permuted_table == d_input)
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: outputs may not alias inputs");
+    if (field < 0 || field > 3) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return lookup_permute_impl(ctx, field, (const fe*)d_input, (const fe*)d_table, usable_rows, (fe*)d_permuted_input, (fe*)d_permuted_table, pick_stream(ctx, stream));
+}
+
+int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* input, const uint64_t* table, size_t usable_rows, uint64_t* permuted_input,
+                                   uint64_t* permuted_table) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!input || !table || !permuted_input || !permuted_table) && usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
+    if (usable_rows == 0) return 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        TRY(dh_ensure(ctx, ctx->ws_poly_io[0], usable_rows * 64));
+        TRY(dh_ensure(ctx, ctx->ws_poly_io[1], usable_rows * 64));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, input, usable_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->ws_poly_io[0].p + usable_rows * 32, table, usable_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    uint64_t* d_in = (uint64_t*)ctx->ws_poly_io[0].p;
+    uint64_t* d_out = (uint64_t*)ctx->ws_poly_io[1].p;
+    TRY(dehalo_permute_expression_pair_device(ctx, field, d_in, d_in + usable_rows * 4, usable_rows, d_out, d_out + usable_rows * 4, nullptr));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipMemcpyAsync(permuted_input, d_out, usable_rows * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(permuted_table, d_out + usable_rows * 4, usable_rows * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -41,7 +41,8 @@ typedef enum {
     DEHALO_ERR_NO_DEVICE = -2,  /* no HIP device / wrong architecture */
     DEHALO_ERR_OOM = -3,        /* device allocation failed */
     DEHALO_ERR_HIP = -4,        /* any other HIP runtime error (see dehalo_last_error) */
-    DEHALO_ERR_UNSUPPORTED = -5 /* e.g. NTT over a field whose two-adicity is too small */
+    DEHALO_ERR_UNSUPPORTED = -5, /* e.g. NTT over a field whose two-adicity is too small */
+    DEHALO_ERR_NOT_IN_TABLE = -6 /* permute_expression_pair: upstream's Error::ConstraintSystemFailure */
 } dehalo_status;
 
 /* halo2curves curve / field identities */
@@ -148,6 +149,17 @@ int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const
  *   upstream builds after its batch_invert ("z.push(one); for row in 1..n { tmp *= product[row-1] }");
  *   the caller appends upstream's blinding rows.  A zero denominator behaves like upstream's
  *   batch_invert (left zero), so the product is zero from that row on.                          */
+/* dehalo_permute_expression_pair: the lookup argument's permuted columns, replacing
+ *   plonk/lookup/prover.rs permute_expression_pair: permuted_input = the `usable_rows` input values
+ *   sorted ascending by canonical value; permuted_table[row] = permuted_input[row] at every first
+ *   occurrence, the table's remaining values (ascending) in the repeated rows taken from the end.
+ *   DEHALO_ERR_NOT_IN_TABLE when an input value does not occur in the table.  The caller appends
+ *   upstream's random blinding rows.  The device form synchronises its stream (it has to return
+ *   that error).                                                                                 */
+int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* input, const uint64_t* table, size_t usable_rows,
+                                   uint64_t* permuted_input, uint64_t* permuted_table);
+int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,
+                                          uint64_t* d_permuted_input, uint64_t* d_permuted_table, void* stream);
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]);
 int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
                                   const uint64_t point[4], uint64_t* d_out, void* stream);

@@ -38,6 +38,7 @@ def lib():
         _LIB.orc_graph_evaluate.argtypes = [C.c_int, P, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, P, P, C.c_uint32, C.c_uint32, P, P, C.c_int]
         _LIB.orc_permutation_h.argtypes = [C.c_int, P, C.c_uint32, P, P, C.c_uint32, C.c_uint32, C.c_int32, P, P, P, P, C.c_uint32, C.c_uint32, P, C.c_int]
         _LIB.orc_lookup_h.argtypes = [C.c_int, P, P, P, P, P, P, P, P, C.c_uint32, C.c_uint32, P, C.c_int]
+        _LIB.orc_permute_expression_pair.argtypes = [C.c_int, P, P, C.c_size_t, P, P]
         _LIB.orc_eval_polynomial.argtypes = [C.c_int, P, C.c_size_t, P, C.c_int, P]
         _LIB.orc_batch_invert.argtypes = [C.c_int, P, C.c_size_t]
         _LIB.orc_grand_product.argtypes = [C.c_int, P, P, C.c_size_t, P]
@@ -203,3 +204,13 @@ def lookup_h(field: int, values, product, permuted_input, permuted_table, table_
     rc = lib().orc_lookup_h(field, *[_p(a) for a in arrs], _p(sc), log_rows, rot_scale, _p(v), threads)
     assert rc == 0
     return v
+
+
+def permute_expression_pair(field: int, input_values, table_values, usable_rows: int):
+    """-> (permuted_input, permuted_table) or None (upstream: Err(ConstraintSystemFailure))."""
+    a = np.ascontiguousarray(input_values, dtype=np.uint64).reshape(-1, 4)
+    t = np.ascontiguousarray(table_values, dtype=np.uint64).reshape(-1, 4)
+    pi, pt = np.zeros((usable_rows, 4), dtype=np.uint64), np.zeros((usable_rows, 4), dtype=np.uint64)
+    rc = lib().orc_permute_expression_pair(field, _p(a), _p(t), usable_rows, _p(pi), _p(pt))
+    assert rc in (0, 1)
+    return None if rc else (pi, pt)

@@ -519,6 +519,44 @@ int orc_grand_product(int field, const u64* num_, const u64* den_, size_t n, u64
     return 0;
 }
 
+/* permute_expression_pair: [UPSTREAM halo2_proofs/src/plonk/lookup/prover.rs] sort the input, give every first
+ * occurrence its own value from the table multiset, pour the leftover table values (ascending) into the
+ * repeated rows from the end.  Returns 1 where upstream returns Err(ConstraintSystemFailure). */
+typedef struct { u64 c[4]; fe m; } lp_item;     /* canonical key + the original Montgomery element */
+static int lp_cmp(const void* a_, const void* b_) {
+    const lp_item* a = a_; const lp_item* b = b_;
+    for (int i = 3; i >= 0; i--) if (a->c[i] != b->c[i]) return a->c[i] < b->c[i] ? -1 : 1;
+    return 0;
+}
+int orc_permute_expression_pair(int field, const u64* input_, const u64* table_, size_t usable, u64* out_input_, u64* out_table_) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    lp_item* A = malloc((usable ? usable : 1) * sizeof(lp_item)); lp_item* T = malloc((usable ? usable : 1) * sizeof(lp_item));
+    size_t* repeated = malloc((usable ? usable : 1) * sizeof(size_t)); unsigned char* consumed = calloc(usable ? usable : 1, 1);
+    for (size_t i = 0; i < usable; i++) {
+        A[i].m = ((const fe*)input_)[i]; f_from_mont(F, A[i].c, &A[i].m);
+        T[i].m = ((const fe*)table_)[i]; f_from_mont(F, T[i].c, &T[i].m);
+    }
+    qsort(A, usable, sizeof(lp_item), lp_cmp); qsort(T, usable, sizeof(lp_item), lp_cmp);
+    fe* oi = (fe*)out_input_; fe* ot = (fe*)out_table_;
+    size_t nrep = 0, tpos = 0;
+    int fail = 0;
+    for (size_t row = 0; row < usable; row++) {
+        oi[row] = A[row].m;
+        if (row == 0 || lp_cmp(&A[row], &A[row - 1]) != 0) {
+            ot[row] = A[row].m;
+            while (tpos < usable && lp_cmp(&T[tpos], &A[row]) < 0) tpos++;      /* first copy of the value in the sorted table */
+            if (tpos < usable && lp_cmp(&T[tpos], &A[row]) == 0) consumed[tpos++] = 1; else { fail = 1; break; }
+        } else repeated[nrep++] = row;
+    }
+    if (!fail)
+        for (size_t j = 0; j < usable; j++)
+            if (!consumed[j]) ot[repeated[--nrep]] = T[j].m;
+    free(A); free(T); free(repeated); free(consumed);
+    return fail;
+}
+
 /* ---------- quotient numerator: [UPSTREAM halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20] ----------
  * GraphEvaluator::evaluate per row, and the permutation / lookup terms of Evaluator::evaluate_h, with upstream's
  * `parallelize` (contiguous row chunks, one per thread).  Montgomery in / out. */

@@ -359,6 +359,31 @@ def grand_product(f: Field, num: Sequence[int], den: Sequence[int]) -> List[int]
     return z
 
 
+def permute_expression_pair(f: Field, input_values: Sequence[int], table_values: Sequence[int], usable_rows: int):
+    """[UPSTREAM halo2_proofs/src/plonk/lookup/prover.rs permute_expression_pair] without the random
+    blinding rows.  Returns (permuted_input, permuted_table) or None where upstream returns
+    Err(ConstraintSystemFailure) (an input value that is not in the table)."""
+    permuted_input = sorted(v % f.p for v in input_values[:usable_rows])
+    leftover = {}
+    for v in table_values[:usable_rows]:
+        leftover[v % f.p] = leftover.get(v % f.p, 0) + 1
+    permuted_table = [0] * usable_rows
+    repeated_rows = []
+    for row, v in enumerate(permuted_input):
+        if row == 0 or v != permuted_input[row - 1]:
+            permuted_table[row] = v
+            if leftover.get(v, 0) == 0:
+                return None
+            leftover[v] -= 1
+        else:
+            repeated_rows.append(row)
+    for v in sorted(leftover):                 # BTreeMap iteration: ascending keys
+        for _ in range(leftover[v]):
+            permuted_table[repeated_rows.pop()] = v
+    assert not repeated_rows
+    return permuted_input, permuted_table
+
+
 # ----------------------------------------------------------------------------
 # Quotient numerator (SURVEY.md 8(f) row 1): [UPSTREAM halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20].
 # Canonical ints.  A graph is a dict {constants, rotations, calcs, num_intermediates}; a source is

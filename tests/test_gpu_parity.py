@@ -664,3 +664,31 @@ def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k):
     want = co.extended_to_coeff(f.id, h, ext_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), 2)
     assert np.array_equal(shape.h.cpu().numpy().view(np.uint64), want)
     bg.release(); bgl.release()
+
+
+# ---------------------------------------------------------------- lookup permutation
+@pytest.mark.parametrize("fid", [0, 2])
+def test_permute_expression_pair_vs_c_oracle(pkg, po, co, ctx, fid):
+    rng = np.random.default_rng(99 + fid)
+    for n, tsize, spread in ((1, 1, 1), (7, 3, 3), (1000, 256, 256), (5000, 256, 9), (1 << 16, 1 << 12, 1 << 12), ((1 << 17) - 6, 1 << 16, 50000)):
+        base = co.fill_scalars(fid, "uniform", tsize, 11 + n % 91)
+        base[::3] = 0
+        base[::3, 0] = np.arange(0, tsize, 3, dtype=np.uint64)        # small canonical-looking Montgomery words: distinct, sort across limbs
+        table = np.concatenate([base, np.repeat(base[:1], n - tsize, axis=0)])
+        inputs = base[rng.integers(0, spread, size=n)]
+        want = co.permute_expression_pair(fid, inputs, table, n)
+        assert want is not None
+        pi, pt = ctx.permute_expression_pair(fid, inputs, table, n)
+        assert np.array_equal(pi, want[0]) and np.array_equal(pt, want[1]), (fid, n)
+    # an input value that is not in the table: upstream's Err(ConstraintSystemFailure)
+    table = co.fill_scalars(fid, "uniform", 300, 5)
+    inputs = table[rng.integers(0, 300, size=300)].copy()
+    inputs[17] = co.fill_scalars(fid, "uniform", 1, 6)[0]
+    assert co.permute_expression_pair(fid, inputs, table, 300) is None
+    with pytest.raises(pkg.DehaloError) as e:
+        ctx.permute_expression_pair(fid, inputs, table, 300)
+    assert e.value.code == -6
+    # the context stays usable after the error
+    pi, pt = ctx.permute_expression_pair(fid, table, table, 300)
+    want = co.permute_expression_pair(fid, table, table, 300)
+    assert np.array_equal(pi, want[0]) and np.array_equal(pt, want[1])

@@ -240,3 +240,38 @@ def test_evalh_c_oracle_vs_python(po, co):
     want = po.lookup_h(f, values, prod, a, s, tv, l0, l_last, l_active, beta, gamma, y, rot_scale)
     got = co.lookup_h(fid, enc(values), enc(prod), enc(a), enc(s), enc(tv), enc(l0), enc(l_last), enc(l_active), e1(beta), e1(gamma), e1(y), ext_k, rot_scale, 3)
     assert _dec(po, f, got) == want
+
+
+def _lookup_case(po, f, rng, n, table_size, spread):
+    """A lookup-shaped pair: a table of `table_size` distinct values padded with repeats of its first
+    entry (halo2 pads range tables with zeros), inputs drawn from the first `spread` table values."""
+    base = [rng.below(f.p) if i % 3 else i for i in range(table_size)]
+    table = base + [base[0]] * (n - table_size)
+    inputs = [base[rng.below(spread)] for _ in range(n)]
+    return inputs, table
+
+
+def test_permute_expression_pair_oracles_agree(po, co):
+    f = po.BN254_FR
+    fid = po.FIELD_IDS[f.name]
+    rng = po.Xoshiro(0x5077)
+    for n, tsize, spread in ((1, 1, 1), (16, 16, 16), (200, 64, 64), (200, 64, 3), (257, 256, 100)):
+        inputs, table = _lookup_case(po, f, rng, n, tsize, spread)
+        want = po.permute_expression_pair(f, inputs, table, n)
+        assert want is not None
+        pi, pt = want
+        assert sorted(pi) == sorted(inputs) and sorted(pt) == sorted(table)                  # both are permutations
+        assert all(pi[r] == pt[r] or pi[r] == pi[r - 1] for r in range(n))                  # the lookup argument's row rule
+        got = co.permute_expression_pair(fid, _enc(po, f, inputs), _enc(po, f, table), n)
+        assert _dec(po, f, got[0]) == pi and _dec(po, f, got[1]) == pt
+    inputs, table = _lookup_case(po, f, rng, 50, 20, 20)
+    inputs[7] = (max(table) + 1) % f.p if (max(table) + 1) % f.p not in table else 12345678901234567
+    assert po.permute_expression_pair(f, inputs, table, 50) is None
+    assert co.permute_expression_pair(fid, _enc(po, f, inputs), _enc(po, f, table), 50) is None
+    # usable_rows shorter than the columns: the tail is ignored
+    inputs, table = _lookup_case(po, f, rng, 80, 30, 30)
+    want = po.permute_expression_pair(f, inputs[:60] + [5] * 20, table[:60] + [7] * 20, 60)
+    got = co.permute_expression_pair(fid, _enc(po, f, inputs[:60] + [5] * 20), _enc(po, f, table[:60] + [7] * 20), 60)
+    assert (want is None) == (got is None)
+    if want is not None:
+        assert _dec(po, f, got[0]) == want[0] and _dec(po, f, got[1]) == want[1]

@@ -37,7 +37,15 @@ for fname in ("bn254_fr", "pasta_fp"):
         c_eval = cpu(lambda: co.eval_polynomial(fid, a, x, threads)) if do_cpu else float("nan")
         c_inv = cpu(lambda: co.batch_invert(fid, b)) if do_cpu else float("nan")
         c_gp = cpu(lambda: co.grand_product(fid, a, b)) if do_cpu else float("nan")
+        # lookup permutation: a 2^12-entry table padded with its first value, inputs drawn from it
+        tsize = min(n, 1 << 12)
+        table = np.concatenate([a[:tsize], np.repeat(a[:1], n - tsize, axis=0)])
+        inputs = a[:tsize][np.random.default_rng(1).integers(0, tsize, size=n)]
+        dt, di = torch.from_numpy(table.view(np.int64).copy()).cuda(), torch.from_numpy(inputs.view(np.int64).copy()).cuda()
+        dpi, dpt = torch.zeros_like(dt), torch.zeros_like(dt)
+        g_lp = timeit(lambda: ctx.permute_expression_pair_device(fid, di.data_ptr(), dt.data_ptr(), n, dpi.data_ptr(), dpt.data_ptr(), 0), reps=10)
+        c_lp = cpu(lambda: co.permute_expression_pair(fid, inputs, table, n)) if do_cpu else float("nan")
         gbs = lambda bytes_per, ms: bytes_per * n / ms / 1e6
         print("%-8s 2^%-2d eval_polynomial %7.3f ms (%6.1f GB/s alg 32 B/coef; cpu %d thr %8.2f ms) | batch_invert %7.3f ms (%6.1f GB/s alg 64 B; cpu 1 thr %8.2f ms) | "
-              "grand_product %7.3f ms (%6.1f GB/s alg 96 B; cpu 1 thr %8.2f ms)" % (fname, log_n, g_eval, gbs(32, g_eval), threads, c_eval, g_inv, gbs(64, g_inv), c_inv,
-                                                                                 g_gp, gbs(96, g_gp), c_gp), flush=True)
+              "grand_product %7.3f ms (%6.1f GB/s alg 96 B; cpu 1 thr %8.2f ms) | permute_expression_pair %7.3f ms (cpu 1 thr %8.2f ms)"
+              % (fname, log_n, g_eval, gbs(32, g_eval), threads, c_eval, g_inv, gbs(64, g_inv), c_inv, g_gp, gbs(96, g_gp), c_gp, g_lp, c_lp), flush=True)
