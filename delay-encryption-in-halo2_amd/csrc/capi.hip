@@ -267,6 +267,7 @@ int dehalo_ctx_create(int device, dehalo_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return DEHALO_ERR_NO_DEVICE;
     dehalo_ctx* ctx = new dehalo_ctx();
     ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
     *out = ctx;
     return 0;

@@ -31,6 +31,7 @@ struct TimedRegion {
 
 struct dehalo_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     std::string err;
     std::mutex mu;

@@ -162,7 +162,7 @@ static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32*
 }
 
 // ---- scans (3 kernels): item offsets and task offsets ------------------------------------
-// in: cnt[total]; out: off[total + 1] = exclusive scan of cnt, toff[total + 1] = exclusive scan
+// in: cnt[total]; out: off[total + 1] = exclusive scan of cnt, nrank[total + 1] = exclusive scan (count of non-empty), formerly
 // of ceil(cnt / L).  Blocks of SCAN_BLOCK entries.
 #define SCAN_THREADS 256
 #define SCAN_PER_THREAD 8
@@ -177,7 +177,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
         u32 idx = base + k;
         u32 v = idx < total ? cnt[idx] : 0;
-        si += v; st += ceil_div_u32(v, L);
+        si += v; st += v ? 1u : 0u;
     }
     s_i[threadIdx.x] = si; s_t[threadIdx.x] = st;
     __syncthreads();
@@ -212,8 +212,12 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_item
     }
 }
 
+// off[b] = points before bucket b.  The accumulation cuts the sorted list into ranges of L points,
+// one per lane, regardless of bucket boundaries; lane g writes one partial sum per bucket its
+// range touches, at record  g + (number of non-empty buckets before that bucket)  -- consecutive
+// for the lanes of one bucket.  rbeg/rend[b] = that bucket's record range (equal when empty).
 static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32 total, u32 L, const u32* bsum_items, const u32* bsum_tasks,
-                                                                    u32* off, u32* toff) {
+                                                                    u32* off, u32* nrank, u32* rbeg, u32* rend) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
     u32 vi[SCAN_PER_THREAD], vt[SCAN_PER_THREAD];
@@ -222,7 +226,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* c
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
         u32 idx = base + k;
         u32 v = idx < total ? cnt[idx] : 0;
-        vi[k] = v; vt[k] = ceil_div_u32(v, L);
+        vi[k] = v; vt[k] = v ? 1u : 0u;
         si += vi[k]; st += vt[k];
     }
     s_i[threadIdx.x] = si; s_t[threadIdx.x] = st;
@@ -238,9 +242,14 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* c
 #pragma unroll
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
         u32 idx = base + k;
-        if (idx < total) { off[idx] = ri; toff[idx] = rt; }
+        if (idx < total) {
+            off[idx] = ri; nrank[idx] = rt;
+            u32 b0 = ri / L + rt;
+            rbeg[idx] = b0;
+            rend[idx] = vi[k] ? (ri + vi[k] - 1) / L + rt + 1 : b0;
+        }
         ri += vi[k]; rt += vt[k];
-        if (idx + 1 == total) { off[total] = ri; toff[total] = rt; }
+        if (idx + 1 == total) { off[total] = ri; nrank[total] = rt; }
     }
 }
 
@@ -361,18 +370,24 @@ FP_DEV aff29 load_point(const affine_t* table, u32 e, bool& is_id) {
     return q;
 }
 
-// ---- level 0: one lane = one task of <= L0 points of one bucket ---------------------------
+// ---- level 0: one lane = L0 consecutive points of the sorted list -----------------------------
+// Every lane gets the same number of points whatever the bucket sizes are (a task-per-bucket
+// split leaves 2.1 "rounds" of tasks for 2.0 rounds of lanes at 2^20: measured 10 % of this
+// kernel).  A lane whose range crosses a bucket boundary flushes its sum and starts the next
+// bucket's; L0 is chosen on the host so that the lanes fill the chip a whole number of times.
 template <class CV>
-__global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* toff,
+__global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* nrank,
                                                                const affine_t* table, xyzz29_rec* partial) {
     typedef typename f29_of<typename CV::Base>::type F;
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 ntasks = toff[total_buckets];
-    if (t >= ntasks) return;
-    u32 b = find_segment(toff, total_buckets, t);
-    u32 j = t - toff[b];
-    u32 beg = off[b] + j * g.L0;
-    u32 end = min(beg + g.L0, off[b + 1]);
+    const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 M = off[total_buckets];
+    const u64 beg64 = (u64)lane * g.L0;
+    if (beg64 >= M) return;
+    const u32 beg = (u32)beg64;
+    const u32 end = (u32)min((u64)M, beg64 + g.L0);
+    u32 b = find_segment(off, total_buckets, beg);      // the (non-empty) bucket holding point `beg`
+    u32 next = off[b + 1];
+    u32 rec = lane + nrank[b];
     // the next point's index is fetched one iteration ahead (dependent idx -> table[idx] chain);
     // measured twice (also after the product-scanning multiplication): prefetching the 64-B point
     // one iteration ahead too changes nothing, although SQ_WAIT_ANY is 24 % of the wave cycles
@@ -391,9 +406,16 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
         is_id = aff_is_identity(pk);
         q = a29_from_packed(pk);
         if (e >> 31) q.y = f29_sub(f29_zero(), q.y, F::KN);   // 2p - y, limbs < 2^30
-        if (!is_id) acc = x29_add_mixed<F>(acc, q);
+        if (p == next) {                                      // bucket boundary inside the range
+            x29_store(&partial[rec], acc);
+            do { b++; } while (off[b + 1] == p);              // skip empty buckets (p < M: terminates)
+            next = off[b + 1];
+            rec = lane + nrank[b];
+            acc = x29_from_affine<F>(q, is_id);
+            if (!is_id) acc.y = f29_norm(acc.y);
+        } else if (!is_id) acc = x29_add_mixed<F>(acc, q);
     }
-    x29_store(&partial[t], acc);
+    x29_store(&partial[rec], acc);
 }
 
 // ---- merging the partial sums of each bucket ---------------------------------------------
@@ -412,11 +434,11 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 // queued in the list of its class (one atomic per wave and class: a single hot counter serialises).
 // lists: [light | class 1 | class 2 | class 3], each with `cap` slots; counters[4].
 template <class CV>
-__global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
+__global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
                                                            u32* counters, u32* lists, u32 cap) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total_buckets) return;
-    u32 beg = toff[b], end = toff[b + 1];
+    u32 beg = rbeg[b], end = rend[b];
     u32 S = end - beg;
     const u32 cls = S <= 1 ? 4u : (S <= MSM_C0_MAX ? 0u : (S <= MSM_C1_MAX ? 1u : (S <= MSM_C2_MAX ? 2u : 3u)));
     const u32 lane = threadIdx.x & 63;
@@ -443,14 +465,14 @@ __global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, c
 // quad-cooperative additions; many (throughput-bound, e.g. every bucket of a large uniform MSM):
 // one lane per bucket.  The choice is made on the device from the list length.
 template <class CV>
-__global__ __launch_bounds__(256) void k_msm_merge_light(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter, const u32* list) {
+__global__ __launch_bounds__(256) void k_msm_merge_light(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter, const u32* list) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     const u32 count = *counter;
     if (count <= 16384) {
         const u32 role = threadIdx.x & 3;
         for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < count; i += (gridDim.x * blockDim.x) >> 2) {
             u32 b = list[i];
-            u32 beg = toff[b], end = toff[b + 1];
+            u32 beg = rbeg[b], end = rend[b];
             xyzz29 acc = x29_load(&partial[beg]);
             for (u32 p = beg + 1; p < end; p++) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
             if (role == 0) x29_store(&buckets[b], acc);
@@ -458,7 +480,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* toff, const 
     } else {
         for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
             u32 b = list[i];
-            u32 beg = toff[b], end = toff[b + 1];
+            u32 beg = rbeg[b], end = rend[b];
             xyzz29 acc = x29_load(&partial[beg]);
             for (u32 p = beg + 1; p < end; p++) acc = x29_add<F>(acc, x29_load(&partial[p]));
             x29_store(&buckets[b], acc);
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* toff, const 
 
 // groups of G lanes (8 or 64) walk a class list: strided lane sums, then a shuffle reduction
 template <class CV, int G>
-__global__ __launch_bounds__(256) void k_msm_merge_group(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter,
+__global__ __launch_bounds__(256) void k_msm_merge_group(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter,
                                                         const u32* list) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     const u32 count = *counter;
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_group(const u32* toff, const 
     const u32 gl = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     for (u32 i = blockIdx.x * groups_per_block + grp; i < count; i += gridDim.x * groups_per_block) {
         u32 b = list[i];
-        u32 beg = toff[b], end = toff[b + 1];
+        u32 beg = rbeg[b], end = rend[b];
         xyzz29 acc = x29_identity();
         u32 p = beg + gl;
         if (p < end) {
@@ -491,7 +513,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_group(const u32* toff, const 
 // 512-thread blocks walk the heaviest class: strided lane sums, shuffle reduction per wave,
 // 16 wave results through LDS, shuffle reduction again.  Chain: ceil(S / 1024) + 10 adds.
 template <class CV>
-__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32* toff, const xyzz29_rec* partial, xyzz29_rec* buckets,
+__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
                                                                      const u32* counter, const u32* list) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[MSM_HEAVY_THREADS / 64];
@@ -499,7 +521,7 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
         u32 b = list[i];
-        u32 beg = toff[b], end = toff[b + 1];
+        u32 beg = rbeg[b], end = rend[b];
         xyzz29 acc = x29_identity();
         u32 p = beg + threadIdx.x;
         if (p < end) {
@@ -666,14 +688,14 @@ __global__ void k_jac_to_affine(const jacobian_t* in, affine_t* out, u32 count) 
 // ==========================================================================================
 // host driver (instantiated once per curve in msm_<curve>.hip)
 // ==========================================================================================
-static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32 L, u32* off, u32* toff, hipStream_t s) {
+static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32 L, u32* off, u32* nrank, u32* rbeg, u32* rend, hipStream_t s) {
     u32 nblocks = (total + SCAN_BLOCK - 1) / SCAN_BLOCK;
     TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)nblocks * 2 * sizeof(u32)));
     u32* bs_i = (u32*)ctx->ws_bsum.p;
     u32* bs_t = bs_i + nblocks;
     k_scan_block_sums<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, L, bs_i, bs_t);
     k_scan_top<<<1, SCAN_THREADS, 0, s>>>(bs_i, bs_t, nblocks);
-    k_scan_apply<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, L, bs_i, bs_t, off, toff);
+    k_scan_apply<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, L, bs_i, bs_t, off, nrank, rbeg, rend);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -696,14 +718,16 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const uint64_t Mmax = (uint64_t)batch * len * g.W;
     if (Mmax >= (1ull << 32) || total_buckets >= (1ull << 31))
         return dh_fail(ctx, DEHALO_ERR_INVALID, "batch * len * windows too large for one launch");
-    {   // task length: enough tasks to fill 256 CUs, short enough to balance
-        uint64_t l0 = Mmax / (512 * 1024);
-        u32 L0 = 4;
-        while (L0 < 32 && L0 < l0) L0 <<= 1;
-        if (const char* e = getenv("DEHALO_L0")) L0 = (u32)std::max(1, atoi(e));  // tuning override
-        g.L0 = L0;
+    {   // points per lane: the lanes fill the chip (4 waves per SIMD of k_msm_accum0) a whole number of times
+        const uint64_t resident = (uint64_t)ctx->num_cus * 4 * 4 * 64;
+        const uint64_t rounds = std::max<uint64_t>(1, (Mmax + resident * 64 - 1) / (resident * 64));
+        uint64_t L0 = (Mmax + rounds * resident - 1) / (rounds * resident);
+        L0 = std::min<uint64_t>(64, std::max<uint64_t>(4, L0));
+        if (const char* e = getenv("DEHALO_L0")) L0 = (uint64_t)std::max(1, atoi(e));  // tuning override
+        g.L0 = (u32)L0;
     }
-    const uint64_t nt0_max = Mmax / g.L0 + total_buckets;
+    const uint64_t lanes_max = (Mmax + g.L0 - 1) / g.L0;
+    const uint64_t nt0_max = lanes_max + total_buckets;        // records: one per lane + one per non-empty bucket (upper bound)
     const u32 per_group = (g.nb + MSM_RED_M - 1) / MSM_RED_M;
     const size_t REC = sizeof(xyzz29_rec);
 
@@ -714,7 +738,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_pcount, total_groups * (size_t)g.slices * P * 4));   // per-(slice, partition) counts
     TRY(dh_ensure(ctx, ctx->ws_pairs, Mmax * 8));                                   // partition-sorted (sub-bucket, reference) pairs
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
-    TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4));
+    TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4 * 3));           // nrank | rbeg | rend
     const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / 2 + 1);
     TRY(dh_ensure(ctx, ctx->ws_merge_lists, (size_t)merge_cap * 4 * 4));   // merge-class lists
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
@@ -726,7 +750,9 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     u32* count = (u32*)ctx->ws_count.p;
     u32* cursor = (u32*)ctx->ws_counters.p;
     u32* off = (u32*)ctx->ws_off.p;
-    u32* toff0 = (u32*)ctx->ws_toff0.p;
+    u32* nrank = (u32*)ctx->ws_toff0.p;
+    u32* rbeg = nrank + (total_buckets + 1);
+    u32* rend = rbeg + (total_buckets + 1);
     u32* merge_lists = (u32*)ctx->ws_merge_lists.p;
     u32* merge_counters = cursor;
     u32* bh = (u32*)ctx->ws_bhist.p;
@@ -751,25 +777,25 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, bh, pc);
         k_msm_colscan<<<(tb + 255) / 256, 256, 0, s>>>(g.nb, g.slices, tb, bh, count);
         k_msm_colscan<<<((u32)total_groups * P + 255) / 256, 256, 0, s>>>(P, g.slices, (u32)total_groups * P, pc, nullptr);
-        TRY(run_scan(ctx, count, tb, g.L0, off, toff0, s));
+        TRY(run_scan(ctx, count, tb, g.L0, off, nrank, rbeg, rend, s));
         k_msm_part<FS><<<grid, MSM_SORT_THREADS, P * 4, s>>>(g, d_scalars, off, pc, pairs);
         k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, 0, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_ACCUMULATE);
-        u32 blocks = (u32)((nt0_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
-        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, 0, s>>>(g, tb, idx, off, toff0, bases->table, partial0);
+        u32 blocks = (u32)((lanes_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
+        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, 0, s>>>(g, tb, idx, off, nrank, bases->table, partial0);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_REDUCE);
         // partial sums -> one point per bucket (by size class)
-        k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, toff0, partial0, buckets, merge_counters, merge_lists, merge_cap);
-        k_msm_merge_light<CV><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
-        k_msm_merge_group<CV, 8><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
-        k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(toff0, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
-        k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 4, MSM_HEAVY_THREADS, 0, s>>>(toff0, partial0, buckets, merge_counters + 3, merge_lists + 3 * (size_t)merge_cap);
+        k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        k_msm_merge_light<CV><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
+        k_msm_merge_group<CV, 8><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
+        k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
+        k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 4, MSM_HEAVY_THREADS, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 3, merge_lists + 3 * (size_t)merge_cap);
         // bucket reduction
         uint64_t nblocks4 = (uint64_t)per_group * total_groups;       // 4-bucket blocks
         if (nblocks4 * 4 <= 96 * 1024) {   // <= ~1.5 waves per SIMD even at 4 lanes per block: latency-bound
