@@ -101,8 +101,9 @@ def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu, with_quotien
     best = min(runs, key=lambda r: r.ms_total)
     out = {"k": k, "curve": curve_name, "gpu_ms": round(best.ms_total, 3), "gpu_msm_ms": round(best.ms_msm, 3), "gpu_ntt_ms": round(best.ms_ntt, 3),
            "gpu_eval_h_ms": round(best.ms_eval_h, 3) if with_quotient else None,
-           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + evaluate_h(4n: gates, 2 permutation sets, 5 lookups)%s + 1 iNTT(4n); host syncs between "
-                       "phases; columns resident in HBM" % ("" if with_quotient else " [skipped]")}
+           "gpu_arguments_ms": round(best.ms_arguments, 3) if with_quotient else None, "gpu_openings_ms": round(best.ms_openings, 3) if with_quotient else None,
+           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + 1 iNTT(4n)%s; host syncs between phases; columns resident in HBM"
+                       % (" + 5 lookup permutations + 7 grand products + evaluate_h(4n: gates, 2 permutation sets, 5 lookups) + 72 eval_polynomial(n)" if with_quotient else "")}
     if with_cpu:
         cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
         f = curve.scalar
@@ -136,7 +137,20 @@ def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu, with_quotien
             th = time.time() - th0
         co.extended_to_coeff(f.id, h, d.extended_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), cores)
         t2 = time.time()
-        out.update({"cpu_ms": round(1e3 * (t2 - t0), 1), "cpu_msm_ms": round(1e3 * (t1 - t0), 1), "cpu_ntt_ms": round(1e3 * (t2 - t1 - th), 1),
+        tp = 0.0
+        if with_quotient:
+            tp0 = time.time()
+            usable = n - 6
+            for i in range(ps.N_LOOKUPS):
+                co.permute_expression_pair(f.id, cols["lookup_inputs"][i], cols["lookup_table"], usable)
+            for i in range(7):
+                co.grand_product(f.id, cols["grand_products"][i], cols["lookup_permuted"][i])
+            for _ in range(3):
+                for i in range(ps.N_INTT):
+                    co.eval_polynomial(f.id, coeffs[i], e(cols["challenges"]["y"]), cores)
+            tp = time.time() - tp0
+            t2 += tp
+        out.update({"cpu_arguments_openings_ms": round(1e3 * tp, 1) if with_quotient else None, "cpu_ms": round(1e3 * (t2 - t0), 1), "cpu_msm_ms": round(1e3 * (t1 - t0), 1), "cpu_ntt_ms": round(1e3 * (t2 - t1 - th - tp), 1),
                     "cpu_eval_h_ms": round(1e3 * th, 1) if with_quotient else None, "cpu_cores": cores, "cpu_kind": "port (oracle/oracle.c)"})
     bg.release(); bgl.release()
     return out

@@ -19,7 +19,7 @@ SYMBOLS = [
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
-    "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device",
+    "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
@@ -110,6 +110,7 @@ def load_library():
     lib.dehalo_prefix_product_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
     lib.dehalo_grand_product.argtypes = [P, C.c_int, u64p, u64p, sz, u64p]
     lib.dehalo_grand_product_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, P]
+    lib.dehalo_grand_product_batch_device.argtypes = [P, C.c_int, u64p, u64p, sz, sz, sz, u64p, P]
     lib.dehalo_permute_expression_pair.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p]
     lib.dehalo_permute_expression_pair_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p, P]
     lib.dehalo_graph_create.argtypes = [P, C.c_int, u64p, u32, C.POINTER(C.c_int32), u32, C.POINTER(CCalculation), u32, C.POINTER(CSource), u32, u32, C.POINTER(P)]
@@ -300,6 +301,9 @@ class Context:
         if a.shape[0]:
             self._check(self.lib.dehalo_grand_product(self.handle, field, _ptr(a), _ptr(b), a.shape[0], _ptr(z)))
         return z
+
+    def grand_product_batch_device(self, field: int, d_num: int, d_den: int, length: int, batch: int, stride: int, d_z: int, stream: int = 0):
+        self._check(self.lib.dehalo_grand_product_batch_device(self.handle, field, d_num, d_den, length, batch, stride, d_z, stream or None))
 
     def grand_product_device(self, field: int, d_num: int, d_den: int, length: int, d_z: int, stream: int = 0):
         self._check(self.lib.dehalo_grand_product_device(self.handle, field, d_num, d_den, length, d_z, stream or None))

@@ -90,8 +90,8 @@ int do_prefix_product(dehalo_ctx* ctx, int field, const fe* in, uint64_t len, fe
     FIELD_SWITCH(ctx, field, CALL)
 #undef CALL
 }
-int do_grand_product(dehalo_ctx* ctx, int field, const fe* num, const fe* den, uint64_t len, fe* z, hipStream_t s) {
-#define CALL(N) grand_product_##N(ctx, num, den, len, z, s)
+int do_grand_product(dehalo_ctx* ctx, int field, const fe* num, const fe* den, uint64_t len, size_t batch, uint64_t stride, fe* z, hipStream_t s) {
+#define CALL(N) grand_product_##N(ctx, num, den, len, batch, stride, z, s)
     FIELD_SWITCH(ctx, field, CALL)
 #undef CALL
 }
@@ -573,12 +573,19 @@ int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_i
     return do_prefix_product(ctx, field, (const fe*)d_in, len, (fe*)d_out, pick_stream(ctx, stream));
 }
 
-int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, uint64_t* d_z, void* stream) {
+int dehalo_grand_product_batch_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, size_t batch, size_t stride_elems,
+                                      uint64_t* d_z, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
-    if ((!d_num || !d_den || !d_z) && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: null argument");
+    if ((!d_num || !d_den || !d_z) && len && batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: null argument");
+    if (batch > 1 && stride_elems < len) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: stride shorter than the columns");
+    if (batch >= 65536) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: batch too large");
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
-    return do_grand_product(ctx, field, (const fe*)d_num, (const fe*)d_den, len, (fe*)d_z, pick_stream(ctx, stream));
+    return do_grand_product(ctx, field, (const fe*)d_num, (const fe*)d_den, len, batch, stride_elems, (fe*)d_z, pick_stream(ctx, stream));
+}
+
+int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, uint64_t* d_z, void* stream) {
+    return dehalo_grand_product_batch_device(ctx, field, d_num, d_den, len, 1, len, d_z, stream);
 }
 
 int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const uint64_t* den, size_t len, uint64_t* z) {

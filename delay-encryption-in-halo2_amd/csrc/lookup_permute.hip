@@ -43,6 +43,23 @@ __global__ void k_lp_limb(const fe* canon, const u32* perm, u32 limb, u64 n, uns
     const u32* w = canon[perm[i]].v;
     keys[i] = (unsigned long long)w[2 * limb] | ((unsigned long long)w[2 * limb + 1] << 32);
 }
+// ors[l] |= every key's 64-bit limb l: limbs that are zero everywhere need no sort pass, and the
+// highest set bit bounds the digits of the others (range tables hold small values)
+__global__ void k_lp_limb_or(const fe* canon, u64 n, unsigned long long* ors) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (i < n) {
+        const u32* w = canon[i].v;
+#pragma unroll
+        for (int l = 0; l < 4; l++) v[l] = (unsigned long long)w[2 * l] | ((unsigned long long)w[2 * l + 1] << 32);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        unsigned long long x = v[l];
+        for (int d = 32; d >= 1; d >>= 1) x |= __shfl_xor(x, d);
+        if ((threadIdx.x & 63) == 0 && x) atomicOr(&ors[l], x);
+    }
+}
 __global__ void k_lp_gather(const fe* canon, const u32* perm, u64 n, fe* sorted) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) f_store(&sorted[i], f_load(&canon[perm[i]]));
@@ -112,17 +129,18 @@ struct Carve {
     }
 };
 
-// canonical keys of `src` sorted ascending; perm_out[i] = original row of the i-th smallest
-int sort_column(dehalo_ctx* ctx, int field, const fe* src, u64 n, fe* canon, fe* sorted, u32* perm_a, u32* perm_b, unsigned long long* keys_a,
+// canonical keys sorted ascending; perm_out[i] = original row of the i-th smallest.  bits[l] = bit
+// length of the OR of limb l over the column (0: the pass is skipped).
+int sort_column(dehalo_ctx* ctx, const fe* canon, u64 n, const unsigned bits[4], fe* sorted, u32* perm_a, u32* perm_b, unsigned long long* keys_a,
                 unsigned long long* keys_b, void* tmp, size_t tmp_bytes, u32** perm_out, hipStream_t s) {
     const u32 blocks = (u32)((n + 255) / 256);
-    TRY(canon_dispatch(ctx, field, src, n, canon, s));
     k_lp_iota<<<blocks, 256, 0, s>>>(perm_a, n);
     u32 *pin = perm_a, *pout = perm_b;
     for (u32 limb = 0; limb < 4; limb++) {
+        if (bits[limb] == 0) continue;
         k_lp_limb<<<blocks, 256, 0, s>>>(canon, pin, limb, n, keys_a);
         size_t bytes = tmp_bytes;
-        HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp, bytes, keys_a, keys_b, pin, pout, n, 0, 64, s));
+        HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp, bytes, keys_a, keys_b, pin, pout, n, 0, bits[limb], s));
         std::swap(pin, pout);
     }
     k_lp_gather<<<blocks, 256, 0, s>>>(canon, pin, n, sorted);
@@ -142,7 +160,7 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_input, const fe*
     HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_tmp, (u32*)nullptr, (u32*)nullptr, 0u, n, rocprim::plus<u32>(), s));
     const size_t tmp_bytes = std::max(sort_tmp, scan_tmp);
     const size_t pad = 256;
-    size_t total = 4 * (n * sizeof(fe) + pad) + 2 * (n * 8 + pad) + 4 * (n * 4 + pad) + 6 * (n * 4 + pad) + tmp_bytes + pad + 256;
+    size_t total = 4 * (n * sizeof(fe) + pad) + 2 * (n * 8 + pad) + 4 * (n * 4 + pad) + 6 * (n * 4 + pad) + tmp_bytes + pad + 1024;
     TRY(dh_ensure(ctx, ctx->ws_lookup, total));
     Carve c{(char*)ctx->ws_lookup.p};
     fe* canon_a = c.take<fe>(n); fe* canon_t = c.take<fe>(n); fe* A = c.take<fe>(n); fe* T = c.take<fe>(n);
@@ -151,11 +169,25 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_input, const fe*
     u32* repeated = c.take<u32>(n); u32* consumed = c.take<u32>(n); u32* leftover = c.take<u32>(n); u32* rrank = c.take<u32>(n); u32* lrank = c.take<u32>(n);
     u32* lsrc = c.take<u32>(n);
     int* err = c.take<int>(1);
+    unsigned long long* ors = c.take<unsigned long long>(8);
     void* tmp = c.take<char>(tmp_bytes);
     u32 *perm_a = nullptr, *perm_t = nullptr;
-    TRY(sort_column(ctx, field, d_input, n, canon_a, A, pa0, pa1, keys_a, keys_b, tmp, tmp_bytes, &perm_a, s));
-    TRY(sort_column(ctx, field, d_table, n, canon_t, T, pt0, pt1, keys_a, keys_b, tmp, tmp_bytes, &perm_t, s));
     const u32 blocks = (u32)((n + 255) / 256);
+    TRY(canon_dispatch(ctx, field, d_input, n, canon_a, s));
+    TRY(canon_dispatch(ctx, field, d_table, n, canon_t, s));
+    HIP_TRY(ctx, hipMemsetAsync(ors, 0, 8 * sizeof(unsigned long long), s));
+    k_lp_limb_or<<<blocks, 256, 0, s>>>(canon_a, n, ors);
+    k_lp_limb_or<<<blocks, 256, 0, s>>>(canon_t, n, ors + 4);
+    unsigned long long host_ors[8];
+    HIP_TRY(ctx, hipMemcpyAsync(host_ors, ors, sizeof(host_ors), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));          // the pass plan depends on the data (the call synchronises at its end anyway)
+    unsigned bits_a[4], bits_t[4];
+    for (int l = 0; l < 4; l++) {
+        bits_a[l] = host_ors[l] ? 64 - (unsigned)__builtin_clzll(host_ors[l]) : 0;
+        bits_t[l] = host_ors[4 + l] ? 64 - (unsigned)__builtin_clzll(host_ors[4 + l]) : 0;
+    }
+    TRY(sort_column(ctx, canon_a, n, bits_a, A, pa0, pa1, keys_a, keys_b, tmp, tmp_bytes, &perm_a, s));
+    TRY(sort_column(ctx, canon_t, n, bits_t, T, pt0, pt1, keys_a, keys_b, tmp, tmp_bytes, &perm_t, s));
     HIP_TRY(ctx, hipMemsetAsync(consumed, 0, n * 4, s));
     HIP_TRY(ctx, hipMemsetAsync(err, 0, sizeof(int), s));
     HIP_TRY(ctx, hipMemsetAsync(lsrc, 0, n * 4, s));          // a failed lookup leaves gaps: keep every index in range

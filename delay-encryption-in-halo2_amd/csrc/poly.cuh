@@ -212,10 +212,14 @@ __global__ __launch_bounds__(POLY_THREADS) void k_batch_invert(fe* v, u64 len, c
 // before them inside the block (scratch_e, packed internal form) and the block total.
 // If `mul_by` is given the scanned sequence is in[i] * mul_by[i] (grand product: den^-1 * num).
 template <class F>
-__global__ __launch_bounds__(POLY_THREADS) void k_pp_block(const fe* in, const fe* mul_by, u64 len, fe* scratch_e, fe* totals) {
+__global__ __launch_bounds__(POLY_THREADS) void k_pp_block(const fe* in, u64 in_stride, const fe* mul_by, u64 mul_stride, u64 len, fe* scratch_e, fe* totals) {
     typedef typename f29_of<F>::type F9;
     __shared__ f29 pre[POLY_THREADS];
     const u32 t = threadIdx.x;
+    in += (u64)blockIdx.y * in_stride;                       // blockIdx.y: independent column of a batch
+    if (mul_by) mul_by += (u64)blockIdx.y * mul_stride;
+    scratch_e += (u64)blockIdx.y * gridDim.x * POLY_THREADS;
+    totals += (u64)blockIdx.y * gridDim.x;
     const u64 base = (u64)blockIdx.x * POLY_PTILE + (u64)t * POLY_K;
     f29 T = f29_one<F9>();
 #pragma unroll
@@ -238,6 +242,8 @@ __global__ __launch_bounds__(POLY_THREADS) void k_pp_top(const fe* totals, u64 n
     typedef typename f29_of<F>::type F9;
     __shared__ f29 pre[POLY_THREADS];
     const u32 t = threadIdx.x;
+    totals += (u64)blockIdx.x * nblocks;                     // one block per column
+    bprefix += (u64)blockIdx.x * nblocks;
     f29 carry = f29_one<F9>();
     for (u64 c0 = 0; c0 < nblocks; c0 += POLY_THREADS) {
         f29 v = c0 + t < nblocks ? poly_load_packed(&totals[c0 + t]) : f29_one<F9>();
@@ -251,9 +257,15 @@ __global__ __launch_bounds__(POLY_THREADS) void k_pp_top(const fe* totals, u64 n
 
 // pass 3: out[i] = bprefix[b] * e[b][t] * in[4t] ... in[i-1]
 template <class F>
-__global__ __launch_bounds__(POLY_THREADS) void k_pp_apply(const fe* in, const fe* mul_by, u64 len, const fe* scratch_e, const fe* bprefix, fe* out) {
+__global__ __launch_bounds__(POLY_THREADS) void k_pp_apply(const fe* in, u64 in_stride, const fe* mul_by, u64 mul_stride, u64 len, const fe* scratch_e,
+                                                           const fe* bprefix, fe* out, u64 out_stride) {
     typedef typename f29_of<F>::type F9;
     const u32 t = threadIdx.x;
+    in += (u64)blockIdx.y * in_stride;
+    if (mul_by) mul_by += (u64)blockIdx.y * mul_stride;
+    out += (u64)blockIdx.y * out_stride;
+    scratch_e += (u64)blockIdx.y * gridDim.x * POLY_THREADS;
+    bprefix += (u64)blockIdx.y * gridDim.x;
     const u64 base = (u64)blockIdx.x * POLY_PTILE + (u64)t * POLY_K;
     if (base >= len) return;
     f29 a[POLY_K];
@@ -334,35 +346,38 @@ int batch_invert_t(dehalo_ctx* ctx, fe* d_v, uint64_t len, hipStream_t s) {
     return 0;
 }
 
-// out[i] = prod_{j < i} in[j] (* mul_by[j]);  in == out allowed
+// out[i] = prod_{j < i} in[j] (* mul_by[j]) for each of `batch` columns;  in == out allowed
 template <class F>
-int prefix_product_t(dehalo_ctx* ctx, const fe* d_in, const fe* d_mul_by, uint64_t len, fe* d_out, hipStream_t s) {
-    if (len == 0) return 0;
+int prefix_product_t(dehalo_ctx* ctx, const fe* d_in, uint64_t in_stride, const fe* d_mul_by, uint64_t mul_stride, uint64_t len, size_t batch, fe* d_out,
+                     uint64_t out_stride, hipStream_t s) {
+    if (len == 0 || batch == 0) return 0;
     ScopedTimer timer(ctx, s, DEHALO_K_POLY);
     const uint64_t nb = (len + POLY_PTILE - 1) / POLY_PTILE;
-    TRY(dh_ensure(ctx, ctx->ws_poly[0], nb * POLY_THREADS * sizeof(fe)));
-    TRY(dh_ensure(ctx, ctx->ws_poly[1], nb * sizeof(fe)));
-    TRY(dh_ensure(ctx, ctx->ws_poly[2], nb * sizeof(fe)));
+    TRY(dh_ensure(ctx, ctx->ws_poly[0], batch * nb * POLY_THREADS * sizeof(fe)));
+    TRY(dh_ensure(ctx, ctx->ws_poly[1], batch * nb * sizeof(fe)));
+    TRY(dh_ensure(ctx, ctx->ws_poly[2], batch * nb * sizeof(fe)));
     fe* e = (fe*)ctx->ws_poly[0].p;
     fe* totals = (fe*)ctx->ws_poly[1].p;
     fe* bprefix = (fe*)ctx->ws_poly[2].p;
-    k_pp_block<F><<<(u32)nb, POLY_THREADS, 0, s>>>(d_in, d_mul_by, len, e, totals);
-    k_pp_top<F><<<1, POLY_THREADS, 0, s>>>(totals, nb, bprefix);
-    k_pp_apply<F><<<(u32)nb, POLY_THREADS, 0, s>>>(d_in, d_mul_by, len, e, bprefix, d_out);
+    const dim3 grid((u32)nb, (u32)batch);
+    k_pp_block<F><<<grid, POLY_THREADS, 0, s>>>(d_in, in_stride, d_mul_by, mul_stride, len, e, totals);
+    k_pp_top<F><<<(u32)batch, POLY_THREADS, 0, s>>>(totals, nb, bprefix);
+    k_pp_apply<F><<<grid, POLY_THREADS, 0, s>>>(d_in, in_stride, d_mul_by, mul_stride, len, e, bprefix, d_out, out_stride);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
-// z[i] = prod_{j < i} num[j] / den[j]   (zero denominators are treated like upstream's
-// batch_invert treats them: left as zero, so the product collapses to zero from there on)
+// z[i] = prod_{j < i} num[j] / den[j] for each of `batch` columns (zero denominators are treated like
+// upstream's batch_invert treats them: left as zero, so the product collapses to zero from there on).
+// All denominators of the batch share ONE batch inversion (one Fermat exponentiation).
 template <class F>
-int grand_product_t(dehalo_ctx* ctx, const fe* d_num, const fe* d_den, uint64_t len, fe* d_z, hipStream_t s) {
-    if (len == 0) return 0;
-    TRY(dh_ensure(ctx, ctx->ws_poly[3], len * sizeof(fe)));
+int grand_product_t(dehalo_ctx* ctx, const fe* d_num, const fe* d_den, uint64_t len, size_t batch, uint64_t stride, fe* d_z, hipStream_t s) {
+    if (len == 0 || batch == 0) return 0;
+    TRY(dh_ensure(ctx, ctx->ws_poly[3], batch * len * sizeof(fe)));
     fe* inv = (fe*)ctx->ws_poly[3].p;
-    HIP_TRY(ctx, hipMemcpyAsync(inv, d_den, len * sizeof(fe), hipMemcpyDeviceToDevice, s));
-    TRY(batch_invert_t<F>(ctx, inv, len, s));
-    return prefix_product_t<F>(ctx, inv, d_num, len, d_z, s);
+    HIP_TRY(ctx, hipMemcpy2DAsync(inv, len * sizeof(fe), d_den, stride * sizeof(fe), len * sizeof(fe), batch, hipMemcpyDeviceToDevice, s));
+    TRY(batch_invert_t<F>(ctx, inv, batch * len, s));
+    return prefix_product_t<F>(ctx, inv, len, d_num, stride, len, batch, d_z, stride, s);
 }
 
 #define DEFINE_POLY_ENTRY(NAME, F)                                                                                                              \
@@ -370,6 +385,6 @@ int grand_product_t(dehalo_ctx* ctx, const fe* d_num, const fe* d_den, uint64_t 
         return eval_poly_t<F>(ctx, c, len, stride, batch, pt, out, s); }                                                                         \
     int batch_invert_##NAME(dehalo_ctx* ctx, fe* v, uint64_t len, hipStream_t s) { return batch_invert_t<F>(ctx, v, len, s); }                    \
     int prefix_product_##NAME(dehalo_ctx* ctx, const fe* in, uint64_t len, fe* out, hipStream_t s) {                                             \
-        return prefix_product_t<F>(ctx, in, nullptr, len, out, s); }                                                                             \
-    int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, fe* z, hipStream_t s) {                                \
-        return grand_product_t<F>(ctx, num, den, len, z, s); }
+        return prefix_product_t<F>(ctx, in, len, nullptr, 0, len, 1, out, len, s); }                                                             \
+    int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, size_t batch, uint64_t stride, fe* z, hipStream_t s) { \
+        return grand_product_t<F>(ctx, num, den, len, batch, stride, z, s); }

@@ -47,6 +47,8 @@ class ProverShapeResult:
     ms_msm: float
     ms_ntt: float
     ms_eval_h: float = 0.0
+    ms_arguments: float = 0.0     # lookup permutations + grand products
+    ms_openings: float = 0.0      # eval_polynomial of the opened polynomials
 
 
 def maingate_graph() -> ev.GraphEvaluator:
@@ -105,6 +107,12 @@ class ProverShape:
             self.h = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")
             self.table_value = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")
             self.challenges = dict(columns["challenges"])                                                  # theta, beta, gamma, y, delta: canonical ints
+            # lookup arguments: a 2^12-entry table padded with its first value (how halo2 pads range tables), inputs drawn from it
+            self.usable = self.n - (-LAST_ROTATION)
+            self.lk_in, self.lk_table = to_dev(columns["lookup_inputs"]), to_dev(columns["lookup_table"])     # (5, n, 4), (n, 4)
+            self.lk_out = torch.zeros((N_LOOKUPS, 2, self.usable, 4), dtype=torch.int64, device="cuda")
+            self.z = torch.zeros((7, self.n, 4), dtype=torch.int64, device="cuda")
+            self.evals = torch.zeros((N_INTT, 4), dtype=torch.int64, device="cuda")
             self.gate_graph = maingate_graph().compile(ctx, curve.scalar)
             self.lookup_graphs = [lookup_graph(i).compile(ctx, curve.scalar) for i in range(N_LOOKUPS)]
 
@@ -126,6 +134,23 @@ class ProverShape:
             ev.lookup_h_device(self.ctx, f, col(self.ext, 17 + i), col(self.ext, 5 + 2 * i), col(self.ext, 6 + 2 * i), self.table_value.data_ptr(), l0, l_last,
                                l_active, ch["beta"], ch["gamma"], ch["y"], log_rows, rot_scale, self.h.data_ptr())
 
+    def arguments(self):
+        """The data-parallel part of lookup::commit_permuted (5 x permute_expression_pair) and of the seven
+        grand products (2 permutation sets + 5 lookups): batch-inverted denominators and the running product.
+        (The element-wise numerator / denominator products that feed them are not modelled.)"""
+        f = self.curve.scalar
+        for i in range(N_LOOKUPS):
+            self.ctx.permute_expression_pair_device(f.id, self.lk_in[i].data_ptr(), self.lk_table.data_ptr(), self.usable, self.lk_out[i, 0].data_ptr(),
+                                                    self.lk_out[i, 1].data_ptr(), 0)
+        num, den = self.cols["grand_products"], self.cols["lookup_permuted"]
+        self.ctx.grand_product_batch_device(f.id, num.data_ptr(), den.data_ptr(), self.n, 7, self.n, self.z.data_ptr(), 0)   # one inversion for all seven
+
+    def openings(self):
+        """eval_polynomial of every opened polynomial: three rotation sets of the 24 coefficient-form columns."""
+        f, x = self.curve.scalar, self.curve.scalar.encode(self.challenges["y"])
+        for _ in range(3):
+            self.ctx.eval_polynomial_device(f.id, self.polys.data_ptr(), self.n, self.n, N_INTT, x, self.evals.data_ptr(), 0)
+
     def _commit(self, name: str, lagrange: bool):
         t = self.cols[name]
         b = self.g_lagrange if lagrange else self.g
@@ -137,10 +162,13 @@ class ProverShape:
         t_msm = t_ntt = 0.0
         self.torch.cuda.synchronize()
         t0 = time.perf_counter()
+        t_arg = t_open = 0.0
         for name in ("advice", "lookup_permuted", "grand_products"):
             self._commit(name, True); sync()                       # transcript squeeze on the host
+            if self.with_quotient and name == "advice":
+                ta = time.perf_counter(); self.arguments(); sync(); t_arg = time.perf_counter() - ta
         self._commit("random", False); sync()
-        t1 = time.perf_counter(); t_msm += t1 - t0
+        t1 = time.perf_counter(); t_msm += t1 - t0 - t_arg
         ctx.intt_scaled_device(f.id, self.polys.data_ptr(), self.k, c["omega_inv"], c["ifft"], N_INTT, 0)
         ctx.coset_ntt_device(f.id, self.polys.data_ptr(), self.k, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega"], c["zeta"], N_COSET, 0)
         t_h = 0.0
@@ -154,10 +182,12 @@ class ProverShape:
         sync()
         t2 = time.perf_counter(); t_ntt += t2 - t1 - t_h
         self._commit("h_pieces", False); sync()
+        if self.with_quotient:
+            to = time.perf_counter(); self.openings(); sync(); t_open = time.perf_counter() - to
         self._commit("openings", False); sync()
-        t3 = time.perf_counter(); t_msm += t3 - t2
+        t3 = time.perf_counter(); t_msm += t3 - t2 - t_open
         outs = np.concatenate([self.out[name].cpu().numpy().view(np.uint64) for name, _, _ in MSM_PHASES])
-        return ProverShapeResult(outs, 1e3 * (t3 - t0), 1e3 * t_msm, 1e3 * t_ntt, 1e3 * t_h)
+        return ProverShapeResult(outs, 1e3 * (t3 - t0), 1e3 * t_msm, 1e3 * t_ntt, 1e3 * t_h, 1e3 * t_arg, 1e3 * t_open)
 
 
 def synthetic_columns(fill_scalars, scalar_field_id: int, k: int, seed: int = 1) -> dict:
@@ -180,6 +210,12 @@ def synthetic_proving_key(fill_scalars, field, k: int, extended_k: int, seed: in
     out = {"pk_fixed": np.stack([fill_scalars(scalar_field_id, "uniform", m, seed + i) for i in range(N_FIXED)]),
            "pk_sigma": np.stack([fill_scalars(scalar_field_id, "uniform", m, seed + 20 + i) for i in range(N_SIGMA)]),
            "pk_l": np.stack([fill_scalars(scalar_field_id, "uniform", m, seed + 30 + i) for i in range(3)])}
+    n = 1 << k
+    tsize = min(n // 2, 1 << 12)                              # inside the usable rows
+    tvals = field.encode_many(list(range(tsize)))            # a range table 0 .. 2^12 - 1, like the circuit's RangeChip tables
+    out["lookup_table"] = np.concatenate([tvals, np.repeat(tvals[:1], n - tsize, axis=0)])
+    rng = np.random.default_rng(seed)
+    out["lookup_inputs"] = np.stack([tvals[rng.integers(0, tsize, size=n)] for _ in range(N_LOOKUPS)])
     ch = field.decode_many(fill_scalars(scalar_field_id, "uniform", 5, seed + 40))
     out["challenges"] = dict(zip(("theta", "beta", "gamma", "y", "delta"), ch))
     return out

@@ -168,6 +168,10 @@ int dehalo_batch_invert_device(dehalo_ctx* ctx, int field, uint64_t* d_values, s
 int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, size_t len, uint64_t* d_out, void* stream);
 int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const uint64_t* den, size_t len, uint64_t* z);
 int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, uint64_t* d_z, void* stream);
+/* `batch` columns, stride_elems apart in num, den and z alike: the denominators of the whole batch share one inversion
+ * (a proof's 2 permutation + 5 lookup products are one call).                                                            */
+int dehalo_grand_product_batch_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, size_t batch,
+                                      size_t stride_elems, uint64_t* d_z, void* stream);
 
 /* ---- quotient numerator: evaluate_h --------------------------------------
  * The row loops of halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20 on device-resident

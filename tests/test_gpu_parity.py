@@ -692,3 +692,32 @@ def test_permute_expression_pair_vs_c_oracle(pkg, po, co, ctx, fid):
     pi, pt = ctx.permute_expression_pair(fid, table, table, 300)
     want = co.permute_expression_pair(fid, table, table, 300)
     assert np.array_equal(pi, want[0]) and np.array_equal(pt, want[1])
+
+
+def test_grand_product_batch_shares_one_inversion(pkg, co, ctx):
+    import torch
+    fid, n, stride, batch = 0, 5000, 5008, 7
+    num = np.stack([np.concatenate([co.fill_scalars(fid, "uniform", n, 60 + b), np.zeros((stride - n, 4), dtype=np.uint64)]) for b in range(batch)])
+    den = np.stack([np.concatenate([co.fill_scalars(fid, "uniform", n, 70 + b), np.zeros((stride - n, 4), dtype=np.uint64)]) for b in range(batch)])
+    den[3, 100] = 0                                                  # a zero denominator in one column must not disturb the others
+    dn, dd = torch.from_numpy(num.view(np.int64)).cuda(), torch.from_numpy(den.view(np.int64)).cuda()
+    dz = torch.zeros_like(dn)
+    ctx.grand_product_batch_device(fid, dn.data_ptr(), dd.data_ptr(), n, batch, stride, dz.data_ptr(), 0)
+    ctx.synchronize()
+    z = dz.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        assert np.array_equal(z[b, :n], co.grand_product(fid, num[b, :n], den[b, :n])), b
+        assert not z[b, n:].any()                                    # the padding between columns is untouched
+
+
+def test_permute_expression_pair_small_values(pkg, co, ctx):
+    """Range-table shaped columns (values < 2^16): the sort skips the limbs that are zero everywhere."""
+    fid, n = 0, 40000
+    small = np.zeros((1 << 12, 4), dtype=np.uint64)
+    small[:, 0] = np.arange(1 << 12, dtype=np.uint64) * 13 % 65521
+    table_c = np.concatenate([small, np.repeat(small[:1], n - (1 << 12), axis=0)])
+    inputs_c = small[np.random.default_rng(3).integers(0, 1 << 12, size=n)]
+    table, inputs = ctx.field_op(fid, "to_mont", table_c), ctx.field_op(fid, "to_mont", inputs_c)
+    want = co.permute_expression_pair(fid, inputs, table, n)
+    pi, pt = ctx.permute_expression_pair(fid, inputs, table, n)
+    assert np.array_equal(pi, want[0]) and np.array_equal(pt, want[1])
