@@ -47,7 +47,7 @@ struct MsmGeom {
     u32 G;          // bucket groups per MSM: 1 (precomputed tables) or W
     u32 batch;      // independent MSMs in this launch
     u32 slices;     // sort blocks per (group, batch)
-    u32 L0;         // level-0 task length
+    u32 L0;         // points per lane of k_msm_accum0
 };
 
 // ---- scalar -> signed digits -------------------------------------------------------------
@@ -161,14 +161,12 @@ static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32*
     if (count) count[gb] = run;
 }
 
-// ---- scans (3 kernels): item offsets and task offsets ------------------------------------
-// in: cnt[total]; out: off[total + 1] = exclusive scan of cnt, nrank[total + 1] = exclusive scan (count of non-empty), formerly
-// of ceil(cnt / L).  Blocks of SCAN_BLOCK entries.
+// ---- scans (3 kernels): point offsets and record ranges -----------------------------------
+// in: cnt[total]; out: off[total + 1] = exclusive scan of cnt, nrank[total + 1] = exclusive count of
+// non-empty buckets, and each bucket's range of partial-sum records.  Blocks of SCAN_BLOCK entries.
 #define SCAN_THREADS 256
 #define SCAN_PER_THREAD 8
 #define SCAN_BLOCK (SCAN_THREADS * SCAN_PER_THREAD)
-
-FP_DEV u32 ceil_div_u32(u32 a, u32 b) { return (a + b - 1) / b; }
 
 static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u32* cnt, u32 total, u32 L, u32* bsum_items, u32* bsum_tasks) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
@@ -350,12 +348,12 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
     }
 }
 
-// largest b in [0, total) with toff[b] <= t   (toff non-decreasing, toff[total] > t)
-FP_DEV u32 find_segment(const u32* toff, u32 total, u32 t) {
-    u32 lo = 0, hi = total;  // invariant: toff[lo] <= t < toff[hi]
+// largest b in [0, total) with off[b] <= t   (off non-decreasing, off[total] > t): the non-empty segment holding t
+FP_DEV u32 find_segment(const u32* off, u32 total, u32 t) {
+    u32 lo = 0, hi = total;  // invariant: off[lo] <= t < off[hi]
     while (hi - lo > 1) {
         u32 mid = (lo + hi) >> 1;
-        if (toff[mid] <= t) lo = mid; else hi = mid;
+        if (off[mid] <= t) lo = mid; else hi = mid;
     }
     return lo;
 }
@@ -738,7 +736,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_pcount, total_groups * (size_t)g.slices * P * 4));   // per-(slice, partition) counts
     TRY(dh_ensure(ctx, ctx->ws_pairs, Mmax * 8));                                   // partition-sorted (sub-bucket, reference) pairs
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
-    TRY(dh_ensure(ctx, ctx->ws_toff0, (total_buckets + 1) * 4 * 3));           // nrank | rbeg | rend
+    TRY(dh_ensure(ctx, ctx->ws_records, (total_buckets + 1) * 4 * 3));           // nrank | rbeg | rend
     const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / 2 + 1);
     TRY(dh_ensure(ctx, ctx->ws_merge_lists, (size_t)merge_cap * 4 * 4));   // merge-class lists
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
@@ -750,7 +748,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     u32* count = (u32*)ctx->ws_count.p;
     u32* cursor = (u32*)ctx->ws_counters.p;
     u32* off = (u32*)ctx->ws_off.p;
-    u32* nrank = (u32*)ctx->ws_toff0.p;
+    u32* nrank = (u32*)ctx->ws_records.p;
     u32* rbeg = nrank + (total_buckets + 1);
     u32* rend = rbeg + (total_buckets + 1);
     u32* merge_lists = (u32*)ctx->ws_merge_lists.p;
