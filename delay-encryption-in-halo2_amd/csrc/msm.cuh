@@ -427,6 +427,9 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 #define MSM_C2_MAX 2048
 #define MSM_HEAVY_THREADS 512    // 2 waves per SIMD: room for the ~170 VGPRs of a group addition (1024 threads would spill)
 #define MSM_MERGE_BLOCKS 1024
+#ifndef MSM_LIGHT_QUAD_MAX
+#define MSM_LIGHT_QUAD_MAX 65536   // listed buckets up to which the light class runs one quad per bucket (2 waves per SIMD of quads)
+#endif
 
 // classification: one lane per bucket.  S = 0 -> identity, S = 1 -> copy; otherwise the bucket is
 // queued in the list of its class (one atomic per wave and class: a single hot counter serialises).
@@ -466,7 +469,7 @@ template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter, const u32* list) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     const u32 count = *counter;
-    if (count <= 16384) {
+    if (count <= MSM_LIGHT_QUAD_MAX) {
         const u32 role = threadIdx.x & 3;
         for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < count; i += (gridDim.x * blockDim.x) >> 2) {
             u32 b = list[i];
