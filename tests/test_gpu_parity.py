@@ -721,3 +721,44 @@ def test_permute_expression_pair_small_values(pkg, co, ctx):
     want = co.permute_expression_pair(fid, inputs, table, n)
     pi, pt = ctx.permute_expression_pair(fid, inputs, table, n)
     assert np.array_equal(pi, want[0]) and np.array_equal(pt, want[1])
+
+
+# ---------------------------------------------------------------- lifecycle
+def test_context_lifecycle_releases_device_memory(pkg, co):
+    """Contexts, SRS tables, compiled programs and every grow-only workspace are freed on destroy."""
+    import torch
+    curve = pkg.fields.CURVES["pallas"]
+    fid = curve.scalar.id
+    n = 1 << 12
+    g = co.synth_bases(curve.id, n)
+    sc = co.fill_scalars(fid, "uniform", n, 1)
+    om = curve.scalar.encode(__import__("__graft_entry__").load_oracle()[0].FIELDS[curve.scalar.name].omega(12))
+    ev = pkg.evaluation
+
+    def cycle():
+        with pkg.Context(0) as c:
+            b = c.register_bases(curve.id, g, 0, True)
+            c.msm(b, sc)
+            c.ntt(fid, sc, 12, om)
+            c.batch_invert(fid, sc)
+            c.grand_product(fid, sc, sc)
+            c.eval_polynomial(fid, sc, sc[0])
+            c.permute_expression_pair(fid, sc, sc, n)
+            gr = ev.GraphEvaluator()
+            gr.add_calculation(ev.MUL, gr.column(ev.ADVICE, 0), gr.column(ev.ADVICE, 0, 1))
+            cg = gr.compile(c, curve.scalar)
+            d = torch.from_numpy(sc.view(np.int64).copy()).cuda()
+            o = torch.zeros_like(d)
+            cg.evaluate_device([], [d.data_ptr()], [], [], None, None, None, None, 12, 1, 0, o.data_ptr())
+            c.synchronize()
+            cg.release()
+            b.release()
+
+    cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)      # nothing accumulates across eight create/use/destroy cycles
