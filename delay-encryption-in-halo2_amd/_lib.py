@@ -20,7 +20,7 @@ SYMBOLS = [
     "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
-    "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device",
+    "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
@@ -113,6 +113,7 @@ def load_library():
     lib.dehalo_grand_product_batch_device.argtypes = [P, C.c_int, u64p, u64p, sz, sz, sz, u64p, P]
     lib.dehalo_permute_expression_pair.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p]
     lib.dehalo_permute_expression_pair_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p, P]
+    lib.dehalo_permute_expression_pair_batch_device.argtypes = [P, C.c_int, u64p, u64p, sz, sz, sz, u64p, u64p, P]
     lib.dehalo_graph_create.argtypes = [P, C.c_int, u64p, u32, C.POINTER(C.c_int32), u32, C.POINTER(CCalculation), u32, C.POINTER(CSource), u32, u32, C.POINTER(P)]
     lib.dehalo_graph_release.argtypes = [P, P]
     lib.dehalo_graph_evaluate_device.argtypes = [P, P, C.POINTER(CEvalInputs), u32, u32, u64p, u64p, P]
@@ -317,6 +318,11 @@ class Context:
         if usable_rows:
             self._check(self.lib.dehalo_permute_expression_pair(self.handle, field, _ptr(a), _ptr(t), usable_rows, _ptr(pi), _ptr(pt)))
         return pi, pt
+
+    def permute_expression_pair_batch_device(self, field: int, d_inputs: int, d_tables: int, usable_rows: int, batch: int, stride: int, d_permuted_inputs: int,
+                                             d_permuted_tables: int, stream: int = 0):
+        self._check(self.lib.dehalo_permute_expression_pair_batch_device(self.handle, field, d_inputs, d_tables, usable_rows, batch, stride, d_permuted_inputs,
+                                                                         d_permuted_tables, stream or None))
 
     def permute_expression_pair_device(self, field: int, d_input: int, d_table: int, usable_rows: int, d_permuted_input: int, d_permuted_table: int, stream: int = 0):
         self._check(self.lib.dehalo_permute_expression_pair_device(self.handle, field, d_input, d_table, usable_rows, d_permuted_input, d_permuted_table, stream or None))

@@ -607,16 +607,25 @@ int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const 
     return 0;
 }
 
-int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,
-                                          uint64_t* d_permuted_input, uint64_t* d_permuted_table, void* stream) {
+int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, const uint64_t* d_inputs, const uint64_t* d_tables, size_t usable_rows, size_t batch,
+                                                size_t stride_elems, uint64_t* d_permuted_inputs, uint64_t* d_permuted_tables, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
-    if ((!d_input || !d_table || !d_permuted_input || !d_permuted_table) && usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
-    if (d_permuted_input == d_input || d_permuted_table == d_table || d_permuted_input == d_table || d_permuted_table == d_input)
+    if ((!d_inputs || !d_tables || !d_permuted_inputs || !d_permuted_tables) && usable_rows && batch)
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
+    if (d_permuted_inputs == d_inputs || d_permuted_tables == d_tables || d_permuted_inputs == d_tables || d_permuted_tables == d_inputs)
         return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: outputs may not alias inputs");
+    if (batch > 1 && stride_elems < usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: stride shorter than the columns");
+    if (batch >= 4096) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: batch too large");
     if (field < 0 || field > 3) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
-    return lookup_permute_impl(ctx, field, (const fe*)d_input, (const fe*)d_table, usable_rows, (fe*)d_permuted_input, (fe*)d_permuted_table, pick_stream(ctx, stream));
+    return lookup_permute_impl(ctx, field, (const fe*)d_inputs, (const fe*)d_tables, usable_rows, batch, stride_elems, (fe*)d_permuted_inputs,
+                               (fe*)d_permuted_tables, pick_stream(ctx, stream));
+}
+
+int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,
+                                          uint64_t* d_permuted_input, uint64_t* d_permuted_table, void* stream) {
+    return dehalo_permute_expression_pair_batch_device(ctx, field, d_input, d_table, usable_rows, 1, usable_rows, d_permuted_input, d_permuted_table, stream);
 }
 
 int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* input, const uint64_t* table, size_t usable_rows, uint64_t* permuted_input,

@@ -164,7 +164,8 @@ DECL_POLY(pasta_fq)
 #undef DECL_POLY
 
 // lookup_permute.hip
-int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_input, const fe* d_table, uint64_t n, fe* d_out_input, fe* d_out_table, hipStream_t s);
+int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe* d_tables, uint64_t n, size_t batch, uint64_t stride, fe* d_out_inputs,
+                        fe* d_out_tables, hipStream_t s);
 
 // quotient-numerator kernels (evalh.cuh)
 struct dehalo_graph;

@@ -17,6 +17,8 @@
 // algorithm), then flag / binary-search / scan / scatter kernels.  Outputs are gathered from the
 // ORIGINAL Montgomery elements, so no value is ever re-encoded.
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -27,28 +29,34 @@
 
 namespace {
 
+// Batched layout: 2B key columns of n rows each, inputs first then tables, at canon[y * n + i].
 template <class F>
-__global__ void k_lp_canon(const fe* in, u64 n, fe* canon) {
+__global__ void k_lp_canon(const fe* inputs, const fe* tables, u64 stride, u32 B, u64 n, fe* canon) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) f_store(&canon[i], f_from_mont<F>(f_load(&in[i])));
+    const u32 y = blockIdx.y;
+    if (i >= n) return;
+    const fe* src = y < B ? inputs + (u64)y * stride : tables + (u64)(y - B) * stride;
+    f_store(&canon[(u64)y * n + i], f_from_mont<F>(f_load(&src[i])));
 }
 __global__ void k_lp_iota(u32* p, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (u32)i;
 }
-// keys[i] = 64-bit limb `limb` of canon[perm[i]]
-__global__ void k_lp_limb(const fe* canon, const u32* perm, u32 limb, u64 n, unsigned long long* keys) {
+// keys[i] = 64-bit limb `limb` of canon[perm[i]]   (limb == 4: the column id perm[i] / n)
+__global__ void k_lp_limb(const fe* canon, const u32* perm, u32 limb, u64 n_col, u64 total, unsigned long long* keys) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32* w = canon[perm[i]].v;
+    if (i >= total) return;
+    const u32 src = perm[i];
+    if (limb == 4) { keys[i] = src / n_col; return; }
+    const u32* w = canon[src].v;
     keys[i] = (unsigned long long)w[2 * limb] | ((unsigned long long)w[2 * limb + 1] << 32);
 }
 // ors[l] |= every key's 64-bit limb l: limbs that are zero everywhere need no sort pass, and the
 // highest set bit bounds the digits of the others (range tables hold small values)
-__global__ void k_lp_limb_or(const fe* canon, u64 n, unsigned long long* ors) {
+__global__ void k_lp_limb_or(const fe* canon, u64 total, unsigned long long* ors) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v[4] = {0, 0, 0, 0};
-    if (i < n) {
+    if (i < total) {
         const u32* w = canon[i].v;
 #pragma unroll
         for (int l = 0; l < 4; l++) v[l] = (unsigned long long)w[2 * l] | ((unsigned long long)w[2 * l + 1] << 32);
@@ -60,9 +68,9 @@ __global__ void k_lp_limb_or(const fe* canon, u64 n, unsigned long long* ors) {
         if ((threadIdx.x & 63) == 0 && x) atomicOr(&ors[l], x);
     }
 }
-__global__ void k_lp_gather(const fe* canon, const u32* perm, u64 n, fe* sorted) {
+__global__ void k_lp_gather(const fe* canon, const u32* perm, u64 total, fe* sorted) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) f_store(&sorted[i], f_load(&canon[perm[i]]));
+    if (i < total) f_store(&sorted[i], f_load(&canon[perm[i]]));
 }
 FP_DEV int lp_cmp(const fe& a, const fe& b) {          // canonical integers, most significant word first
 #pragma unroll
@@ -71,50 +79,65 @@ FP_DEV int lp_cmp(const fe& a, const fe& b) {          // canonical integers, mo
     }
     return 0;
 }
-// repeated[i] = A[i] == A[i-1]; every first occurrence looks its value up in T (sorted) and marks
-// the FIRST copy there as consumed; a miss raises *err.
-__global__ void k_lp_flags(const fe* A, const fe* T, u64 n, u32* repeated, u32* consumed, int* err) {
+// lookup y: A = S[y], T = S[B + y] (both sorted).  repeated[i] = A[i] == A[i-1]; every first
+// occurrence looks its value up in T and marks the FIRST copy there as consumed; a miss raises err[y].
+__global__ void k_lp_flags(const fe* S, u32 B, u64 n, u32* repeated, u32* consumed, int* err) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 y = blockIdx.y;
     if (i >= n) return;
+    const fe* A = S + (u64)y * n;
+    const fe* T = S + (u64)(B + y) * n;
     const fe a = f_load(&A[i]);
     bool first = i == 0 || lp_cmp(a, f_load(&A[i - 1])) != 0;
-    repeated[i] = first ? 0u : 1u;
+    repeated[(u64)y * n + i] = first ? 0u : 1u;
     if (!first) return;
     u64 lo = 0, hi = n;                                   // lower bound of a in T
     while (lo < hi) {
         u64 mid = (lo + hi) >> 1;
         if (lp_cmp(f_load(&T[mid]), a) < 0) lo = mid + 1; else hi = mid;
     }
-    if (lo < n && lp_cmp(f_load(&T[lo]), a) == 0) consumed[lo] = 1u;
-    else atomicExch(err, 1);
+    if (lo < n && lp_cmp(f_load(&T[lo]), a) == 0) consumed[(u64)y * n + lo] = 1u;
+    else atomicExch(&err[y], 1);
 }
-__global__ void k_lp_not(const u32* consumed, u64 n, u32* leftover) {
+__global__ void k_lp_not(const u32* consumed, u64 total, u32* leftover) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) leftover[i] = consumed[i] ? 0u : 1u;
+    if (i < total) leftover[i] = consumed[i] ? 0u : 1u;
 }
-// lsrc[q] = original table row of the q-th leftover (ascending)
-__global__ void k_lp_compact(const u32* leftover, const u32* lrank, const u32* perm_t, u64 n, u32* lsrc) {
+// lsrc[y][q] = original table row of lookup y's q-th leftover (ascending); ranks are global scans,
+// made column-local by subtracting the rank at the column's first row
+__global__ void k_lp_compact(const u32* leftover, const u32* lrank, const u32* perm, u32 B, u64 n, u32* lsrc) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n && leftover[j]) lsrc[lrank[j]] = perm_t[j];
+    const u32 y = blockIdx.y;
+    if (j >= n) return;
+    const u64 base = (u64)y * n;
+    if (leftover[base + j]) lsrc[base + (lrank[base + j] - lrank[base])] = perm[(u64)(B + y) * n + j] - (u32)((u64)(B + y) * n);
 }
-__global__ void k_lp_emit(const fe* input, const fe* table, const u32* perm_a, const u32* repeated, const u32* rrank, const u32* lsrc, u64 n, fe* out_input,
-                          fe* out_table) {
+__global__ void k_lp_emit(const fe* inputs, const fe* tables, u64 stride, const u32* perm, const u32* repeated, const u32* rrank, const u32* lsrc, u32 B, u64 n,
+                          fe* out_inputs, fe* out_tables) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 y = blockIdx.y;
     if (i >= n) return;
-    const fe a = f_load(&input[perm_a[i]]);
-    f_store(&out_input[i], a);
-    if (!repeated[i]) { f_store(&out_table[i], a); return; }
-    const u32 m = rrank[n - 1] + repeated[n - 1];         // number of repeated rows = number of leftovers
-    f_store(&out_table[i], f_load(&table[lsrc[m - 1 - rrank[i]]]));
+    const u64 base = (u64)y * n;
+    const fe* input = inputs + (u64)y * stride;
+    const fe* table = tables + (u64)y * stride;
+    const fe a = f_load(&input[perm[base + i] - (u32)base]);
+    f_store(&out_inputs[(u64)y * stride + i], a);
+    if (!repeated[base + i]) { f_store(&out_tables[(u64)y * stride + i], a); return; }
+    const u32 m = rrank[base + n - 1] + repeated[base + n - 1] - rrank[base];   // repeated rows of this lookup = its leftovers
+    const u32 r = rrank[base + i] - rrank[base];
+    f_store(&out_tables[(u64)y * stride + i], f_load(&table[lsrc[base + (m - 1 - r)]]));
 }
 
-int canon_dispatch(dehalo_ctx* ctx, int field, const fe* in, u64 n, fe* out, hipStream_t s) {
-    const u32 blocks = (u32)((n + 255) / 256);
+template <class F>
+void launch_canon(const fe* in, const fe* tab, u64 stride, u32 B, u64 n, fe* out, hipStream_t s) {
+    k_lp_canon<F><<<dim3((u32)((n + 255) / 256), 2 * B), 256, 0, s>>>(in, tab, stride, B, n, out);
+}
+int canon_dispatch(dehalo_ctx* ctx, int field, const fe* in, const fe* tab, u64 stride, u32 B, u64 n, fe* out, hipStream_t s) {
     switch (field) {
-        case DEHALO_FIELD_BN254_FR: k_lp_canon<Bn254Fr><<<blocks, 256, 0, s>>>(in, n, out); break;
-        case DEHALO_FIELD_BN254_FQ: k_lp_canon<Bn254Fq><<<blocks, 256, 0, s>>>(in, n, out); break;
-        case DEHALO_FIELD_PASTA_FP: k_lp_canon<PastaFp><<<blocks, 256, 0, s>>>(in, n, out); break;
-        case DEHALO_FIELD_PASTA_FQ: k_lp_canon<PastaFq><<<blocks, 256, 0, s>>>(in, n, out); break;
+        case DEHALO_FIELD_BN254_FR: launch_canon<Bn254Fr>(in, tab, stride, B, n, out, s); break;
+        case DEHALO_FIELD_BN254_FQ: launch_canon<Bn254Fq>(in, tab, stride, B, n, out, s); break;
+        case DEHALO_FIELD_PASTA_FP: launch_canon<PastaFp>(in, tab, stride, B, n, out, s); break;
+        case DEHALO_FIELD_PASTA_FQ: launch_canon<PastaFq>(in, tab, stride, B, n, out, s); break;
         default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
     }
     return 0;
@@ -129,80 +152,72 @@ struct Carve {
     }
 };
 
-// canonical keys sorted ascending; perm_out[i] = original row of the i-th smallest.  bits[l] = bit
-// length of the OR of limb l over the column (0: the pass is skipped).
-int sort_column(dehalo_ctx* ctx, const fe* canon, u64 n, const unsigned bits[4], fe* sorted, u32* perm_a, u32* perm_b, unsigned long long* keys_a,
-                unsigned long long* keys_b, void* tmp, size_t tmp_bytes, u32** perm_out, hipStream_t s) {
-    const u32 blocks = (u32)((n + 255) / 256);
-    k_lp_iota<<<blocks, 256, 0, s>>>(perm_a, n);
-    u32 *pin = perm_a, *pout = perm_b;
-    for (u32 limb = 0; limb < 4; limb++) {
-        if (bits[limb] == 0) continue;
-        k_lp_limb<<<blocks, 256, 0, s>>>(canon, pin, limb, n, keys_a);
-        size_t bytes = tmp_bytes;
-        HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp, bytes, keys_a, keys_b, pin, pout, n, 0, bits[limb], s));
-        std::swap(pin, pout);
-    }
-    k_lp_gather<<<blocks, 256, 0, s>>>(canon, pin, n, sorted);
-    HIP_TRY(ctx, hipGetLastError());
-    *perm_out = pin;
-    return 0;
-}
-
 }  // namespace
 
-int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_input, const fe* d_table, uint64_t n, fe* d_out_input, fe* d_out_table, hipStream_t s) {
-    if (n == 0) return 0;
-    if (n >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: too many rows");
+// `batch` lookups at once: column y of inputs / tables / outputs starts y * stride elements in.
+// All 2 * batch key columns go through the SAME global sort passes (value limbs, then a last
+// stable pass on the column id), so the number of launches does not grow with the batch.
+int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe* d_tables, uint64_t n, size_t batch, uint64_t stride, fe* d_out_inputs,
+                        fe* d_out_tables, hipStream_t s) {
+    if (n == 0 || batch == 0) return 0;
+    const u32 B = (u32)batch;
+    const u64 total = 2ull * B * n, half = (u64)B * n;
+    if (total >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: too many rows");
     ScopedTimer timer(ctx, s, DEHALO_K_POLY);
     size_t sort_tmp = 0, scan_tmp = 0;
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (u32*)nullptr, (u32*)nullptr, n, 0, 64, s));
-    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_tmp, (u32*)nullptr, (u32*)nullptr, 0u, n, rocprim::plus<u32>(), s));
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0, 64, s));
+    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_tmp, (u32*)nullptr, (u32*)nullptr, 0u, half, rocprim::plus<u32>(), s));
     const size_t tmp_bytes = std::max(sort_tmp, scan_tmp);
     const size_t pad = 256;
-    size_t total = 4 * (n * sizeof(fe) + pad) + 2 * (n * 8 + pad) + 4 * (n * 4 + pad) + 6 * (n * 4 + pad) + tmp_bytes + pad + 1024;
-    TRY(dh_ensure(ctx, ctx->ws_lookup, total));
+    size_t bytes_total = 2 * (total * sizeof(fe) + pad) + 2 * (total * 8 + pad) + 2 * (total * 4 + pad) + 6 * (half * 4 + pad) + (B * 4 + pad) + 1024 + tmp_bytes + pad;
+    TRY(dh_ensure(ctx, ctx->ws_lookup, bytes_total));
     Carve c{(char*)ctx->ws_lookup.p};
-    fe* canon_a = c.take<fe>(n); fe* canon_t = c.take<fe>(n); fe* A = c.take<fe>(n); fe* T = c.take<fe>(n);
-    unsigned long long* keys_a = c.take<unsigned long long>(n); unsigned long long* keys_b = c.take<unsigned long long>(n);
-    u32* pa0 = c.take<u32>(n); u32* pa1 = c.take<u32>(n); u32* pt0 = c.take<u32>(n); u32* pt1 = c.take<u32>(n);
-    u32* repeated = c.take<u32>(n); u32* consumed = c.take<u32>(n); u32* leftover = c.take<u32>(n); u32* rrank = c.take<u32>(n); u32* lrank = c.take<u32>(n);
-    u32* lsrc = c.take<u32>(n);
-    int* err = c.take<int>(1);
-    unsigned long long* ors = c.take<unsigned long long>(8);
+    fe* canon = c.take<fe>(total); fe* S = c.take<fe>(total);
+    unsigned long long* keys_a = c.take<unsigned long long>(total); unsigned long long* keys_b = c.take<unsigned long long>(total);
+    u32* p0 = c.take<u32>(total); u32* p1 = c.take<u32>(total);
+    u32* repeated = c.take<u32>(half); u32* consumed = c.take<u32>(half); u32* leftover = c.take<u32>(half); u32* rrank = c.take<u32>(half);
+    u32* lrank = c.take<u32>(half); u32* lsrc = c.take<u32>(half);
+    int* err = c.take<int>(B);
+    unsigned long long* ors = c.take<unsigned long long>(4);
     void* tmp = c.take<char>(tmp_bytes);
-    u32 *perm_a = nullptr, *perm_t = nullptr;
-    const u32 blocks = (u32)((n + 255) / 256);
-    TRY(canon_dispatch(ctx, field, d_input, n, canon_a, s));
-    TRY(canon_dispatch(ctx, field, d_table, n, canon_t, s));
-    HIP_TRY(ctx, hipMemsetAsync(ors, 0, 8 * sizeof(unsigned long long), s));
-    k_lp_limb_or<<<blocks, 256, 0, s>>>(canon_a, n, ors);
-    k_lp_limb_or<<<blocks, 256, 0, s>>>(canon_t, n, ors + 4);
-    unsigned long long host_ors[8];
+
+    const u32 blocks_n = (u32)((n + 255) / 256), blocks_total = (u32)((total + 255) / 256), blocks_half = (u32)((half + 255) / 256);
+    TRY(canon_dispatch(ctx, field, d_inputs, d_tables, stride, B, n, canon, s));
+    HIP_TRY(ctx, hipMemsetAsync(ors, 0, 4 * sizeof(unsigned long long), s));
+    k_lp_limb_or<<<blocks_total, 256, 0, s>>>(canon, total, ors);
+    unsigned long long host_ors[4];
     HIP_TRY(ctx, hipMemcpyAsync(host_ors, ors, sizeof(host_ors), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));          // the pass plan depends on the data (the call synchronises at its end anyway)
-    unsigned bits_a[4], bits_t[4];
-    for (int l = 0; l < 4; l++) {
-        bits_a[l] = host_ors[l] ? 64 - (unsigned)__builtin_clzll(host_ors[l]) : 0;
-        bits_t[l] = host_ors[4 + l] ? 64 - (unsigned)__builtin_clzll(host_ors[4 + l]) : 0;
+    k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
+    u32 *pin = p0, *pout = p1;
+    for (u32 limb = 0; limb <= 4; limb++) {
+        unsigned bits;
+        if (limb < 4) bits = host_ors[limb] ? 64 - (unsigned)__builtin_clzll(host_ors[limb]) : 0;
+        else bits = 2 * B > 1 ? 32 - (unsigned)__builtin_clz(2 * B - 1) : 0;        // last: the column id, stable
+        if (bits == 0) continue;
+        k_lp_limb<<<blocks_total, 256, 0, s>>>(canon, pin, limb, n, total, keys_a);
+        size_t bytes = tmp_bytes;
+        HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp, bytes, keys_a, keys_b, pin, pout, total, 0, bits, s));
+        std::swap(pin, pout);
     }
-    TRY(sort_column(ctx, canon_a, n, bits_a, A, pa0, pa1, keys_a, keys_b, tmp, tmp_bytes, &perm_a, s));
-    TRY(sort_column(ctx, canon_t, n, bits_t, T, pt0, pt1, keys_a, keys_b, tmp, tmp_bytes, &perm_t, s));
-    HIP_TRY(ctx, hipMemsetAsync(consumed, 0, n * 4, s));
-    HIP_TRY(ctx, hipMemsetAsync(err, 0, sizeof(int), s));
-    HIP_TRY(ctx, hipMemsetAsync(lsrc, 0, n * 4, s));          // a failed lookup leaves gaps: keep every index in range
-    k_lp_flags<<<blocks, 256, 0, s>>>(A, T, n, repeated, consumed, err);
-    k_lp_not<<<blocks, 256, 0, s>>>(consumed, n, leftover);
+    k_lp_gather<<<blocks_total, 256, 0, s>>>(canon, pin, total, S);
+    HIP_TRY(ctx, hipMemsetAsync(consumed, 0, half * 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(err, 0, B * sizeof(int), s));
+    HIP_TRY(ctx, hipMemsetAsync(lsrc, 0, half * 4, s));       // a failed lookup leaves gaps: keep every index in range
+    k_lp_flags<<<dim3(blocks_n, B), 256, 0, s>>>(S, B, n, repeated, consumed, err);
+    k_lp_not<<<blocks_half, 256, 0, s>>>(consumed, half, leftover);
     size_t bytes = tmp_bytes;
-    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, repeated, rrank, 0u, n, rocprim::plus<u32>(), s));
+    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, repeated, rrank, 0u, half, rocprim::plus<u32>(), s));
     bytes = tmp_bytes;
-    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, leftover, lrank, 0u, n, rocprim::plus<u32>(), s));
-    k_lp_compact<<<blocks, 256, 0, s>>>(leftover, lrank, perm_t, n, lsrc);
-    k_lp_emit<<<blocks, 256, 0, s>>>(d_input, d_table, perm_a, repeated, rrank, lsrc, n, d_out_input, d_out_table);
+    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, leftover, lrank, 0u, half, rocprim::plus<u32>(), s));
+    k_lp_compact<<<dim3(blocks_n, B), 256, 0, s>>>(leftover, lrank, pin, B, n, lsrc);
+    k_lp_emit<<<dim3(blocks_n, B), 256, 0, s>>>(d_inputs, d_tables, stride, pin, repeated, rrank, lsrc, B, n, d_out_inputs, d_out_tables);
     HIP_TRY(ctx, hipGetLastError());
-    int host_err = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&host_err, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    std::vector<int> host_err(B);
+    HIP_TRY(ctx, hipMemcpyAsync(host_err.data(), err, B * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));     // upstream returns Err(ConstraintSystemFailure) from this call: so must we
-    if (host_err) return dh_fail(ctx, DEHALO_ERR_NOT_IN_TABLE, "permute_expression_pair: an input value is not in the table (ConstraintSystemFailure)");
+    for (u32 y = 0; y < B; y++)
+        if (host_err[y])
+            return dh_fail(ctx, DEHALO_ERR_NOT_IN_TABLE, "permute_expression_pair: lookup " + std::to_string(y) + ": an input value is not in the table (ConstraintSystemFailure)");
     return 0;
 }

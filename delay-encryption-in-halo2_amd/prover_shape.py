@@ -109,8 +109,9 @@ class ProverShape:
             self.challenges = dict(columns["challenges"])                                                  # theta, beta, gamma, y, delta: canonical ints
             # lookup arguments: a 2^12-entry table padded with its first value (how halo2 pads range tables), inputs drawn from it
             self.usable = self.n - (-LAST_ROTATION)
-            self.lk_in, self.lk_table = to_dev(columns["lookup_inputs"]), to_dev(columns["lookup_table"])     # (5, n, 4), (n, 4)
-            self.lk_out = torch.zeros((N_LOOKUPS, 2, self.usable, 4), dtype=torch.int64, device="cuda")
+            self.lk_in = to_dev(columns["lookup_inputs"])                                                      # (5, n, 4)
+            self.lk_table = to_dev(np.repeat(columns["lookup_table"][None], N_LOOKUPS, axis=0))               # (5, n, 4): one table column per lookup
+            self.lk_out = torch.zeros((2, N_LOOKUPS, self.n, 4), dtype=torch.int64, device="cuda")
             self.z = torch.zeros((7, self.n, 4), dtype=torch.int64, device="cuda")
             self.evals = torch.zeros((N_INTT, 4), dtype=torch.int64, device="cuda")
             self.gate_graph = maingate_graph().compile(ctx, curve.scalar)
@@ -139,9 +140,8 @@ class ProverShape:
         grand products (2 permutation sets + 5 lookups): batch-inverted denominators and the running product.
         (The element-wise numerator / denominator products that feed them are not modelled.)"""
         f = self.curve.scalar
-        for i in range(N_LOOKUPS):
-            self.ctx.permute_expression_pair_device(f.id, self.lk_in[i].data_ptr(), self.lk_table.data_ptr(), self.usable, self.lk_out[i, 0].data_ptr(),
-                                                    self.lk_out[i, 1].data_ptr(), 0)
+        self.ctx.permute_expression_pair_batch_device(f.id, self.lk_in.data_ptr(), self.lk_table.data_ptr(), self.usable, N_LOOKUPS, self.n,
+                                                      self.lk_out[0].data_ptr(), self.lk_out[1].data_ptr(), 0)          # the five lookups share the sort passes
         num, den = self.cols["grand_products"], self.cols["lookup_permuted"]
         self.ctx.grand_product_batch_device(f.id, num.data_ptr(), den.data_ptr(), self.n, 7, self.n, self.z.data_ptr(), 0)   # one inversion for all seven
 

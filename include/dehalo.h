@@ -160,6 +160,10 @@ int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* i
                                    uint64_t* permuted_input, uint64_t* permuted_table);
 int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,
                                           uint64_t* d_permuted_input, uint64_t* d_permuted_table, void* stream);
+/* `batch` lookup arguments in one call (a proof's five): column y of each of the four arrays starts y * stride_elems elements in.
+ * All key columns share the sort passes, so the cost barely grows with the batch.                                                */
+int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, const uint64_t* d_inputs, const uint64_t* d_tables, size_t usable_rows, size_t batch,
+                                                size_t stride_elems, uint64_t* d_permuted_inputs, uint64_t* d_permuted_tables, void* stream);
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]);
 int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
                                   const uint64_t point[4], uint64_t* d_out, void* stream);

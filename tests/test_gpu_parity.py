@@ -762,3 +762,30 @@ def test_context_lifecycle_releases_device_memory(pkg, co):
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, (free0, free1)      # nothing accumulates across eight create/use/destroy cycles
+
+
+def test_permute_expression_pair_batch(pkg, co, ctx):
+    """Five lookups in one call (shared sort passes) against the oracle column by column; a miss in one of them is reported."""
+    import torch
+    fid, n, stride, B = 0, 3000, 3072, 5
+    rng = np.random.default_rng(12)
+    ins, tabs = np.zeros((B, stride, 4), dtype=np.uint64), np.zeros((B, stride, 4), dtype=np.uint64)
+    for y in range(B):
+        tsize = 100 * (y + 1)
+        base = co.fill_scalars(fid, "uniform", tsize, 200 + y) if y % 2 else ctx.field_op(fid, "to_mont", np.pad(np.arange(tsize, dtype=np.uint64)[:, None], ((0, 0), (0, 3))))
+        tabs[y, :n] = np.concatenate([base, np.repeat(base[:1], n - tsize, axis=0)])
+        ins[y, :n] = base[rng.integers(0, tsize, size=n)]
+        tabs[y, n:], ins[y, n:] = co.fill_scalars(fid, "uniform", stride - n, 300 + y), co.fill_scalars(fid, "uniform", stride - n, 400 + y)   # beyond usable rows: ignored
+    di, dt = torch.from_numpy(ins.view(np.int64)).cuda(), torch.from_numpy(tabs.view(np.int64)).cuda()
+    oi, ot = torch.zeros_like(di), torch.zeros_like(dt)
+    ctx.permute_expression_pair_batch_device(fid, di.data_ptr(), dt.data_ptr(), n, B, stride, oi.data_ptr(), ot.data_ptr(), 0)
+    gi, gt = oi.cpu().numpy().view(np.uint64), ot.cpu().numpy().view(np.uint64)
+    for y in range(B):
+        want = co.permute_expression_pair(fid, ins[y], tabs[y], n)
+        assert np.array_equal(gi[y, :n], want[0]) and np.array_equal(gt[y, :n], want[1]), y
+        assert not gi[y, n:].any() and not gt[y, n:].any()
+    ins[3, 5] = co.fill_scalars(fid, "uniform", 1, 999)[0]
+    di = torch.from_numpy(ins.view(np.int64)).cuda()
+    with pytest.raises(pkg.DehaloError) as e:
+        ctx.permute_expression_pair_batch_device(fid, di.data_ptr(), dt.data_ptr(), n, B, stride, oi.data_ptr(), ot.data_ptr(), 0)
+    assert e.value.code == -6 and "lookup 3" in str(e.value)
