@@ -14,8 +14,10 @@ g = co.synth_bases(curve.id, n); gl = g[::-1].copy()
 cols = ps.synthetic_columns(lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed), curve.scalar.id, k, 7)
 wb = int(os.environ.get('WINDOW_BITS', '0'))
 bg, bgl = ctx.register_bases(curve.id, g, wb, True), ctx.register_bases(curve.id, gl, wb, True)
-shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
+fill = lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed)
+cols.update(ps.synthetic_proving_key(fill, curve.scalar, k, k + 2, 55))
+shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols, with_quotient=True)
 shape.run()
 for _ in range(3):
     r = shape.run()
-    print("total %.3f ms  msm %.3f  ntt %.3f" % (r.ms_total, r.ms_msm, r.ms_ntt))
+    print("total %.3f ms  msm %.3f  ntt %.3f  evaluate_h %.3f  arguments %.3f  openings %.3f" % (r.ms_total, r.ms_msm, r.ms_ntt, r.ms_eval_h, r.ms_arguments, r.ms_openings))
