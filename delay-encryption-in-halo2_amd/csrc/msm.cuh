@@ -556,23 +556,29 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u3
     u32 grp = gid / per_group, t = gid % per_group;
     u32 k0 = t * MSM_RED_M, k1 = min(k0 + MSM_RED_M, nb);
     const xyzz29_rec* B = buckets + (u64)grp * nb;
-    auto add = [](const xyzz29& a, const xyzz29& b) { return QUAD ? x29_add_quad<F>(a, b) : x29_add<F>(a, b); };
-    auto dbl = [](const xyzz29& a) { return QUAD ? x29_double_quad<F>(a) : x29_double<F>(a); };
+    // (always_inline: left to itself hipcc emits these lambdas as real functions whose 36-word point
+    // arguments travel through scratch memory -- ~230 scratch accesses per group operation)
+    auto add = [](const xyzz29& a, const xyzz29& b) __attribute__((always_inline)) { return QUAD ? x29_add_quad<F>(a, b) : x29_add<F>(a, b); };
+    auto dbl = [](const xyzz29& a) __attribute__((always_inline)) { return QUAD ? x29_double_quad<F>(a) : x29_double<F>(a); };
     xyzz29 run = x29_load(&B[k1 - 1]);
     xyzz29 acc = run;
     for (u32 k = k1 - 1; k-- > k0;) {
         run = add(run, x29_load(&B[k]));
         acc = add(acc, run);
     }
-    // k0 * run, MSB-first double-and-add (k0 < 2^15); nothing to weight when the block is empty
+    // k0 * run, MSB-first double-and-add (k0 < 2^15); nothing to weight when the block is empty.
+    // acc is parked in LDS for the duration (LDS operations of one wave complete in order, so no
+    // barrier is needed): three live points plus an addition's temporaries spill to scratch.
+    __shared__ xyzz29_rec park[MSM_ACC_THREADS];
     if (k0 && !f29_all_zero(run.zz)) {
+        x29_store(&park[threadIdx.x], acc);
         int top = 31 - __clz(k0);
         xyzz29 w = run;
         for (int bit = top - 1; bit >= 0; bit--) {
             w = dbl(w);
             if ((k0 >> bit) & 1) w = add(w, run);
         }
-        acc = add(acc, w);
+        acc = add(x29_load(&park[threadIdx.x]), w);
     }
     if (!QUAD || (threadIdx.x & 3) == 0) x29_store(&contrib[gid], acc);
 }
