@@ -284,7 +284,7 @@ def main():
         red_ms, red_cnt = tsum(_lib.K_MSM_REDUCE)
         ntt_ms, ntt_cnt = tsum(_lib.K_NTT_PASS)
         acc_avg_ms = acc_ms / max(acc_cnt, 1)
-        c_bits = args.window_bits or (16 if log_n >= 20 else 15 if log_n >= 13 else 13 if log_n >= 10 else max(6, log_n + 1))   # as dehalo_bases_register chooses it
+        c_bits = args.window_bits or (16 if log_n >= 20 else 15 if log_n >= 17 else 13 if log_n >= 10 else max(6, log_n + 1))   # as dehalo_bases_register chooses it
         n_windows = -(-256 // c_bits)
         achieved = MSM_BYTES_PER_TERM * n / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
         traffic = None

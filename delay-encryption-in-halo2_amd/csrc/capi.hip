@@ -13,12 +13,14 @@ namespace {
 
 hipStream_t pick_stream(dehalo_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
-// Window bits by measurement on MI355X (tools/sweep_c.py): below 2^20 points the bucket reduction
-// (cost ~ 2^(c-1)) outweighs one or two extra windows, so c = 15; tiny problems want fewer buckets.
+// Window bits by measurement on MI355X (tools/sweep_c.py, tools/profile_prover.py with WINDOW_BITS): the bucket
+// reduction costs ~ 2^(c-1) group operations on a latency chain, the accumulation n * ceil(256 / c) additions.
+// 2^20 and up: 16; 2^17 .. 2^19: 15; 2^10 .. 2^16: 13 (prover-shaped schedule at k = 14: 2.9 ms of MSMs with
+// c = 13, 3.1 with 15, 3.5 with 14 -- even c leaves a top window of few bits whose buckets are hot).
 uint32_t choose_window(size_t n) {
     uint32_t l = log2_ceil(n ? n : 1);
     if (l >= 20) return 16;
-    if (l >= 13) return 15;
+    if (l >= 17) return 15;
     if (l >= 10) return 13;
     return std::max<uint32_t>(6, l + 1);
 }

@@ -65,7 +65,8 @@ __global__ void k_lp_limb_or(const fe* canon, u64 total, unsigned long long* ors
     for (int l = 0; l < 4; l++) {
         unsigned long long x = v[l];
         for (int d = 32; d >= 1; d >>= 1) x |= __shfl_xor(x, d);
-        if ((threadIdx.x & 63) == 0 && x) atomicOr(&ors[l], x);
+        // only a wave that would ADD bits touches the shared word (4 hot addresses otherwise serialise ~10^5 atomics)
+        if ((threadIdx.x & 63) == 0 && (x & ~__atomic_load_n(&ors[l], __ATOMIC_RELAXED)) != 0) atomicOr(&ors[l], x);
     }
 }
 __global__ void k_lp_gather(const fe* canon, const u32* perm, u64 total, fe* sorted) {
