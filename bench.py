@@ -36,6 +36,7 @@ MADS_PER_FIELD_MUL = {"pasta_fp": 135, "pasta_fq": 135, "bn254_fr": 162, "bn254_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the extra one-step-at-a-time pass (profiling: keeps per-kernel averages of the timed region clean)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
@@ -264,7 +265,7 @@ def main():
         return {kid: (sum(c.timing_get(kid)[0] for c in cs), sum(c.timing_get(kid)[1] for c in cs))
                 for kid in (_lib.K_MSM_ACCUMULATE, _lib.K_MSM_SORT, _lib.K_MSM_REDUCE, _lib.K_NTT_PASS)}
     overlapped = collect(ctxs) if rank == 0 else None
-    ss_steps = min(10, args.steps)
+    ss_steps = 0 if args.no_single_stream else min(10, args.steps)
     ctx.timing_reset(); ctx.timing_enable(True)
     torch.cuda.synchronize()
     ts = time.perf_counter()
@@ -322,7 +323,7 @@ def main():
                                   "frac": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (acc_avg_ms * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4) if acc_avg_ms > 0 else 0.0}},
             "breakdown_ms_per_step": {"msm_sort": round(sort_ms / max(sort_cnt, 1), 4), "msm_accumulate": round(acc_avg_ms, 4),
                                       "msm_reduce": round(red_ms / max(red_cnt, 1), 4), "ntt": round(ntt_ms / max(ntt_cnt, 1), 4)},
-            "single_stream": {"ms_per_step": round(ss_ms, 4), "steps": ss_steps,
+            "single_stream": None if ss_steps == 0 else {"ms_per_step": round(ss_ms, 4), "steps": ss_steps,
                               "kernel_ms": {name: round(single[kid][0] / max(single[kid][1], 1), 4) for name, kid in
                                             (("msm_sort", _lib.K_MSM_SORT), ("msm_accumulate", _lib.K_MSM_ACCUMULATE), ("msm_reduce", _lib.K_MSM_REDUCE), ("ntt", _lib.K_NTT_PASS))},
                               "note": "same step, one at a time (not the metric): kernel times without overlap from the %d steps in flight" % inflight},
@@ -339,7 +340,7 @@ def main():
         out["ntt_roofline"]["valu"] = {"muls_per_launch": ntt_muls, "mads_per_mul": mads_per_mul, "peak_tmad_per_s": VMAD_PEAK_TMADS,
                                        "achieved_tmad_per_s": round(ntt_muls * mads_per_mul / (ntt_avg_ms * 1e-3) / 1e12, 2) if ntt_avg_ms > 0 else 0.0}
         out["ntt_roofline"]["valu"]["frac"] = round(out["ntt_roofline"]["valu"]["achieved_tmad_per_s"] / VMAD_PEAK_TMADS, 4)
-        ss = out["single_stream"]["kernel_ms"]
+        ss = out["single_stream"]["kernel_ms"] if out["single_stream"] else {"msm_accumulate": 0, "ntt": 0}
         if ss["msm_accumulate"] > 0 and ss["ntt"] > 0:
             out["single_stream"]["valu_frac"] = {"k_msm_accum0": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (ss["msm_accumulate"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4),
                                                  "k_ntt_pass": round(ntt_muls * mads_per_mul / (ss["ntt"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4)}
