@@ -310,11 +310,8 @@ int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_i
     A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale;
     A.previous = d_previous; A.out = d_out; A.spill = (fe*)ctx->ws_evh[3].p; A.rows = rows; A.result = g->result;
     const size_t lds = (size_t)std::max<u32>(1, g->lds_slots) * EVH_SLOT_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (lds > 48 * 1024)   // per call: the attribute belongs to the device the context is bound to
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_graph_eval<F>, hipFuncAttributeMaxDynamicSharedMemorySize, EVH_LDS_BYTES));
-        attr_set = true;
-    }
     k_graph_eval<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, lds, s>>>(A);
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -730,7 +730,6 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         const uint64_t rounds = std::max<uint64_t>(1, (Mmax + resident * 64 - 1) / (resident * 64));
         uint64_t L0 = (Mmax + rounds * resident - 1) / (rounds * resident);
         L0 = std::min<uint64_t>(64, std::max<uint64_t>(4, L0));
-        if (const char* e = getenv("DEHALO_L0")) L0 = (uint64_t)std::max(1, atoi(e));  // tuning override
         g.L0 = (u32)L0;
     }
     const uint64_t lanes_max = (Mmax + g.L0 - 1) / g.L0;

@@ -364,12 +364,9 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         TRY(dh_ensure(ctx, ctx->ws_ntt_scratch, batch * N * sizeof(fe)));
         scratch = (fe*)ctx->ws_ntt_scratch.p;
     }
-    static bool attr_set = false;  // one process drives one GPU
     const size_t lds_max = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(f29);
-    if (!attr_set) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        attr_set = true;
-    }
+    // per call: the attribute belongs to the device the context is bound to
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     uint32_t log_m = log_n;
     for (uint32_t p = 0; p < L; p++) {
         NttPassParams P;
