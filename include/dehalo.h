@@ -21,9 +21,13 @@
  *  - "host" entry points take host pointers and are synchronous; "_device" entry points
  *    take device pointers and a hipStream_t (as void*; NULL = the context's stream) and
  *    are asynchronous on that stream;
- *  - a context is bound to one device; calls on one context are serialised by the caller
- *    or by stream order.  There is NO CPU fallback: without a usable gfx950 device
- *    dehalo_ctx_create fails with DEHALO_ERR_NO_DEVICE.
+ *  - a context is bound to one device and owns one grow-only workspace in HBM that every call on
+ *    it uses: entry points may be called from several threads (a mutex serialises them), but
+ *    the device work of one context must be ordered -- use the context's own stream, or one
+ *    stream of yours per context.  Work that should overlap (independent proofs, columns of
+ *    different phases) goes to DIFFERENT contexts; registered bases and compiled graphs may be
+ *    shared between contexts of the same device.  There is NO CPU fallback: without a usable
+ *    gfx950 device dehalo_ctx_create fails with DEHALO_ERR_NO_DEVICE.
  */
 #ifndef DEHALO_H
 #define DEHALO_H
