@@ -28,7 +28,7 @@ MSM_BYTES_PER_TERM = 96  # 64 B affine base + 32 B scalar
 NTT_BYTES_PER_ELEM = 64  # read once + write once
 # v_mad_u64_u32 per XYZZ mixed addition in k_msm_accum0's loop (ISA count) and the measured issue
 # peak of that instruction on MI355X (profiles/r01_ubench_instruction_rates.txt)
-MADS_PER_MIXED_ADD = {"pallas": 1278, "vesta": 1278, "bn254": 1548}
+MADS_PER_MIXED_ADD = {"pallas": 1224, "vesta": 1224, "bn254": 1467}
 VMAD_PEAK_TMADS = 30.5
 MADS_PER_FIELD_MUL = {"pasta_fp": 135, "pasta_fq": 135, "bn254_fr": 162, "bn254_fq": 162}   # f29_mul, ISA count
 

@@ -105,7 +105,12 @@ FP_DEV xyzz29 x29_add_mixed(const xyzz29& a, const aff29& q) {
     xyzz29 r;
     r.x = f29_norm(f29_sub(r2, f29_add(ppp, f29_dbl(qq)), F::KB));
     f29 t = f29_sub(qq, r.x, F::KA);
-    r.y = f29_norm(f29_sub(f29_mul<F>(rr, t), f29_mul<F>(a.y, ppp), F::KM));
+    if constexpr (f29_is_lat<F>::value) {
+        r.y = f29_norm(f29_sub(f29_mul<F>(rr, t), f29_mul<F>(a.y, ppp), F::KM));
+    } else {
+        // R (Q - X3) - Y1 PPP as ONE reduction of two products: R (Q - X3) + (10p - Y1) PPP
+        r.y = f29_mul2<F>(rr, t, f29_norm(f29_sub(f29_zero(), a.y, F::KA)), ppp);
+    }
     r.zz = f29_mul<F>(a.zz, pp);
     r.zzz = f29_mul<F>(a.zzz, ppp);
     if (__builtin_expect(f29_maybe_zero_lt2p<F>(r.zz), 0)) {

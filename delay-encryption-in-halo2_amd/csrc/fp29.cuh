@@ -254,6 +254,21 @@ FP_DEV f29 f29_mul(const f29& a, const f29& b) {
     });
 }
 
+// (a * b + c * d) * 2^-261 with ONE reduction: both products go into the same columns
+// (result < (a b + c d) / 2^261 + p).  Column budget: limbs of a, c, d < 2^29 and of b < 2^31:
+// 9 * 2^60 + 9 * 2^58 products + 9 * 2^58 reduction terms + carry < 2^64 (tools/fp29_model.py mont2).
+template <class F>
+FP_DEV f29 f29_mul2(const f29& a, const f29& b, const f29& c, const f29& d) {
+    return f29_montgomery_columns<F>([&](int k, u64& acc) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 9) {
+                f29_col_mad(acc, a.v[i], b.v[k - i]);
+                f29_col_mad(acc, c.v[i], d.v[k - i]);
+            }
+    });
+}
+
 // a^2 * 2^-261: cross products once, against the doubled operand (limbs < 2^30 for a normalized a)
 template <class F>
 FP_DEV f29 f29_sqr(const f29& a) {

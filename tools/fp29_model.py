@@ -99,6 +99,39 @@ class F29:
                 out.append(v)
         return out
 
+    def mont2(self, a, b, c, d):
+        """(a * b + c * d) * 2^-261 mod p with ONE reduction (f29_mul2): both products go into the same columns."""
+        for x in (a, b, c, d):
+            assert len(x) == L and all(0 <= v < U32 for v in x)
+        acc = [0] * (2 * L)
+        for i in range(L):
+            for j in range(L):
+                acc[i + j] += a[i] * b[j] + c[i] * d[j]
+        # column totals including every reduction term and carry must fit 64 bits (product scanning keeps ONE accumulator per column)
+        carry = 0
+        m = [0] * L
+        tot = list(acc)
+        out = []
+        for k in range(2 * L - 1):
+            col = tot[k] + carry
+            for i in range(L):
+                if i < k and k - i < L and i < L:
+                    col += m[i] * self.P[k - i] if i < L and k - i >= 1 else 0
+            if k < L:
+                m[k] = ((col & 0xFFFFFFFF) * self.INV) & MASK
+                col += m[k] * self.P[0]
+                assert col & MASK == 0
+            assert col < U64, "fused column overflow"
+            if k >= L:
+                out.append(col & MASK)
+            carry = col >> B
+        assert carry < (1 << B), "result exceeds 2^261"
+        out.append(carry)
+        want = (value(a) * value(b) + value(c) * value(d)) * pow(1 << RBITS, -1, self.p) % self.p
+        assert value(out) % self.p == want
+        assert value(out) < (value(a) * value(b) + value(c) * value(d)) // (1 << RBITS) + self.p + 1
+        return out
+
     def sqr(self, a):
         """a^2 * 2^-261 with cross products taken once against the doubled operand (f29_sqr)."""
         assert all(0 <= x < U32 for x in a)
@@ -237,7 +270,8 @@ class XYZZ29:
         RR = F.sqr(Rr)
         X3 = F.norm(F.sub(RR, F.add(PPP, F.dbl(Q)), F.KB))
         T = F.sub(Q, X3, F.KA)
-        Y3 = F.norm(F.sub(F.mont(Rr, T), F.mont(Y1, PPP), F.KM))
+        NY = F.norm(F.sub([0] * L, Y1, F.KA))           # -Y1 + 10p
+        Y3 = F.mont2(Rr, T, NY, PPP)                     # R (Q - X3) - Y1 PPP, one reduction
         ZZ3 = F.mont(ZZ1, PP)
         ZZZ3 = F.mont(ZZZ1, PPP)
         for n, v in (("P", P), ("X3", X3), ("Y3", Y3), ("ZZ3", ZZ3), ("ZZZ3", ZZZ3), ("T", T), ("PPP", PPP)):
