@@ -21,6 +21,7 @@ SYMBOLS = [
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device",
+    "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
@@ -38,19 +39,21 @@ class CCalculation(C.Structure):
 class CEvalInputs(C.Structure):
     _fields_ = [("fixed", C.POINTER(C.c_void_p)), ("num_fixed", C.c_uint32), ("advice", C.POINTER(C.c_void_p)), ("num_advice", C.c_uint32),
                 ("instance", C.POINTER(C.c_void_p)), ("num_instance", C.c_uint32), ("challenges", C.c_void_p), ("num_challenges", C.c_uint32),
-                ("beta", C.c_void_p), ("gamma", C.c_void_p), ("theta", C.c_void_p), ("y", C.c_void_p)]
+                ("beta", C.c_void_p), ("gamma", C.c_void_p), ("theta", C.c_void_p), ("y", C.c_void_p), ("form_flags", C.c_uint32)]
 
 
 class CPermInputs(C.Structure):
     _fields_ = [("z", C.POINTER(C.c_void_p)), ("num_sets", C.c_uint32), ("columns", C.POINTER(C.c_void_p)), ("sigma", C.POINTER(C.c_void_p)),
                 ("num_columns", C.c_uint32), ("chunk_len", C.c_uint32), ("last_rotation", C.c_int32),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
-                ("beta", C.c_void_p), ("gamma", C.c_void_p), ("y", C.c_void_p), ("delta", C.c_void_p), ("beta_zeta", C.c_void_p), ("extended_omega", C.c_void_p)]
+                ("beta", C.c_void_p), ("gamma", C.c_void_p), ("y", C.c_void_p), ("delta", C.c_void_p), ("beta_zeta", C.c_void_p), ("extended_omega", C.c_void_p),
+                ("form_flags", C.c_uint32)]
 
 
 class CLookupInputs(C.Structure):
     _fields_ = [("product_coset", C.c_void_p), ("permuted_input_coset", C.c_void_p), ("permuted_table_coset", C.c_void_p), ("table_value", C.c_void_p),
-                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p), ("beta", C.c_void_p), ("gamma", C.c_void_p), ("y", C.c_void_p)]
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p), ("beta", C.c_void_p), ("gamma", C.c_void_p), ("y", C.c_void_p),
+                ("form_flags", C.c_uint32)]
 
 
 class DehaloError(RuntimeError):
@@ -114,6 +117,9 @@ def load_library():
     lib.dehalo_permute_expression_pair.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p]
     lib.dehalo_permute_expression_pair_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p, P]
     lib.dehalo_permute_expression_pair_batch_device.argtypes = [P, C.c_int, u64p, u64p, sz, sz, sz, u64p, u64p, P]
+    lib.dehalo_convert_form_device.argtypes = [P, C.c_int, u64p, u64p, sz, C.c_int, P]
+    lib.dehalo_coset_ntt_form_device.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p, sz, u32, P]
+    lib.dehalo_coset_intt_form_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p, sz, u32, P]
     lib.dehalo_graph_create.argtypes = [P, C.c_int, u64p, u32, C.POINTER(C.c_int32), u32, C.POINTER(CCalculation), u32, C.POINTER(CSource), u32, u32, C.POINTER(P)]
     lib.dehalo_graph_release.argtypes = [P, P]
     lib.dehalo_graph_evaluate_device.argtypes = [P, P, C.POINTER(CEvalInputs), u32, u32, u64p, u64p, P]
@@ -259,6 +265,18 @@ class Context:
         self._check(self.lib.dehalo_coset_ntt_device(self.handle, field, d_coeffs, log_n, d_ext, log_ext, _ptr(_u64(omega_ext, 4)), _ptr(_u64(zeta, 4)), batch,
                                                      stream or None))
 
+    # optional device-internal element form (dehalo.h): FORM_OUT_INTERNAL = 1, FORM_IN_INTERNAL = 2
+    def convert_form_device(self, field: int, d_in: int, d_out: int, n: int, to_internal: bool, stream: int = 0):
+        self._check(self.lib.dehalo_convert_form_device(self.handle, field, d_in, d_out, n, int(to_internal), stream or None))
+
+    def coset_ntt_form_device(self, field: int, d_coeffs: int, log_n: int, d_ext: int, log_ext: int, omega_ext, zeta, batch: int, form_flags: int, stream: int = 0):
+        self._check(self.lib.dehalo_coset_ntt_form_device(self.handle, field, d_coeffs, log_n, d_ext, log_ext, _ptr(_u64(omega_ext, 4)), _ptr(_u64(zeta, 4)), batch,
+                                                          form_flags, stream or None))
+
+    def coset_intt_form_device(self, field: int, d_a: int, log_ext: int, omega_ext_inv, ext_n_inv, zeta, batch: int, form_flags: int, stream: int = 0):
+        self._check(self.lib.dehalo_coset_intt_form_device(self.handle, field, d_a, log_ext, _ptr(_u64(omega_ext_inv, 4)), _ptr(_u64(ext_n_inv, 4)),
+                                                           _ptr(_u64(zeta, 4)), batch, form_flags, stream or None))
+
     def coset_intt_device(self, field: int, d_a: int, log_ext: int, omega_ext_inv, ext_n_inv, zeta, batch: int = 1, stream: int = 0):
         self._check(self.lib.dehalo_coset_intt_device(self.handle, field, d_a, log_ext, _ptr(_u64(omega_ext_inv, 4)), _ptr(_u64(ext_n_inv, 4)),
                                                       _ptr(_u64(zeta, 4)), batch, stream or None))
@@ -349,26 +367,26 @@ class Context:
         return (C.c_void_p * max(1, len(ptrs)))(*ptrs)
 
     def graph_evaluate_device(self, graph, fixed, advice, instance, challenges, beta, gamma, theta, y, log_rows: int, rot_scale: int, d_previous: int,
-                              d_out: int, stream: int = 0):
+                              d_out: int, stream: int = 0, form_flags: int = 0):
         """fixed / advice / instance: lists of device pointers; challenges: k x 4 u64; beta..y: 4 u64 or None."""
         keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) if v is not None else None for v in (beta, gamma, theta, y)]
         ch = _u64(challenges, 4) if challenges is not None and len(challenges) else np.zeros((0, 4), dtype=np.uint64)
         tf, ta, ti = self._ptr_table(fixed), self._ptr_table(advice), self._ptr_table(instance)
         inp = CEvalInputs(tf, len(fixed), ta, len(advice), ti, len(instance), ch.ctypes.data if ch.shape[0] else None, ch.shape[0],
-                          *[k.ctypes.data if k is not None else None for k in keep])
+                          *[k.ctypes.data if k is not None else None for k in keep], form_flags)
         self._check(self.lib.dehalo_graph_evaluate_device(self.handle, graph, C.byref(inp), log_rows, rot_scale, d_previous or None, d_out, stream or None))
 
     def permutation_h_device(self, field: int, z, columns, sigma, chunk_len: int, last_rotation: int, l0: int, l_last: int, l_active: int, beta, gamma, y,
-                             delta, beta_zeta, extended_omega, log_rows: int, rot_scale: int, d_values: int, stream: int = 0):
+                             delta, beta_zeta, extended_omega, log_rows: int, rot_scale: int, d_values: int, stream: int = 0, form_flags: int = 0):
         keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y, delta, beta_zeta, extended_omega)]
         tz, tc, ts = self._ptr_table(z), self._ptr_table(columns), self._ptr_table(sigma)
-        inp = CPermInputs(tz, len(z), tc, ts, len(columns), chunk_len, last_rotation, l0, l_last, l_active, *[k.ctypes.data for k in keep])
+        inp = CPermInputs(tz, len(z), tc, ts, len(columns), chunk_len, last_rotation, l0, l_last, l_active, *[k.ctypes.data for k in keep], form_flags)
         self._check(self.lib.dehalo_permutation_h_device(self.handle, field, C.byref(inp), log_rows, rot_scale, d_values, stream or None))
 
     def lookup_h_device(self, field: int, product: int, permuted_input: int, permuted_table: int, table_value: int, l0: int, l_last: int, l_active: int,
-                        beta, gamma, y, log_rows: int, rot_scale: int, d_values: int, stream: int = 0):
+                        beta, gamma, y, log_rows: int, rot_scale: int, d_values: int, stream: int = 0, form_flags: int = 0):
         keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y)]
-        inp = CLookupInputs(product, permuted_input, permuted_table, table_value, l0, l_last, l_active, *[k.ctypes.data for k in keep])
+        inp = CLookupInputs(product, permuted_input, permuted_table, table_value, l0, l_last, l_active, *[k.ctypes.data for k in keep], form_flags)
         self._check(self.lib.dehalo_lookup_h_device(self.handle, field, C.byref(inp), log_rows, rot_scale, d_values, stream or None))
 
     # ---- measurement ----

@@ -98,6 +98,11 @@ int do_grand_product(dehalo_ctx* ctx, int field, const fe* num, const fe* den, u
 #undef CALL
 }
 
+int do_convert_form(dehalo_ctx* ctx, int field, const fe* in, fe* out, uint64_t n, int to_internal, hipStream_t s) {
+#define CALL(N) convert_form_##N(ctx, in, out, n, to_internal, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
 int do_graph_upload(dehalo_ctx* ctx, int field, dehalo_graph* g, const uint64_t* constants, hipStream_t s) {
 #define CALL(N) graph_upload_##N(ctx, g, constants, s)
     FIELD_SWITCH(ctx, field, CALL)
@@ -409,23 +414,49 @@ int dehalo_intt_scaled_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_
     return ntt_device_impl(ctx, field, d_a, N, N, d_a, N, log_n, omega_inv, batch, sc, stream);
 }
 
+static int form_shift_of(uint32_t flags) {   // OUT_INTERNAL: x 2^5; IN_INTERNAL: x 2^-5; both: no change of scale
+    return (flags & DEHALO_FORM_OUT_INTERNAL ? 1 : 0) - (flags & DEHALO_FORM_IN_INTERNAL ? 1 : 0);
+}
+
 int dehalo_coset_ntt_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, uint32_t log_n, uint64_t* d_ext_out, uint32_t log_ext,
                             const uint64_t omega_ext[4], const uint64_t zeta[4], size_t batch, void* stream) {
+    return dehalo_coset_ntt_form_device(ctx, field, d_coeffs, log_n, d_ext_out, log_ext, omega_ext, zeta, batch, 0, stream);
+}
+
+int dehalo_coset_ntt_form_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, uint32_t log_n, uint64_t* d_ext_out, uint32_t log_ext,
+                                 const uint64_t omega_ext[4], const uint64_t zeta[4], size_t batch, uint32_t form_flags, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
     if (!zeta || log_ext < log_n) return dh_fail(ctx, DEHALO_ERR_INVALID, "coset_ntt: bad argument");
     if (d_coeffs == d_ext_out) return dh_fail(ctx, DEHALO_ERR_INVALID, "coset_ntt: coeffs and ext_out may not alias");
     NttScale sc;
+    sc.form_shift = form_shift_of(form_flags);
     sc.pre_mode = 1; sc.pre_z = fe_from_u64(zeta);  // zeta^2 is formed inside the kernel
     uint64_t n = 1ull << (log_n & 63), N = 1ull << (log_ext & 63);
     return ntt_device_impl(ctx, field, d_coeffs, n, n, d_ext_out, N, log_ext, omega_ext, batch, sc, stream);
 }
 
-int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_ext, const uint64_t omega_ext_inv[4],
-                             const uint64_t ext_n_inv[4], const uint64_t zeta[4], size_t batch, void* stream) {
+int dehalo_coset_intt_form_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_ext, const uint64_t omega_ext_inv[4],
+                                  const uint64_t ext_n_inv[4], const uint64_t zeta[4], size_t batch, uint32_t form_flags, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
     if (!zeta || !ext_n_inv) return dh_fail(ctx, DEHALO_ERR_INVALID, "coset_intt: null argument");
     NttScale sc;
     sc.post_mode = 2; sc.post0 = fe_from_u64(ext_n_inv); sc.post_z = fe_from_u64(zeta);
+    sc.form_shift = form_shift_of(form_flags);
     uint64_t N = 1ull << (log_ext & 63);
     return ntt_device_impl(ctx, field, d_a, N, N, d_a, N, log_ext, omega_ext_inv, batch, sc, stream);
+}
+
+int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_ext, const uint64_t omega_ext_inv[4],
+                             const uint64_t ext_n_inv[4], const uint64_t zeta[4], size_t batch, void* stream) {
+    return dehalo_coset_intt_form_device(ctx, field, d_a, log_ext, omega_ext_inv, ext_n_inv, zeta, batch, 0, stream);
+}
+
+int dehalo_convert_form_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, uint64_t* d_out, size_t n, int to_internal, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_in || !d_out) && n) return dh_fail(ctx, DEHALO_ERR_INVALID, "convert_form: null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_convert_form(ctx, field, (const fe*)d_in, (fe*)d_out, n, to_internal, pick_stream(ctx, stream));
 }
 
 // host-buffer forms: upload, transform, download

@@ -34,6 +34,7 @@ struct EvhArgs {
     fe* spill;                    // [hbm slot][row], internal packed
     u64 rows;
     DevSrc result;
+    u32 cols_internal, vals_internal;
 };
 
 // ---- lazily reduced helpers: every stored value is < 2p with normalized limbs ----------------
@@ -65,12 +66,14 @@ FP_DEV f29 evh_fetch(const EvhArgs& A, const EvhLds& L, const DevSrc& s, u64 row
         case EVS_SCALAR: return f29_unpack(f_load(&A.scalars[s.index]));
         case EVS_SLOT_LDS: return L.load(s.index);
         case EVS_SLOT_HBM: return f29_unpack(f_load(&A.spill[(u64)s.index * A.rows + row]));
-        case EVS_PREVIOUS: return A.previous ? f29_from_std<F9>(f_load(&A.previous[row])) : f29_zero();
+        case EVS_PREVIOUS:
+            if (!A.previous) return f29_zero();
+            return A.vals_internal ? f29_unpack(f_load(&A.previous[row])) : f29_from_std<F9>(f_load(&A.previous[row]));
         default: {
             u32 base = s.kind == EVS_FIXED ? A.fixed_base : (s.kind == EVS_ADVICE ? A.advice_base : A.instance_base);
             const fe* col = A.columns[base + s.index];
             u32 r = ((u32)row + (u32)(s.rot * (int32_t)A.rot_scale)) & A.rows_mask;    // rem_euclid for a power of two
-            return f29_from_std<F9>(f_load(&col[r]));
+            return A.cols_internal ? f29_unpack(f_load(&col[r])) : f29_from_std<F9>(f_load(&col[r]));
         }
     }
 }
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(EVH_THREADS) void k_graph_eval(EvhArgs A) {
         else f_store(&A.spill[(u64)c.target_slot * A.rows + row], f29_to_packed_canon<F9>(r));
     }
     f29 res = A.num_calcs ? evh_fetch<F9>(A, L, A.result, row) : f29_zero();
-    f_store(&A.out[row], f29_to_std<F9>(res));
+    f_store(&A.out[row], A.vals_internal ? f29_to_packed_canon<F9>(res) : f29_to_std<F9>(res));
 }
 
 // standard-form scalars -> the internal packed table.  Per-call values (challenges, beta, ...)
@@ -115,6 +118,14 @@ __global__ void k_evh_scalars(const fe* std_in, fe* out, u32 n) {
     typedef typename f29_of<F>::type F9;
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) f_store(&out[i], f29_to_packed_canon<F9>(f29_from_std<F9>(f_load(&std_in[i]))));
+}
+template <class F>
+__global__ void k_convert_form(const fe* in, fe* out, u64 n, int to_internal) {
+    typedef typename f29_of<F>::type F9;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (to_internal) f_store(&out[i], f29_to_packed_canon<F9>(f29_from_std<F9>(f_load(&in[i]))));
+    else f_store(&out[i], f29_to_std<F9>(f29_unpack(f_load(&in[i]))));
 }
 struct FeBatch { fe v[8]; };
 template <class F>
@@ -147,8 +158,9 @@ struct PermArgs {
     u32 nsets, ncols, chunk_len;
     u32 rows_mask, rot_scale;
     int32_t last_rotation;     // -(blinding_factors + 1)
-    fe* values;                // in/out, standard form
+    fe* values;                // in/out
     u64 rows;
+    u32 cols_internal, vals_internal;
 };
 
 template <class F>
@@ -161,8 +173,8 @@ __global__ __launch_bounds__(EVH_THREADS) void k_perm_h(PermArgs A) {
     const f29 one = f29_one<F9>();
     const u32 r_next = ((u32)row + A.rot_scale) & A.rows_mask;
     const u32 r_last = ((u32)row + (u32)(A.last_rotation * (int32_t)A.rot_scale)) & A.rows_mask;
-    auto ld = [&](const fe* p, u64 i) { return f29_from_std<F9>(f_load(&p[i])); };
-    f29 v = ld(A.values, row);
+    auto ld = [&](const fe* p, u64 i) __attribute__((always_inline)) { return A.cols_internal ? f29_unpack(f_load(&p[i])) : f29_from_std<F9>(f_load(&p[i])); };
+    f29 v = A.vals_internal ? f29_unpack(f_load(&A.values[row])) : f29_from_std<F9>(f_load(&A.values[row]));
     const f29 l0 = ld(A.l0, row), l_last = ld(A.l_last, row), l_active = ld(A.l_active, row);
     if (A.nsets) {
         f29 z0 = ld(A.z[0], row);
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(EVH_THREADS) void k_perm_h(PermArgs A) {
             v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(left, right), l_active));
         }
     }
-    f_store(&A.values[row], f29_to_std<F9>(v));
+    f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
 }
 
 // ---- lookup argument terms (Evaluator::evaluate_h, "Lookup constraints") ----------------------
@@ -210,6 +222,7 @@ struct LookupArgs {
     u32 rows_mask, rot_scale;
     fe* values;
     u64 rows;
+    u32 cols_internal, vals_internal;
 };
 
 template <class F>
@@ -221,20 +234,21 @@ __global__ __launch_bounds__(EVH_THREADS) void k_lookup_h(LookupArgs A) {
     const f29 one = f29_one<F9>();
     const u32 r_next = ((u32)row + A.rot_scale) & A.rows_mask;
     const u32 r_prev = ((u32)row - A.rot_scale) & A.rows_mask;
-    auto ld = [&](const fe* p, u64 i) { return f29_from_std<F9>(f_load(&p[i])); };
-    f29 v = ld(A.values, row);
+    auto ld = [&](const fe* p, u64 i) __attribute__((always_inline)) { return A.cols_internal ? f29_unpack(f_load(&p[i])) : f29_from_std<F9>(f_load(&p[i])); };
+    auto ldv = [&](const fe* p, u64 i) __attribute__((always_inline)) { return A.vals_internal ? f29_unpack(f_load(&p[i])) : f29_from_std<F9>(f_load(&p[i])); };
+    f29 v = ldv(A.values, row);
     const f29 l0 = ld(A.l0, row), l_last = ld(A.l_last, row), l_active = ld(A.l_active, row);
     const f29 z = ld(A.z, row), a = ld(A.a_perm, row), s = ld(A.s_perm, row);
     const f29 a_minus_s = evh_sub<F9>(a, s);
     v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(one, z), l0));
     v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(f29_sqr<F9>(z), z), l_last));
     f29 lhs = f29_mul<F9>(f29_mul<F9>(ld(A.z, r_next), evh_add<F9>(a, beta)), evh_add<F9>(s, gamma));
-    f29 rhs = f29_mul<F9>(z, ld(A.table_value, row));
+    f29 rhs = f29_mul<F9>(z, ldv(A.table_value, row));
     v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(lhs, rhs), l_active));
     v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(a_minus_s, l0));
     f29 t = f29_mul<F9>(a_minus_s, evh_sub<F9>(a, ld(A.a_perm, r_prev)));
     v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(t, l_active));
-    f_store(&A.values[row], f29_to_std<F9>(v));
+    f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
 }
 
 // ==========================================================================================
@@ -309,6 +323,7 @@ int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_i
     A.num_calcs = g->num_calcs; A.fixed_base = 0; A.advice_base = in->num_fixed; A.instance_base = in->num_fixed + in->num_advice;
     A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale;
     A.previous = d_previous; A.out = d_out; A.spill = (fe*)ctx->ws_evh[3].p; A.rows = rows; A.result = g->result;
+    A.cols_internal = in->form_flags & DEHALO_EVAL_COLUMNS_INTERNAL; A.vals_internal = in->form_flags & DEHALO_EVAL_VALUES_INTERNAL;
     const size_t lds = (size_t)std::max<u32>(1, g->lds_slots) * EVH_SLOT_BYTES;
     if (lds > 48 * 1024)   // per call: the attribute belongs to the device the context is bound to
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_graph_eval<F>, hipFuncAttributeMaxDynamicSharedMemorySize, EVH_LDS_BYTES));
@@ -340,6 +355,7 @@ int perm_h_t(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, u
     A.nsets = in->num_sets; A.ncols = in->num_columns; A.chunk_len = in->chunk_len;
     A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale; A.last_rotation = in->last_rotation;
     A.values = d_values; A.rows = rows; A.tw = tw;
+    A.cols_internal = in->form_flags & DEHALO_EVAL_COLUMNS_INTERNAL; A.vals_internal = in->form_flags & DEHALO_EVAL_VALUES_INTERNAL;
     k_perm_h<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, 0, s>>>(A);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -358,12 +374,17 @@ int lookup_h_t(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_row
     A.l0 = (const fe*)in->l0; A.l_last = (const fe*)in->l_last; A.l_active = (const fe*)in->l_active_row;
     A.scalars = (const fe*)ctx->ws_evh[0].p;
     A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale; A.values = d_values; A.rows = rows;
+    A.cols_internal = in->form_flags & DEHALO_EVAL_COLUMNS_INTERNAL; A.vals_internal = in->form_flags & DEHALO_EVAL_VALUES_INTERNAL;
     k_lookup_h<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, 0, s>>>(A);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
 #define DEFINE_EVALH_ENTRY(NAME, F)                                                                                                              \
+    int convert_form_##NAME(dehalo_ctx* ctx, const fe* in, fe* out, uint64_t n, int to_internal, hipStream_t s) {                                \
+        if (n) k_convert_form<F><<<(u32)((n + 255) / 256), 256, 0, s>>>(in, out, n, to_internal);                                                  \
+        HIP_TRY(ctx, hipGetLastError());                                                                                                         \
+        return 0; }                                                                                                                              \
     int graph_upload_##NAME(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, hipStream_t s) { return graph_upload_t<F>(ctx, g, constants, s); } \
     int graph_evaluate_##NAME(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,      \
                               const fe* prev, fe* out, hipStream_t s) { return graph_evaluate_t<F>(ctx, g, in, log_rows, rot_scale, prev, out, s); } \

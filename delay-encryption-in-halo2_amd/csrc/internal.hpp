@@ -128,6 +128,7 @@ inline uint32_t log2_ceil(size_t n) {
 struct NttScale {
     uint32_t pre_mode = 0, post_mode = 0;
     fe pre_z{}, post0{}, post_z{};
+    int form_shift = 0;   // +1: emit the internal form (x * 2^261, canonical, packed); -1: the input is in it
 };
 
 // per-curve / per-field entry points (one translation unit each: msm_*.hip, ntt_*.hip)
@@ -170,6 +171,7 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe
 // quotient-numerator kernels (evalh.cuh)
 struct dehalo_graph;
 #define DECL_EVALH(NAME)                                                                                                                    \
+    int convert_form_##NAME(dehalo_ctx* ctx, const fe* in, fe* out, uint64_t n, int to_internal, hipStream_t s);                           \
     int graph_upload_##NAME(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, hipStream_t s);                                   \
     int graph_evaluate_##NAME(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale, \
                               const fe* prev, fe* out, hipStream_t s);                                                                     \

@@ -53,6 +53,7 @@ struct NttPassParams {
     u64 dst_stride;
     u32 pre_mode;        // 1: x [1, z, z^2][i % 3] on the very first load (z = pre_z)
     u32 post_mode;       // 1: x post0 ; 2: x post0 * [1, z^2, z][i % 3] on the last store (z = post_z)
+    int form_shift;      // +1 / -1: fold 2^5 / 2^-5 into the output multiplication (internal <-> standard form, see dehalo.h)
     fe pre_z;
     fe post0, post_z;
 };
@@ -219,8 +220,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
 
     // ---- store: row k holds output digit k; one multiplication brings every element below 2p ----
     f29 post0m = f29_one<F9>(), post1m = f29_zero(), post2m = f29_zero();
-    if (P.is_final && P.post_mode) {
-        post0m = f29_from_std<F9>(P.post0);
+    if (P.is_final && (P.post_mode || P.form_shift)) {
+        if (P.post_mode) post0m = f29_from_std<F9>(P.post0);
+        // the transform is linear, so a change of Montgomery radix is one more factor of the output
+        // multiplication: 2^266 (standard -> internal) or 2^256 (internal -> standard), both * 2^-261
+        if (P.form_shift > 0) post0m = f29_mul<F9>(post0m, f29_const<F9>(F9::TO29));
+        if (P.form_shift < 0) post0m = f29_mul<F9>(post0m, f29_const<F9>(F9::FROM29));
         if (P.post_mode == 2) {
             f29 z = f29_from_std<F9>(P.post_z);
             post2m = f29_mul<F9>(post0m, z);
@@ -382,6 +387,7 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         else { P.dst = scratch; P.dst_stride = N; }
         if (first && sc.pre_mode) { P.pre_mode = sc.pre_mode; P.pre_z = sc.pre_z; }
         if (last && sc.post_mode) { P.post_mode = sc.post_mode; P.post0 = sc.post0; P.post_z = sc.post_z; }
+        if (last) P.form_shift = sc.form_shift;
         uint32_t log_c;
         if (!last) {
             uint32_t log_cols = log_m - rad[p];

@@ -18,6 +18,10 @@ ADD, SUB, MUL, SQUARE, DOUBLE, NEGATE, HORNER, STORE = range(8)
 
 Source = Tuple[int, int, int]          # (kind, index, rotation index)
 
+# dehalo.h: optional device-internal element form
+FORM_OUT_INTERNAL, FORM_IN_INTERNAL = 1, 2
+COLUMNS_INTERNAL, VALUES_INTERNAL = 1, 2
+
 
 @dataclass
 class GraphEvaluator:
@@ -70,13 +74,13 @@ class CompiledGraph:
 
     def evaluate_device(self, fixed: Sequence[int], advice: Sequence[int], instance: Sequence[int], challenges: Sequence[int], beta: Optional[int],
                         gamma: Optional[int], theta: Optional[int], y: Optional[int], log_rows: int, rot_scale: int, d_previous: int, d_out: int,
-                        stream: int = 0):
+                        stream: int = 0, form_flags: int = 0):
         """Column arguments are device pointers (extended-domain cosets, 1 << log_rows elements)."""
         e = self.field.encode
         enc = lambda v: None if v is None else e(v)
         ch = self.field.encode_many(list(challenges)) if challenges else None
         self.ctx.graph_evaluate_device(self.handle, list(fixed), list(advice), list(instance), ch, enc(beta), enc(gamma), enc(theta), enc(y), log_rows, rot_scale,
-                                       d_previous, d_out, stream)
+                                       d_previous, d_out, stream, form_flags)
 
     def release(self):
         if self.handle is not None:
@@ -86,18 +90,18 @@ class CompiledGraph:
 
 def permutation_h_device(ctx: Context, field: FieldSpec, z: Sequence[int], columns: Sequence[int], sigma: Sequence[int], chunk_len: int, last_rotation: int,
                          l0: int, l_last: int, l_active_row: int, beta: int, gamma: int, y: int, delta: int, zeta: int, extended_omega: int, log_rows: int,
-                         rot_scale: int, d_values: int, stream: int = 0):
+                         rot_scale: int, d_values: int, stream: int = 0, form_flags: int = 0):
     """Evaluator::evaluate_h's permutation terms folded into d_values in place (device pointers)."""
     if len(columns) != len(sigma):
         raise ValueError("permutation: columns.len() != cosets.len()")
     e = field.encode
     ctx.permutation_h_device(field.id, list(z), list(columns), list(sigma), chunk_len, last_rotation, l0, l_last, l_active_row, e(beta), e(gamma), e(y), e(delta),
-                             e(beta * zeta % field.p), e(extended_omega), log_rows, rot_scale, d_values, stream)
+                             e(beta * zeta % field.p), e(extended_omega), log_rows, rot_scale, d_values, stream, form_flags)
 
 
 def lookup_h_device(ctx: Context, field: FieldSpec, product: int, permuted_input: int, permuted_table: int, table_value: int, l0: int, l_last: int,
-                    l_active_row: int, beta: int, gamma: int, y: int, log_rows: int, rot_scale: int, d_values: int, stream: int = 0):
+                    l_active_row: int, beta: int, gamma: int, y: int, log_rows: int, rot_scale: int, d_values: int, stream: int = 0, form_flags: int = 0):
     """Evaluator::evaluate_h's five terms of one lookup argument folded into d_values in place."""
     e = field.encode
     ctx.lookup_h_device(field.id, product, permuted_input, permuted_table, table_value, l0, l_last, l_active_row, e(beta), e(gamma), e(y), log_rows, rot_scale,
-                        d_values, stream)
+                        d_values, stream, form_flags)

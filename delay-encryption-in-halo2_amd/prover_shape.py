@@ -103,6 +103,9 @@ class ProverShape:
         if with_quotient:
             # proving-key columns in the extended domain (resident for the life of the key) and the challenges
             self.pk = {name: to_dev(columns["pk_" + name]) for name in ("fixed", "sigma", "l")}          # (15 | 6 | 3, 4n, 4)
+            for t in self.pk.values():   # key columns go to the kernels' internal form once (dehalo.h): no conversion per load later
+                ctx.convert_form_device(curve.scalar.id, t.data_ptr(), t.data_ptr(), t.shape[0] * t.shape[1], True, 0)
+            self.forms = ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL
             self.instance = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")               # the circuit has no public inputs
             self.h = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")
             self.table_value = torch.zeros((self.ext_n, 4), dtype=torch.int64, device="cuda")
@@ -126,14 +129,16 @@ class ProverShape:
         fixed = [col(self.pk["fixed"], i) for i in range(N_FIXED)]
         advice = [col(self.ext, i) for i in range(5)]
         l0, l_last, l_active = (col(self.pk["l"], i) for i in range(3))
-        self.gate_graph.evaluate_device(fixed, advice, [self.instance.data_ptr()], [], None, None, None, ch["y"], log_rows, rot_scale, 0, self.h.data_ptr())
+        ff = self.forms
+        self.gate_graph.evaluate_device(fixed, advice, [self.instance.data_ptr()], [], None, None, None, ch["y"], log_rows, rot_scale, 0, self.h.data_ptr(), 0, ff)
         ev.permutation_h_device(self.ctx, f, [col(self.ext, 15), col(self.ext, 16)], advice + [fixed[14]], [col(self.pk["sigma"], i) for i in range(N_SIGMA)],
                                 PERM_CHUNK, LAST_ROTATION, l0, l_last, l_active, ch["beta"], ch["gamma"], ch["y"], ch["delta"], self.domain.g_coset,
-                                self.domain.extended_omega, log_rows, rot_scale, self.h.data_ptr())
+                                self.domain.extended_omega, log_rows, rot_scale, self.h.data_ptr(), 0, ff)
         for i in range(N_LOOKUPS):
-            self.lookup_graphs[i].evaluate_device(fixed, advice, [], [], ch["beta"], ch["gamma"], ch["theta"], None, log_rows, rot_scale, 0, self.table_value.data_ptr())
+            self.lookup_graphs[i].evaluate_device(fixed, advice, [], [], ch["beta"], ch["gamma"], ch["theta"], None, log_rows, rot_scale, 0, self.table_value.data_ptr(),
+                                                  0, ff)
             ev.lookup_h_device(self.ctx, f, col(self.ext, 17 + i), col(self.ext, 5 + 2 * i), col(self.ext, 6 + 2 * i), self.table_value.data_ptr(), l0, l_last,
-                               l_active, ch["beta"], ch["gamma"], ch["y"], log_rows, rot_scale, self.h.data_ptr())
+                               l_active, ch["beta"], ch["gamma"], ch["y"], log_rows, rot_scale, self.h.data_ptr(), 0, ff)
 
     def arguments(self):
         """The data-parallel part of lookup::commit_permuted (5 x permute_expression_pair) and of the seven
@@ -170,14 +175,16 @@ class ProverShape:
         self._commit("random", False); sync()
         t1 = time.perf_counter(); t_msm += t1 - t0 - t_arg
         ctx.intt_scaled_device(f.id, self.polys.data_ptr(), self.k, c["omega_inv"], c["ifft"], N_INTT, 0)
-        ctx.coset_ntt_device(f.id, self.polys.data_ptr(), self.k, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega"], c["zeta"], N_COSET, 0)
         t_h = 0.0
-        if self.with_quotient:
+        if self.with_quotient:   # the cosets stay in the kernels' internal form from the NTT to evaluate_h and back
+            ctx.coset_ntt_form_device(f.id, self.polys.data_ptr(), self.k, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega"], c["zeta"], N_COSET,
+                                      ev.FORM_OUT_INTERNAL, 0)
             sync(); th0 = time.perf_counter()
             self.evaluate_h()
             sync(); t_h = time.perf_counter() - th0
-            ctx.coset_intt_device(f.id, self.h.data_ptr(), self.domain.extended_k, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], N_EXT_INTT, 0)
+            ctx.coset_intt_form_device(f.id, self.h.data_ptr(), self.domain.extended_k, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], N_EXT_INTT, ev.FORM_IN_INTERNAL, 0)
         else:
+            ctx.coset_ntt_device(f.id, self.polys.data_ptr(), self.k, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega"], c["zeta"], N_COSET, 0)
             ctx.coset_intt_device(f.id, self.ext.data_ptr(), self.domain.extended_k, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], N_EXT_INTT, 0)
         sync()
         t2 = time.perf_counter(); t_ntt += t2 - t1 - t_h

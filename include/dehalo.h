@@ -205,6 +205,23 @@ int dehalo_grand_product_batch_device(dehalo_ctx* ctx, int field, const uint64_t
  *   lookup:      l0 (1 - z); l_last (z^2 - z); l_active (z(wX)(a' + beta)(s' + gamma) - z(X) table_value);
  *                l0 (a' - s'); l_active (a' - s')(a' - a'(w^-1 X)),
  *                table_value = the lookup's GraphEvaluator output for the row.                    */
+/* Optional device-internal element form.  Every `_device` entry point above takes and returns
+ * upstream's standard form; converting it costs the evaluate_h kernels one multiplication per
+ * column load.  Columns that only travel between this library's kernels can stay in the kernels'
+ * own form instead (x * 2^261 mod p, canonical, 32 B -- opaque to the caller):
+ *   dehalo_convert_form_device             standard <-> internal, element-wise (proving-key columns, once);
+ *   dehalo_coset_ntt_form_device           coeff_to_extended emitting the internal form (DEHALO_FORM_OUT_INTERNAL);
+ *   dehalo_coset_intt_form_device          extended_to_coeff consuming it (DEHALO_FORM_IN_INTERNAL);
+ *   form_flags of the three *_inputs structs below: DEHALO_EVAL_COLUMNS_INTERNAL (every column pointer of the
+ *   struct), DEHALO_EVAL_VALUES_INTERNAL (d_previous / d_out / d_values / table_value).              */
+enum { DEHALO_FORM_OUT_INTERNAL = 1, DEHALO_FORM_IN_INTERNAL = 2 };
+enum { DEHALO_EVAL_COLUMNS_INTERNAL = 1, DEHALO_EVAL_VALUES_INTERNAL = 2 };
+int dehalo_convert_form_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, uint64_t* d_out, size_t n, int to_internal, void* stream);
+int dehalo_coset_ntt_form_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, uint32_t log_n, uint64_t* d_ext_out, uint32_t log_ext,
+                                 const uint64_t omega_ext[4], const uint64_t zeta[4], size_t batch, uint32_t form_flags, void* stream);
+int dehalo_coset_intt_form_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_ext, const uint64_t omega_ext_inv[4],
+                                  const uint64_t ext_n_inv[4], const uint64_t zeta[4], size_t batch, uint32_t form_flags, void* stream);
+
 typedef enum {
     DEHALO_SRC_CONSTANT = 0, DEHALO_SRC_INTERMEDIATE = 1, DEHALO_SRC_FIXED = 2, DEHALO_SRC_ADVICE = 3, DEHALO_SRC_INSTANCE = 4,
     DEHALO_SRC_CHALLENGE = 5, DEHALO_SRC_BETA = 6, DEHALO_SRC_GAMMA = 7, DEHALO_SRC_THETA = 8, DEHALO_SRC_Y = 9, DEHALO_SRC_PREVIOUS = 10
@@ -231,6 +248,7 @@ typedef struct {
     const uint64_t* const* instance; uint32_t num_instance;
     const uint64_t* challenges; uint32_t num_challenges;     /* host, 4 u64 each */
     const uint64_t *beta, *gamma, *theta, *y;                /* host, 4 u64 each; NULL = 0 */
+    uint32_t form_flags;                                     /* 0, or DEHALO_EVAL_* */
 } dehalo_eval_inputs;
 int dehalo_graph_evaluate_device(dehalo_ctx* ctx, const dehalo_graph* graph, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,
                                  const uint64_t* d_previous, uint64_t* d_out, void* stream);
@@ -241,6 +259,7 @@ typedef struct {
     int32_t last_rotation;                                   /* -(blinding_factors + 1) */
     const uint64_t *l0, *l_last, *l_active_row;              /* device */
     const uint64_t *beta, *gamma, *y, *delta, *beta_zeta, *extended_omega;   /* host, 4 u64 each */
+    uint32_t form_flags;                                     /* 0, or DEHALO_EVAL_* */
 } dehalo_perm_inputs;
 int dehalo_permutation_h_device(dehalo_ctx* ctx, int field, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
                                 void* stream);
@@ -248,6 +267,7 @@ typedef struct {
     const uint64_t *product_coset, *permuted_input_coset, *permuted_table_coset, *table_value;   /* device */
     const uint64_t *l0, *l_last, *l_active_row;              /* device */
     const uint64_t *beta, *gamma, *y;                        /* host */
+    uint32_t form_flags;                                     /* 0, or DEHALO_EVAL_*; table_value counts as a value */
 } dehalo_lookup_inputs;
 int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
                            void* stream);

@@ -643,7 +643,15 @@ def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k):
     res = shape.run()
     assert res.ms_eval_h > 0
     d, e = shape.domain, f.encode
-    ext = shape.ext.cpu().numpy().view(np.uint64)                       # cosets as the device produced them (checked elsewhere)
+    # the schedule keeps the cosets in the kernels' internal form: bring a copy back to the standard form, and check it
+    # against the oracle's coeff_to_extended while at it
+    std = shape.ext.clone()
+    ctx.convert_form_device(f.id, std.data_ptr(), std.data_ptr(), std.shape[0] * std.shape[1], False, 0)
+    ctx.synchronize()
+    ext = std.cpu().numpy().view(np.uint64)
+    coeffs_dev = shape.polys.cpu().numpy().view(np.uint64)
+    for i in (0, 7, 22):
+        assert np.array_equal(ext[i], co.coeff_to_extended(f.id, coeffs_dev[i], k, d.extended_k, e(d.extended_omega), e(d.g_coset), 2)), i
     pk = {name: cols["pk_" + name] for name in ("fixed", "sigma", "l")}
     ch = cols["challenges"]
     ext_k, rot_scale = d.extended_k, (1 << d.extended_k) // n
@@ -789,3 +797,82 @@ def test_permute_expression_pair_batch(pkg, co, ctx):
     with pytest.raises(pkg.DehaloError) as e:
         ctx.permute_expression_pair_batch_device(fid, di.data_ptr(), dt.data_ptr(), n, B, stride, oi.data_ptr(), ot.data_ptr(), 0)
     assert e.value.code == -6 and "lookup 3" in str(e.value)
+
+
+def test_internal_form_round_trip_and_flags(pkg, po, co, ctx):
+    """The optional device-internal element form: convert there and back, coset NTT emitting / consuming it, and the three
+    evaluate_h entry points with every column and value in it -- all equal to the standard-form results."""
+    import torch
+    ev = pkg.evaluation
+    f, spec = po.BN254_FR, pkg.fields.BN254_FR
+    fid = spec.id
+    rng = po.Xoshiro(0x1F0)
+    k, ext_k = 6, 8
+    rows, rot_scale = 1 << ext_k, 1 << (ext_k - k)
+    x = co.fill_scalars(fid, "uniform", 5000, 3)
+    dx = torch.from_numpy(x.view(np.int64).copy()).cuda()
+    di = torch.zeros_like(dx)
+    ctx.convert_form_device(fid, dx.data_ptr(), di.data_ptr(), 5000, True)
+    back = torch.zeros_like(dx)
+    ctx.convert_form_device(fid, di.data_ptr(), back.data_ptr(), 5000, False)
+    ctx.synchronize()
+    assert np.array_equal(back.cpu().numpy().view(np.uint64), x)
+    # internal = value * 2^261 mod p (canonical): check one element against Python integers
+    got = po.from_limbs64(di[7].cpu().numpy().view(np.uint64))
+    assert got == spec.decode(x[7]) * pow(2, 261, f.p) % f.p
+    to_int = lambda t: (ctx.convert_form_device(fid, t.data_ptr(), t.data_ptr(), t.numel() // 4, True), t)[1]
+    to_std = lambda t: (ctx.convert_form_device(fid, t.data_ptr(), t.data_ptr(), t.numel() // 4, False), ctx.synchronize(), t)[2]   # the context's stream is not torch's
+
+    # coset NTT out-internal, then coset iNTT in-internal == identity on the coefficients
+    dom = pkg.EvaluationDomain(ctx, spec, 5, k)
+    e = spec.encode
+    coeffs = co.fill_scalars(fid, "uniform", 1 << k, 9)
+    dc = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
+    dext = torch.zeros((1 << dom.extended_k, 4), dtype=torch.int64, device="cuda")
+    ctx.coset_ntt_form_device(fid, dc.data_ptr(), k, dext.data_ptr(), dom.extended_k, e(dom.extended_omega), e(dom.g_coset), 1, ev.FORM_OUT_INTERNAL)
+    want_ext = co.coeff_to_extended(fid, coeffs, k, dom.extended_k, e(dom.extended_omega), e(dom.g_coset), 2)
+    chk = dext.clone(); to_std(chk); ctx.synchronize()
+    assert np.array_equal(chk.cpu().numpy().view(np.uint64), want_ext)
+    ctx.coset_intt_form_device(fid, dext.data_ptr(), dom.extended_k, e(dom.extended_omega_inv), e(dom.extended_ifft_divisor), e(dom.g_coset), 1, ev.FORM_IN_INTERNAL)
+    ctx.synchronize()
+    got = dext.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got[: 1 << k], coeffs) and not got[1 << k:].any()
+
+    # evaluate_h entry points with internal columns and values
+    col = lambda: [rng.below(f.p) for _ in range(rows)]
+    env = {"fixed": [col() for _ in range(3)], "advice": [col() for _ in range(4)], "instance": [col()], "challenges": [rng.below(f.p) for _ in range(2)],
+           "beta": rng.below(f.p), "gamma": rng.below(f.p), "theta": rng.below(f.p), "y": rng.below(f.p)}
+    g = _random_graph(po, f, rng, 40, 3, 4, 1, 2, 20)
+    previous = col()
+    want = po.graph_evaluate(f, g, env, rows, rot_scale, previous)
+    ge = ev.GraphEvaluator(constants=list(g["constants"]), rotations=list(g["rotations"]), calculations=list(g["calcs"]), num_intermediates=g["num_intermediates"])
+    cg = ge.compile(ctx, spec)
+    cols = {kk: [to_int(_dev(spec, c)) for c in env[kk]] for kk in ("fixed", "advice", "instance")}
+    prev = to_int(_dev(spec, previous))
+    cg.evaluate_device([t.data_ptr() for t in cols["fixed"]], [t.data_ptr() for t in cols["advice"]], [t.data_ptr() for t in cols["instance"]], env["challenges"],
+                       env["beta"], env["gamma"], env["theta"], env["y"], ext_k, rot_scale, prev.data_ptr(), prev.data_ptr(), 0, ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL)
+    assert _host(spec, to_std(prev)) == want
+    cg.release()
+    z, pc, sg = [col() for _ in range(2)], [col() for _ in range(5)], [col() for _ in range(5)]
+    l0, l_last, l_active, values = col(), col(), col(), col()
+    beta, gamma, y, delta = (rng.below(f.p) for _ in range(4))
+    zeta, w = po.zeta(f), f.omega(ext_k)
+    want = po.permutation_h(f, values, z, pc, sg, 3, -6, l0, l_last, l_active, beta, gamma, y, delta, zeta, w, rot_scale)
+    D = lambda c: to_int(_dev(spec, c))
+    dz, dcols, dsg, dl, dv = [D(c) for c in z], [D(c) for c in pc], [D(c) for c in sg], [D(l0), D(l_last), D(l_active)], D(values)
+    ev.permutation_h_device(ctx, spec, [t.data_ptr() for t in dz], [t.data_ptr() for t in dcols], [t.data_ptr() for t in dsg], 3, -6, dl[0].data_ptr(), dl[1].data_ptr(),
+                            dl[2].data_ptr(), beta, gamma, y, delta, zeta, w, ext_k, rot_scale, dv.data_ptr(), 0, ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL)
+    assert _host(spec, to_std(dv)) == want
+    prod, a, s_, tv = col(), col(), col(), col()
+    want = po.lookup_h(f, values, prod, a, s_, tv, l0, l_last, l_active, beta, gamma, y, rot_scale)
+    dv = D(values)
+    dp, da, ds, dtv = D(prod), D(a), D(s_), D(tv)
+    ev.lookup_h_device(ctx, spec, dp.data_ptr(), da.data_ptr(), ds.data_ptr(), dtv.data_ptr(), dl[0].data_ptr(), dl[1].data_ptr(), dl[2].data_ptr(), beta, gamma, y, ext_k,
+                       rot_scale, dv.data_ptr(), 0, ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL)
+    assert _host(spec, to_std(dv)) == want
+    # mixed: standard columns, internal values
+    dv = D(values)
+    ev.lookup_h_device(ctx, spec, (tp := _dev(spec, prod)).data_ptr(), (ta := _dev(spec, a)).data_ptr(), (ts := _dev(spec, s_)).data_ptr(), dtv.data_ptr(),
+                       (t0 := _dev(spec, l0)).data_ptr(), (t1 := _dev(spec, l_last)).data_ptr(), (t2 := _dev(spec, l_active)).data_ptr(), beta, gamma, y, ext_k, rot_scale,
+                       dv.data_ptr(), 0, ev.VALUES_INTERNAL)
+    assert _host(spec, to_std(dv)) == want
