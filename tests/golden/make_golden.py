@@ -105,9 +105,55 @@ def poly_vectors():
         out.append({"op": "grand_product", "field": fname, "num": [hx(v) for v in num], "den": [hx(v) for v in den], "result": [hx(v) for v in po.grand_product(f, num, den)]})
     return out
 
+def evalh_vectors():
+    """Quotient-numerator kernels and the lookup permutation on tiny domains, canonical hex.
+    The programs come from the same seeded generator the tests use (tests/conftest.py random_graph)."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from conftest import random_graph
+    out = []
+    for fname in ("bn254_fr", "pasta_fp"):
+        f = po.FIELDS[fname]
+        rng = po.Xoshiro(0xE5A1 + po.FIELD_IDS[fname])
+        k, ext_k = 3, 5
+        rows, rot_scale = 1 << ext_k, 1 << (ext_k - k)
+        col = lambda: [rng.below(f.p) for _ in range(rows)]
+        env = {"fixed": [col() for _ in range(2)], "advice": [col() for _ in range(3)], "instance": [col()], "challenges": [rng.below(f.p)],
+               "beta": rng.below(f.p), "gamma": rng.below(f.p), "theta": rng.below(f.p), "y": rng.below(f.p)}
+        for n_calcs, long_lived in ((8, 0), (30, 16)):
+            g = random_graph(po, f, rng, n_calcs, 2, 3, 1, 1, long_lived)
+            prev = col()
+            res = po.graph_evaluate(f, g, env, rows, rot_scale, prev)
+            hxl = lambda v: [hx(x) for x in v]
+            out.append({"op": "graph", "field": fname, "ext_k": ext_k, "rot_scale": rot_scale,
+                        "graph": {"constants": hxl(g["constants"]), "rotations": g["rotations"], "num_intermediates": g["num_intermediates"],
+                                  "calcs": [[op, list(a), list(b), [list(q) for q in parts], t] for op, a, b, parts, t in g["calcs"]]},
+                        "env": {"fixed": [hxl(c) for c in env["fixed"]], "advice": [hxl(c) for c in env["advice"]], "instance": [hxl(c) for c in env["instance"]],
+                                "challenges": hxl(env["challenges"]), "beta": hx(env["beta"]), "gamma": hx(env["gamma"]), "theta": hx(env["theta"]), "y": hx(env["y"])},
+                        "previous": hxl(prev), "result": hxl(res)})
+        z, cols, sigma = [col() for _ in range(2)], [col() for _ in range(4)], [col() for _ in range(4)]
+        l0, l_last, l_active, values = col(), col(), col(), col()
+        beta, gamma, y, delta = (rng.below(f.p) for _ in range(4))
+        zeta, w = po.zeta(f), f.omega(ext_k)
+        res = po.permutation_h(f, values, z, cols, sigma, 3, -2, l0, l_last, l_active, beta, gamma, y, delta, zeta, w, rot_scale)
+        hxl = lambda v: [hx(x) for x in v]
+        out.append({"op": "permutation", "field": fname, "ext_k": ext_k, "rot_scale": rot_scale, "chunk_len": 3, "last_rotation": -2,
+                    "z": [hxl(c) for c in z], "columns": [hxl(c) for c in cols], "sigma": [hxl(c) for c in sigma], "l0": hxl(l0), "l_last": hxl(l_last),
+                    "l_active": hxl(l_active), "values": hxl(values), "beta": hx(beta), "gamma": hx(gamma), "y": hx(y), "delta": hx(delta), "zeta": hx(zeta),
+                    "extended_omega": hx(w), "result": hxl(res)})
+        prod, a, s, tv = col(), col(), col(), col()
+        res = po.lookup_h(f, values, prod, a, s, tv, l0, l_last, l_active, beta, gamma, y, rot_scale)
+        out.append({"op": "lookup", "field": fname, "ext_k": ext_k, "rot_scale": rot_scale, "product": hxl(prod), "permuted_input": hxl(a), "permuted_table": hxl(s),
+                    "table_value": hxl(tv), "l0": hxl(l0), "l_last": hxl(l_last), "l_active": hxl(l_active), "values": hxl(values), "beta": hx(beta), "gamma": hx(gamma),
+                    "y": hx(y), "result": hxl(res)})
+        table = [3, 1, 4, 1, 5, 9, 2, 6] + [3] * 8
+        inputs = [1, 1, 9, 3, 3, 3, 2, 6, 5, 5, 4, 1, 9, 9, 2, 3]
+        pi, pt = po.permute_expression_pair(f, inputs, table, 14)
+        out.append({"op": "permute", "field": fname, "usable": 14, "input": hxl(inputs), "table": hxl(table), "permuted_input": hxl(pi), "permuted_table": hxl(pt)})
+    return out
+
 if __name__ == "__main__":
     po.self_check()
-    for name, fn in (("ntt", ntt_vectors), ("domain", domain_vectors), ("msm", msm_vectors), ("bases", bases_vectors), ("poly", poly_vectors)):
+    for name, fn in (("ntt", ntt_vectors), ("domain", domain_vectors), ("msm", msm_vectors), ("bases", bases_vectors), ("poly", poly_vectors), ("evalh", evalh_vectors)):
         with open(os.path.join(HERE, name + ".json"), "w") as fh:
             json.dump(fn(), fh, separators=(",", ":"))
         print("wrote", name)

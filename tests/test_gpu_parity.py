@@ -876,3 +876,48 @@ def test_internal_form_round_trip_and_flags(pkg, po, co, ctx):
                        (t0 := _dev(spec, l0)).data_ptr(), (t1 := _dev(spec, l_last)).data_ptr(), (t2 := _dev(spec, l_active)).data_ptr(), beta, gamma, y, ext_k, rot_scale,
                        dv.data_ptr(), 0, ev.VALUES_INTERNAL)
     assert _host(spec, to_std(dv)) == want
+
+
+def test_evalh_golden(pkg, po, ctx):
+    """The committed vectors of tests/golden/evalh.json through the device kernels."""
+    import torch
+    ev = pkg.evaluation
+    ints = lambda l: [int(x, 16) for x in l]
+    for v in golden("evalh"):
+        spec = pkg.fields.FIELDS[v["field"]]
+        D = lambda c: _dev(spec, ints(c))
+        if v["op"] == "graph":
+            g = v["graph"]
+            ge = ev.GraphEvaluator(constants=ints(g["constants"]), rotations=list(g["rotations"]), num_intermediates=g["num_intermediates"],
+                                   calculations=[(op, tuple(a), tuple(b), tuple(tuple(q) for q in parts), t) for op, a, b, parts, t in g["calcs"]])
+            cg = ge.compile(ctx, spec)
+            cols = {k: [D(c) for c in v["env"][k]] for k in ("fixed", "advice", "instance")}
+            prev = D(v["previous"])
+            cg.evaluate_device([t.data_ptr() for t in cols["fixed"]], [t.data_ptr() for t in cols["advice"]], [t.data_ptr() for t in cols["instance"]],
+                               ints(v["env"]["challenges"]), *[int(v["env"][k], 16) for k in ("beta", "gamma", "theta", "y")], v["ext_k"], v["rot_scale"],
+                               prev.data_ptr(), prev.data_ptr())
+            ctx.synchronize()
+            assert _host(spec, prev) == ints(v["result"])
+            cg.release()
+        elif v["op"] == "permutation":
+            z, cols, sigma = ([D(c) for c in v[k]] for k in ("z", "columns", "sigma"))
+            l0, l_last, l_active, values = (D(v[k]) for k in ("l0", "l_last", "l_active", "values"))
+            sc = {k: int(v[k], 16) for k in ("beta", "gamma", "y", "delta", "zeta", "extended_omega")}
+            ev.permutation_h_device(ctx, spec, [t.data_ptr() for t in z], [t.data_ptr() for t in cols], [t.data_ptr() for t in sigma], v["chunk_len"], v["last_rotation"],
+                                    l0.data_ptr(), l_last.data_ptr(), l_active.data_ptr(), sc["beta"], sc["gamma"], sc["y"], sc["delta"], sc["zeta"], sc["extended_omega"],
+                                    v["ext_k"], v["rot_scale"], values.data_ptr())
+            ctx.synchronize()
+            assert _host(spec, values) == ints(v["result"])
+        elif v["op"] == "lookup":
+            t = {k: D(v[k]) for k in ("product", "permuted_input", "permuted_table", "table_value", "l0", "l_last", "l_active", "values")}
+            ev.lookup_h_device(ctx, spec, t["product"].data_ptr(), t["permuted_input"].data_ptr(), t["permuted_table"].data_ptr(), t["table_value"].data_ptr(),
+                               t["l0"].data_ptr(), t["l_last"].data_ptr(), t["l_active"].data_ptr(), int(v["beta"], 16), int(v["gamma"], 16), int(v["y"], 16), v["ext_k"],
+                               v["rot_scale"], t["values"].data_ptr())
+            ctx.synchronize()
+            assert _host(spec, t["values"]) == ints(v["result"])
+        else:
+            pi, pt = pkg.lookup.permute_expression_pair(ctx, spec, spec.encode_many(ints(v["input"])), spec.encode_many(ints(v["table"])), v["usable"])
+            assert spec.decode_many(pi) == ints(v["permuted_input"]) and spec.decode_many(pt) == ints(v["permuted_table"])
+    with pytest.raises(pkg.lookup.ConstraintSystemFailure):
+        spec = pkg.fields.BN254_FR
+        pkg.lookup.permute_expression_pair(ctx, spec, spec.encode_many([1, 2, 77]), spec.encode_many([1, 2, 3]), 3)

@@ -275,3 +275,54 @@ def test_permute_expression_pair_oracles_agree(po, co):
     assert (want is None) == (got is None)
     if want is not None:
         assert _dec(po, f, got[0]) == want[0] and _dec(po, f, got[1]) == want[1]
+
+
+def _golden_graph(v):
+    g = v["graph"]
+    return {"constants": [int(c, 16) for c in g["constants"]], "rotations": g["rotations"], "num_intermediates": g["num_intermediates"],
+            "calcs": [(op, tuple(a), tuple(b), tuple(tuple(q) for q in parts), t) for op, a, b, parts, t in g["calcs"]]}
+
+
+def test_evalh_golden_vs_both_oracles(po, co, golden_loader):
+    ints = lambda l: [int(x, 16) for x in l]
+    for v in golden_loader("evalh"):
+        f = po.FIELDS[v["field"]]
+        fid = po.FIELD_IDS[v["field"]]
+        enc = lambda vals: _enc(po, f, vals)
+        e1 = lambda x: enc([x])[0]
+        if v["op"] == "graph":
+            g = _golden_graph(v)
+            env = {k: [ints(c) for c in v["env"][k]] for k in ("fixed", "advice", "instance")}
+            env.update(challenges=ints(v["env"]["challenges"]), **{k: int(v["env"][k], 16) for k in ("beta", "gamma", "theta", "y")})
+            want, prev = ints(v["result"]), ints(v["previous"])
+            assert po.graph_evaluate(f, g, env, 1 << v["ext_k"], v["rot_scale"], prev) == want
+            got = co.graph_evaluate(fid, enc(g["constants"]), g["rotations"], g["calcs"], g["num_intermediates"], [enc(c) for c in env["fixed"]],
+                                    [enc(c) for c in env["advice"]], [enc(c) for c in env["instance"]], enc(env["challenges"]), e1(env["beta"]), e1(env["gamma"]),
+                                    e1(env["theta"]), e1(env["y"]), v["ext_k"], v["rot_scale"], enc(prev), 3)
+            assert _dec(po, f, got) == want
+        elif v["op"] == "permutation":
+            a = {k: ints(v[k]) for k in ("l0", "l_last", "l_active", "values")}
+            z, cols, sigma = ([ints(c) for c in v[k]] for k in ("z", "columns", "sigma"))
+            sc = {k: int(v[k], 16) for k in ("beta", "gamma", "y", "delta", "zeta", "extended_omega")}
+            want = ints(v["result"])
+            assert po.permutation_h(f, a["values"], z, cols, sigma, v["chunk_len"], v["last_rotation"], a["l0"], a["l_last"], a["l_active"], sc["beta"], sc["gamma"],
+                                    sc["y"], sc["delta"], sc["zeta"], sc["extended_omega"], v["rot_scale"]) == want
+            got = co.permutation_h(fid, enc(a["values"]), [enc(c) for c in z], [enc(c) for c in cols], [enc(c) for c in sigma], v["chunk_len"], v["last_rotation"],
+                                   enc(a["l0"]), enc(a["l_last"]), enc(a["l_active"]), e1(sc["beta"]), e1(sc["gamma"]), e1(sc["y"]), e1(sc["delta"]),
+                                   e1(sc["beta"] * sc["zeta"] % f.p), e1(sc["extended_omega"]), v["ext_k"], v["rot_scale"], 2)
+            assert _dec(po, f, got) == want
+        elif v["op"] == "lookup":
+            a = {k: ints(v[k]) for k in ("product", "permuted_input", "permuted_table", "table_value", "l0", "l_last", "l_active", "values")}
+            sc = {k: int(v[k], 16) for k in ("beta", "gamma", "y")}
+            want = ints(v["result"])
+            assert po.lookup_h(f, a["values"], a["product"], a["permuted_input"], a["permuted_table"], a["table_value"], a["l0"], a["l_last"], a["l_active"],
+                               sc["beta"], sc["gamma"], sc["y"], v["rot_scale"]) == want
+            got = co.lookup_h(fid, enc(a["values"]), enc(a["product"]), enc(a["permuted_input"]), enc(a["permuted_table"]), enc(a["table_value"]), enc(a["l0"]),
+                              enc(a["l_last"]), enc(a["l_active"]), e1(sc["beta"]), e1(sc["gamma"]), e1(sc["y"]), v["ext_k"], v["rot_scale"], 2)
+            assert _dec(po, f, got) == want
+        else:
+            inp, tab = ints(v["input"]), ints(v["table"])
+            want = (ints(v["permuted_input"]), ints(v["permuted_table"]))
+            assert po.permute_expression_pair(f, inp, tab, v["usable"]) == want
+            got = co.permute_expression_pair(fid, enc(inp), enc(tab), v["usable"])
+            assert (_dec(po, f, got[0]), _dec(po, f, got[1])) == want
