@@ -431,6 +431,8 @@ def emit():
                 "  static constexpr uint32_t P2[9] = {%s};  // 2p" % w(limbs(2 * F.p)),
                 "  static constexpr uint32_t P4[9] = {%s};  // 4p" % w(limbs(4 * F.p)),
                 "  static constexpr uint32_t P8[9] = {%s};  // 8p" % w(limbs(8 * F.p)),
+                "  static constexpr uint32_t R3[9] = {%s};  // 2^783 mod p: mont(v, R3) = v * 2^522 (integer inverse -> internal form)" % w(limbs(pow(2, 783, F.p))),
+                "  static constexpr uint32_t PINV30 = 0x%08xu;       // p^-1 mod 2^30 (safegcd inversion, 30-bit signed limbs)" % pow(F.p, -1, 1 << 30),
                 "};", ""]
     out += ["template <class F> struct f29_of;"]
     for fname, sn in names.items():
