@@ -64,8 +64,8 @@ FP_DEV f29 f29_inv(const f29& a) {
 // the Bezout pair d, e modulo p; 20 rounds = 600 divsteps, enough for 256-bit moduli).  Signed
 // 30-bit limbs in int32, int64 accumulators.  About 12 k instructions on one dependent chain
 // against ~67 k for the Fermat exponentiation above: the latency floor of a batch inversion drops
-// from ~0.26 to ~0.06 ms.  tools/fp29_model.py's sibling model (same limb arithmetic in Python)
-// checks every intermediate range; the parity tests compare against the oracle's Fermat inverses.
+// from ~0.26 to ~0.06 ms.  The limb arithmetic was first written as a bit-accurate Python model that
+// asserts every intermediate range; the parity tests compare the results with Fermat inverses.
 struct s30x9 { int32_t v[9]; };
 #define S30_MASK 0x3fffffff
 
