@@ -103,7 +103,7 @@ def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu, with_quotien
     out = {"k": k, "curve": curve_name, "gpu_ms": round(best.ms_total, 3), "gpu_msm_ms": round(best.ms_msm, 3), "gpu_ntt_ms": round(best.ms_ntt, 3),
            "gpu_eval_h_ms": round(best.ms_eval_h, 3) if with_quotient else None,
            "gpu_arguments_ms": round(best.ms_arguments, 3) if with_quotient else None, "gpu_openings_ms": round(best.ms_openings, 3) if with_quotient else None,
-           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + 1 iNTT(4n)%s; host syncs between phases; columns resident in HBM"
+           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + 1 iNTT(4n)%s; after every commit phase the commitments are converted to affine and copied to the host (transcript); columns resident in HBM"
                        % (" + 5 lookup permutations + 7 grand products + evaluate_h(4n: gates, 2 permutation sets, 5 lookups) + 72 eval_polynomial(n)" if with_quotient else "")}
     if with_cpu:
         cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)

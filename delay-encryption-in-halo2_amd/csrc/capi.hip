@@ -374,6 +374,16 @@ int dehalo_best_multiexp(dehalo_ctx* ctx, int curve, const uint64_t* scalars, co
     return rc;
 }
 
+int dehalo_to_affine_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobian, size_t count, uint64_t* d_affine_xy, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_jacobian || !d_affine_xy) && count) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: null argument");
+    if (count == 0) return 0;
+    if (count >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: too many points");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_to_affine(ctx, curve, (const jacobian_t*)d_jacobian, (affine_t*)d_affine_xy, (uint32_t)count, pick_stream(ctx, stream));
+}
+
 int dehalo_to_affine(dehalo_ctx* ctx, int curve, const uint64_t* jacobian, size_t count, uint64_t* affine_xy) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!jacobian || !affine_xy) && count) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: null argument");

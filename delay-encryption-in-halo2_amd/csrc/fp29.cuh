@@ -344,3 +344,106 @@ FP_DEV fe f29_to_std(const f29& a) {
 // internal lazily reduced -> internal canonical, packed in 8 words (SRS table format)
 template <class F>
 FP_DEV fe f29_to_packed_canon(const f29& a_norm) { return f29_pack(f29_canon<F>(a_norm)); }
+
+// a^-1 by the Bernstein-Yang "safegcd" algorithm in its constant-time batched form (30 divsteps on
+// the low words give a 2x2 transition matrix, which is then applied to the full-width f, g and to
+// the Bezout pair d, e modulo p; 20 rounds = 600 divsteps, enough for 256-bit moduli).  Signed
+// 30-bit limbs in int32, int64 accumulators.  About 12 k instructions on one dependent chain
+// against ~67 k for the Fermat exponentiation above: the latency floor of a batch inversion drops
+// from ~0.26 to ~0.06 ms.  The limb arithmetic was first written as a bit-accurate Python model that
+// asserts every intermediate range; the parity tests compare the results with Fermat inverses.
+struct s30x9 { int32_t v[9]; };
+#define S30_MASK 0x3fffffff
+
+template <class F9>
+FP_DEV f29 f29_inv_safegcd(const f29& a) {
+    typedef typename F9::Std F;
+    // the integer V = a mod p (the caller's internal form is just an integer here) and the modulus, as 9 x 30-bit limbs
+    const fe wv = f29_pack(f29_canon<F9>(a));
+    s30x9 f, g, d, e;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 30 * i, word = bit >> 5, sh = bit & 31;
+        u64 pv = (u64)F::P[word] | (word + 1 < 8 ? (u64)F::P[word + 1] << 32 : 0);
+        u64 gv = (u64)wv.v[word] | (word + 1 < 8 ? (u64)wv.v[word + 1] << 32 : 0);
+        f.v[i] = (int32_t)((pv >> sh) & S30_MASK);
+        g.v[i] = (int32_t)((gv >> sh) & S30_MASK);
+        d.v[i] = 0; e.v[i] = 0;
+    }
+    s30x9 P30 = f;
+    e.v[0] = 1;
+    int32_t zeta = -1;
+    for (int round = 0; round < 20; round++) {
+        // ---- 30 divsteps on the low limbs -> transition matrix t = [[u, v], [q, r]] ----
+        u32 u = 1, v = 0, q = 0, r = 1;
+        u32 fl = (u32)f.v[0] | ((u32)f.v[1] << 30), gl = (u32)g.v[0] | ((u32)g.v[1] << 30);
+        for (int i = 0; i < 30; i++) {
+            u32 c1 = (u32)(zeta >> 31);
+            u32 c2 = 0u - (gl & 1u);
+            u32 x = (fl ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+            gl += x & c2; q += y & c2; r += z & c2;
+            c1 &= c2;
+            zeta = (int32_t)((u32)zeta ^ c1) - 1;
+            fl += gl & c1; u += q & c1; v += r & c1;
+            gl >>= 1; u <<= 1; v <<= 1;
+        }
+        const int64_t tu = (int32_t)u, tv = (int32_t)v, tq = (int32_t)q, tr = (int32_t)r;
+        // ---- d, e <- t * [d, e] / 2^30 mod p ----
+        {
+            const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+            int32_t md = ((int32_t)u & sd) + ((int32_t)v & se), me = ((int32_t)q & sd) + ((int32_t)r & se);
+            int64_t cd = tu * d.v[0] + tv * e.v[0], ce = tq * d.v[0] + tr * e.v[0];
+            md -= (int32_t)((F9::PINV30 * (u32)cd + (u32)md) & S30_MASK);
+            me -= (int32_t)((F9::PINV30 * (u32)ce + (u32)me) & S30_MASK);
+            cd += (int64_t)P30.v[0] * md; ce += (int64_t)P30.v[0] * me;
+            cd >>= 30; ce >>= 30;
+#pragma unroll
+            for (int i = 1; i < 9; i++) {
+                cd += tu * d.v[i] + tv * e.v[i] + (int64_t)P30.v[i] * md;
+                ce += tq * d.v[i] + tr * e.v[i] + (int64_t)P30.v[i] * me;
+                d.v[i - 1] = (int32_t)cd & S30_MASK; cd >>= 30;
+                e.v[i - 1] = (int32_t)ce & S30_MASK; ce >>= 30;
+            }
+            d.v[8] = (int32_t)cd; e.v[8] = (int32_t)ce;
+        }
+        // ---- f, g <- t * [f, g] / 2^30 (exact) ----
+        {
+            int64_t cf = tu * f.v[0] + tv * g.v[0], cg = tq * f.v[0] + tr * g.v[0];
+            cf >>= 30; cg >>= 30;
+#pragma unroll
+            for (int i = 1; i < 9; i++) {
+                cf += tu * f.v[i] + tv * g.v[i];
+                cg += tq * f.v[i] + tr * g.v[i];
+                f.v[i - 1] = (int32_t)cf & S30_MASK; cf >>= 30;
+                g.v[i - 1] = (int32_t)cg & S30_MASK; cg >>= 30;
+            }
+            f.v[8] = (int32_t)cf; g.v[8] = (int32_t)cg;
+        }
+    }
+    // g = 0 and f = +-1 now; the inverse is sign(f) * d, brought into [0, p)
+    {
+        int32_t add = d.v[8] >> 31;
+#pragma unroll
+        for (int i = 0; i < 9; i++) d.v[i] += P30.v[i] & add;
+        const int32_t neg = f.v[8] >> 31;
+#pragma unroll
+        for (int i = 0; i < 9; i++) d.v[i] = (d.v[i] ^ neg) - neg;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { d.v[i + 1] += d.v[i] >> 30; d.v[i] &= S30_MASK; }
+        add = d.v[8] >> 31;
+#pragma unroll
+        for (int i = 0; i < 9; i++) d.v[i] += P30.v[i] & add;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { d.v[i + 1] += d.v[i] >> 30; d.v[i] &= S30_MASK; }
+    }
+    // 30-bit limbs -> 8 words -> 29-bit limbs; V^-1 * 2^783 * 2^-261 = (x 2^261)^-1 2^522 = x^-1 2^261
+    fe out;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int bit = 32 * j, limb = bit / 30, sh = bit % 30;
+        u64 lo = (u64)(u32)d.v[limb] | ((u64)(u32)d.v[limb + 1] << 30) | (limb + 2 < 9 ? (u64)(u32)d.v[limb + 2] << 60 : 0);
+        out.v[j] = (u32)(lo >> sh);
+    }
+    return f29_mul<F9>(f29_unpack(out), f29_const<F9>(F9::R3));
+}
+

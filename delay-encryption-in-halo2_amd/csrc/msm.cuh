@@ -684,7 +684,8 @@ __global__ void k_jac_to_affine(const jacobian_t* in, affine_t* out, u32 count) 
     affine_t a;
     if (f_is_zero(z)) { a.x = f_zero(); a.y = f_zero(); }
     else {
-        fe zi = f_inv<F>(z);
+        typedef typename f29_of<F>::type F9;
+        fe zi = f29_to_std<F9>(f29_inv_safegcd<F9>(f29_from_std<F9>(z)));   // ~6x fewer instructions than the Fermat chain
         fe zi2 = f_sqr<F>(zi);
         a.x = f_mul<F>(x, zi2);
         a.y = f_mul<F>(y, f_mul<F>(zi2, zi));

@@ -96,6 +96,8 @@ class ProverShape:
         self.polys = to_dev(columns["polys"])                      # (24, n, 4): columns taken through iNTT
         self.ext = torch.zeros((N_COSET, self.ext_n, 4), dtype=torch.int64, device="cuda")
         self.out = {name: torch.zeros((cnt, 12), dtype=torch.int64, device="cuda") for name, cnt, _ in MSM_PHASES}
+        self.out_affine = {name: torch.zeros((cnt, 8), dtype=torch.int64, device="cuda") for name, cnt, _ in MSM_PHASES}
+        self.transcript_points = {name: torch.zeros((cnt, 8), dtype=torch.int64).pin_memory() for name, cnt, _ in MSM_PHASES}
         d, e = self.domain, curve.scalar.encode
         self._c = dict(omega_inv=e(d.omega_inv), ifft=e(d.ifft_divisor), ext_omega=e(d.extended_omega), ext_omega_inv=e(d.extended_omega_inv),
                        ext_ifft=e(d.extended_ifft_divisor), zeta=e(d.g_coset))
@@ -160,6 +162,10 @@ class ProverShape:
         t = self.cols[name]
         b = self.g_lagrange if lagrange else self.g
         self.ctx.msm_device(b, t.data_ptr(), self.n, t.shape[0], self.out[name].data_ptr(), 0)
+        # what the transcript absorbs: the phase's commitments as affine points, on the host
+        self.ctx.to_affine_device(self.curve.id, self.out[name].data_ptr(), t.shape[0], self.out_affine[name].data_ptr(), 0)
+        self.ctx.synchronize()
+        self.transcript_points[name].copy_(self.out_affine[name])
 
     def run(self) -> ProverShapeResult:
         ctx, c, f = self.ctx, self._c, self.curve.scalar

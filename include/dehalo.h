@@ -99,6 +99,8 @@ int dehalo_best_multiexp(dehalo_ctx* ctx, int curve, const uint64_t* scalars, co
                          uint64_t out_jacobian[12]);
 /* G1::to_affine / batch_normalize of MSM outputs: count x 12 u64 -> count x 8 u64 (host buffers). */
 int dehalo_to_affine(dehalo_ctx* ctx, int curve, const uint64_t* jacobian, size_t count, uint64_t* affine_xy);
+/* device-pointer form: `count` Jacobian points (96 B each) -> affine (64 B each), asynchronous on the stream */
+int dehalo_to_affine_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobian, size_t count, uint64_t* d_affine_xy, void* stream);
 
 /* ---- NTT == halo2_proofs::arithmetic::best_fft(a, omega, log_n) ---------------------------
  * [halo2_proofs/src/arithmetic.rs].  In place, natural order in and out,

@@ -295,6 +295,9 @@ def test_prover_shape_vs_oracle(pkg, po, co, ctx, cname, k):
     res = shape.run()
     assert res.commitments.shape == (31, 12)
     got = ctx.to_affine(curve.id, res.commitments)
+    # the affine points the schedule hands to the transcript after every phase (device-side conversion) are the same ones
+    tp = np.concatenate([shape.transcript_points[name].numpy().view(np.uint64) for name, _, _ in ps.MSM_PHASES])
+    assert np.array_equal(tp, got)
     row = 0
     for name, cnt, _ in ps.MSM_PHASES:
         basis = gl if name in ("advice", "lookup_permuted", "grand_products") else g
