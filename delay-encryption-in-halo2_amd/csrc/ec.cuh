@@ -9,6 +9,7 @@
 // projective = Jacobian {x, y, z}, identity z = 0.
 #pragma once
 #include "fp.cuh"
+#include "fp29.cuh"   // f29_inv_safegcd
 
 struct alignas(16) affine_t {
     fe x, y;
@@ -157,7 +158,7 @@ FP_DEV jacobian_t xyzz_to_jacobian(const xyzz_t& p) {
     return r;
 }
 
-// XYZZ -> affine (one Fermat inversion; setup paths only)
+// XYZZ -> affine (one inversion per point: safegcd, ~20x fewer instructions than the 32-bit Fermat chain)
 template <class F>
 __device__ affine_t xyzz_to_affine(const xyzz_t& p) {
     affine_t r;
@@ -165,7 +166,8 @@ __device__ affine_t xyzz_to_affine(const xyzz_t& p) {
         r.x = f_zero(); r.y = f_zero();
         return r;
     }
-    fe zi = f_inv<F>(p.zzz);            // 1/ZZZ
+    typedef typename f29_of<F>::type F9;
+    fe zi = f29_to_std<F9>(f29_inv_safegcd<F9>(f29_from_std<F9>(p.zzz)));   // 1/ZZZ
     fe t = f_mul<F>(zi, p.zz);          // ZZ/ZZZ = 1/Z
     fe zz_inv = f_sqr<F>(t);            // 1/Z^2 = 1/ZZ
     r.x = f_mul<F>(p.x, zz_inv);
