@@ -420,7 +420,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 // Signed-digit carries of small witness values pile thousands of points into bucket 0 (digit
 // +-1) and 0/1 columns put half the column into one bucket, so the number S of partial sums per
 // bucket spans 0 .. 10^5.  Buckets are classed by S and merged by a lane group sized to it:
-//   S <= 24: one lane or quad | S <= 128: 8 lanes | S <= 2048: one wave | larger: a 512-thread block;
+//   S <= 24: one lane or quad | S <= 128: 32 lanes | S <= 2048: one wave | larger: a 512-thread block;
 // chain length <= S/g + log2 g group additions instead of S.
 #define MSM_C0_MAX 24
 #define MSM_C1_MAX 128
@@ -800,7 +800,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // partial sums -> one point per bucket (by size class)
         k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
         k_msm_merge_light<CV><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
-        k_msm_merge_group<CV, 8><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
+        k_msm_merge_group<CV, 32><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
         k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
         k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 4, MSM_HEAVY_THREADS, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 3, merge_lists + 3 * (size_t)merge_cap);
         // bucket reduction
