@@ -94,14 +94,15 @@ FP_DEV xyzz29 x29_double(const xyzz29& a) {
 // A + q, q affine (internal, canonical or negated-loose y), q != identity
 template <class F>
 FP_DEV xyzz29 x29_add_mixed(const xyzz29& a, const aff29& q) {
-    f29 u2 = f29_mul<F>(q.x, a.zz);
-    f29 s2 = f29_mul<F>(q.y, a.zzz);
+    // independent products are issued in pairs (f29_mul_pair / f29_sqr_pair): interleaved instruction streams
+    f29 u2, s2;
+    f29_mul_pair<F>(q.x, a.zz, q.y, a.zzz, u2, s2);
     f29 p = f29_norm(f29_sub(u2, a.x, F::KA));
     f29 rr = f29_norm(f29_sub(s2, a.y, F::KA));
-    f29 pp = f29_sqr<F>(p);
-    f29 ppp = f29_mul<F>(p, pp);
-    f29 qq = f29_mul<F>(a.x, pp);
-    f29 r2 = f29_sqr<F>(rr);
+    f29 pp, r2;
+    f29_sqr_pair<F>(p, rr, pp, r2);
+    f29 ppp, qq;
+    f29_mul_pair<F>(p, pp, a.x, pp, ppp, qq);
     xyzz29 r;
     r.x = f29_norm(f29_sub(r2, f29_add(ppp, f29_dbl(qq)), F::KB));
     f29 t = f29_sub(qq, r.x, F::KA);
@@ -111,8 +112,7 @@ FP_DEV xyzz29 x29_add_mixed(const xyzz29& a, const aff29& q) {
         // R (Q - X3) - Y1 PPP as ONE reduction of two products: R (Q - X3) + (10p - Y1) PPP
         r.y = f29_mul2<F>(rr, t, f29_norm(f29_sub(f29_zero(), a.y, F::KA)), ppp);
     }
-    r.zz = f29_mul<F>(a.zz, pp);
-    r.zzz = f29_mul<F>(a.zzz, ppp);
+    f29_mul_pair<F>(a.zz, pp, a.zzz, ppp, r.zz, r.zzz);
     if (__builtin_expect(f29_maybe_zero_lt2p<F>(r.zz), 0)) {
         if (f29_is_zero_lt2p<F>(r.zz)) {
             // exact resolution (rare): identity accumulator, doubling, or cancellation

@@ -242,6 +242,101 @@ FP_DEV f29 f29_montgomery_columns(const PROD& products) {
     return r;
 }
 
+// as f29_col_mad, and the machine scheduler may not move anything across it: keeps two interleaved
+// chains interleaved (left alone, the scheduler re-serialises them)
+FP_DEV void f29_col_mad_pin(u64& acc, u32 a, u32 b) {
+    acc = mad_wide(a, b, acc);
+    asm("" : "+v"(acc));
+    __builtin_amdgcn_sched_barrier(0);
+}
+// Two independent reductions in lockstep: the instruction stream alternates between the two column
+// accumulators, so a multiply-add never directly follows the one it depends on (hipcc otherwise has
+// to separate dependent v_mad_u64_u32 by s_nop wait states: ~130 per multiplication).
+template <class F, class PROD1, class PROD2>
+FP_DEV void f29_montgomery_columns2(const PROD1& products1, const PROD2& products2, f29& r1, f29& r2) {
+    u32 m1[9], m2[9], P[9];
+    f29_load_p<F>(P);
+    u64 x = 0, y = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        products1(k, x);
+        products2(k, y);
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (i < k && k - i < 9 && F::P[k - i] != 0) { f29_col_mad_pin(x, m1[i], P[k - i]); f29_col_mad_pin(y, m2[i], P[k - i]); }
+        if (k < 9) {
+            if (F::INV == F29_MASK) { m1[k] = (0u - (u32)x) & F29_MASK; m2[k] = (0u - (u32)y) & F29_MASK; }
+            else { m1[k] = ((u32)x * F::INV) & F29_MASK; m2[k] = ((u32)y * F::INV) & F29_MASK; }
+            f29_col_mad_pin(x, m1[k], P[0]);
+            f29_col_mad_pin(y, m2[k], P[0]);
+        } else {
+            r1.v[k - 9] = (u32)x & F29_MASK;
+            r2.v[k - 9] = (u32)y & F29_MASK;
+        }
+        x >>= F29_BITS;
+        y >>= F29_BITS;
+    }
+    r1.v[8] = (u32)x;
+    r2.v[8] = (u32)y;
+}
+// r1 = a * b, r2 = c * d (each * 2^-261), interleaved
+template <class F>
+FP_DEV void f29_mul_pair(const f29& a, const f29& b, const f29& c, const f29& d, f29& r1, f29& r2) {
+    if constexpr (f29_is_lat<F>::value) { r1 = f29_mul_os<F>(a, b); r2 = f29_mul_os<F>(c, d); }
+    else {
+        // the products of one column alternate between the two accumulators too
+        u32 m1[9], m2[9], P[9];
+        f29_load_p<F>(P);
+        u64 x = 0, y = 0;
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (k - i >= 0 && k - i < 9) { f29_col_mad_pin(x, a.v[i], b.v[k - i]); f29_col_mad_pin(y, c.v[i], d.v[k - i]); }
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i < k && k - i < 9 && F::P[k - i] != 0) { f29_col_mad_pin(x, m1[i], P[k - i]); f29_col_mad_pin(y, m2[i], P[k - i]); }
+            if (k < 9) {
+                if (F::INV == F29_MASK) { m1[k] = (0u - (u32)x) & F29_MASK; m2[k] = (0u - (u32)y) & F29_MASK; }
+                else { m1[k] = ((u32)x * F::INV) & F29_MASK; m2[k] = ((u32)y * F::INV) & F29_MASK; }
+                f29_col_mad_pin(x, m1[k], P[0]);
+                f29_col_mad_pin(y, m2[k], P[0]);
+            } else {
+                r1.v[k - 9] = (u32)x & F29_MASK;
+                r2.v[k - 9] = (u32)y & F29_MASK;
+            }
+            x >>= F29_BITS;
+            y >>= F29_BITS;
+        }
+        r1.v[8] = (u32)x;
+        r2.v[8] = (u32)y;
+    }
+}
+// r1 = a^2, r2 = c^2, interleaved
+template <class F>
+FP_DEV void f29_sqr_pair(const f29& a, const f29& c, f29& r1, f29& r2) {
+    if constexpr (f29_is_lat<F>::value) { r1 = f29_sqr_os<F>(a); r2 = f29_sqr_os<F>(c); }
+    else {
+        u32 da[9], dc[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { da[i] = a.v[i] << 1; dc[i] = c.v[i] << 1; }
+        f29_montgomery_columns2<F>(
+            [&](int k, u64& acc) {
+#pragma unroll
+                for (int i = 0; i < 9; i++)
+                    if (k - i > i && k - i < 9) f29_col_mad_pin(acc, da[i], a.v[k - i]);
+                if ((k & 1) == 0 && k / 2 < 9) f29_col_mad_pin(acc, a.v[k / 2], a.v[k / 2]);
+            },
+            [&](int k, u64& acc) {
+#pragma unroll
+                for (int i = 0; i < 9; i++)
+                    if (k - i > i && k - i < 9) f29_col_mad_pin(acc, dc[i], c.v[k - i]);
+                if ((k & 1) == 0 && k / 2 < 9) f29_col_mad_pin(acc, c.v[k / 2], c.v[k / 2]);
+            },
+            r1, r2);
+    }
+}
+
 // a * b * 2^-261 mod p, lazily reduced: result limbs normalized, value < a*b/2^261 + p.
 // Limb-size contract: bits(max a limb) + bits(max b limb) <= 60.
 template <class F>
