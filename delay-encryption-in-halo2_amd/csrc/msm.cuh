@@ -262,12 +262,26 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* c
 //                  blocks of a partition are given block ids congruent mod 8 (one XCD under the
 //                  observed round-robin placement -- speed only), so that XCD's L2 merges them.
 // Positions are known without atomics on global memory: bucket offsets + per-slice prefixes.
+// Every WAVE groups the 64 x 8 pairs of a sub-round by partition in its own LDS slice (count, scan,
+// place -- wave-synchronous, no block barrier), reserves its share of every partition run with one
+// returning atomic per partition, and copies the staged pairs out in staging order: a store
+// instruction then touches ~8-16 cache lines instead of 64 (these kernels wait to ISSUE stores).
+#define MSM_PART_WAVE_LDS (4 * 128 * 4 + 512 * 8 + 512 * 2)
 template <class FS>
 __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const fe* scalars, const u32* off, const u32* pc, unsigned long long* pairs) {
-    extern __shared__ u32 pcur[];
+    extern __shared__ __align__(8) unsigned char part_smem[];
     const u32 grp = blockIdx.y, bat = blockIdx.z;
     const u64 gidx = (u64)bat * g.G + grp;
     const u32 sub = msm_sub_bits(g.c), P = g.nb >> sub, submask = (1u << sub) - 1;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    u32* pcur = reinterpret_cast<u32*>(part_smem);                               // block-shared run cursors [128]
+    unsigned char* wbase = part_smem + 512 + (size_t)wave * MSM_PART_WAVE_LDS;  // this wave's slice
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(wbase);   // [512]
+    u32* lcnt = reinterpret_cast<u32*>(wbase + 512 * 8);                         // [128] pairs per partition
+    u32* lbase = lcnt + 128;                                                     // first staging slot
+    u32* lcur = lbase + 128;                                                     // placement cursor
+    u32* gbase = lcur + 128;                                                     // reserved global position
+    unsigned short* stageq = reinterpret_cast<unsigned short*>(gbase + 128);     // [512] partition of a staged pair
     const u32* prel = pc + (gidx * g.slices + blockIdx.x) * P;
     const u32* goff = off + gidx * g.nb;
     for (u32 q = threadIdx.x; q < P; q += blockDim.x) pcur[q] = goff[q << sub] + prel[q];
@@ -276,29 +290,62 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
     const fe* sc = scalars + (u64)bat * g.n;
     const u32 per = (g.n + g.slices - 1) / g.slices;
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
-    for (u32 i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    (void)nwaves;
+    for (u32 i0 = beg + wave * 64; i0 < end; i0 += blockDim.x) {       // every lane of a wave runs the same trip count
+        const u32 i = i0 + lane;
+        const bool have = i < end;
         DigitStream ds;
-        ds.template init<FS>(f_load(&sc[i]), g.c);
+        if (have) ds.template init<FS>(f_load(&sc[i]), g.c);
         for (u32 w0 = 0; w0 < w_hi; w0 += 8) {
-            u32 bk[8], pos[8];
+            u32 bk[8];
             bool ng[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 bk[j] = 0xffffffffu; ng[j] = false;
-                if (w0 + j < w_hi) {
+                if (have && w0 + j < w_hi) {
                     ds.next(bk[j], ng[j]);
                     if (w0 + j < w_lo) bk[j] = 0xffffffffu;
                 }
             }
+            // count
+            for (u32 q = lane; q < P; q += 64) lcnt[q] = 0;
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if (bk[j] != 0xffffffffu) pos[j] = atomicAdd(&pcur[bk[j] >> sub], 1u);   // eight LDS atomics in flight
+                if (bk[j] != 0xffffffffu) atomicAdd(&lcnt[bk[j] >> sub], 1u);
+            __builtin_amdgcn_wave_barrier();
+            // scan (P <= 128: two entries per lane) and reservation in the partition runs
+            u32 run = 0;
+            for (u32 q0 = 0; q0 < P; q0 += 64) {
+                const u32 q = q0 + lane;
+                const u32 v = q < P ? lcnt[q] : 0;
+                u32 x = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+                if (q < P) {
+                    lbase[q] = run + x - v; lcur[q] = run + x - v;
+                    gbase[q] = v ? atomicAdd(&pcur[q], v) : 0u;
+                }
+                run += __shfl(x, 63);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // place
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 if (bk[j] != 0xffffffffu) {
-                    u32 tidx = g.G == 1 ? (w0 + j) * g.table_n + i : i;
-                    pairs[pos[j]] = ((unsigned long long)(bk[j] & submask) << 32) | (tidx | (ng[j] ? 0x80000000u : 0u));
+                    const u32 q = bk[j] >> sub;
+                    const u32 pos = atomicAdd(&lcur[q], 1u);
+                    const u32 tidx = g.G == 1 ? (w0 + j) * g.table_n + i : i;
+                    stage[pos] = ((unsigned long long)(bk[j] & submask) << 32) | (tidx | (ng[j] ? 0x80000000u : 0u));
+                    stageq[pos] = (unsigned short)q;
                 }
+            __builtin_amdgcn_wave_barrier();
+            // copy out in staging order
+            for (u32 e = lane; e < run; e += 64) {
+                const u32 q = stageq[e];
+                pairs[gbase[q] + (e - lbase[q])] = stage[e];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -776,6 +823,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     if (lds_hist > 48 * 1024) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_hist<FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
     }
+    const size_t lds_part = 512 + (size_t)(MSM_SORT_THREADS / 64) * MSM_PART_WAVE_LDS;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_part<FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
     const u32 tb = (u32)total_buckets;
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
@@ -785,7 +834,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_colscan<<<(tb + 255) / 256, 256, 0, s>>>(g.nb, g.slices, tb, bh, count);
         k_msm_colscan<<<((u32)total_groups * P + 255) / 256, 256, 0, s>>>(P, g.slices, (u32)total_groups * P, pc, nullptr);
         TRY(run_scan(ctx, count, tb, g.L0, off, nrank, rbeg, rend, s));
-        k_msm_part<FS><<<grid, MSM_SORT_THREADS, P * 4, s>>>(g, d_scalars, off, pc, pairs);
+        k_msm_part<FS><<<grid, MSM_SORT_THREADS, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, 0, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
         HIP_TRY(ctx, hipGetLastError());
     }
