@@ -378,20 +378,51 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
     const u32 beg = pbase + pc[(gidx * slices + k0) * P + p];
     const u32 end = k1 < slices ? pbase + pc[(gidx * slices + k1) * P + p] : goff[nsub];   // off has total + 1 entries
     __syncthreads();
-    for (u32 i0 = beg + threadIdx.x; i0 < end; i0 += 8 * blockDim.x) {   // eight loads, then eight atomics, then eight stores
+    // Rounds of <= 2048 pairs: grouped by sub-bucket in LDS (count, scan, place), then copied out in
+    // staging order -- a store instruction touches ~8 lines (32-byte runs) instead of 64.
+    __shared__ u32 cnt[256], sbase[256], scur[256], wsum[4];
+    __shared__ u32 stage[2048];
+    __shared__ unsigned short stageq[2048];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 r0 = beg; r0 < end; r0 += 2048) {
+        const u32 rend = min(r0 + 2048u, end);
         unsigned long long pr[8];
-        u32 pos[8];
+        if (tid < nsub) cnt[tid] = 0;
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            u32 i = i0 + j * blockDim.x;
-            pr[j] = i < end ? pairs[i] : ~0ull;
+            u32 i = r0 + tid + j * 256;
+            pr[j] = i < rend ? pairs[i] : ~0ull;
+            if (pr[j] != ~0ull) atomicAdd(&cnt[(u32)(pr[j] >> 32)], 1u);
         }
+        __syncthreads();
+        {   // exclusive scan of the (<= 256) counts: one per thread
+            u32 v = tid < nsub ? cnt[tid] : 0, x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+            if (lane == 63) wsum[wave] = x;
+            __syncthreads();
+            u32 before = 0;
+            for (u32 w = 0; w < wave; w++) before += wsum[w];
+            if (tid < nsub) { sbase[tid] = before + x - v; scur[tid] = before + x - v; }
+        }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (pr[j] != ~0ull) pos[j] = atomicAdd(&lcur[(u32)(pr[j] >> 32)], 1u);
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (pr[j] != ~0ull) idx_out[pos[j]] = (u32)pr[j];
+            if (pr[j] != ~0ull) {
+                const u32 sb = (u32)(pr[j] >> 32);
+                const u32 pos = atomicAdd(&scur[sb], 1u);
+                stage[pos] = (u32)pr[j];
+                stageq[pos] = (unsigned short)sb;
+            }
+        __syncthreads();
+        const u32 total = rend - r0;
+        for (u32 e = tid; e < total; e += 256) {
+            const u32 sb = stageq[e];
+            idx_out[lcur[sb] + (e - sbase[sb])] = stage[e];
+        }
+        __syncthreads();
+        if (tid < nsub) lcur[tid] += cnt[tid];     // the next round continues where this one ended
     }
 }
 
