@@ -111,9 +111,15 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_hist(MsmGeom g, const 
     const fe* sc = scalars + (u64)bat * g.n;
     const u32 per = (g.n + g.slices - 1) / g.slices;
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
-    for (u32 i = beg + threadIdx.x; i < end; i += blockDim.x) {
-        fe s = f_load(&sc[i]);
-        for_each_digit<FS>(s, g.c, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
+    for (u32 i0 = beg + threadIdx.x; i0 < end; i0 += 4 * blockDim.x) {      // four scalar loads in flight per lane
+        fe s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (i0 + j * blockDim.x < end) s4[j] = f_load(&sc[i0 + j * blockDim.x]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (i0 + j * blockDim.x < end)
+                for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
     }
     __syncthreads();
     u32* out = bh + (((u64)bat * g.G + grp) * g.slices + blockIdx.x) * g.nb;
