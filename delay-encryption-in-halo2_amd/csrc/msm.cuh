@@ -297,11 +297,15 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
     const u32 per = (g.n + g.slices - 1) / g.slices;
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
     (void)nwaves;
+    fe s_next;
+    if (beg + wave * 64 + lane < end) s_next = f_load(&sc[beg + wave * 64 + lane]);
     for (u32 i0 = beg + wave * 64; i0 < end; i0 += blockDim.x) {       // every lane of a wave runs the same trip count
         const u32 i = i0 + lane;
         const bool have = i < end;
+        const fe s_cur = s_next;
+        if (i + blockDim.x < end) s_next = f_load(&sc[i + blockDim.x]);   // the next round's scalar is in flight during this one
         DigitStream ds;
-        if (have) ds.template init<FS>(f_load(&sc[i]), g.c);
+        if (have) ds.template init<FS>(s_cur, g.c);
         for (u32 w0 = 0; w0 < w_hi; w0 += 8) {
             u32 bk[8];
             bool ng[8];
