@@ -308,7 +308,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u256 Montgomery (9 x 29-bit limbs in u32, 64-bit v_mad_u64_u32 accumulators)",
+            "dtype": "u256 (9 x 29-bit limbs, u64 multiply-add)",
             "data": "synthetic",
             "config": {"workload": "1 x MSM(2^%d, %s) + 1 x NTT(2^%d, %s) per step per GPU, %s scalars, SRS tables resident" % (log_n, args.curve, log_n, args.ntt_field, args.dist),
                        "configs_index": 1, "steps_in_flight": inflight,
