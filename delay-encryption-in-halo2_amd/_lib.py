@@ -14,7 +14,7 @@ _LIB = None
 SYMBOLS = [
     "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len",
-    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device",
+    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
@@ -98,6 +98,7 @@ def load_library():
     lib.dehalo_best_multiexp.argtypes = [P, C.c_int, u64p, u64p, sz, u64p]
     lib.dehalo_to_affine.argtypes = [P, C.c_int, u64p, sz, u64p]
     lib.dehalo_to_affine_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
+    lib.dehalo_point_sum_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
     lib.dehalo_ntt.argtypes = [P, C.c_int, u64p, u32, u64p]
     lib.dehalo_ntt_device.argtypes = [P, C.c_int, u64p, u32, u64p, sz, P]
     lib.dehalo_intt_scaled.argtypes = [P, C.c_int, u64p, u32, u64p, u64p]
@@ -223,6 +224,9 @@ class Context:
         out = np.zeros((j.shape[0], 8), dtype=np.uint64)
         self._check(self.lib.dehalo_to_affine(self.handle, curve, _ptr(j), j.shape[0], _ptr(out)))
         return out
+
+    def point_sum_device(self, curve: int, d_jacobian: int, count: int, d_out: int, stream: int = 0):
+        self._check(self.lib.dehalo_point_sum_device(self.handle, curve, d_jacobian, count, d_out, stream or None))
 
     def to_affine_device(self, curve: int, d_jacobian: int, count: int, d_affine: int, stream: int = 0):
         self._check(self.lib.dehalo_to_affine_device(self.handle, curve, d_jacobian, count, d_affine, stream or None))

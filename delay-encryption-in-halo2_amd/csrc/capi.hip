@@ -49,6 +49,14 @@ int do_to_affine(dehalo_ctx* ctx, int curve, const jacobian_t* d_in, affine_t* d
         default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown curve id");
     }
 }
+int do_point_sum(dehalo_ctx* ctx, int curve, const jacobian_t* d_in, uint32_t count, jacobian_t* d_out, hipStream_t s) {
+    switch (curve) {
+        case DEHALO_CURVE_BN254_G1: return point_sum_bn254(ctx, d_in, count, d_out, s);
+        case DEHALO_CURVE_PALLAS: return point_sum_pallas(ctx, d_in, count, d_out, s);
+        case DEHALO_CURVE_VESTA: return point_sum_vesta(ctx, d_in, count, d_out, s);
+        default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown curve id");
+    }
+}
 int do_ntt(dehalo_ctx* ctx, int field, const fe* src, uint64_t src_len, uint64_t src_stride, fe* dst, uint64_t dst_stride, uint32_t log_n,
            const uint64_t omega[4], size_t batch, const NttScale& sc, hipStream_t s) {
     switch (field) {
@@ -372,6 +380,15 @@ int dehalo_best_multiexp(dehalo_ctx* ctx, int curve, const uint64_t* scalars, co
     int rc = dehalo_msm(ctx, b, scalars, len, out_jacobian);
     dehalo_bases_release(ctx, b);
     return rc;
+}
+
+int dehalo_point_sum_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobian, size_t count, uint64_t* d_out_jacobian, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_jacobian && count) || !d_out_jacobian) return dh_fail(ctx, DEHALO_ERR_INVALID, "point_sum: null argument");
+    if (count >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "point_sum: too many points");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_point_sum(ctx, curve, (const jacobian_t*)d_jacobian, (uint32_t)count, (jacobian_t*)d_out_jacobian, pick_stream(ctx, stream));
 }
 
 int dehalo_to_affine_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobian, size_t count, uint64_t* d_affine_xy, void* stream) {

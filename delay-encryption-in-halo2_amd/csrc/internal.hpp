@@ -136,7 +136,8 @@ struct NttScale {
     int run_msm_##NAME(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, size_t len, size_t batch, jacobian_t* d_out,     \
                        hipStream_t s);                                                                                                   \
     int build_table_##NAME(dehalo_ctx* ctx, dehalo_bases* b, const affine_t* d_std_points, hipStream_t s);                               \
-    int to_affine_##NAME(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32_t count, hipStream_t s);
+    int to_affine_##NAME(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32_t count, hipStream_t s);                      \
+    int point_sum_##NAME(dehalo_ctx* ctx, const jacobian_t* d_in, uint32_t count, jacobian_t* d_out, hipStream_t s);
 DECL_MSM(bn254)
 DECL_MSM(pallas)
 DECL_MSM(vesta)

@@ -926,6 +926,38 @@ int build_table_t(dehalo_ctx* ctx, dehalo_bases* b, const affine_t* d_std_points
     return 0;
 }
 
+// sum of `count` Jacobian points (standard form) -> one Jacobian point: the combine step of an MSM that
+// was split by point range over several GPUs: one wave, strided lane sums, shuffle tree
+template <class CV>
+__global__ __launch_bounds__(64) void k_point_sum(const jacobian_t* in, u32 count, jacobian_t* out) {
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;
+    const u32 lane = threadIdx.x;
+    xyzz29 acc = x29_identity();
+    for (u32 i = lane; i < count; i += 64) {
+        fe z = f_load(&in[i].z);
+        if (f_is_zero(z)) continue;
+        xyzz29 p;
+        f29 z29 = f29_from_std<F>(z);
+        p.x = f29_from_std<F>(f_load(&in[i].x));
+        p.y = f29_from_std<F>(f_load(&in[i].y));
+        p.zz = f29_sqr<F>(z29);                    // Jacobian (X, Y, Z) is XYZZ (X, Y, Z^2, Z^3)
+        p.zzz = f29_mul<F>(p.zz, z29);
+        acc = x29_add<F>(acc, p);
+    }
+    acc = x29_group_reduce<F, 64>(acc);
+    if (lane == 0) {
+        jacobian_t j = x29_to_jacobian_std<F>(acc);
+        f_store(&out->x, j.x); f_store(&out->y, j.y); f_store(&out->z, j.z);
+    }
+}
+
+template <class CV>
+int point_sum_t(dehalo_ctx* ctx, const jacobian_t* d_in, uint32_t count, jacobian_t* d_out, hipStream_t s) {
+    k_point_sum<CV><<<1, 64, 0, s>>>(d_in, count, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 template <class CV>
 int to_affine_t(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32_t count, hipStream_t s) {
     k_jac_to_affine<CV><<<(count + 63) / 64, 64, 0, s>>>(d_in, d_out, count);
@@ -939,4 +971,6 @@ int to_affine_t(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32
     int build_table_##NAME(dehalo_ctx* ctx, dehalo_bases* b, const affine_t* d_std_points, hipStream_t s) {                               \
         return build_table_t<CV>(ctx, b, d_std_points, s); }                                                                              \
     int to_affine_##NAME(dehalo_ctx* ctx, const jacobian_t* d_in, affine_t* d_out, uint32_t count, hipStream_t s) {                       \
-        return to_affine_t<CV>(ctx, d_in, d_out, count, s); }
+        return to_affine_t<CV>(ctx, d_in, d_out, count, s); }                                                                             \
+    int point_sum_##NAME(dehalo_ctx* ctx, const jacobian_t* d_in, uint32_t count, jacobian_t* d_out, hipStream_t s) {                     \
+        return point_sum_t<CV>(ctx, d_in, count, d_out, s); }

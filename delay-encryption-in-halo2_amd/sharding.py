@@ -42,3 +42,25 @@ def max_over_ranks(value: float) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- one large MSM split by point range (SURVEY.md 8e, optional) -----------------------------
+def point_range_for_rank(n: int, rank: int, world: int):
+    """[lo, hi) of the bases / scalars rank `rank` owns: contiguous, sizes differ by at most one."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def combine_partial_msm(ctx, curve_id: int, local_partial, rank: int, world: int):
+    """local_partial: (1, 12) int64 tensor on this rank's device (the MSM over its point range) ->
+    (1, 12) tensor holding the whole MSM on every rank: one all-gather of world x 96 B, then
+    world - 1 group additions on the device (dehalo_point_sum_device)."""
+    import torch
+
+    parts = all_gather_commitments(local_partial, world, rank, world) if world > 1 else local_partial
+    parts = parts.contiguous()
+    out = torch.zeros((1, 12), dtype=parts.dtype, device=parts.device)
+    ctx.point_sum_device(curve_id, parts.data_ptr(), parts.shape[0], out.data_ptr(), 0)
+    ctx.synchronize()
+    return out

@@ -99,6 +99,10 @@ int dehalo_best_multiexp(dehalo_ctx* ctx, int curve, const uint64_t* scalars, co
                          uint64_t out_jacobian[12]);
 /* G1::to_affine / batch_normalize of MSM outputs: count x 12 u64 -> count x 8 u64 (host buffers). */
 int dehalo_to_affine(dehalo_ctx* ctx, int curve, const uint64_t* jacobian, size_t count, uint64_t* affine_xy);
+/* Sum of `count` Jacobian points -> one Jacobian point (identity for count == 0): the combine step when ONE large MSM
+ * is split by point range over several GPUs: each rank registers its slice of the bases, runs
+ * dehalo_msm_device on its slice of the scalars, the 96-byte partial results are all-gathered (RCCL) and summed here.   */
+int dehalo_point_sum_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobian, size_t count, uint64_t* d_out_jacobian, void* stream);
 /* device-pointer form: `count` Jacobian points (96 B each) -> affine (64 B each), asynchronous on the stream */
 int dehalo_to_affine_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobian, size_t count, uint64_t* d_affine_xy, void* stream);
 

@@ -924,3 +924,37 @@ def test_evalh_golden(pkg, po, ctx):
     with pytest.raises(pkg.lookup.ConstraintSystemFailure):
         spec = pkg.fields.BN254_FR
         pkg.lookup.permute_expression_pair(ctx, spec, spec.encode_many([1, 2, 77]), spec.encode_many([1, 2, 3]), 3)
+
+
+def test_msm_split_by_point_range(pkg, co, ctx):
+    """One MSM split over four 'ranks' by point range (each registers its slice of the bases), partial results summed on
+    the device: equals the undivided MSM.  (The all-gather between real ranks is covered by the gloo test.)"""
+    import torch
+    from dehalo2_amd import sharding
+    curve = pkg.fields.CURVES["bn254"]
+    n, world = 5003, 4
+    g = co.synth_bases(curve.id, n)
+    sc = co.fill_scalars(curve.scalar.id, "witness", n, 77)
+    parts = torch.zeros((world + 1, 12), dtype=torch.int64, device="cuda")      # + one identity entry
+    handles = []
+    for r in range(world):
+        lo, hi = sharding.point_range_for_rank(n, r, world)
+        h = ctx.register_bases(curve.id, g[lo:hi], 0, True); handles.append(h)
+        d = torch.from_numpy(sc[lo:hi].view(np.int64).copy()).cuda()
+        ctx.msm_device(h, d.data_ptr(), hi - lo, 1, parts[r].data_ptr(), 0)
+        ctx.synchronize()
+    assert [sharding.point_range_for_rank(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    out = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    ctx.point_sum_device(curve.id, parts.data_ptr(), world + 1, out.data_ptr(), 0)
+    ctx.synchronize()
+    got = ctx.to_affine(curve.id, out.cpu().numpy().view(np.uint64))[0]
+    want = co.to_affine(curve.id, co.best_multiexp(curve.id, sc, g, 4))
+    assert np.array_equal(got, want)
+    # through the sharding helper at world size 1, and the empty sum
+    one = sharding.combine_partial_msm(ctx, curve.id, out, 0, 1)
+    assert np.array_equal(ctx.to_affine(curve.id, one.cpu().numpy().view(np.uint64))[0], want)
+    ctx.point_sum_device(curve.id, parts.data_ptr(), 0, out.data_ptr(), 0)
+    ctx.synchronize()
+    assert not out.cpu().numpy().view(np.uint64)[0, 8:].any()                    # z = 0: identity
+    for h in handles:
+        h.release()
