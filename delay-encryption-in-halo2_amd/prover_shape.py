@@ -167,6 +167,42 @@ class ProverShape:
         self.ctx.synchronize()
         self.transcript_points[name].copy_(self.out_affine[name])
 
+    # columns whose coefficient form / coset can be computed as soon as the column exists: (first poly, count) per commit phase
+    NTT_GROUPS = {"advice": (0, 6), "lookup_permuted": (6, 10), "grand_products": (16, 8)}
+
+    def _ntt_group(self, ctx2: Context, first: int, count: int):
+        """lagrange_to_coeff + coeff_to_extended of polys[first : first + count] on the second context's stream."""
+        f, c = self.curve.scalar, self._c
+        n_coset = min(count, N_COSET - first)
+        p = self.polys[first].data_ptr()
+        ctx2.intt_scaled_device(f.id, p, self.k, c["omega_inv"], c["ifft"], count, 0)
+        if n_coset > 0:
+            ctx2.coset_ntt_form_device(f.id, p, self.k, self.ext[first].data_ptr(), self.domain.extended_k, c["ext_omega"], c["zeta"], n_coset, ev.FORM_OUT_INTERNAL, 0)
+
+    def run_overlapped(self, ctx2: Context) -> float:
+        """The same schedule (with_quotient) with the NTTs of a phase's columns issued on a SECOND context while the
+        first one runs that phase's MSMs: they fill the latency-bound tails of the bucket reductions.  A column's
+        NTT starts when the column exists, never earlier.  Returns the wall time in ms."""
+        assert self.with_quotient
+        ctx, c, f = self.ctx, self._c, self.curve.scalar
+        sync = ctx.synchronize
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for name in ("advice", "lookup_permuted", "grand_products"):
+            self._ntt_group(ctx2, *self.NTT_GROUPS[name])
+            self._commit(name, True); sync()
+            if name == "advice":
+                self.arguments(); sync()
+        self._commit("random", False); sync()
+        ctx2.synchronize()
+        self.evaluate_h()
+        ctx.coset_intt_form_device(f.id, self.h.data_ptr(), self.domain.extended_k, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], N_EXT_INTT, ev.FORM_IN_INTERNAL, 0)
+        sync()
+        self._commit("h_pieces", False); sync()
+        self.openings(); sync()
+        self._commit("openings", False); sync()
+        return 1e3 * (time.perf_counter() - t0)
+
     def run(self) -> ProverShapeResult:
         ctx, c, f = self.ctx, self._c, self.curve.scalar
         sync = ctx.synchronize

@@ -628,8 +628,8 @@ def test_lookup_h_vs_oracle(pkg, po, ctx, fname):
     assert _host(spec, d["values"]) == want
 
 
-@pytest.mark.parametrize("cname,k", [("bn254", 7), ("pallas", 8)])
-def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k):
+@pytest.mark.parametrize("cname,k,overlapped", [("bn254", 7, False), ("pallas", 8, False), ("bn254", 8, True)])
+def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k, overlapped):
     """The same schedule with evaluate_h on the device: custom gates + 2 permutation sets + 5 lookups over the
     extended domain, then extended_to_coeff, against the C oracle run on the same cosets."""
     from dehalo2_amd import prover_shape as ps
@@ -643,8 +643,13 @@ def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k):
     shape0 = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
     cols.update(ps.synthetic_proving_key(fill, f, k, shape0.domain.extended_k, 55))
     shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols, with_quotient=True)
-    res = shape.run()
-    assert res.ms_eval_h > 0
+    if overlapped:   # NTTs on a second context, overlapping the MSM phases: same results
+        ctx2 = pkg.Context(0)
+        assert shape.run_overlapped(ctx2) > 0
+        ctx2.close()
+    else:
+        res = shape.run()
+        assert res.ms_eval_h > 0
     d, e = shape.domain, f.encode
     # the schedule keeps the cosets in the kernels' internal form: bring a copy back to the standard form, and check it
     # against the oracle's coeff_to_extended while at it
