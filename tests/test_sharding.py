@@ -57,6 +57,16 @@ def test_units_for_rank(pkg):
     assert got == list(range(31))
 
 
+def test_point_ranges_cover_without_overlap(pkg):
+    sharding = __import__("importlib").import_module("dehalo2_amd.sharding")
+    for n, world in ((10, 4), (1 << 20, 8), (7, 8), (0, 3), (5003, 4)):
+        ranges = [sharding.point_range_for_rank(n, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in ranges]
+        assert max(sizes) - min(sizes) <= 1
+
+
 @pytest.mark.timeout(300)
 def test_all_gather_world_size_2(tmp_path):
     script = tmp_path / "worker.py"
