@@ -22,6 +22,7 @@ SYMBOLS = [
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device",
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
+    "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
@@ -119,6 +120,10 @@ def load_library():
     lib.dehalo_permute_expression_pair.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p]
     lib.dehalo_permute_expression_pair_device.argtypes = [P, C.c_int, u64p, u64p, sz, u64p, u64p, P]
     lib.dehalo_permute_expression_pair_batch_device.argtypes = [P, C.c_int, u64p, u64p, sz, sz, sz, u64p, u64p, P]
+    lib.dehalo_lincomb_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), u64p, sz, sz, u64p, u64p, P]
+    lib.dehalo_scale_device.argtypes = [P, C.c_int, u64p, sz, u64p, u32, u64p, P]
+    lib.dehalo_kate_division.argtypes = [P, C.c_int, u64p, sz, u64p, u64p]
+    lib.dehalo_kate_division_device.argtypes = [P, C.c_int, u64p, sz, u64p, u64p, P]
     lib.dehalo_convert_form_device.argtypes = [P, C.c_int, u64p, u64p, sz, C.c_int, P]
     lib.dehalo_coset_ntt_form_device.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p, sz, u32, P]
     lib.dehalo_coset_intt_form_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p, sz, u32, P]
@@ -334,6 +339,32 @@ class Context:
 
     def grand_product_device(self, field: int, d_num: int, d_den: int, length: int, d_z: int, stream: int = 0):
         self._check(self.lib.dehalo_grand_product_device(self.handle, field, d_num, d_den, length, d_z, stream or None))
+
+    def lincomb_device(self, field: int, d_cols: Sequence[int], coefs, length: int, d_out: int, sub_const=None, stream: int = 0):
+        """out[i] = sum_j coefs[j] * cols[j][i], minus sub_const at i = 0 (device column pointers, host coefficients k x 4 u64)."""
+        cf = _u64(coefs, 4) if len(d_cols) else np.zeros((0, 4), dtype=np.uint64)
+        if cf.shape[0] != len(d_cols):
+            raise ValueError("lincomb: one coefficient per column")
+        tbl = (C.c_void_p * max(1, len(d_cols)))(*d_cols)
+        sub = _ptr(_u64(sub_const, 4)) if sub_const is not None else None
+        self._check(self.lib.dehalo_lincomb_device(self.handle, field, tbl, _ptr(cf) if cf.shape[0] else None, len(d_cols), length, d_out, sub, stream or None))
+
+    def scale_device(self, field: int, d_a: int, length: int, pattern=None, d_factor: int = 0, stream: int = 0):
+        """a[i] *= pattern[i mod len(pattern)] (host, 1/2/4/8 elements) and / or *= the element at device pointer d_factor."""
+        pat = _u64(pattern, 4) if pattern is not None else None
+        self._check(self.lib.dehalo_scale_device(self.handle, field, d_a, length, _ptr(pat) if pat is not None else None, pat.shape[0] if pat is not None else 0,
+                                                 d_factor or None, stream or None))
+
+    def kate_division(self, field: int, a, point) -> np.ndarray:
+        a = _u64(a, 4)
+        if a.shape[0] == 0:
+            raise ValueError("kate_division: empty polynomial")   # upstream: a.len() - 1 underflows
+        q = np.zeros((a.shape[0] - 1, 4), dtype=np.uint64)
+        self._check(self.lib.dehalo_kate_division(self.handle, field, _ptr(a), a.shape[0], _ptr(_u64(point, 4)), _ptr(q) if q.shape[0] else None))
+        return q
+
+    def kate_division_device(self, field: int, d_a: int, length: int, point, d_q: int, stream: int = 0):
+        self._check(self.lib.dehalo_kate_division_device(self.handle, field, d_a, length, _ptr(_u64(point, 4)), d_q, stream or None))
 
     def permute_expression_pair(self, field: int, input_values, table_values, usable_rows: int):
         """-> (permuted_input, permuted_table), usable_rows x 4 u64 each; DehaloError(-6) when an input value is not in the table."""

@@ -106,6 +106,22 @@ int do_grand_product(dehalo_ctx* ctx, int field, const fe* num, const fe* den, u
 #undef CALL
 }
 
+int do_lincomb(dehalo_ctx* ctx, int field, const fe* const* cols, const uint64_t* coefs, size_t count, uint64_t len, fe* out, const uint64_t* sub0, hipStream_t s) {
+#define CALL(N) lincomb_##N(ctx, cols, coefs, count, len, out, sub0, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_scale(dehalo_ctx* ctx, int field, fe* a, uint64_t len, const uint64_t* pattern, uint32_t period, const fe* d_factor, hipStream_t s) {
+#define CALL(N) scale_##N(ctx, a, len, pattern, period, d_factor, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_kate_division(dehalo_ctx* ctx, int field, const fe* a, uint64_t len, const uint64_t pt[4], fe* q, hipStream_t s) {
+#define CALL(N) kate_division_##N(ctx, a, len, pt, q, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+
 int do_convert_form(dehalo_ctx* ctx, int field, const fe* in, fe* out, uint64_t n, int to_internal, hipStream_t s) {
 #define CALL(N) convert_form_##N(ctx, in, out, n, to_internal, s)
     FIELD_SWITCH(ctx, field, CALL)
@@ -317,14 +333,14 @@ int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy,
                           dehalo_bases** out) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if (curve < 0 || curve > 2) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown curve id");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return register_impl(ctx, curve, affine_xy, n, stride_bytes, window_bits, precompute, out);
 }
 
 int dehalo_bases_release(dehalo_ctx* ctx, dehalo_bases* bases) {
     if (!ctx || !bases) return DEHALO_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(bases->table);
@@ -339,7 +355,7 @@ int dehalo_msm_device(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!bases || (!d_scalars && len) || !d_out_jacobian) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: null argument");
     if (len > bases->n) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: more scalars than registered bases");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_msm(ctx, bases, (const fe*)d_scalars, len, batch, (jacobian_t*)d_out_jacobian, pick_stream(ctx, stream));
 }
@@ -350,8 +366,9 @@ int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t*
     if (len > bases->n) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: more scalars than registered bases");
     for (size_t b = 0; b < batch; b++)
         if (!scalars[b] && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: null scalar column");
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_scalars, std::max<size_t>(32, batch * len * 32)));
         TRY(dh_ensure(ctx, ctx->ws_out, std::max<size_t>(96, batch * 96)));
@@ -359,7 +376,7 @@ int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t*
             HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->ws_scalars.p + b * len * 32, scalars[b], len * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     TRY(dehalo_msm_device(ctx, bases, (const uint64_t*)ctx->ws_scalars.p, len, batch, (uint64_t*)ctx->ws_out.p, nullptr));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipMemcpyAsync(out_jacobian, ctx->ws_out.p, batch * 96, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -375,6 +392,7 @@ int dehalo_best_multiexp(dehalo_ctx* ctx, int curve, const uint64_t* scalars, co
     if (!out_jacobian || ((!scalars || !affine_xy) && len)) return dh_fail(ctx, DEHALO_ERR_INVALID, "best_multiexp: null argument");
     if (curve < 0 || curve > 2) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown curve id");
     if (len == 0) { memset(out_jacobian, 0, 96); return 0; }
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);
     dehalo_bases* b = nullptr;
     TRY(dehalo_bases_register(ctx, curve, affine_xy, len, 64, 0, 0, &b));
     int rc = dehalo_msm(ctx, b, scalars, len, out_jacobian);
@@ -386,7 +404,7 @@ int dehalo_point_sum_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobi
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!d_jacobian && count) || !d_out_jacobian) return dh_fail(ctx, DEHALO_ERR_INVALID, "point_sum: null argument");
     if (count >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "point_sum: too many points");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_point_sum(ctx, curve, (const jacobian_t*)d_jacobian, (uint32_t)count, (jacobian_t*)d_out_jacobian, pick_stream(ctx, stream));
 }
@@ -396,7 +414,7 @@ int dehalo_to_affine_device(dehalo_ctx* ctx, int curve, const uint64_t* d_jacobi
     if ((!d_jacobian || !d_affine_xy) && count) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: null argument");
     if (count == 0) return 0;
     if (count >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: too many points");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_to_affine(ctx, curve, (const jacobian_t*)d_jacobian, (affine_t*)d_affine_xy, (uint32_t)count, pick_stream(ctx, stream));
 }
@@ -405,7 +423,7 @@ int dehalo_to_affine(dehalo_ctx* ctx, int curve, const uint64_t* jacobian, size_
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!jacobian || !affine_xy) && count) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: null argument");
     if (count == 0) return 0;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     TRY(dh_ensure(ctx, ctx->ws_fop[0], count * 96));
     TRY(dh_ensure(ctx, ctx->ws_fop[1], count * 64));
@@ -421,7 +439,7 @@ static int ntt_device_impl(dehalo_ctx* ctx, int field, const uint64_t* d_src, ui
                            uint64_t dst_stride, uint32_t log_n, const uint64_t omega[4], size_t batch, const NttScale& sc, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!d_src || !d_dst || !omega) return dh_fail(ctx, DEHALO_ERR_INVALID, "ntt: null argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_ntt(ctx, field, (const fe*)d_src, src_len, src_stride, (fe*)d_dst, dst_stride, log_n, omega, batch, sc, pick_stream(ctx, stream));
 }
@@ -481,7 +499,7 @@ int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t
 int dehalo_convert_form_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, uint64_t* d_out, size_t n, int to_internal, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!d_in || !d_out) && n) return dh_fail(ctx, DEHALO_ERR_INVALID, "convert_form: null argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_convert_form(ctx, field, (const fe*)d_in, (fe*)d_out, n, to_internal, pick_stream(ctx, stream));
 }
@@ -492,8 +510,9 @@ static int with_host_io(dehalo_ctx* ctx, const uint64_t* in, size_t in_elems, ui
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!in || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "null buffer");
     uint64_t *d_in, *d_out;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_ntt_io, std::max<size_t>(32, in_elems * 32)));
         d_in = (uint64_t*)ctx->ws_ntt_io.p;
@@ -505,7 +524,7 @@ static int with_host_io(dehalo_ctx* ctx, const uint64_t* in, size_t in_elems, ui
         HIP_TRY(ctx, hipMemcpyAsync(d_in, in, in_elems * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     TRY(fn(ctx, d_in, d_out, arg));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipMemcpyAsync(out, d_out, out_elems * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -558,7 +577,7 @@ int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!a || !out || op < 0 || op > 6) return dh_fail(ctx, DEHALO_ERR_INVALID, "field_op: bad argument");
     if (n == 0) return 0;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     TRY(dh_ensure(ctx, ctx->ws_fop[0], n * 32));
     TRY(dh_ensure(ctx, ctx->ws_fop[1], n * 32));
@@ -578,7 +597,7 @@ int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_
     if ((!d_coeffs && len) || !point || !d_out) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: null argument");
     if (batch > 1 && stride_elems < len) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: stride shorter than the polynomial");
     if (batch >= 65536) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: batch too large");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_eval_poly(ctx, field, (const fe*)d_coeffs, len, stride_elems, batch, point, (fe*)d_out, pick_stream(ctx, stream));
 }
@@ -586,15 +605,16 @@ int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!coeffs && len) || !point || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: null argument");
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_poly_io[0], std::max<size_t>(32, len * 32)));
         TRY(dh_ensure(ctx, ctx->ws_poly_io[1], 32));
         if (len) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, coeffs, len * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     TRY(dehalo_eval_polynomial_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, len, len, 1, point, (uint64_t*)ctx->ws_poly_io[1].p, nullptr));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->ws_poly_io[1].p, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -603,7 +623,7 @@ int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, s
 int dehalo_batch_invert_device(dehalo_ctx* ctx, int field, uint64_t* d_values, size_t len, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!d_values && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "batch_invert: null argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_batch_invert(ctx, field, (fe*)d_values, len, pick_stream(ctx, stream));
 }
@@ -612,14 +632,15 @@ int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!values && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "batch_invert: null argument");
     if (len == 0) return 0;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_poly_io[0], len * 32));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, values, len * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     TRY(dehalo_batch_invert_device(ctx, field, (uint64_t*)ctx->ws_poly_io[0].p, len, nullptr));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipMemcpyAsync(values, ctx->ws_poly_io[0].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -628,7 +649,7 @@ int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len
 int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, size_t len, uint64_t* d_out, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!d_in || !d_out) && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "prefix_product: null argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_prefix_product(ctx, field, (const fe*)d_in, len, (fe*)d_out, pick_stream(ctx, stream));
 }
@@ -639,7 +660,7 @@ int dehalo_grand_product_batch_device(dehalo_ctx* ctx, int field, const uint64_t
     if ((!d_num || !d_den || !d_z) && len && batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: null argument");
     if (batch > 1 && stride_elems < len) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: stride shorter than the columns");
     if (batch >= 65536) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: batch too large");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_grand_product(ctx, field, (const fe*)d_num, (const fe*)d_den, len, batch, stride_elems, (fe*)d_z, pick_stream(ctx, stream));
 }
@@ -652,8 +673,9 @@ int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const 
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!num || !den || !z) && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: null argument");
     if (len == 0) return 0;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         for (int i = 0; i < 3; i++) TRY(dh_ensure(ctx, ctx->ws_poly_io[i], len * 32));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, num, len * 32, hipMemcpyHostToDevice, ctx->stream));
@@ -661,8 +683,52 @@ int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const 
     }
     TRY(dehalo_grand_product_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, (const uint64_t*)ctx->ws_poly_io[1].p, len,
                                     (uint64_t*)ctx->ws_poly_io[2].p, nullptr));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipMemcpyAsync(z, ctx->ws_poly_io[2].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dehalo_lincomb_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_cols, const uint64_t* coefs, size_t count, size_t len, uint64_t* d_out,
+                          const uint64_t* sub_const, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((count && (!d_cols || !coefs)) || (!d_out && len)) return dh_fail(ctx, DEHALO_ERR_INVALID, "lincomb: null argument");
+    for (size_t j = 0; j < count; j++)
+        if (!d_cols[j] && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "lincomb: null column");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_lincomb(ctx, field, (const fe* const*)d_cols, coefs, count, len, (fe*)d_out, sub_const, pick_stream(ctx, stream));
+}
+
+int dehalo_scale_device(dehalo_ctx* ctx, int field, uint64_t* d_a, size_t len, const uint64_t* pattern, uint32_t period, const uint64_t* d_factor, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_a && len) || (period && !pattern)) return dh_fail(ctx, DEHALO_ERR_INVALID, "scale: null argument");
+    if (period > 8 || (period & (period - 1))) return dh_fail(ctx, DEHALO_ERR_INVALID, "scale: period must be 0, 1, 2, 4 or 8");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_scale(ctx, field, (fe*)d_a, len, pattern, period, (const fe*)d_factor, pick_stream(ctx, stream));
+}
+
+int dehalo_kate_division_device(dehalo_ctx* ctx, int field, const uint64_t* d_a, size_t len, const uint64_t point[4], uint64_t* d_q, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (((!d_a || !d_q) && len > 1) || !point) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division: null argument");
+    if (d_a == d_q) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division: a and q may not alias");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_kate_division(ctx, field, (const fe*)d_a, len, point, (fe*)d_q, pick_stream(ctx, stream));
+}
+
+int dehalo_kate_division(dehalo_ctx* ctx, int field, const uint64_t* a, size_t len, const uint64_t point[4], uint64_t* q) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (((!a || !q) && len > 1) || !point) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division: null argument");
+    if (len <= 1) return 0;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    TRY(dh_ensure(ctx, ctx->ws_poly_io[0], len * 32));
+    TRY(dh_ensure(ctx, ctx->ws_poly_io[1], len * 32));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, a, len * 32, hipMemcpyHostToDevice, ctx->stream));
+    TRY(dehalo_kate_division_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, len, point, (uint64_t*)ctx->ws_poly_io[1].p, nullptr));
+    HIP_TRY(ctx, hipMemcpyAsync(q, ctx->ws_poly_io[1].p, (len - 1) * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -677,7 +743,7 @@ int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, cons
     if (batch > 1 && stride_elems < usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: stride shorter than the columns");
     if (batch >= 4096) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: batch too large");
     if (field < 0 || field > 3) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return lookup_permute_impl(ctx, field, (const fe*)d_inputs, (const fe*)d_tables, usable_rows, batch, stride_elems, (fe*)d_permuted_inputs,
                                (fe*)d_permuted_tables, pick_stream(ctx, stream));
@@ -693,8 +759,9 @@ int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* i
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!input || !table || !permuted_input || !permuted_table) && usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
     if (usable_rows == 0) return 0;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_poly_io[0], usable_rows * 64));
         TRY(dh_ensure(ctx, ctx->ws_poly_io[1], usable_rows * 64));
@@ -704,7 +771,7 @@ int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* i
     uint64_t* d_in = (uint64_t*)ctx->ws_poly_io[0].p;
     uint64_t* d_out = (uint64_t*)ctx->ws_poly_io[1].p;
     TRY(dehalo_permute_expression_pair_device(ctx, field, d_in, d_in + usable_rows * 4, usable_rows, d_out, d_out + usable_rows * 4, nullptr));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipMemcpyAsync(permuted_input, d_out, usable_rows * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(permuted_table, d_out + usable_rows * 4, usable_rows * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -720,7 +787,7 @@ int dehalo_graph_create(dehalo_ctx* ctx, int field, const uint64_t* constants, u
         return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_create: null argument");
     if (field < 0 || field > 3) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
     if (num_calcs > (1u << 20) || num_intermediates > (1u << 20)) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_create: program too large");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     dehalo_graph* g = new dehalo_graph();
     memset(g, 0, sizeof(*g));
@@ -746,7 +813,7 @@ int dehalo_graph_create(dehalo_ctx* ctx, int field, const uint64_t* constants, u
 
 int dehalo_graph_release(dehalo_ctx* ctx, dehalo_graph* g) {
     if (!ctx || !g) return DEHALO_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(g->d_calcs); (void)hipFree(g->d_parts); (void)hipFree(g->d_constants);
@@ -763,7 +830,7 @@ int dehalo_graph_evaluate_device(dehalo_ctx* ctx, const dehalo_graph* g, const d
         return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate: the program reads a column or challenge that was not supplied");
     if ((in->num_fixed && !in->fixed) || (in->num_advice && !in->advice) || (in->num_instance && !in->instance) || (in->num_challenges && !in->challenges))
         return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate: null column table");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_graph_evaluate(ctx, g, in, log_rows, rot_scale, (const fe*)d_previous, (fe*)d_out, pick_stream(ctx, stream));
 }
@@ -776,7 +843,7 @@ int dehalo_permutation_h_device(dehalo_ctx* ctx, int field, const dehalo_perm_in
     if ((in->num_sets && !in->z) || (in->num_columns && (!in->columns || !in->sigma))) return dh_fail(ctx, DEHALO_ERR_INVALID, "permutation_h: null column table");
     if (log_rows == 0 || log_rows > 30 || in->chunk_len == 0 || (uint64_t)in->num_sets * in->chunk_len < in->num_columns)
         return dh_fail(ctx, DEHALO_ERR_INVALID, "permutation_h: sets * chunk_len must cover the columns");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_perm_h(ctx, field, in, log_rows, rot_scale, (fe*)d_values, pick_stream(ctx, stream));
 }
@@ -788,7 +855,7 @@ int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_input
         !in->l_active_row || !in->beta || !in->gamma || !in->y)
         return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h: null argument");
     if (log_rows > 30) return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h: log_rows > 30");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_lookup_h(ctx, field, in, log_rows, rot_scale, (fe*)d_values, pick_stream(ctx, stream));
 }
@@ -796,7 +863,7 @@ int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_input
 // ---- measurement ------------------------------------------------------------------------------
 int dehalo_timing_enable(dehalo_ctx* ctx, int on) {
     if (!ctx) return DEHALO_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     ctx->timing = on != 0;
     return 0;
 }
@@ -818,7 +885,7 @@ static int timing_collect(dehalo_ctx* ctx) {
 
 int dehalo_timing_reset(dehalo_ctx* ctx) {
     if (!ctx) return DEHALO_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     TRY(timing_collect(ctx));
     for (int i = 0; i < DEHALO_K_COUNT; i++) { ctx->timing_ms[i] = 0; ctx->timing_cnt[i] = 0; }
     return 0;
@@ -826,7 +893,7 @@ int dehalo_timing_reset(dehalo_ctx* ctx) {
 
 int dehalo_timing_get(dehalo_ctx* ctx, int kernel_id, double* total_ms, uint64_t* count) {
     if (!ctx || kernel_id < 0 || kernel_id >= DEHALO_K_COUNT || !total_ms || !count) return DEHALO_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     TRY(timing_collect(ctx));
     *total_ms = ctx->timing_ms[kernel_id];
     *count = ctx->timing_cnt[kernel_id];

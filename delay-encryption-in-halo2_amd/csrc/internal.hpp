@@ -34,7 +34,7 @@ struct dehalo_ctx {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     std::string err;
-    std::mutex mu;
+    std::recursive_mutex mu;   // recursive: host-buffer entry points hold it across their device-form calls
     // workspace (grow-only)
     DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_records, ws_merge_lists, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
         ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[5], ws_poly_io[3], ws_evh[4], ws_lookup;
@@ -158,7 +158,10 @@ DECL_NTT(pasta_fq)
     int eval_poly_##NAME(dehalo_ctx* ctx, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s); \
     int batch_invert_##NAME(dehalo_ctx* ctx, fe* v, uint64_t len, hipStream_t s);                                                           \
     int prefix_product_##NAME(dehalo_ctx* ctx, const fe* in, uint64_t len, fe* out, hipStream_t s);                                         \
-    int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, size_t batch, uint64_t stride, fe* z, hipStream_t s);
+    int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, size_t batch, uint64_t stride, fe* z, hipStream_t s); \
+    int lincomb_##NAME(dehalo_ctx* ctx, const fe* const* cols, const uint64_t* coefs, size_t count, uint64_t len, fe* out, const uint64_t* sub0, hipStream_t s); \
+    int scale_##NAME(dehalo_ctx* ctx, fe* a, uint64_t len, const uint64_t* pattern, uint32_t period, const fe* d_factor, hipStream_t s);    \
+    int kate_division_##NAME(dehalo_ctx* ctx, const fe* a, uint64_t len, const uint64_t pt[4], fe* q, hipStream_t s);
 DECL_POLY(bn254_fr)
 DECL_POLY(bn254_fq)
 DECL_POLY(pasta_fp)

@@ -287,6 +287,109 @@ __global__ __launch_bounds__(POLY_THREADS) void k_pp_apply(const fe* in, u64 in_
     }
 }
 
+
+// ---- linear combination of columns ---------------------------------------------------------------
+// out[i] = sum_j coef[j] * cols[j][i]  (+ out[i] if accumulate)  -  sub0 at i = 0.
+// [UPSTREAM plonk/prover.rs + poly/kzg/multiopen/gwc/prover.rs: "poly_batch = sum_i v^i poly_i; poly_batch -=
+//  eval_batch" before kate_division, and vanishing::Constructed::evaluate's fold of the h pieces with x^n].
+// Pointers and coefficients travel as kernel arguments; the block converts the coefficients to the internal
+// form once (LDS), columns stay plain integers of their standard form: (c 2^261)(v 2^256) 2^-261 = c v 2^256.
+#define POLY_LC_MAX 40
+#define POLY_LC_EPT 4
+struct LincombArgs {
+    const fe* cols[POLY_LC_MAX];
+    fe coef[POLY_LC_MAX];
+    u32 count;
+};
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_lincomb(LincombArgs A, u64 len, fe* out, int accumulate, fe sub0, int has_sub0) {
+    typedef typename f29_of<F>::type F9;
+    __shared__ f29 cf[POLY_LC_MAX];
+    const u32 t = threadIdx.x;
+    if (t < A.count) cf[t] = f29_from_std<F9>(A.coef[t]);
+    __syncthreads();
+    const u64 i0 = (u64)blockIdx.x * (POLY_THREADS * POLY_LC_EPT) + t;
+#pragma unroll
+    for (int e = 0; e < POLY_LC_EPT; e++) {
+        const u64 i = i0 + (u64)e * POLY_THREADS;
+        if (i >= len) continue;
+        f29 acc = accumulate ? f29_unpack(f_load(&out[i])) : f29_zero();
+        for (u32 j = 0; j < A.count; j++) {
+            f29 pr = f29_mul<F9>(cf[j], f29_unpack(f_load(&A.cols[j][i])));      // < 2p
+            acc = f29_norm(f29_add(acc, pr));                                     // < (1 + 2 * 40) p  << 2^261
+        }
+        if (has_sub0 && i == 0) acc = f29_norm(f29_sub(acc, f29_unpack(sub0), F9::KM));
+        f29 r = f29_mul<F9>(acc, f29_one<F9>());                                  // value * 2^261 * 2^256 / 2^261: standard form, < 2p
+        f_store(&out[i], f29_pack(f29_cond_sub(r, F9::P)));
+    }
+}
+
+// ---- element-wise scaling --------------------------------------------------------------------------
+// a[i] *= pattern[i mod period] (period a power of two <= 8; vanishing-polynomial division on the extended
+// domain: t(X)^-1 takes 2^(extended_k - k) values [UPSTREAM poly/domain.rs divide_by_vanishing_poly]) and / or
+// *= *factor, one element read from device memory (the running value carried from one permutation product
+// column into the next [UPSTREAM plonk/permutation/prover.rs: "z = vec![last_z]"]).
+struct ScaleArgs { fe pattern[8]; u32 period; };
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_scale(fe* a, u64 len, ScaleArgs S, const fe* d_factor) {
+    typedef typename f29_of<F>::type F9;
+    const u64 i = (u64)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (i >= len) return;
+    f29 v = f29_unpack(f_load(&a[i]));                                            // plain integer of the standard form
+    if (S.period) v = f29_mul<F9>(v, f29_from_std<F9>(S.pattern[i & (S.period - 1)]));
+    if (d_factor) v = f29_mul<F9>(f29_norm(v), f29_from_std<F9>(f_load(d_factor)));
+    if (!S.period && !d_factor) return;
+    v = f29_mul<F9>(v, f29_one<F9>());   // (x 2^256 < 2p) -> canonical range below
+    f_store(&a[i], f29_pack(f29_cond_sub(v, F9::P)));
+}
+
+// ---- kate_division -----------------------------------------------------------------------------------
+// q = (a(X) - a(z)) / (X - z):  q[i] = a[i+1] + z q[i+1], q has len - 1 coefficients
+// [UPSTREAM halo2_proofs/src/arithmetic.rs kate_division: a sequential recurrence from the top coefficient].
+// Here E(i) = sum_{j >= i} a[j] z^(j-i) is a suffix scan and q[i-1] = E(i):
+//   (1) k_poly_eval gives every 2048-block's S_b = sum_j a[2048 b + j] z^j and z^2048;
+//   (2) the carries C_b = E(2048 (b+1)) are the kate division of the S sequence by z^2048 (recursion);
+//   (3) k_kate_apply: a thread's 8 coefficients, a 257-slot Hillis-Steele suffix scan in LDS (slot 256 = C_b),
+//       then Horner down the thread's coefficients, storing E(i) to q[i-1].
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_kate_apply(const fe* a, u64 len, fe point_val, const fe* point_ptr, const fe* carries, fe* q) {
+    typedef typename f29_of<F>::type F9;
+    __shared__ f29 sh[POLY_THREADS + 1];
+    const u32 t = threadIdx.x;
+    const f29 x = f29_from_std<F9>(point_ptr ? f_load(point_ptr) : point_val);
+    const u64 base = (u64)blockIdx.x * POLY_EVAL_TILE + (u64)t * POLY_EVAL_EPT;
+    f29 c[POLY_EVAL_EPT];
+    f29 acc = f29_zero();
+#pragma unroll
+    for (int j = POLY_EVAL_EPT - 1; j >= 0; j--) {
+        c[j] = base + j < len ? f29_unpack(f_load(&a[base + j])) : f29_zero();
+        acc = f29_norm(f29_add(f29_mul<F9>(acc, x), c[j]));                      // values carry the factor 2^256 (standard form as integers)
+    }
+    sh[t] = acc;
+    if (t == 0) sh[POLY_THREADS] = carries ? f29_unpack(f_load(&carries[blockIdx.x])) : f29_zero();
+    f29 X = f29_sqr<F9>(f29_sqr<F9>(f29_sqr<F9>(x)));                            // x^8
+    __syncthreads();
+    for (u32 d = 1; d <= POLY_THREADS; d <<= 1) {
+        f29 v = sh[t];
+        if (t + d <= POLY_THREADS) v = f29_norm(f29_add(v, f29_mul<F9>(sh[t + d], X)));   // grows by < 2p per level
+        __syncthreads();
+        sh[t] = v;
+        X = f29_sqr<F9>(X);
+        __syncthreads();
+    }
+    // E at the end of this thread's coefficients
+    f29 e = sh[t + 1];
+#pragma unroll
+    for (int j = POLY_EVAL_EPT - 1; j >= 0; j--) {
+        e = f29_norm(f29_add(f29_mul<F9>(e, x), c[j]));                            // E(base + j)
+        const u64 i = base + j;
+        if (i >= 1 && i < len) {
+            f29 r = f29_mul<F9>(e, f29_one<F9>());
+            f_store(&q[i - 1], f29_pack(f29_cond_sub(r, F9::P)));
+        }
+    }
+}
+
 // ==========================================================================================
 // host drivers (instantiated once per field next to the NTT in ntt_<field>.hip)
 // ==========================================================================================
@@ -380,6 +483,68 @@ int grand_product_t(dehalo_ctx* ctx, const fe* d_num, const fe* d_den, uint64_t 
     return prefix_product_t<F>(ctx, inv, len, d_num, stride, len, batch, d_z, stride, s);
 }
 
+
+template <class F>
+int lincomb_t(dehalo_ctx* ctx, const fe* const* d_cols, const uint64_t* coefs, size_t count, uint64_t len, fe* d_out, const uint64_t* sub0, hipStream_t s) {
+    if (len == 0) return 0;
+    ScopedTimer timer(ctx, s, DEHALO_K_POLY);
+    const u32 grid = (u32)((len + POLY_THREADS * POLY_LC_EPT - 1) / (POLY_THREADS * POLY_LC_EPT));
+    if (count == 0) HIP_TRY(ctx, hipMemsetAsync(d_out, 0, len * sizeof(fe), s));
+    fe s0 = sub0 ? fe_from_u64(sub0) : fe{};
+    for (size_t first = 0; first < count || (first == 0 && sub0); first += POLY_LC_MAX) {
+        LincombArgs A;
+        A.count = (u32)std::min<size_t>(POLY_LC_MAX, count - first);
+        for (u32 j = 0; j < A.count; j++) { A.cols[j] = d_cols[first + j]; A.coef[j] = fe_from_u64(coefs + 4 * (first + j)); }
+        const bool last = first + POLY_LC_MAX >= count;
+        k_lincomb<F><<<grid, POLY_THREADS, 0, s>>>(A, len, d_out, first != 0 || count == 0, s0, sub0 && last ? 1 : 0);
+        if (count == 0) break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class F>
+int scale_t(dehalo_ctx* ctx, fe* d_a, uint64_t len, const uint64_t* pattern, uint32_t period, const fe* d_factor, hipStream_t s) {
+    if (len == 0 || (!period && !d_factor)) return 0;
+    ScopedTimer timer(ctx, s, DEHALO_K_POLY);
+    ScaleArgs S{};
+    S.period = period;
+    for (uint32_t i = 0; i < period; i++) S.pattern[i] = fe_from_u64(pattern + 4 * i);
+    k_scale<F><<<(u32)((len + POLY_THREADS - 1) / POLY_THREADS), POLY_THREADS, 0, s>>>(d_a, len, S, d_factor);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// level of the kate recursion: a (len coefficients, standard form) / (X - point) -> q (len - 1); scratch holds the
+// block sums and carries of every level: [S: nb][C: nb][point: 1] then the next level
+template <class F>
+int kate_level(dehalo_ctx* ctx, const fe* d_a, uint64_t len, fe point_val, const fe* point_ptr, fe* d_q, fe* scratch, hipStream_t s) {
+    const uint64_t nb = (len + POLY_EVAL_TILE - 1) / POLY_EVAL_TILE;
+    if (nb == 1) {
+        k_kate_apply<F><<<1, POLY_THREADS, 0, s>>>(d_a, len, point_val, point_ptr, nullptr, d_q);
+        return 0;
+    }
+    fe* S = scratch;
+    fe* C = scratch + nb;
+    fe* next_pt = scratch + 2 * nb;
+    k_poly_eval<F><<<dim3((u32)nb, 1), POLY_THREADS, 0, s>>>(d_a, len, len, point_val, point_ptr, S, nb, next_pt);
+    HIP_TRY(ctx, hipMemsetAsync(C, 0, nb * sizeof(fe), s));                        // C[nb - 1] = 0: nothing above the last block
+    TRY((kate_level<F>(ctx, S, nb, fe{}, next_pt, C, scratch + 2 * nb + 8, s)));   // C[b] = E_S(b + 1), b < nb - 1
+    k_kate_apply<F><<<(u32)nb, POLY_THREADS, 0, s>>>(d_a, len, point_val, point_ptr, C, d_q);
+    return 0;
+}
+
+template <class F>
+int kate_division_t(dehalo_ctx* ctx, const fe* d_a, uint64_t len, const uint64_t point[4], fe* d_q, hipStream_t s) {
+    if (len <= 1) return 0;
+    ScopedTimer timer(ctx, s, DEHALO_K_POLY);
+    const uint64_t nb = (len + POLY_EVAL_TILE - 1) / POLY_EVAL_TILE;
+    TRY(dh_ensure(ctx, ctx->ws_poly[0], (2 * nb + 8) * 2 * sizeof(fe) + 4096));
+    TRY((kate_level<F>(ctx, d_a, len, fe_from_u64(point), nullptr, d_q, (fe*)ctx->ws_poly[0].p, s)));
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 #define DEFINE_POLY_ENTRY(NAME, F)                                                                                                              \
     int eval_poly_##NAME(dehalo_ctx* ctx, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s) { \
         return eval_poly_t<F>(ctx, c, len, stride, batch, pt, out, s); }                                                                         \
@@ -387,4 +552,10 @@ int grand_product_t(dehalo_ctx* ctx, const fe* d_num, const fe* d_den, uint64_t 
     int prefix_product_##NAME(dehalo_ctx* ctx, const fe* in, uint64_t len, fe* out, hipStream_t s) {                                             \
         return prefix_product_t<F>(ctx, in, len, nullptr, 0, len, 1, out, len, s); }                                                             \
     int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, size_t batch, uint64_t stride, fe* z, hipStream_t s) { \
-        return grand_product_t<F>(ctx, num, den, len, batch, stride, z, s); }
+        return grand_product_t<F>(ctx, num, den, len, batch, stride, z, s); }                                                                   \
+    int lincomb_##NAME(dehalo_ctx* ctx, const fe* const* cols, const uint64_t* coefs, size_t count, uint64_t len, fe* out, const uint64_t* sub0, hipStream_t s) { \
+        return lincomb_t<F>(ctx, cols, coefs, count, len, out, sub0, s); }                                                                       \
+    int scale_##NAME(dehalo_ctx* ctx, fe* a, uint64_t len, const uint64_t* pattern, uint32_t period, const fe* d_factor, hipStream_t s) {        \
+        return scale_t<F>(ctx, a, len, pattern, period, d_factor, s); }                                                                          \
+    int kate_division_##NAME(dehalo_ctx* ctx, const fe* a, uint64_t len, const uint64_t pt[4], fe* q, hipStream_t s) {                           \
+        return kate_division_t<F>(ctx, a, len, pt, q, s); }

@@ -16,7 +16,7 @@ class FieldSpec:
     id: int          # dehalo_field
     p: int
     gen: int         # multiplicative generator (halo2curves MULTIPLICATIVE_GENERATOR)
-    zeta_pow: int    # ZETA = (gen^((p-1)/3))^zeta_pow  [UPSTREAM constant, SURVEY.md A.3]
+    zeta: int        # F::ZETA, the literal constant of halo2curves / pasta_curves [UPSTREAM; SURVEY.md A.3]: a primitive cube root of unity
 
     @property
     def two_adicity(self) -> int:
@@ -29,10 +29,6 @@ class FieldSpec:
     @property
     def root_of_unity(self) -> int:
         return pow(self.gen, (self.p - 1) >> self.two_adicity, self.p)
-
-    @property
-    def zeta(self) -> int:
-        return pow(pow(self.gen, (self.p - 1) // 3, self.p), self.zeta_pow, self.p)
 
     # halo2curves in-memory form: 4 x u64 LE limbs of a * 2^256 mod p
     def encode(self, a: int) -> np.ndarray:
@@ -50,10 +46,14 @@ class FieldSpec:
         return [self.decode(r) for r in np.asarray(arr).reshape(-1, 4)]
 
 
-BN254_FR = FieldSpec("bn254_fr", 0, 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 7, 2)
-BN254_FQ = FieldSpec("bn254_fq", 1, 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47, 3, 2)
-PASTA_FP = FieldSpec("pasta_fp", 2, 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001, 5, 2)
-PASTA_FQ = FieldSpec("pasta_fq", 3, 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001, 5, 1)
+BN254_FR = FieldSpec("bn254_fr", 0, 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 7,
+                     0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD)
+BN254_FQ = FieldSpec("bn254_fq", 1, 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47, 3,
+                     0x30644E72E131A0295E6DD9E7E0ACCCB0C28F069FBB966E3DE4BD44E5607CFD48)
+PASTA_FP = FieldSpec("pasta_fp", 2, 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001, 5,
+                     0x12CCCA834ACDBA712CAAD5DC57AAB1B01D1F8BD237AD31491DAD5EBDFDFE4AB9)
+PASTA_FQ = FieldSpec("pasta_fq", 3, 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001, 5,
+                     0x06819A58283E528E511DB4D81CF70F5A0FED467D47C033AF2AA9D2E050AA0E4F)
 FIELDS = {f.name: f for f in (BN254_FR, BN254_FQ, PASTA_FP, PASTA_FQ)}
 
 

@@ -187,6 +187,23 @@ int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_nu
 int dehalo_grand_product_batch_device(dehalo_ctx* ctx, int field, const uint64_t* d_num, const uint64_t* d_den, size_t len, size_t batch,
                                       size_t stride_elems, uint64_t* d_z, void* stream);
 
+/* ---- the remaining element-wise steps of create_proof (so that a proof's columns never leave HBM) ----------
+ * dehalo_lincomb_device: out[i] = sum_j coefs[j] * cols[j][i]; sub_const (may be NULL) is subtracted from out[0].
+ *   d_cols = HOST array of `count` DEVICE column pointers (len elements each), coefs = host, count x 4 u64.
+ *   Replaces the polynomial folds of plonk/prover.rs / vanishing::Constructed::evaluate (h pieces with x^n) and
+ *   poly/kzg/multiopen/gwc/prover.rs ("poly_batch = sum v^i poly_i; poly_batch - eval_batch").  out may alias no column.
+ * dehalo_scale_device: a[i] *= pattern[i mod period] (host pattern, period in {0 (none), 1, 2, 4, 8}) and, if
+ *   d_factor != NULL, *= *d_factor (one element in DEVICE memory).  Replaces EvaluationDomain::divide_by_vanishing_poly
+ *   (poly/domain.rs: t_evaluations has 2^(extended_k - k) entries) and the "z = vec![last_z]" carry between the
+ *   permutation argument's product columns (plonk/permutation/prover.rs).
+ * dehalo_kate_division: q = (a(X) - a(point)) / (X - point), len - 1 coefficients; replaces
+ *   halo2_proofs::arithmetic::kate_division (called once per opening point by ProverGWC::create_proof).          */
+int dehalo_lincomb_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_cols, const uint64_t* coefs, size_t count, size_t len, uint64_t* d_out,
+                          const uint64_t* sub_const, void* stream);
+int dehalo_scale_device(dehalo_ctx* ctx, int field, uint64_t* d_a, size_t len, const uint64_t* pattern, uint32_t period, const uint64_t* d_factor, void* stream);
+int dehalo_kate_division(dehalo_ctx* ctx, int field, const uint64_t* a, size_t len, const uint64_t point[4], uint64_t* q);
+int dehalo_kate_division_device(dehalo_ctx* ctx, int field, const uint64_t* d_a, size_t len, const uint64_t point[4], uint64_t* d_q, void* stream);
+
 /* ---- quotient numerator: evaluate_h --------------------------------------
  * The row loops of halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20 on device-resident
  * extended-domain columns (each `rows = 1 << log_rows` elements, standard Montgomery form), so the

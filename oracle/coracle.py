@@ -42,6 +42,11 @@ def lib():
         _LIB.orc_eval_polynomial.argtypes = [C.c_int, P, C.c_size_t, P, C.c_int, P]
         _LIB.orc_batch_invert.argtypes = [C.c_int, P, C.c_size_t]
         _LIB.orc_grand_product.argtypes = [C.c_int, P, P, C.c_size_t, P]
+        _LIB.orc_kate_division.argtypes = [C.c_int, P, C.c_size_t, P, P]
+        _LIB.orc_lincomb.argtypes = [C.c_int, P, P, C.c_size_t, C.c_size_t, P, P]
+        _LIB.orc_scale_periodic.argtypes = [C.c_int, P, C.c_size_t, P, C.c_size_t]
+        _LIB.orc_fixed_base_mul.argtypes = [C.c_int, P, C.c_size_t, C.c_int, P]
+        _LIB.orc_powers.argtypes = [C.c_int, P, P, C.c_size_t, P]
     return _LIB
 
 
@@ -214,3 +219,41 @@ def permute_expression_pair(field: int, input_values, table_values, usable_rows:
     rc = lib().orc_permute_expression_pair(field, _p(a), _p(t), usable_rows, _p(pi), _p(pt))
     assert rc in (0, 1)
     return None if rc else (pi, pt)
+
+
+# ---- round 2: element-wise steps of create_proof, SRS generation ----
+def kate_division(field: int, a: np.ndarray, point: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    q = np.zeros((a.shape[0] - 1, 4), dtype=np.uint64)
+    assert lib().orc_kate_division(field, _p(a), a.shape[0], _p(np.ascontiguousarray(point, dtype=np.uint64)), _p(q) if q.shape[0] else None) == 0
+    return q
+
+
+def lincomb(field: int, cols, coefs, sub0=None) -> np.ndarray:
+    keep, tbl = _cols(cols)
+    cf = np.ascontiguousarray(coefs, dtype=np.uint64).reshape(-1, 4)
+    assert cf.shape[0] == len(keep) and len(keep) > 0
+    out = np.zeros_like(keep[0])
+    sp = _p(np.ascontiguousarray(sub0, dtype=np.uint64).reshape(4)) if sub0 is not None else None
+    assert lib().orc_lincomb(field, tbl, _p(cf), len(keep), out.shape[0], _p(out), sp) == 0
+    return out
+
+
+def scale_periodic(field: int, a, pattern) -> np.ndarray:
+    a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+    pat = np.ascontiguousarray(pattern, dtype=np.uint64).reshape(-1, 4)
+    assert lib().orc_scale_periodic(field, _p(a), a.shape[0], _p(pat), pat.shape[0]) == 0
+    return a
+
+
+def fixed_base_mul(curve: int, scalars, threads: int = 1) -> np.ndarray:
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((s.shape[0], 8), dtype=np.uint64)
+    assert lib().orc_fixed_base_mul(curve, _p(s), s.shape[0], threads, _p(out)) == 0
+    return out
+
+
+def powers(field: int, base, first, n: int) -> np.ndarray:
+    out = np.zeros((n, 4), dtype=np.uint64)
+    assert lib().orc_powers(field, _p(np.ascontiguousarray(base, dtype=np.uint64).reshape(4)), _p(np.ascontiguousarray(first, dtype=np.uint64).reshape(4)), n, _p(out)) == 0
+    return out

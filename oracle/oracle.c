@@ -851,3 +851,94 @@ int orc_synth_bases(int curve, size_t n, u64* out_xy) {
     free(js); free(pre);
     return 0;
 }
+
+/* ---------- round 2: the element-wise steps of create_proof + SRS generation (test infrastructure) ---------- */
+/* kate_division: [UPSTREAM halo2_proofs/src/arithmetic.rs kate_division] q = (a(X) - a(b)) / (X - b), len - 1 coefficients:
+ * "for (q, r) in q.iter_mut().rev().zip(a.rev()) { lead = r - tmp; *q = lead; tmp = lead * (-b) }". */
+int orc_kate_division(int field, const u64* a_, size_t n, const u64 point[4], u64* q_) {
+    if (field < 0 || field > 3 || n == 0) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    const fe* a = (const fe*)a_; fe* q = (fe*)q_;
+    fe nb, tmp; f_neg(F, &nb, (const fe*)point); memset(&tmp, 0, sizeof(tmp));
+    for (size_t i = n - 1; i >= 1; i--) {            /* q[i-1] pairs with a[i] */
+        fe lead; f_sub(F, &lead, &a[i], &tmp);
+        q[i - 1] = lead;
+        f_mul(F, &tmp, &lead, &nb);
+    }
+    return 0;
+}
+/* out[i] = sum_j coef[j] cols[j][i]; sub0 (may be NULL) subtracted from out[0]: the polynomial folds of
+ * [UPSTREAM plonk/vanishing/prover.rs Constructed::evaluate, poly/kzg/multiopen/gwc/prover.rs]. */
+int orc_lincomb(int field, const u64* const* cols, const u64* coefs, size_t count, size_t n, u64* out_, const u64* sub0) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    fe* out = (fe*)out_;
+    memset(out, 0, n * sizeof(fe));
+    for (size_t j = 0; j < count; j++) {
+        const fe* c = (const fe*)cols[j]; const fe* k = (const fe*)(coefs + 4 * j);
+        for (size_t i = 0; i < n; i++) { fe t; f_mul(F, &t, &c[i], k); f_add(F, &out[i], &out[i], &t); }
+    }
+    if (sub0 && n) f_sub(F, &out[0], &out[0], (const fe*)sub0);
+    return 0;
+}
+/* a[i] *= pattern[i % period] ([UPSTREAM poly/domain.rs divide_by_vanishing_poly: "*h *= t_evaluations[index % len]"]) */
+int orc_scale_periodic(int field, u64* a_, size_t n, const u64* pattern, size_t period) {
+    if (field < 0 || field > 3 || period == 0) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    fe* a = (fe*)a_;
+    for (size_t i = 0; i < n; i++) f_mul(F, &a[i], &a[i], (const fe*)(pattern + 4 * (i % period)));
+    return 0;
+}
+/* out[i] = [scalars[i]] G (affine), G the curve's generator: ParamsKZG::setup's g = [s^i]G and g_lagrange = [L_i(s)]G
+ * ([UPSTREAM poly/kzg/commitment.rs setup]: both are fixed-base multiplications once the scalars are known).  8-bit
+ * windows over a 32 x 255 table, threads split the outputs. */
+typedef struct { const curve_t* C; const field_t* FS; const aff* table; const fe* scalars; aff* out; size_t lo, hi; } fbm_job;
+static void* fbm_worker(void* arg) {
+    fbm_job* j = arg;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        u64 t[4]; f_from_mont(j->FS, t, &j->scalars[i]);
+        const unsigned char* b = (const unsigned char*)t;
+        jac acc; jac_set_id(&acc);
+        for (int w = 0; w < 32; w++) if (b[w]) jac_add_mixed(j->C, &acc, &acc, &j->table[w * 255 + b[w] - 1]);
+        jac_to_affine(j->C, &j->out[i], &acc);
+    }
+    return NULL;
+}
+int orc_fixed_base_mul(int curve, const u64* scalars, size_t n, int threads, u64* out_xy) {
+    if (curve < 0 || curve > 2) return -1;
+    init_curves();
+    const curve_t* C = &CURVES[curve];
+    aff* table = malloc(32 * 255 * sizeof(aff));
+    jac base; base.x = C->g.x; base.y = C->g.y; base.z = C->F->r;
+    for (int w = 0; w < 32; w++) {
+        jac cur = base;
+        for (int d = 1; d <= 255; d++) {
+            jac_to_affine(C, &table[w * 255 + d - 1], &cur);
+            jac nx; jac_add(C, &nx, &cur, &base); cur = nx;
+        }
+        base = cur;                                   /* 256 * base */
+    }
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    fbm_job jobs[256]; pthread_t th[256];
+    size_t chunk = (n + threads - 1) / threads; int used = 0;
+    for (size_t lo = 0; lo < n; lo += chunk, used++) {
+        jobs[used] = (fbm_job){C, scalar_field_of(curve), table, (const fe*)scalars, (aff*)out_xy, lo, lo + chunk < n ? lo + chunk : n};
+        pthread_create(&th[used], NULL, fbm_worker, &jobs[used]);
+    }
+    for (int i = 0; i < used; i++) pthread_join(th[i], NULL);
+    free(table);
+    return 0;
+}
+/* out[i] = base^i * first (a column of powers: s^i, omega^i), serial like upstream's setup loop */
+int orc_powers(int field, const u64 base[4], const u64 first[4], size_t n, u64* out_) {
+    if (field < 0 || field > 3) return -1;
+    init_fields();
+    const field_t* F = &FIELDS[field];
+    fe* out = (fe*)out_; fe cur = *(const fe*)first;
+    for (size_t i = 0; i < n; i++) { out[i] = cur; f_mul(F, &cur, &cur, (const fe*)base); }
+    return 0;
+}

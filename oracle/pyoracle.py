@@ -116,17 +116,18 @@ FIELDS = {f.name: f for f in (BN254_FR, BN254_FQ, PASTA_FP, PASTA_FQ)}
 FIELD_IDS = {"bn254_fr": 0, "bn254_fq": 1, "pasta_fp": 2, "pasta_fq": 3}
 
 
-def zeta(field: Field) -> int:
-    """F::ZETA as upstream defines it [UPSTREAM, from memory; SURVEY.md A.3 risk].
+ZETA = {   # F::ZETA literals of halo2curves (bn256) / pasta_curves [UPSTREAM, from memory; SURVEY.md A.3 risk]
+    "bn254_fr": 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD,
+    "bn254_fq": 0x30644E72E131A0295E6DD9E7E0ACCCB0C28F069FBB966E3DE4BD44E5607CFD48,
+    "pasta_fp": 0x12CCCA834ACDBA712CAAD5DC57AAB1B01D1F8BD237AD31491DAD5EBDFDFE4AB9,
+    "pasta_fq": 0x06819A58283E528E511DB4D81CF70F5A0FED467D47C033AF2AA9D2E050AA0E4F,
+}
 
-    pasta::Fp and bn256::Fr use (g^((p-1)/3))^2; pasta::Fq uses g^((p-1)/3).
-    zeta is always a caller-supplied argument at the C-ABI, so this choice only
-    affects the host mirror's default.
-    """
-    c = field.cube_root
-    if field.name == "pasta_fq":
-        return c
-    return c * c % field.p
+
+def zeta(field: Field) -> int:
+    """F::ZETA as upstream defines it: a literal per field (a primitive cube root of unity).  zeta is always a
+    caller-supplied argument at the C-ABI, so the choice only affects the host mirror's default."""
+    return ZETA[field.name]
 
 
 def limbs64(a: int) -> List[int]:

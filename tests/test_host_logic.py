@@ -8,8 +8,7 @@ def test_field_specs_match_oracle_constants(pkg, po):
         f = po.FIELDS[name]
         assert spec.p == f.p and spec.id == po.FIELD_IDS[name]
         assert spec.two_adicity == f.S and spec.root_of_unity == f.root_of_unity
-        if (f.p - 1) % 3 == 0 and name != "bn254_fq":
-            assert spec.zeta == po.zeta(f)
+        assert spec.zeta == po.zeta(f)
         for x in (0, 1, f.p - 1, 12345678901234567890):
             assert po.from_limbs64(spec.encode(x)) == f.to_mont(x)
             assert spec.decode(spec.encode(x)) == x % f.p
@@ -18,11 +17,18 @@ def test_field_specs_match_oracle_constants(pkg, po):
         assert c.id == po.CURVE_IDS[name] and c.base.p == oc.base.p and c.scalar.p == oc.scalar.p and c.b == oc.b
 
 
-def test_upstream_zeta_prefixes(pkg):
-    # upstream ZETA(pasta::Fp) = 0x12ccca83..., ZETA(bn256::Fr) = 0x30644e72...6f23
-    assert hex(pkg.fields.PASTA_FP.zeta).startswith("0x12ccca83") and hex(pkg.fields.PASTA_FP.zeta).endswith("4ab9")
-    assert hex(pkg.fields.BN254_FR.zeta).startswith("0x30644e72") and hex(pkg.fields.BN254_FR.zeta).endswith("6f23")
-    assert hex(pkg.fields.PASTA_FQ.zeta).startswith("0x6819a58")
+def test_upstream_zeta_literals(pkg):
+    """F::ZETA pinned as the literal constants of halo2curves' bn256::{Fr,Fq} and pasta_curves' Fp / Fq [UPSTREAM; ADVICE r1]:
+    bn256::Fr::ZETA is the 192-bit root 0xb3c4d79d...90dd (= 7^((r-1)/3)), not its square."""
+    F = pkg.fields
+    want = {"bn254_fr": 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD,
+            "bn254_fq": 0x30644E72E131A0295E6DD9E7E0ACCCB0C28F069FBB966E3DE4BD44E5607CFD48,
+            "pasta_fp": 0x12CCCA834ACDBA712CAAD5DC57AAB1B01D1F8BD237AD31491DAD5EBDFDFE4AB9,
+            "pasta_fq": 0x06819A58283E528E511DB4D81CF70F5A0FED467D47C033AF2AA9D2E050AA0E4F}
+    for name, z in want.items():
+        f = F.FIELDS[name]
+        assert f.zeta == z and z != 1 and pow(z, 3, f.p) == 1
+    assert F.BN254_FR.zeta == pow(7, (F.BN254_FR.p - 1) // 3, F.BN254_FR.p)
 
 
 @pytest.mark.parametrize("fname,j,k", [("bn254_fr", 5, 17), ("bn254_fr", 3, 11), ("pasta_fp", 5, 14), ("pasta_fq", 4, 6)])
