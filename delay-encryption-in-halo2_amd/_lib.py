@@ -12,12 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SYMBOLS = [
-    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize",
+    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_ctx_stream",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len",
     "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
-    "dehalo_field_op", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
+    "dehalo_field_op", "dehalo_field_op_device", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device",
@@ -89,6 +89,8 @@ def load_library():
     lib.dehalo_ctx_destroy.argtypes = [P]
     lib.dehalo_ctx_destroy.restype = None
     lib.dehalo_ctx_synchronize.argtypes = [P]
+    lib.dehalo_ctx_stream.argtypes = [P]
+    lib.dehalo_ctx_stream.restype = C.c_void_p
     lib.dehalo_bases_register.argtypes = [P, C.c_int, u64p, sz, sz, C.c_int, C.c_int, C.POINTER(P)]
     lib.dehalo_bases_release.argtypes = [P, P]
     lib.dehalo_bases_len.argtypes = [P]
@@ -109,6 +111,7 @@ def load_library():
     lib.dehalo_coset_ntt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p, sz, P]
     lib.dehalo_coset_intt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p, sz, P]
     lib.dehalo_field_op.argtypes = [P, C.c_int, C.c_int, u64p, u64p, u64p, sz]
+    lib.dehalo_field_op_device.argtypes = [P, C.c_int, C.c_int, u64p, u64p, u64p, sz, P]
     lib.dehalo_eval_polynomial.argtypes = [P, C.c_int, u64p, sz, u64p, u64p]
     lib.dehalo_eval_polynomial_device.argtypes = [P, C.c_int, u64p, sz, sz, sz, u64p, u64p, P]
     lib.dehalo_batch_invert.argtypes = [P, C.c_int, u64p, sz]
@@ -190,6 +193,16 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.dehalo_ctx_synchronize(self.handle))
+
+    def torch_stream(self):
+        """The context's stream as a torch stream: `with torch.cuda.stream(ctx.torch_stream()):` puts torch's own copies and
+        fills on the stream the library's kernels run on, so they are ordered with them (the context's stream is
+        non-blocking: nothing orders it with torch's default stream)."""
+        import torch
+
+        if getattr(self, "_tstream", None) is None:
+            self._tstream = torch.cuda.ExternalStream(self.lib.dehalo_ctx_stream(self.handle))
+        return torch.cuda.stream(self._tstream)
 
     # ---- bases / MSM ----
     def register_bases(self, curve: int, affine_xy, window_bits: int = 0, precompute: bool = True) -> Bases:
@@ -303,6 +316,9 @@ class Context:
         bp = _ptr(_u64(b, 4)) if b is not None else None
         self._check(self.lib.dehalo_field_op(self.handle, field, self.OPS[op], _ptr(a), bp, _ptr(out), a.shape[0]))
         return out
+
+    def field_op_device(self, field: int, op: str, d_a: int, d_b: int, d_out: int, n: int, stream: int = 0):
+        self._check(self.lib.dehalo_field_op_device(self.handle, field, self.OPS[op], d_a, d_b or None, d_out, n, stream or None))
 
     # ---- field-vector primitives around the path ----
     def eval_polynomial(self, field: int, coeffs, point) -> np.ndarray:

@@ -323,6 +323,8 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
 
 const char* dehalo_last_error(const dehalo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+void* dehalo_ctx_stream(dehalo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 int dehalo_ctx_synchronize(dehalo_ctx* ctx) {
     if (!ctx) return DEHALO_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -588,6 +590,15 @@ int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->ws_fop[2].p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+int dehalo_field_op_device(dehalo_ctx* ctx, int field, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (((!d_a || !d_out) && n) || op < 0 || op > 6) return dh_fail(ctx, DEHALO_ERR_INVALID, "field_op: bad argument");
+    if (n == 0) return 0;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_field_op(ctx, field, op, (const fe*)d_a, (const fe*)d_b, (fe*)d_out, n, pick_stream(ctx, stream));
 }
 
 // ---- field-vector primitives (poly.cuh) ---------------------------------------------------------

@@ -337,10 +337,9 @@ __global__ __launch_bounds__(POLY_THREADS) void k_scale(fe* a, u64 len, ScaleArg
     if (i >= len) return;
     f29 v = f29_unpack(f_load(&a[i]));                                            // plain integer of the standard form
     if (S.period) v = f29_mul<F9>(v, f29_from_std<F9>(S.pattern[i & (S.period - 1)]));
-    if (d_factor) v = f29_mul<F9>(f29_norm(v), f29_from_std<F9>(f_load(d_factor)));
+    if (d_factor) v = f29_mul<F9>(v, f29_from_std<F9>(f_load(d_factor)));
     if (!S.period && !d_factor) return;
-    v = f29_mul<F9>(v, f29_one<F9>());   // (x 2^256 < 2p) -> canonical range below
-    f_store(&a[i], f29_pack(f29_cond_sub(v, F9::P)));
+    f_store(&a[i], f29_pack(f29_cond_sub(v, F9::P)));                            // a product is < 2p; the element keeps its form (the map is linear)
 }
 
 // ---- kate_division -----------------------------------------------------------------------------------

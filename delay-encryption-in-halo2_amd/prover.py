@@ -1,0 +1,412 @@
+"""`create_proof` -- the data flow of halo2_proofs::plonk::create_proof over KZG / GWC
+[UPSTREAM halo2_proofs/src/plonk/prover.rs, plonk/{lookup,permutation,vanishing}/prover.rs,
+poly/kzg/multiopen/gwc/prover.rs @ v2023_04_20], the call the reference times at benches/delay_enc.rs:123-131
+(mod_pow.rs:201-209, pose_enc.rs:127-135): every column lives in HBM from the witness upload to the last
+opening; the host only hashes the transcript and orders the phases.
+
+Given the witness (advice columns), what is committed is what was computed:
+  advice + blinding rows -> commit -> theta -> theta-compressed lookup expressions -> permute_expression_pair ->
+  commit a', s' -> beta, gamma -> permutation and lookup grand products -> commit z -> random polynomial -> y ->
+  lagrange_to_coeff, coeff_to_extended, evaluate_h, division by the vanishing polynomial, extended_to_coeff,
+  split -> commit h pieces -> x -> evaluations -> v -> per opening point: sum v^i poly_i, kate_division, commit.
+Witness generation (Circuit::synthesize) is the caller's: advice arrives as columns.
+
+Field values are canonical ints on the host side of this file and 4 x u64 Montgomery limbs on the device.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field as dc_field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import evaluation as ev
+from . import plonk
+from .keygen import ParamsKZG, ProvingKey, array_to_ints, decode_points, delta_of, omega_powers_device, to_device, to_host
+from .transcript import Blake2bWrite
+
+
+class SeededRng:
+    """Source of the prover's random scalars (blinding rows, blinds, the vanishing argument's random polynomial).
+    Upstream draws them from the caller's RngCore (benches/delay_enc.rs:128 passes OsRng) one by one, in program
+    order; this one is deterministic so that a proof is reproducible: elements are raw 253-bit values taken as
+    Montgomery representations (every 253-bit integer is below the four moduli)."""
+
+    def __init__(self, seed: int):
+        self.gen = np.random.Generator(np.random.PCG64(seed))
+
+    def scalars(self, count: int) -> np.ndarray:
+        a = self.gen.integers(0, 1 << 64, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 61) - 1)
+        return a
+
+
+@dataclass
+class ProofTimings:
+    phases_ms: Dict[str, float] = dc_field(default_factory=dict)
+    total_ms: float = 0.0
+
+
+def rotate_omega(domain, x: int, rot: int) -> int:
+    p = domain.field.p
+    return x * pow(domain.omega if rot >= 0 else domain.omega_inv, abs(rot), p) % p
+
+
+class Prover:
+    """Owns the device buffers of one proof for a given proving key (allocated once, reused by every create_proof)."""
+
+    def __init__(self, params: ParamsKZG, pk: ProvingKey):
+        with pk.ctx.torch_stream():        # torch's copies and fills go on the context's stream, ordered with the kernels
+            self._init(params, pk)
+
+    def _init(self, params: ParamsKZG, pk: ProvingKey):
+        import torch
+
+        self.torch = torch
+        self.params, self.pk, self.ctx = params, pk, pk.ctx
+        self.cs, self.domain, self.curve = pk.vk.cs, pk.domain, pk.vk.curve
+        self.f = self.curve.scalar
+        cs, d = self.cs, self.domain
+        self.n, self.m, self.k, self.ek = d.n, d.extended_len(), d.k, d.extended_k
+        self.bf = cs.blinding_factors()
+        self.u = self.n - (self.bf + 1)                         # usable rows
+        self.A, self.L, self.S = cs.num_advice, len(cs.lookups), cs.num_permutation_sets()
+        self.I = cs.num_instance
+        A, L, S, n, m = self.A, self.L, self.S, self.n, self.m
+        z = lambda *shape: torch.zeros(shape, dtype=torch.int64, device="cuda")
+        # committed columns, one contiguous block: [advice | permuted (input_0, table_0, input_1, ...) | perm z | lookup z | random]
+        self.NC = A + 2 * L + S + L + 1
+        self.cols = z(self.NC, n, 4)
+        self.o_adv, self.o_perm, self.o_pz, self.o_lz, self.o_rand = 0, A, A + 2 * L, A + 2 * L + S, A + 2 * L + S + L
+        self.instance = z(max(self.I, 1), n, 4)
+        self.compressed = z(max(2 * L, 1), n, 4)                # theta-compressed (input_l, table_l)
+        self.num = z(S + L, n, 4)
+        self.den = z(S + L, n, 4)
+        self.ext = z(self.NC - 1 + self.I, m, 4)                # cosets of every committed column but the random one, then the instance columns
+        self.h = z(m, 4)
+        self.table_value = z(m, 4)
+        self.hfold = z(n, 4)
+        self.qbuf = z(4, n, 4)                                  # per opening point: the batched polynomial
+        self.wbuf = z(8, n, 4)                                  # ... and its quotient (last coefficient zero)
+        self.jac = z(max(self.NC, 8), 12)
+        self.aff = z(max(self.NC, 8), 8)
+        self.evals = z(64 + 4 * (self.NC + cs.num_fixed + len(cs.permutation_columns)), 4)
+        self.omega_col = omega_powers_device(self.ctx, d)
+        e = self.f.encode
+        self._c = dict(omega_inv=e(d.omega_inv), ifft=e(d.ifft_divisor), ext_omega=e(d.extended_omega), ext_omega_inv=e(d.extended_omega_inv),
+                       ext_ifft=e(d.extended_ifft_divisor), zeta=e(d.g_coset))
+        # t(X)^-1 on the coset: 2^(extended_k - k) values (EvaluationDomain::new)
+        p = self.f.p
+        orig, step = pow(d.g_coset, n, p), pow(d.extended_omega, n, p)
+        self.t_inv = self.f.encode_many([pow((orig * pow(step, i, p) - 1) % p, -1, p) for i in range(1 << (self.ek - self.k))])
+        # permutation product programs: per set, denominator prod(col + beta sigma + gamma) and numerator prod(col + delta^j beta omega^i + gamma)
+        self.perm_graphs = self._permutation_graphs()
+        self.lookup_product_graphs = self._lookup_product_graphs()
+        self.ctx.synchronize()
+
+    # ---- programs for the grand products (run over the n rows of the original domain) ----
+    def _permutation_graphs(self):
+        """advice slots: the circuit's advice columns; fixed slots: [circuit fixed..., sigma_0.., omega column]; instance: instance columns;
+        challenges: delta^j * beta per permutation column."""
+        cs, p, out = self.cs, self.f.p, []
+        chunk = cs.permutation_chunk_len()
+        nf, npc = cs.num_fixed, len(cs.permutation_columns)
+        kind = {plonk.ADVICE: ev.ADVICE, plonk.FIXED: ev.FIXED, plonk.INSTANCE: ev.INSTANCE}
+        for s in range(self.S):
+            gd, gn = ev.GraphEvaluator(), ev.GraphEvaluator()
+            dacc = nacc = None
+            for j in range(s * chunk, min((s + 1) * chunk, npc)):
+                ck, ci = cs.permutation_columns[j]
+                for g, is_den in ((gd, True), (gn, False)):
+                    col = g.column(kind[ck], ci)
+                    if is_den:
+                        t = g.add_calculation(ev.MUL, (ev.BETA, 0, 0), g.column(ev.FIXED, nf + j))
+                    else:
+                        t = g.add_calculation(ev.MUL, (ev.CHALLENGE, j, 0), g.column(ev.FIXED, nf + npc))
+                    t = g.add_calculation(ev.ADD, g.add_calculation(ev.ADD, col, t), (ev.GAMMA, 0, 0))
+                    if is_den:
+                        dacc = t if dacc is None else g.add_calculation(ev.MUL, dacc, t)
+                    else:
+                        nacc = t if nacc is None else g.add_calculation(ev.MUL, nacc, t)
+            gd.add_calculation(ev.STORE, dacc)
+            gn.add_calculation(ev.STORE, nacc)
+            out.append((gd.compile(self.ctx, self.f), gn.compile(self.ctx, self.f)))
+        return out
+
+    def _lookup_product_graphs(self):
+        """advice slots: [compressed_input, compressed_table, permuted_input, permuted_table]."""
+        gd, gn = ev.GraphEvaluator(), ev.GraphEvaluator()
+        gd.add_calculation(ev.MUL, gd.add_calculation(ev.ADD, gd.column(ev.ADVICE, 2), (ev.BETA, 0, 0)), gd.add_calculation(ev.ADD, gd.column(ev.ADVICE, 3), (ev.GAMMA, 0, 0)))
+        gn.add_calculation(ev.MUL, gn.add_calculation(ev.ADD, gn.column(ev.ADVICE, 0), (ev.BETA, 0, 0)), gn.add_calculation(ev.ADD, gn.column(ev.ADVICE, 1), (ev.GAMMA, 0, 0)))
+        return gd.compile(self.ctx, self.f), gn.compile(self.ctx, self.f)
+
+    # ---- helpers ----
+    def _commit(self, transcript: Blake2bWrite, first: int, count: int, lagrange: bool, src=None):
+        """commit `count` consecutive columns, normalise, absorb: the transcript needs affine points on the host."""
+        t = self.cols if src is None else src
+        self.params.commit_device(t[first].data_ptr(), count, self.jac.data_ptr(), lagrange)
+        self.ctx.to_affine_device(self.curve.id, self.jac.data_ptr(), count, self.aff.data_ptr(), 0)
+        self.ctx.synchronize()
+        pts = decode_points(self.curve, to_host(self.aff[:count]))
+        for P in pts:
+            transcript.write_point(P)
+        return pts
+
+    def _blind_rows(self, rng, first_col: int, count: int, first_row: int):
+        """random values into rows [first_row, n) of `count` consecutive columns (column after column, as upstream draws them)."""
+        rows = self.n - first_row
+        vals = rng.scalars(count * rows).reshape(count, rows, 4)
+        self.cols[first_col:first_col + count, first_row:] = to_device(vals)
+
+    def _ptrs(self, t, first=0, count=None):
+        count = t.shape[0] - first if count is None else count
+        return [t[first + i].data_ptr() for i in range(count)]
+
+    # ---- the proof ----
+    def create_proof(self, advice, instances: Sequence[Sequence[int]], rng: SeededRng, transcript: Blake2bWrite,
+                     timings: Optional[ProofTimings] = None):
+        with self.ctx.torch_stream():
+            return self._create_proof(advice, instances, rng, transcript, timings)
+
+    def _create_proof(self, advice, instances: Sequence[Sequence[int]], rng: SeededRng, transcript: Blake2bWrite,
+                      timings: Optional[ProofTimings] = None):
+        """advice: (num_advice, n, 4) u64 Montgomery (host array or device tensor); instances: one list of canonical ints per
+        instance column (the reference passes &[&[&[]]]: none).  Appends the proof to `transcript`."""
+        torch, ctx, f, cs, d, pk, c = self.torch, self.ctx, self.f, self.cs, self.domain, self.pk, self._c
+        n, m, k, ek, u, bf, A, L, S = self.n, self.m, self.k, self.ek, self.u, self.bf, self.A, self.L, self.S
+        p, enc = f.p, f.encode
+        cols, fid = self.cols, f.id
+        rot_scale = m // n
+        t_phase = time.perf_counter()
+        t_start = t_phase
+
+        def mark(name):
+            nonlocal t_phase
+            if timings is not None:
+                ctx.synchronize()
+                now = time.perf_counter()
+                timings.phases_ms[name] = timings.phases_ms.get(name, 0.0) + 1e3 * (now - t_phase)
+                t_phase = now
+
+        transcript.common_scalar(pk.vk.transcript_repr)          # vk.hash_into
+        # -- instance columns: values into the transcript (KZG: QUERY_INSTANCE = false), polynomials on the device
+        if len(instances) != self.I:
+            raise ValueError("instances.len() != num_instance_columns")       # upstream: Error::InvalidInstances
+        self.instance.zero_()
+        for i, vals in enumerate(instances):
+            if len(vals) > u:
+                raise ValueError("instance column too long")                   # upstream: Error::InstanceTooLarge
+            for v in vals:
+                transcript.common_scalar(v)
+            if len(vals):
+                self.instance[i, :len(vals)] = to_device(f.encode_many(list(vals)))
+        instance_values = self.instance.clone() if self.I else self.instance
+        if self.I:
+            ctx.intt_scaled_device(fid, self.instance.data_ptr(), k, c["omega_inv"], c["ifft"], self.I, 0)      # instance polys
+
+        # -- advice: witness, blinding rows, commitments
+        adv = advice if torch.is_tensor(advice) else to_device(np.ascontiguousarray(advice, dtype=np.uint64).reshape(A, n, 4))
+        if tuple(adv.shape) != (A, n, 4):
+            raise ValueError("advice must be num_advice x n x 4")
+        cols[self.o_adv:self.o_adv + A].copy_(adv)
+        self._blind_rows(rng, self.o_adv, A, u)
+        rng.scalars(A)                                           # the commitments' blinds: drawn, unused by KZG
+        self._commit(transcript, self.o_adv, A, True)
+        mark("advice")
+        theta = transcript.squeeze_challenge_scalar()
+
+        # -- lookups: compress, permute, blind, commit
+        fixed_v = self._ptrs(pk.fixed_values)
+        adv_v = self._ptrs(cols, self.o_adv, A)
+        inst_v = self._ptrs(instance_values, 0, self.I)
+        if L:
+            for l in range(L):
+                gi, gt = pk.compress_graphs[l]
+                gi.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l].data_ptr(), 0, 0)
+                gt.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l + 1].data_ptr(), 0, 0)
+            # permuted columns are interleaved (input_l, table_l) with a stride of two columns
+            base = cols[self.o_perm].data_ptr()
+            ctx.permute_expression_pair_batch_device(fid, self.compressed[0].data_ptr(), self.compressed[1].data_ptr(), u, L, 2 * n, base, base + 32 * n, 0)
+            self._blind_rows_lookup(rng)
+            self._commit(transcript, self.o_perm, 2 * L, True)
+        mark("lookup_permuted")
+        beta = transcript.squeeze_challenge_scalar()
+        gamma = transcript.squeeze_challenge_scalar()
+
+        # -- grand products: permutation sets, then lookups; one batched inversion
+        npc = len(cs.permutation_columns)
+        delta, chal, dj = delta_of(f), [], beta
+        for _ in range(npc):
+            chal.append(dj)
+            dj = dj * delta % p
+        perm_fixed = fixed_v + self._ptrs(pk.perm_values) + [self.omega_col.data_ptr()]
+        for s in range(S):
+            gd, gn = self.perm_graphs[s]
+            gd.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.den[s].data_ptr(), 0, 0)
+            gn.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.num[s].data_ptr(), 0, 0)
+        for l in range(L):
+            gd, gn = self.lookup_product_graphs
+            four = [self.compressed[2 * l].data_ptr(), self.compressed[2 * l + 1].data_ptr(), cols[self.o_perm + 2 * l].data_ptr(), cols[self.o_perm + 2 * l + 1].data_ptr()]
+            gd.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.den[S + l].data_ptr(), 0, 0)
+            gn.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.num[S + l].data_ptr(), 0, 0)
+        if S + L:
+            ctx.grand_product_batch_device(fid, self.num.data_ptr(), self.den.data_ptr(), n, S + L, n, cols[self.o_pz].data_ptr(), 0)
+        for s in range(1, S):                                    # z_s starts where z_{s-1} ended: z = vec![last_z]
+            ctx.scale_device(fid, cols[self.o_pz + s].data_ptr(), n, None, cols[self.o_pz + s - 1][u].data_ptr(), 0)
+        for j in range(S + L):                                   # blinding rows n - bf .. n, then the (unused) commitment blind
+            self._blind_rows(rng, self.o_pz + j, 1, n - bf)
+            rng.scalars(1)
+        if S + L:
+            self._commit(transcript, self.o_pz, S + L, True)
+        mark("grand_products")
+
+        # -- vanishing argument: a random polynomial
+        cols[self.o_rand].copy_(to_device(rng.scalars(n)))
+        rng.scalars(1)
+        self._commit(transcript, self.o_rand, 1, False)
+        mark("random_poly")
+        y = transcript.squeeze_challenge_scalar()
+
+        # -- coefficient forms and cosets of everything committed so far
+        nco = self.NC - 1
+        ctx.intt_scaled_device(fid, cols.data_ptr(), k, c["omega_inv"], c["ifft"], nco, 0)
+        ctx.coset_ntt_form_device(fid, cols.data_ptr(), k, self.ext.data_ptr(), ek, c["ext_omega"], c["zeta"], nco, ev.FORM_OUT_INTERNAL, 0)
+        if self.I:
+            ctx.coset_ntt_form_device(fid, self.instance.data_ptr(), k, self.ext[nco].data_ptr(), ek, c["ext_omega"], c["zeta"], self.I, ev.FORM_OUT_INTERNAL, 0)
+        mark("ntt")
+
+        # -- evaluate_h, / t(X), extended_to_coeff
+        FF = ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL
+        fixed_c, adv_c, inst_c = self._ptrs(pk.fixed_cosets), self._ptrs(self.ext, self.o_adv, A), self._ptrs(self.ext, nco, self.I)
+        l0, l_last, l_active = (pk.l_ext[i].data_ptr() for i in range(3))
+        pk.custom_gates.evaluate_device(fixed_c, adv_c, inst_c, [], None, None, None, y, ek, rot_scale, 0, self.h.data_ptr(), 0, FF)
+        if S:
+            kindmap = {plonk.ADVICE: adv_c, plonk.FIXED: fixed_c, plonk.INSTANCE: inst_c}
+            pcols = [kindmap[ck][ci] for ck, ci in cs.permutation_columns]
+            ev.permutation_h_device(ctx, f, self._ptrs(self.ext, self.o_pz, S), pcols, self._ptrs(pk.perm_cosets), cs.permutation_chunk_len(), -(bf + 1), l0, l_last,
+                                    l_active, beta, gamma, y, delta, d.g_coset, d.extended_omega, ek, rot_scale, self.h.data_ptr(), 0, FF)
+        for l in range(L):
+            pk.lookup_graphs[l].evaluate_device(fixed_c, adv_c, inst_c, [], beta, gamma, theta, None, ek, rot_scale, 0, self.table_value.data_ptr(), 0, FF)
+            ev.lookup_h_device(ctx, f, self.ext[self.o_lz + l].data_ptr(), self.ext[self.o_perm + 2 * l].data_ptr(), self.ext[self.o_perm + 2 * l + 1].data_ptr(),
+                               self.table_value.data_ptr(), l0, l_last, l_active, beta, gamma, y, ek, rot_scale, self.h.data_ptr(), 0, FF)
+        mark("evaluate_h")
+        ctx.scale_device(fid, self.h.data_ptr(), m, self.t_inv, 0, 0)                                     # divide_by_vanishing_poly
+        ctx.coset_intt_form_device(fid, self.h.data_ptr(), ek, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], 1, ev.FORM_IN_INTERNAL, 0)
+        pieces = d.quotient_poly_degree
+        rng.scalars(pieces)                                      # h_blinds
+        self._commit(transcript, 0, pieces, False, src=self.h.view(m // n, n, 4))
+        mark("h_pieces")
+        x = transcript.squeeze_challenge_scalar()
+        xn = pow(x, n, p)
+
+        # -- evaluations, in upstream's order.  Every coefficient-form column is evaluated at every rotation it is opened at
+        # with one batched launch per (buffer, point).
+        rots = sorted({r for _, r in cs.advice_queries} | {r for _, r in cs.fixed_queries} | {0, 1, -1, -(bf + 1)})
+        point = {r: rotate_omega(d, x, r) for r in rots}
+        nfix, off = cs.num_fixed, 0
+        slots: Dict[Tuple[str, int], int] = {}
+        for r in rots:                                           # evals[slots[(buffer, r)] + column]
+            for name, t, first, cnt in (("cols", cols, 0, self.NC), ("fixed", pk.fixed_polys, 0, nfix), ("sigma", pk.perm_polys, 0, npc)):
+                need = (name == "cols") or (name == "fixed" and any(rr == r for _, rr in cs.fixed_queries)) or (name == "sigma" and r == 0)
+                if not need or cnt == 0:
+                    continue
+                slots[(name, r)] = off
+                ctx.eval_polynomial_device(fid, t[first].data_ptr(), n, n, cnt, enc(point[r]), self.evals[off].data_ptr(), 0)
+                off += cnt
+        # the folded quotient  h(X) = sum_i x^(n i) h_i(X)  and its value at x
+        hp = self.h.view(m // n, n, 4)
+        xs, cur = [], 1
+        for _ in range(pieces):
+            xs.append(cur)
+            cur = cur * xn % p
+        ctx.lincomb_device(fid, self._ptrs(hp, 0, pieces), f.encode_many(xs), n, self.hfold.data_ptr(), None, 0)
+        slots[("hfold", 0)] = off
+        ctx.eval_polynomial_device(fid, self.hfold.data_ptr(), n, n, 1, enc(x), self.evals[off].data_ptr(), 0)
+        off += 1
+        ctx.synchronize()
+        ev_host = array_to_ints(to_host(self.evals[:off]))
+        rinv = pow(1 << 256, -1, p)
+        val = lambda name, col, r: ev_host[slots[(name, r)] + col] * rinv % p
+
+        for col, r in cs.advice_queries:
+            transcript.write_scalar(val("cols", self.o_adv + col, r))
+        for col, r in cs.fixed_queries:
+            transcript.write_scalar(val("fixed", col, r))
+        transcript.write_scalar(val("cols", self.o_rand, 0))                    # vanishing: random_eval
+        for j in range(npc):                                                     # pk.permutation.evaluate: sigma(x)
+            transcript.write_scalar(val("sigma", j, 0))
+        last = -(bf + 1)
+        for s in range(S):                                                       # permutation products
+            transcript.write_scalar(val("cols", self.o_pz + s, 0))
+            transcript.write_scalar(val("cols", self.o_pz + s, 1))
+            if s != S - 1:
+                transcript.write_scalar(val("cols", self.o_pz + s, last))
+        for l in range(L):                                                       # lookups
+            zc, ai, ti = self.o_lz + l, self.o_perm + 2 * l, self.o_perm + 2 * l + 1
+            for colr in ((zc, 0), (zc, 1), (ai, 0), (ai, -1), (ti, 0)):
+                transcript.write_scalar(val("cols", *colr))
+        mark("evaluations")
+
+        # -- queries (point rotation, device polynomial, evaluation), in upstream's order
+        Q: List[Tuple[int, int, int]] = []
+        for col, r in cs.advice_queries:
+            Q.append((r, cols[self.o_adv + col].data_ptr(), val("cols", self.o_adv + col, r)))
+        for s in range(S):                                                       # permutation::Constructed::open
+            zc = self.o_pz + s
+            Q.append((0, cols[zc].data_ptr(), val("cols", zc, 0)))
+            Q.append((1, cols[zc].data_ptr(), val("cols", zc, 1)))
+        for s in range(S - 1):
+            zc = self.o_pz + s
+            Q.append((last, cols[zc].data_ptr(), val("cols", zc, last)))
+        for l in range(L):                                                       # lookup::Evaluated::open
+            zc, ai, ti = self.o_lz + l, self.o_perm + 2 * l, self.o_perm + 2 * l + 1
+            for colr in ((zc, 0), (ai, 0), (ti, 0), (ai, -1), (zc, 1)):
+                Q.append((colr[1], cols[colr[0]].data_ptr(), val("cols", *colr)))
+        for col, r in cs.fixed_queries:
+            Q.append((r, pk.fixed_polys[col].data_ptr(), val("fixed", col, r)))
+        for j in range(npc):                                                     # pk.permutation.open
+            Q.append((0, pk.perm_polys[j].data_ptr(), val("sigma", j, 0)))
+        Q.append((0, self.hfold.data_ptr(), val("hfold", 0, 0)))                 # vanishing::Evaluated::open
+        Q.append((0, cols[self.o_rand].data_ptr(), val("cols", self.o_rand, 0)))
+
+        # -- ProverGWC::create_proof: one witness polynomial per distinct point, in order of first appearance
+        v = transcript.squeeze_challenge_scalar()
+        order: List[int] = []
+        groups: Dict[int, List[Tuple[int, int]]] = {}
+        for r, ptr, e in Q:
+            if r not in groups:
+                groups[r] = []
+                order.append(r)
+            groups[r].append((ptr, e))
+        if len(order) > self.qbuf.shape[0]:
+            raise ValueError("more opening points than the prover's buffers hold")
+        self.wbuf.zero_()
+        for gi, r in enumerate(order):
+            ptrs, coefs, eval_batch, pw = [], [], 0, 1
+            for ptr, e in groups[r]:
+                ptrs.append(ptr)
+                coefs.append(pw)
+                eval_batch = (eval_batch + pw * e) % p
+                pw = pw * v % p
+            ctx.lincomb_device(fid, ptrs, f.encode_many(coefs), n, self.qbuf[gi].data_ptr(), enc(eval_batch), 0)
+            ctx.kate_division_device(fid, self.qbuf[gi].data_ptr(), n, enc(point[r]), self.wbuf[gi].data_ptr(), 0)
+        self._commit(transcript, 0, len(order), False, src=self.wbuf)
+        mark("openings")
+        if timings is not None:
+            timings.total_ms = 1e3 * (time.perf_counter() - t_start)
+        return transcript
+
+    def _blind_rows_lookup(self, rng):
+        """permute_expression_pair's blinding: per lookup, bf + 1 values for the permuted input, then bf + 1 for the permuted
+        table, then the two (unused) commitment blinds."""
+        rows = self.bf + 1
+        for l in range(self.L):
+            vals = rng.scalars(2 * rows).reshape(2, rows, 4)
+            self.cols[self.o_perm + 2 * l:self.o_perm + 2 * l + 2, self.u:] = to_device(vals)
+            rng.scalars(2)
+
+
+def create_proof(params: ParamsKZG, pk: ProvingKey, advice, instances, rng: SeededRng, transcript: Blake2bWrite) -> Blake2bWrite:
+    """One-shot form (allocates the proof's device buffers for this call)."""
+    return Prover(params, pk).create_proof(advice, instances, rng, transcript)

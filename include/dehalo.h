@@ -61,6 +61,9 @@ int dehalo_ctx_create(int device, dehalo_ctx** out);
 void dehalo_ctx_destroy(dehalo_ctx* ctx);
 /* Human-readable text of the last error on this context (valid until the next call). */
 const char* dehalo_last_error(const dehalo_ctx* ctx);
+/* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
+ * kernels by enqueueing it on the same stream. */
+void* dehalo_ctx_stream(dehalo_ctx* ctx);
 /* Blocks until everything queued on the context's own stream has finished. */
 int dehalo_ctx_synchronize(dehalo_ctx* ctx);
 
@@ -140,6 +143,8 @@ int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t
  * op: 0 add, 1 sub, 2 mul, 3 invert, 4 canonical->Montgomery, 5 Montgomery->canonical,
  *     6 mul evaluated through the kernels' internal carry-free 29-bit-limb representation.     */
 int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* device-pointer form (d_b may be NULL for the unary ops; d_out may alias d_a): e.g. canonical -> Montgomery of a column uploaded as raw integers */
+int dehalo_field_op_device(dehalo_ctx* ctx, int field, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n, void* stream);
 
 /* ---- field-vector primitives around the path ---------------------------
  * Everything create_proof does between two commitments that is a scan over a column of field
