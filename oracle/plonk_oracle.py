@@ -366,7 +366,6 @@ def create_proof(curve: po.Curve, srs, key: dict, advice_mont: np.ndarray, insta
     h = co.scale_periodic(F.id, h, t_inv)
     hc = co.extended_to_coeff(F.id, h, sh.ext_k, mm(d.ext_omega_inv), mm(d.ext_ifft_divisor), mm(d.g_coset), threads)
     pieces_n = sh.degree - 1
-    trace["h_tail_is_zero"] = not hc[pieces_n * n:].any()
     pieces = [np.ascontiguousarray(hc[i * n:(i + 1) * n]) for i in range(pieces_n)]
     rng.scalars(pieces_n)
     for pc in pieces:
