@@ -8,7 +8,13 @@ in HBM: one 2^20-term Pallas MSM (== best_multiexp / commit over a registered SR
 all-gather of the commitment vector across ranks (a no-op at N = 1).  One process per GPU;
 N > 1 is launched by torch.distributed.run, units are independent per rank (weak scaling).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--no-cpu-baseline]
+After the timed region (never inside it) rank 0 also (a) checks the 2^20 MSM and NTT results of the measured configuration
+against the CPU port that serves as `cpu_baseline`, (b) makes REAL proofs with the device `create_proof` for the reference's two
+circuit shapes -- delay_enc (k = 17, 5 lookups, degree 5) and pose_enc (k = 11) -- asserts them byte-identical to the CPU
+restatement's proofs (whose time is the CPU figure beside them) and accepted by the verifier, and (c) proves a small batch per
+GPU and all-gathers the commitments (configs[4]: `--proofs 64` on 8 GPUs).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--no-cpu-baseline] [--proofs P] [--proof-k 17]
 """
 from __future__ import annotations
 
@@ -30,6 +36,7 @@ NTT_BYTES_PER_ELEM = 64  # read once + write once
 # peak of that instruction on MI355X (profiles/r01_ubench_instruction_rates.txt)
 MADS_PER_MIXED_ADD = {"pallas": 1224, "vesta": 1224, "bn254": 1467}
 VMAD_PEAK_TMADS = 30.5
+KERNEL_REV = "r02a"   # bumped whenever k_msm_accum0 changes: a PMC traffic figure measured on another revision is not reported
 MADS_PER_FIELD_MUL = {"pasta_fp": 135, "pasta_fq": 135, "bn254_fr": 162, "bn254_fq": 162}   # f29_mul, ISA count
 
 
@@ -47,121 +54,211 @@ def parse():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --force-device rehearse N > 1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1)
-    ap.add_argument("--prover-k", type=int, default=17, help="also time the delay_enc-shaped MSM/NTT schedule at this k (0 = skip)")
-    ap.add_argument("--prover-curve", default="bn254")
+    ap.add_argument("--proof-k", type=int, default=17, help="k of the delay_enc-shaped create_proof (0 = skip every proof section)")
+    ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 4 per GPU; 0 = skip)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
     ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
 
 
-def cpu_baseline(co, po, curve, field, log_n, dist):
-    """The oracle's C restatement of best_multiexp + best_fft (same chunk-per-thread split as
-    upstream's rayon code) on this host's cores: a reported baseline, not the target."""
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def cpu_baseline(co, po, curve, field, log_n, bases, scalars, a):
+    """The oracle's C restatement of best_multiexp + best_fft (same chunk-per-thread split as upstream's rayon code) on
+    every core this process may use: a reported baseline, not the target.  It runs on the SAME bases / scalars / polynomial
+    as rank 0's timed steps, so its results double as the parity check of the measured configuration.
+    -> (json dict, MSM result as affine Montgomery limbs, NTT result)."""
+    cores = host_cores()
+    threads = min(cores, 256)                      # the port's thread tables hold 256 entries
     n = 1 << log_n
-    bases = co.synth_bases(curve.id, n)
-    scalars = co.fill_scalars(curve.scalar.id, dist, n, 1)
-    a = co.fill_scalars(field.id, "uniform", n, 2)
     omega = field.encode(po.FIELDS[field.name].omega(log_n))
     reps, t_msm, t_ntt = 0, 0.0, 0.0
     t_start = time.time()
+    msm_res = ntt_res = None
     while reps < 3 and (reps == 0 or time.time() - t_start < 20.0):
         t0 = time.time()
-        co.best_multiexp(curve.id, scalars, bases, cores)
+        msm_res = co.best_multiexp(curve.id, scalars, bases, threads)
         t1 = time.time()
-        co.best_fft(field.id, a, omega, log_n, cores)
+        ntt_res = co.best_fft(field.id, a, omega, log_n, threads)
         t2 = time.time()
         t_msm += t1 - t0
         t_ntt += t2 - t1
         reps += 1
     step_s = (t_msm + t_ntt) / reps
     return {
-        "value": round(n / step_s / 1e6, 4), "unit": "Mpoints/s", "cores": cores, "kind": "port",
-        "sample": "%d x (2^%d-term MSM + 2^%d-point NTT), oracle/oracle.c best_multiexp+best_fft, %d threads" % (reps, log_n, log_n, cores),
+        "value": round(n / step_s / 1e6, 4), "unit": "Mpoints/s", "cores": threads, "host_cores": cores, "kind": "port",
+        "sample": "%d x (2^%d-term MSM + 2^%d-point NTT) on rank 0's own inputs, oracle/oracle.c best_multiexp+best_fft, %d threads" % (reps, log_n, log_n, threads),
         "msm_ms": round(1e3 * t_msm / reps, 2), "ntt_ms": round(1e3 * t_ntt / reps, 2),
-    }
+    }, co.to_affine(curve.id, msm_res), ntt_res
 
 
-def prover_shape_numbers(pkg, co, po, ctx, k, curve_name, with_cpu, with_quotient=True):
-    """The k~17 half of the metric: the MSM/NTT schedule of one delay_enc create_proof
-    (31 MSM(n) + 24 iNTT(n) + 23 coset NTT(n -> 4n) + 1 iNTT(4n), phases separated by host
-    syncs), synthetic device-resident columns; CPU = the same calls through oracle/oracle.c."""
+def secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n):
+    """What the headline does not show: the cost of building the resident SRS table, the same MSM over a single-row table
+    (no precomputed window multiples) and the literal drop-in `best_multiexp(coeffs, bases)` over host buffers that are not
+    registered (upload + one-row table + MSM + download: PCIe-inclusive)."""
     import numpy as np
-    from dehalo2_amd import prover_shape as ps
-    curve = pkg.fields.CURVES[curve_name]
-    n = 1 << k
-    g = co.synth_bases(curve.id, n)
-    gl = g[::-1].copy()
-    cols = ps.synthetic_columns(lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed), curve.scalar.id, k, 7)
-    bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, gl, 0, True)
-    fill = lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed)
-    if with_quotient:
-        cols.update(ps.synthetic_proving_key(fill, curve.scalar, k, k + 2, 55))
-    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols, with_quotient=with_quotient)
-    shape.run()                                   # warm-up (twiddle tables, workspace)
-    runs = [shape.run() for _ in range(5)]
-    best = min(runs, key=lambda r: r.ms_total)
-    overlapped = None
-    if with_quotient:   # the same schedule with the NTTs on a second context (stream), overlapping the MSM phases
-        ctx2 = pkg.Context(0)
-        shape.run_overlapped(ctx2)
-        overlapped = min(shape.run_overlapped(ctx2) for _ in range(5))
-        ctx2.close()
-    out = {"k": k, "curve": curve_name, "gpu_ms": round(best.ms_total, 3), "gpu_msm_ms": round(best.ms_msm, 3), "gpu_ntt_ms": round(best.ms_ntt, 3),
-           "gpu_ms_ntt_overlapped": round(overlapped, 3) if overlapped is not None else None,
-           "gpu_eval_h_ms": round(best.ms_eval_h, 3) if with_quotient else None,
-           "gpu_arguments_ms": round(best.ms_arguments, 3) if with_quotient else None, "gpu_openings_ms": round(best.ms_openings, 3) if with_quotient else None,
-           "schedule": "31 MSM(n) + 24 iNTT(n) + 23 coset-NTT(n->4n) + 1 iNTT(4n)%s; after every commit phase the commitments are converted to affine and copied to the host (transcript); columns resident in HBM"
-                       % (" + 5 lookup permutations + 7 grand products + evaluate_h(4n: gates, 2 permutation sets, 5 lookups) + 72 eval_polynomial(n)" if with_quotient else "")}
-    if with_cpu:
-        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
-        f = curve.scalar
-        d = shape.domain
-        e = f.encode
-        t0 = time.time()
-        for name, cnt, _ in ps.MSM_PHASES:
-            basis = gl if name in ("advice", "lookup_permuted", "grand_products") else g
-            for i in range(cnt):
-                co.best_multiexp(curve.id, cols[name][i], basis, cores)
-        t1 = time.time()
-        coeffs = [co.lagrange_to_coeff(f.id, cols["polys"][i], k, e(d.omega_inv), e(d.ifft_divisor), cores) for i in range(ps.N_INTT)]
-        exts = [co.coeff_to_extended(f.id, coeffs[i], k, d.extended_k, e(d.extended_omega), e(d.g_coset), cores) for i in range(ps.N_COSET)]
-        th = 0.0
-        h = exts[0]
-        if with_quotient:
-            th0 = time.time()
-            ch, ext_k, rs = cols["challenges"], d.extended_k, 1 << (d.extended_k - k)
-            fixed, advice, L = [cols["pk_fixed"][i] for i in range(ps.N_FIXED)], exts[:5], cols["pk_l"]
-            mg = ps.maingate_graph()
-            h = co.graph_evaluate(f.id, f.encode_many(mg.constants), mg.rotations, mg.calculations, mg.num_intermediates, fixed, advice,
-                                  [np.zeros((1 << ext_k, 4), dtype=np.uint64)], None, None, None, None, e(ch["y"]), ext_k, rs, None, cores)
-            h = co.permutation_h(f.id, h, [exts[15], exts[16]], advice + [fixed[14]], [cols["pk_sigma"][i] for i in range(ps.N_SIGMA)], ps.PERM_CHUNK, ps.LAST_ROTATION,
-                                 L[0], L[1], L[2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]), e(ch["delta"]), e(ch["beta"] * d.g_coset % f.p), e(d.extended_omega),
-                                 ext_k, rs, cores)
-            for i in range(ps.N_LOOKUPS):
-                lg = ps.lookup_graph(i)
-                tv = co.graph_evaluate(f.id, f.encode_many(lg.constants), lg.rotations, lg.calculations, lg.num_intermediates, fixed, advice, [], None, e(ch["beta"]),
-                                       e(ch["gamma"]), e(ch["theta"]), None, ext_k, rs, None, cores)
-                h = co.lookup_h(f.id, h, exts[17 + i], exts[5 + 2 * i], exts[6 + 2 * i], tv, L[0], L[1], L[2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]), ext_k, rs, cores)
-            th = time.time() - th0
-        co.extended_to_coeff(f.id, h, d.extended_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), cores)
-        t2 = time.time()
-        tp = 0.0
-        if with_quotient:
-            tp0 = time.time()
-            usable = n - 6
-            for i in range(ps.N_LOOKUPS):
-                co.permute_expression_pair(f.id, cols["lookup_inputs"][i], cols["lookup_table"], usable)
-            for i in range(7):
-                co.grand_product(f.id, cols["grand_products"][i], cols["lookup_permuted"][i])
-            for _ in range(3):
-                for i in range(ps.N_INTT):
-                    co.eval_polynomial(f.id, coeffs[i], e(cols["challenges"]["y"]), cores)
-            tp = time.time() - tp0
-            t2 += tp
-        out.update({"cpu_arguments_openings_ms": round(1e3 * tp, 1) if with_quotient else None, "cpu_ms": round(1e3 * (t2 - t0), 1), "cpu_msm_ms": round(1e3 * (t1 - t0), 1), "cpu_ntt_ms": round(1e3 * (t2 - t1 - th - tp), 1),
-                    "cpu_eval_h_ms": round(1e3 * th, 1) if with_quotient else None, "cpu_cores": cores, "cpu_kind": "port (oracle/oracle.c)"})
-    bg.release(); bgl.release()
+    import torch
+    n = 1 << log_n
+    out = {}
+    t = time.perf_counter(); b = ctx.register_bases(curve.id, bases_h, 0, True); out["table_build_ms_precomputed"] = round(1e3 * (time.perf_counter() - t), 2)
+    out["table_windows"], out["table_bytes"] = b.windows, b.windows * n * 64
+    b.release()
+    t = time.perf_counter(); b1 = ctx.register_bases(curve.id, bases_h, 0, False); out["table_build_ms_single_row"] = round(1e3 * (time.perf_counter() - t), 2)
+    d_s = torch.from_numpy(scalars_h.view(np.int64)).cuda()
+    d_o = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(4):
+        t = time.perf_counter(); ctx.msm_device(b1, d_s.data_ptr(), n, 1, d_o.data_ptr(), 0); ctx.synchronize(); ts.append(time.perf_counter() - t)
+    out["msm_single_row_device_ms"] = round(1e3 * min(ts[1:]), 3)
+    b1.release()
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter(); ctx.best_multiexp(curve.id, scalars_h, bases_h); ts.append(time.perf_counter() - t)
+    out["best_multiexp_host_buffers_ms"] = round(1e3 * min(ts[1:]), 3)
+    out["best_multiexp_host_buffers_mpoints_per_s"] = round(n / min(ts[1:]) / 1e6, 1)
     return out
+
+
+class ProofSetup:
+    """Circuit, SRS, proving key and a Prover for one (k, shape): the one-time work the reference caches on disk
+    (benches/delay_enc.rs:41-54, 84-115).  The SRS travels through ParamsKZG's RawBytes format, as the reference's does."""
+
+    def __init__(self, pkg, ctx, k, range_lookups, threads):
+        import io
+        import plonk_oracle as PO          # synthetic-input generation (the SRS) + the cpu_baseline / checker leg
+        import pairing as pr
+        import numpy as np
+        from dehalo2_amd import circuits, keygen, prover
+
+        po = sys.modules["pyoracle"]
+        self.curve, self.ocurve, self.k, self.range_lookups = pkg.fields.BN254, po.BN254, k, range_lookups
+        self.s = 0x64656C6179656E63 * 0x9E3779B97F4A7C15 % self.curve.scalar.p
+        t0 = time.time()
+        self.circ = circuits.synthesize(self.curve.scalar.p, k, range_lookups, seed=3)
+        self.srs = PO.setup_srs(self.ocurve, k, self.s, threads)
+        t1 = time.time()
+        buf = io.BytesIO()
+        buf.write(k.to_bytes(4, "little") + np.ascontiguousarray(self.srs["g"]).tobytes() + np.ascontiguousarray(self.srs["g_lagrange"]).tobytes() +
+                  pr.g2_to_raw(pr.G2) + pr.g2_to_raw(pr.g2_mul(self.s, pr.G2)))
+        buf.seek(0)
+        self.params = keygen.ParamsKZG.read(ctx, self.curve, buf)
+        t2 = time.time()
+        self.pk = keygen.keygen(ctx, self.params, self.circ.cs, self.circ.fixed, self.circ.assembly, self.circ.selectors)
+        ctx.synchronize()
+        t3 = time.time()
+        self.prover = prover.Prover(self.params, self.pk)
+        with ctx.torch_stream():
+            self.advice = keygen.to_device(self.circ.advice)          # the witness, resident in HBM (Montgomery form)
+            ctx.field_op_device(self.curve.scalar.id, "to_mont", self.advice.data_ptr(), 0, self.advice.data_ptr(), self.advice.numel() // 4, 0)
+        ctx.synchronize()
+        self.setup_s = {"circuit_and_srs": round(t1 - t0, 2), "params_read_and_tables": round(t2 - t1, 2), "keygen_gpu": round(t3 - t2, 3)}
+
+    def prove(self, seed, timings=None):
+        from dehalo2_amd import prover, transcript
+        tr = transcript.Blake2bWrite(self.curve)
+        self.prover.create_proof(self.advice, [[]], prover.SeededRng(seed), tr, timings)
+        return tr.finalize()
+
+    def release(self):
+        self.params.release()
+
+
+def proof_numbers(pkg, co, po, ctx, k, range_lookups, with_cpu, verify, reps=5):
+    """One half of BASELINE's metric: create_proof of the delay_enc (or pose_enc) circuit shape -- a real proof: what is
+    committed is what was computed, challenges come from the Blake2b transcript.  With `with_cpu` the CPU restatement makes the
+    same proof from the same witness, blinding and SRS: its bytes must equal the device's (asserted) and its time is the CPU
+    figure; the verifier (pairing check) must accept."""
+    from dehalo2_amd import prover
+    threads = min(host_cores(), 256)
+    st = ProofSetup(pkg, ctx, k, range_lookups, threads)
+    for _ in range(2):
+        proof = st.prove(7)
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        again = st.prove(7)
+        ts.append(1e3 * (time.perf_counter() - t))
+        assert again == proof, "the same witness, SRS and blinding gave different proof bytes"
+    tm = prover.ProofTimings()
+    st.prove(7, tm)
+    cs = st.circ.cs
+    n_evals = len(cs.advice_queries) + len(cs.fixed_queries) + 1 + len(cs.permutation_columns) + max(0, 3 * cs.num_permutation_sets() - 1) + 5 * len(cs.lookups)
+    out = {"circuit": "delay_enc / mod_pow shape (MainGate + RangeChip: 5 advice, 15 fixed, 5 lookups, degree 5)" if range_lookups else
+                      "pose_enc shape (MainGate only: 5 advice, 9 fixed, degree 3)",
+           "k": k, "curve": "bn254 (KZG, GWC)", "rows_used": st.circ.used_rows, "commitments": len(proof) // 32 - n_evals,
+           "proof_bytes": len(proof), "gpu_ms": round(min(ts), 3), "gpu_ms_median": round(sorted(ts)[len(ts) // 2], 3),
+           "gpu_phase_ms_with_syncs": {a: round(b, 3) for a, b in tm.phases_ms.items()},
+           "witness": "resident in HBM (synthetic satisfied circuit, witness-like value distribution); blinding scalars generated on the host inside the timed call",
+           "one_time_setup_s": st.setup_s}
+    if with_cpu:
+        import plonk_oracle as PO
+        import numpy as np
+        t0 = time.time()
+        key = PO.keygen(st.ocurve, st.srs, cs.description(), k, st.circ.fixed, st.circ.assembly.mapping, threads)
+        t1 = time.time()
+        rep = PO.transcript_repr(st.ocurve, key, st.circ.selectors)
+        adv = np.stack([co.field_op(st.curve.scalar.id, "to_mont", st.circ.advice[i]) for i in range(cs.num_advice)])
+        # the port parallelises with plain pthreads per call: on a many-core host fewer threads can be faster, so both are timed
+        cpu_runs = {}
+        for th in sorted({threads, min(threads, 32)}):
+            t2 = time.time()
+            want, _ = PO.create_proof(st.ocurve, st.srs, key, adv, [[]], prover.SeededRng(7), rep, th)
+            cpu_runs[th] = time.time() - t2
+        best_th = min(cpu_runs, key=cpu_runs.get)
+        t2, t3 = 0.0, cpu_runs[best_th]
+        assert rep == st.pk.vk.transcript_repr, "verifying key differs from the CPU restatement's"
+        assert proof == want, "device proof differs from the CPU restatement's proof"
+        out.update({"identical_to_cpu_proof": True, "cpu_ms": round(1e3 * (t3 - t2), 1), "cpu_keygen_ms": round(1e3 * (t1 - t0), 1), "cpu_cores": best_th, "host_cores": host_cores(),
+                    "cpu_ms_by_threads": {str(a): round(1e3 * b, 1) for a, b in cpu_runs.items()},
+                    "cpu_kind": "port (oracle/plonk_oracle.py over oracle/oracle.c)", "speedup_vs_cpu_port": round(1e3 * (t3 - t2) / min(ts), 1)})
+        if verify:
+            import pairing as pr
+            import verifier as V
+            tv = time.time()
+            ok = V.verify_proof(st.ocurve, cs.description(), k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(st.s, pr.G2), [[]], proof)
+            assert ok, "the verifier rejected the device proof"
+            out.update({"verifier_accepts": True, "verify_s_python": round(time.time() - tv, 2)})
+    st.release()
+    return out
+
+
+def batch_proofs(pkg, ctx, k, total, rank, world, backend):
+    """configs[4]: a batch of delay_enc-shaped proofs dealt round-robin to the ranks (proof p -> rank p mod N, SRS and proving
+    key replicated), then ONE all-gather of every proof's commitments (31 x 64 B affine each).  -> dict on every rank."""
+    import torch
+    from dehalo2_amd import sharding, transcript, keygen
+    st = ProofSetup(pkg, ctx, k, True, min(host_cores(), 256))
+    mine = sharding.units_for_rank(total, rank, world)
+    st.prove(1000)                                            # warm-up
+    per = 31
+    local = torch.zeros((len(mine), per * 4), dtype=torch.int64)
+    fence_all(world)
+    t0 = time.perf_counter()
+    for j, p in enumerate(mine):
+        proof = st.prove(1000 + p)                            # every proof its own blinding
+        pts = proof[:32 * 27] + proof[-32 * 4:]               # the 27 commitments before the evaluations + the 4 opening quotients
+        local[j] = torch.frombuffer(bytearray(pts), dtype=torch.int64)
+    dev = local if backend != "nccl" else local.cuda()
+    allc = sharding.all_gather_commitments(dev, total, rank, world)
+    fence_all(world)
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+    assert allc.shape[0] == total
+    st.release()
+    return {"k": k, "proofs": total, "n_gpus": world, "proofs_per_s": round(total / elapsed, 2), "ms_per_proof_per_gpu": round(1e3 * elapsed / max(1, len(mine)), 3),
+            "gathered": "%d proofs x %d compressed commitments (32 B each) on every rank, one all_gather" % (total, per),
+            "parallelism": "proof p -> rank p mod N; SRS / proving key replicated; no data-path collective"}
+
+
+def fence_all(world):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
 
 
 def main():
@@ -244,13 +341,7 @@ def main():
     for _ in range(args.warmup):
         step()
     gather_commitments(0, max(args.warmup, 1))
-    # parity spot-check of the measured configuration, outside the timed region (rank 0, once)
     fence()
-    if rank == 0 and log_n <= 14:
-        got = ctx.to_affine(curve.id, d_out.cpu().numpy().view(np.uint64).reshape(1, 12))[0]
-        want = co.to_affine(curve.id, co.best_multiexp(curve.id, scalars_h, bases_h, 4))
-        assert np.array_equal(got, want), "bench MSM result differs from the oracle"
-
     for c in ctxs:
         c.timing_enable(True)
         c.timing_reset()
@@ -284,6 +375,11 @@ def main():
     ctx.timing_enable(False)
     single = collect([ctx]) if rank == 0 else None
 
+    n_proofs = args.proofs if args.proofs >= 0 else 4 * world
+    batch = None
+    if args.proof_k > 0 and n_proofs > 0:
+        batch = batch_proofs(pkg, ctx, args.proof_k, n_proofs, rank, world, args.dist_backend)
+
     if rank == 0:
         def tsum(kid):
             return overlapped[kid]
@@ -292,16 +388,18 @@ def main():
         red_ms, red_cnt = tsum(_lib.K_MSM_REDUCE)
         ntt_ms, ntt_cnt = tsum(_lib.K_NTT_PASS)
         acc_avg_ms = acc_ms / max(acc_cnt, 1)
-        c_bits = args.window_bits or (16 if log_n >= 20 else 15 if log_n >= 17 else 13 if log_n >= 10 else max(6, log_n + 1))   # as dehalo_bases_register chooses it
-        n_windows = -(-256 // c_bits)
+        c_bits, n_windows = bases.window_bits, bases.windows          # as dehalo_bases_register chose them (dehalo_bases_info)
         achieved = MSM_BYTES_PER_TERM * n / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
+        # HBM traffic cannot be read by the process itself: it comes from separate rocprofv3 --pmc passes over this same command
+        # (profiles/README.md), summarised by tools/pmc_summary.py into profiles/pmc_traffic.json together with the source revision
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("log_n") == log_n and rec.get("curve") == args.curve:
+                if rec.get("log_n") == log_n and rec.get("curve") == args.curve and rec.get("window_bits") == c_bits and rec.get("kernel_rev") == KERNEL_REV:
                     traffic = rec.get("msm_accumulate_hbm_bytes_per_launch")
+                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel_rev %s)" % rec.get("kernel_rev")
             except Exception:
                 traffic = None
         out = {
@@ -321,7 +419,7 @@ def main():
                        "configs_index": 1, "steps_in_flight": inflight,
                        "parallelism": "independent units per rank; RCCL all-gather of commitments" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accum0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": MSM_BYTES_PER_TERM * n, "avg_kernel_ms": round(acc_avg_ms, 4),
                          "note": "MSM is integer-VALU-bound (group adds), not HBM-bound: a low HBM fraction is expected (SURVEY.md 8d)",
                          # the honest ceiling of this kernel: wide integer multiplies issued vs the measured v_mad_u64_u32 peak
@@ -352,12 +450,24 @@ def main():
             out["single_stream"]["valu_frac"] = {"k_msm_accum0": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (ss["msm_accumulate"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4),
                                                  "k_ntt_pass": round(ntt_muls * mads_per_mul / (ss["ntt"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(co, po, curve, field, log_n, args.dist)
-        if world == 1 and args.prover_k > 0:
-            out["prover_shape"] = prover_shape_numbers(pkg, co, po, ctx, args.prover_k, args.prover_curve, not args.no_cpu_baseline)
-            # the other two sizes the north star names (GPU only: the CPU port takes ~1 min at k = 20)
-            out["prover_shape_other_k"] = [prover_shape_numbers(pkg, co, po, ctx, k, args.prover_curve, False, with_quotient=(k < 20))
-                                           for k in (14, 20) if k != args.prover_k]
+            # the CPU port on rank 0's own inputs: the reported baseline AND the parity check of the measured 2^20 configuration
+            out["cpu_baseline"], want_msm, want_ntt = cpu_baseline(co, po, curve, field, log_n, bases_h, scalars_h, poly_h)
+            got = ctx.to_affine(curve.id, d_out_all[args.warmup:args.warmup + args.steps].cpu().numpy().view(np.uint64))
+            assert all(np.array_equal(g, want_msm) for g in got), "a timed step's MSM result differs from the CPU port's"
+            chk = torch.from_numpy(poly_h.view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            ctx.ntt_device(field.id, chk.data_ptr(), log_n, omega, 1, 0)
+            ctx.synchronize()
+            assert np.array_equal(chk.cpu().numpy().view(np.uint64), want_ntt), "the 2^%d NTT differs from the CPU port's" % log_n
+            out["parity_of_timed_configuration"] = "all %d timed MSM results and the 2^%d NTT equal the CPU port's (checked after the timed region)" % (args.steps, log_n)
+            out["secondary"] = secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n)
+        if world == 1 and args.proof_k > 0:
+            with_cpu = not args.no_cpu_baseline
+            out["proof"] = proof_numbers(pkg, co, po, ctx, args.proof_k, True, with_cpu, not args.no_verify)
+            out["proof_pose_enc"] = proof_numbers(pkg, co, po, ctx, 11, False, with_cpu, not args.no_verify)
+            out["proof_other_k"] = [proof_numbers(pkg, co, po, ctx, k, True, False, False, reps=3) for k in (14, 20) if k != args.proof_k]
+        if batch is not None:
+            out["batch_proofs"] = batch
         print(json.dumps(out), flush=True)
 
     bases.release()

@@ -13,7 +13,7 @@ _LIB = None
 
 SYMBOLS = [
     "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_ctx_stream",
-    "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len",
+    "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
     "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
@@ -95,6 +95,7 @@ def load_library():
     lib.dehalo_bases_release.argtypes = [P, P]
     lib.dehalo_bases_len.argtypes = [P]
     lib.dehalo_bases_len.restype = sz
+    lib.dehalo_bases_info.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     lib.dehalo_msm.argtypes = [P, P, u64p, sz, u64p]
     lib.dehalo_msm_batch.argtypes = [P, P, C.POINTER(C.c_void_p), sz, sz, u64p]
     lib.dehalo_msm_device.argtypes = [P, P, u64p, sz, sz, u64p, P]
@@ -157,6 +158,9 @@ class Bases:
 
     def __init__(self, ctx: "Context", handle, curve: int, n: int):
         self.ctx, self.handle, self.curve, self.n = ctx, handle, curve, n
+        c, w, pre = C.c_uint32(), C.c_uint32(), C.c_int()
+        ctx._check(ctx.lib.dehalo_bases_info(handle, C.byref(c), C.byref(w), C.byref(pre)))
+        self.window_bits, self.windows, self.precomputed = c.value, w.value, bool(pre.value)
 
     def release(self):
         if self.handle is not None:

@@ -29,8 +29,32 @@ class SyntheticCircuit:
     used_rows: int
 
 
+TILE_FROM_K = 17
+
+
+def _tile(small: SyntheticCircuit, k: int) -> SyntheticCircuit:
+    """A 2^k-row circuit made of 2^(k - small.k) copies of `small` stacked row-wise: every block keeps its own table rows,
+    copy constraints and zero tail (the gate and the lookups are row-local, the last block's tail covers the blinding rows)."""
+    nb, n = 1 << small.k, 1 << k
+    reps = n // nb
+    fixed, advice = np.tile(small.fixed, (1, reps, 1)), np.tile(small.advice, (1, reps, 1))
+    ncol = small.assembly.num_columns
+    asm = plonk.Assembly(ncol, n)
+    m = small.assembly.mapping.reshape(ncol, nb)
+    tc, tr = m // nb, m % nb                                        # target column / row inside the block
+    big = np.empty((ncol, reps, nb), dtype=np.int64)
+    for b in range(reps):
+        big[:, b, :] = tc * n + b * nb + tr
+    asm.mapping = big.reshape(-1)
+    selectors = [np.tile(s, reps) for s in small.selectors]
+    return SyntheticCircuit(small.cs, k, fixed, advice, asm, selectors, small.used_rows * reps)
+
+
 def synthesize(p: int, k: int, range_lookups: bool, seed: int = 1, fill: float = 0.8, copies_per_row: float = 0.25) -> SyntheticCircuit:
-    """p: the scalar field's modulus.  `fill`: fraction of the usable rows that hold circuit rows."""
+    """p: the scalar field's modulus.  `fill`: fraction of the usable rows that hold circuit rows.  Above 2^17 rows the
+    circuit is a stack of 2^17-row blocks (Python-integer synthesis of a million rows would take a minute)."""
+    if k > TILE_FROM_K:
+        return _tile(synthesize(p, TILE_FROM_K, range_lookups, seed, fill, copies_per_row), k)
     cs = plonk.maingate_cs(range_lookups)
     n = 1 << k
     bf = cs.blinding_factors()

@@ -352,6 +352,14 @@ int dehalo_bases_release(dehalo_ctx* ctx, dehalo_bases* bases) {
 
 size_t dehalo_bases_len(const dehalo_bases* bases) { return bases ? bases->n : 0; }
 
+int dehalo_bases_info(const dehalo_bases* bases, uint32_t* window_bits, uint32_t* windows, int* precomputed) {
+    if (!bases) return DEHALO_ERR_INVALID;
+    if (window_bits) *window_bits = bases->c;
+    if (windows) *windows = bases->W;
+    if (precomputed) *precomputed = bases->precomp;
+    return 0;
+}
+
 int dehalo_msm_device(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* d_scalars, size_t len, size_t batch, uint64_t* d_out_jacobian,
                       void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;

@@ -53,14 +53,17 @@ def point_range_for_rank(n: int, rank: int, world: int):
 
 
 def combine_partial_msm(ctx, curve_id: int, local_partial, rank: int, world: int):
-    """local_partial: (1, 12) int64 tensor on this rank's device (the MSM over its point range) ->
-    (1, 12) tensor holding the whole MSM on every rank: one all-gather of world x 96 B, then
-    world - 1 group additions on the device (dehalo_point_sum_device)."""
+    """local_partial: (1, 12) int64 tensor on this rank's device (the MSM over its point range), COMPLETE on torch's current
+    stream (synchronise the context that produced it first) -> (1, 12) tensor holding the whole MSM on every rank: one
+    all-gather of world x 96 B, then world - 1 group additions on the device (dehalo_point_sum_device).
+    The gather, the re-ordering and the zero-fill of the output run on torch's current stream and are waited for before the
+    addition is enqueued on the context's own (non-blocking) stream: nothing else orders the two streams."""
     import torch
 
     parts = all_gather_commitments(local_partial, world, rank, world) if world > 1 else local_partial
     parts = parts.contiguous()
     out = torch.zeros((1, 12), dtype=parts.dtype, device=parts.device)
+    torch.cuda.current_stream().synchronize()
     ctx.point_sum_device(curve_id, parts.data_ptr(), parts.shape[0], out.data_ptr(), 0)
     ctx.synchronize()
     return out

@@ -82,6 +82,8 @@ int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy,
                           int window_bits, int precompute, dehalo_bases** out);
 int dehalo_bases_release(dehalo_ctx* ctx, dehalo_bases* bases);
 size_t dehalo_bases_len(const dehalo_bases* bases);
+/* The Pippenger window c chosen for these bases, the number of windows ceil(256 / c) and whether their multiples are stored. */
+int dehalo_bases_info(const dehalo_bases* bases, uint32_t* window_bits, uint32_t* windows, int* precomputed);
 
 /* ---- MSM == halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve ------------
  * [halo2_proofs/src/arithmetic.rs; reached from ParamsKZG::commit / commit_lagrange].

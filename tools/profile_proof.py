@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-phase timings of the device create_proof (steady state).   python tools/profile_proof.py [k] [range_lookups] [reps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import __graft_entry__ as entry
+
+pkg = entry.load_package(); po, co = entry.load_oracle()
+import plonk_oracle as PO, pairing as pr
+from dehalo2_amd import circuits, prover, keygen, transcript
+
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
+rl = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+curve = pkg.fields.BN254
+circ = circuits.synthesize(curve.scalar.p, k, rl, seed=3)
+srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
+with pkg.Context(0) as ctx:
+    params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"])
+    pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
+    P = prover.Prover(params, pk)
+    with ctx.torch_stream():
+        adv = keygen.to_device(circ.advice)
+        ctx.field_op_device(curve.scalar.id, "to_mont", adv.data_ptr(), 0, adv.data_ptr(), adv.numel() // 4, 0)
+    ctx.synchronize()
+    for _ in range(2):
+        P.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve))
+    best, best_t = 1e9, None
+    for _ in range(reps):
+        tm = prover.ProofTimings()
+        P.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve), tm)
+        if tm.total_ms < best:
+            best, best_t = tm.total_ms, tm
+    print("with per-phase syncs: total %.2f ms" % best, {a: round(b, 2) for a, b in best_t.phases_ms.items()})
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); P.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve)); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
+    print("no extra syncs: best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
+    params.release()
