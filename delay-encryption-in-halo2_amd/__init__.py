@@ -15,8 +15,8 @@ from . import fields  # noqa: F401
 from ._lib import Context, DehaloError, Bases, library_path, load_library  # noqa: F401
 from .arithmetic import batch_invert, best_fft, best_multiexp, eval_polynomial, grand_product  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
-from .commitment import Params  # noqa: F401
+from .commitment import Params, ParamsIPA  # noqa: F401
 from . import evaluation, lookup  # noqa: F401
 
-__all__ = ["Context", "DehaloError", "Bases", "best_multiexp", "best_fft", "eval_polynomial", "batch_invert", "grand_product", "EvaluationDomain", "Params", "fields",
+__all__ = ["Context", "DehaloError", "Bases", "best_multiexp", "best_fft", "eval_polynomial", "batch_invert", "grand_product", "EvaluationDomain", "Params", "ParamsIPA", "fields",
            "library_path", "load_library"]

@@ -13,6 +13,19 @@ namespace {
 
 hipStream_t pick_stream(dehalo_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+// Caller buffers of the host entry points are ordinary pageable memory (a Rust Vec<F>): large ones are pinned for the duration of the
+// call so that the copy engine reads / writes them directly instead of going through the runtime's bounce buffers (measured on
+// MI355X, profiles/r02_host_path_measurements.txt: dehalo_ntt at 2^20, 32 MiB each way, 5.73 -> 1.35 ms).  Registration failing (already pinned, exotic mapping) just leaves the pageable path.
+struct HostPin {
+    void* p = nullptr;
+    HostPin(const void* ptr, size_t bytes) {
+        if (ptr && bytes >= HOST_PIN_MIN_BYTES && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+    static constexpr size_t HOST_PIN_MIN_BYTES = 4u << 20;
+};
+
 // Window bits by measurement on MI355X (tools/sweep_c.py, tools/profile_prover.py with WINDOW_BITS): the bucket
 // reduction costs ~ 2^(c-1) group operations on a latency chain, the accumulation n * ceil(256 / c) additions.
 // 2^20 and up: 16; 2^17 .. 2^19: 15; 2^10 .. 2^16: 13 (prover-shaped schedule at k = 14: 2.9 ms of MSMs with
@@ -382,8 +395,11 @@ int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t*
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_scalars, std::max<size_t>(32, batch * len * 32)));
         TRY(dh_ensure(ctx, ctx->ws_out, std::max<size_t>(96, batch * 96)));
-        for (size_t b = 0; b < batch && len; b++)
+        for (size_t b = 0; b < batch && len; b++) {
+            HostPin pin(scalars[b], len * 32);
             HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->ws_scalars.p + b * len * 32, scalars[b], len * 32, hipMemcpyHostToDevice, ctx->stream));
+            if (pin.p) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the pin ends with this scope
+        }
     }
     TRY(dehalo_msm_device(ctx, bases, (const uint64_t*)ctx->ws_scalars.p, len, batch, (uint64_t*)ctx->ws_out.p, nullptr));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -519,6 +535,7 @@ static int with_host_io(dehalo_ctx* ctx, const uint64_t* in, size_t in_elems, ui
                         int (*fn)(dehalo_ctx*, uint64_t*, uint64_t*, void*), void* arg) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!in || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "null buffer");
+    HostPin pin_in(in, in_elems * 32), pin_out(out == in ? nullptr : out, out_elems * 32);
     uint64_t *d_in, *d_out;
     std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
@@ -624,6 +641,7 @@ int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!coeffs && len) || !point || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial: null argument");
+    HostPin pin_c(coeffs, len * 32);
     std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -650,6 +668,7 @@ int dehalo_batch_invert_device(dehalo_ctx* ctx, int field, uint64_t* d_values, s
 int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!values && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "batch_invert: null argument");
+    HostPin pin_v(values, len * 32);
     if (len == 0) return 0;
     std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
@@ -691,6 +710,7 @@ int dehalo_grand_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_nu
 int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const uint64_t* den, size_t len, uint64_t* z) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!num || !den || !z) && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "grand_product: null argument");
+    HostPin pin_n(num, len * 32), pin_d(den, len * 32), pin_z(z, len * 32);
     if (len == 0) return 0;
     std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {
@@ -740,6 +760,7 @@ int dehalo_kate_division_device(dehalo_ctx* ctx, int field, const uint64_t* d_a,
 int dehalo_kate_division(dehalo_ctx* ctx, int field, const uint64_t* a, size_t len, const uint64_t point[4], uint64_t* q) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if (((!a || !q) && len > 1) || !point) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division: null argument");
+    HostPin pin_a(a, len * 32), pin_q(q, (len - 1) * 32);
     if (len <= 1) return 0;
     std::lock_guard<std::recursive_mutex> hold(ctx->mu);
     (void)hipSetDevice(ctx->device);
@@ -777,6 +798,7 @@ int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* i
                                    uint64_t* permuted_table) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!input || !table || !permuted_input || !permuted_table) && usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
+    HostPin pin_i(input, usable_rows * 32), pin_t(table, usable_rows * 32), pin_pi(permuted_input, usable_rows * 32), pin_pt(permuted_table, usable_rows * 32);
     if (usable_rows == 0) return 0;
     std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
     {

@@ -963,3 +963,29 @@ def test_msm_split_by_point_range(pkg, co, ctx):
     assert not out.cpu().numpy().view(np.uint64)[0, 8:].any()                    # z = 0: identity
     for h in handles:
         h.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname", ["pallas", "vesta"])
+@pytest.mark.parametrize("k", [4, 10, 13])
+def test_params_ipa_commit_vs_oracle(pkg, co, ctx, cname, k):
+    """ParamsIPA::{commit, commit_lagrange}(poly, r) = <poly, g> + r * w (n + 1 terms; reference: the IPA variant kept at
+    benches/delay_enc.rs:42,51-52) against the C oracle's best_multiexp over g || w."""
+    curve = pkg.fields.CURVES[cname]
+    n = 1 << k
+    pts = co.synth_bases(curve.id, 2 * n + 1)
+    g, gl, w = pts[:n], pts[n:2 * n], pts[2 * n:]
+    params = pkg.ParamsIPA(ctx, curve, k, g, gl, w)
+    for dist, seed in (("uniform", 1), ("witness", 2)):
+        poly = co.fill_scalars(curve.scalar.id, dist, n, seed)
+        r = co.fill_scalars(curve.scalar.id, "uniform", 1, 100 + seed)
+        for fn, basis in ((params.commit, g), (params.commit_lagrange, gl)):
+            got = ctx.to_affine(curve.id, fn(poly, r))[0]
+            want = co.to_affine(curve.id, co.best_multiexp(curve.id, np.concatenate([poly, r]), np.concatenate([basis, w]), 3))
+            assert np.array_equal(got, want)
+    zero = np.zeros((1, 4), dtype=np.uint64)
+    poly = co.fill_scalars(curve.scalar.id, "uniform", n, 9)
+    assert np.array_equal(ctx.to_affine(curve.id, params.commit(poly, zero))[0], co.to_affine(curve.id, co.best_multiexp(curve.id, poly, g, 2)))
+    with pytest.raises(ValueError):
+        params.commit(poly[:-1], zero)
+    params.release()
