@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--proof-k", type=int, default=17, help="k of the delay_enc-shaped create_proof (0 = skip every proof section)")
     ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 4 per GPU; 0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
-    ap.add_argument("--inflight", type=int, default=3, help="independent steps in flight, each on its own HIP stream / workspace")
+    ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves (0 = library default)")
+    ap.add_argument("--inflight", type=int, default=4, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
 
 
@@ -298,6 +299,9 @@ def main():
     inflight = max(1, args.inflight)
     ctxs = [pkg.Context(local_rank) for _ in range(inflight)]
     ctx = ctxs[0]
+    if args.acc_waves:
+        for c in ctxs:
+            c.set_tuning("msm_acc_waves", args.acc_waves)
     # synthetic SRS and witnesses; every rank gets its own scalar column
     bases_h = co.synth_bases(curve.id, n)
     scalars_h = co.fill_scalars(curve.scalar.id, args.dist, n, 1000 + rank)

@@ -336,6 +336,17 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
 
 const char* dehalo_last_error(const dehalo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return DEHALO_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!strcmp(key, "msm_acc_waves")) {
+        if (value < 1 || value > 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_acc_waves must be in [1, 4]");
+        ctx->msm_acc_waves = value;
+        return 0;
+    }
+    return dh_fail(ctx, DEHALO_ERR_INVALID, std::string("unknown tuning key: ") + key);
+}
+
 void* dehalo_ctx_stream(dehalo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int dehalo_ctx_synchronize(dehalo_ctx* ctx) {

@@ -815,10 +815,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     if (Mmax >= (1ull << 32) || total_buckets >= (1ull << 31))
         return dh_fail(ctx, DEHALO_ERR_INVALID, "batch * len * windows too large for one launch");
     {   // points per lane: the lanes fill the chip (4 waves per SIMD of k_msm_accum0) a whole number of times
-        const uint64_t resident = (uint64_t)ctx->num_cus * 4 * 4 * 64;
-        const uint64_t rounds = std::max<uint64_t>(1, (Mmax + resident * 64 - 1) / (resident * 64));
+        const uint64_t resident = (uint64_t)ctx->num_cus * 4 * (uint64_t)ctx->msm_acc_waves * 64;
+        const uint64_t lmax = 64 * 4 / (uint64_t)ctx->msm_acc_waves;
+        const uint64_t rounds = std::max<uint64_t>(1, (Mmax + resident * lmax - 1) / (resident * lmax));
         uint64_t L0 = (Mmax + rounds * resident - 1) / (rounds * resident);
-        L0 = std::min<uint64_t>(64, std::max<uint64_t>(4, L0));
+        L0 = std::min<uint64_t>(lmax, std::max<uint64_t>(4, L0));
         g.L0 = (u32)L0;
     }
     const uint64_t lanes_max = (Mmax + g.L0 - 1) / g.L0;

@@ -61,6 +61,10 @@ int dehalo_ctx_create(int device, dehalo_ctx** out);
 void dehalo_ctx_destroy(dehalo_ctx* ctx);
 /* Human-readable text of the last error on this context (valid until the next call). */
 const char* dehalo_last_error(const dehalo_ctx* ctx);
+/* Launch-geometry knobs (results never depend on them).  "msm_acc_waves" in [1, 4]: waves per SIMD the bucket-accumulation grid of
+ * an MSM is sized for; below 4 the kernel leaves wave slots and registers free, so that the latency-bound kernels of OTHER contexts
+ * (sort, bucket reduction of a neighbouring column) run beside it instead of behind it. */
+int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
  * kernels by enqueueing it on the same stream. */
 void* dehalo_ctx_stream(dehalo_ctx* ctx);
