@@ -1,0 +1,159 @@
+"""Witness generation: the reference's native helpers pinned by the reference's own vectors, the
+laid-out rows checked against the constraint system, and proofs made from the real witness."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def rsa_vectors():
+    return json.load(open(os.path.join(HERE, "golden", "rsa_vectors.json")))
+
+
+def test_big_pow_mod_on_reference_rsa_vectors(pkg):
+    """src/rsa/chip.rs:706-716, 751-761: signature^65537 mod n is the PKCS#1 v1.5 encoding of the SHA-256 digest -- exactly the
+    limb values RSAChip::verify_pkcs1v15_signature compares against (src/rsa/chip.rs:140-203)."""
+    from dehalo2_amd import witness as W
+
+    for v in rsa_vectors():
+        n, s, d = int(v["n"]), int(v["signature"]), int(v["sha256_digest"])
+        em = W.big_pow_mod(s, v["e"], n)
+        limbs = W.limbs_of(em)
+        assert limbs[:4] == W.limbs_of(d, 4)
+        assert limbs[4] == 217300885422736416 and limbs[5] == 938447882527703397           # DigestInfo prefix, src/rsa/chip.rs:152-155
+        assert limbs[6] == (0xFFFFFFFF << 32) | 3158320 and all(l == (1 << 64) - 1 for l in limbs[7:31]) and limbs[31] == 562949953421311
+    assert W.big_pow_mod(5, 0, 7) == 1 and W.big_pow_mod(3, 5, 1000) == 243
+
+
+def test_poseidon_spec_reproduces_reference_kats(pkg):
+    """src/poseidon/permutation.rs:154-158, 190-196 through the package's own Grain / MDS / permutation restatement."""
+    from dehalo2_amd import witness as W
+
+    p = pkg.fields.BN254_FR.p
+    num = lambda x: int(x, 0) if isinstance(x, str) else int(x)
+    for kat in golden("poseidon_kat"):
+        assert W.PoseidonSpec(p, kat["t"], kat["r_f"], kat["r_p"]).permute([num(x) for x in kat["input"]]) == [num(x) for x in kat["expected"]]
+
+
+@pytest.fixture(scope="module")
+def small_delay_witness(pkg):
+    from dehalo2_amd import witness as W
+
+    v = rsa_vectors()[0]
+    p = pkg.fields.BN254_FR.p
+    return W.delay_enc_witness(p, 14, int(v["n"]), 0b1, int(v["signature"]), 1, [11, 22]), int(v["n"]), int(v["signature"])
+
+
+def test_delay_enc_rows_satisfy_the_constraint_system(pkg, small_delay_witness):
+    from dehalo2_amd import witness as W
+
+    (circ, info), n, x = small_delay_witness
+    p = pkg.fields.BN254_FR.p
+    assert info.rsa_result == pow(x, 1, n) and info.total_rows == circ.used_rows
+    assert W.check_rows(circ, p) == info.total_rows
+    # the native cipher of the same key gives the in-circuit ciphertext (src/lib.rs:270-312)
+    assert len(info.cipher) == 3
+    # about 3.5 k rows per mul_mod (reference: 3.99 k, benches/README.md:77-78), two mul_mod per exponent bit
+    assert 6000 < info.rsa_rows < 9000
+    # value classes of the witness: mostly small values
+    from dehalo2_amd.keygen import array_to_ints
+    vals = [v for c in range(5) for v in array_to_ints(circ.advice[c])[:circ.used_rows]]
+    small = sum(1 for v in vals if v < (1 << 8)) / len(vals)
+    wide = sum(1 for v in vals if v >= (1 << 134)) / len(vals)
+    assert small > 0.4 and wide < 0.35            # (the 1-bit exponent of this test leaves the Poseidon rows a large share)
+
+
+def test_pose_enc_witness_fits_the_reference_k(pkg):
+    """benches/pose_enc.rs:184 runs PoseidonEncCircuit at K = 11: the cipher region alone fits 2^11 rows, satisfies the
+    MainGate-only constraint system, and carries the native ciphertext."""
+    from dehalo2_amd import witness as W
+
+    p = pkg.fields.BN254_FR.p
+    circ, info = W.pose_enc_witness(p, 11, [5, 7], [11, 22])
+    assert circ.cs.num_fixed == 9 and not circ.cs.lookups and info.total_rows < (1 << 11) - 6
+    assert W.check_rows(circ, p) == info.total_rows
+    assert info.cipher == W.NativeCipher(W.PoseidonSpec(p, 5, 8, 57), [5, 7]).encrypt([11, 22], 1)
+
+
+def test_a_broken_witness_is_caught(pkg, small_delay_witness):
+    from dehalo2_amd import witness as W
+
+    (circ, info), _, _ = small_delay_witness
+    bad = W.SyntheticCircuit(circ.cs, circ.k, circ.fixed, circ.advice.copy(), circ.assembly, circ.selectors, circ.used_rows)
+    bad.advice[3, 1000, 0] ^= np.uint64(1)
+    with pytest.raises(AssertionError):
+        W.check_rows(bad, pkg.fields.BN254_FR.p)
+
+
+def _oracle_chain(po, co, circ, k, threads):
+    import plonk_oracle as PO
+    import pairing as pr
+
+    s = 0x5EED5EED5EED5EED
+    srs = PO.setup_srs(po.BN254, k, s, threads)
+    desc = circ.cs.description()
+    key = PO.keygen(po.BN254, srs, desc, k, circ.fixed, circ.assembly.mapping, threads)
+    rep = PO.transcript_repr(po.BN254, key, circ.selectors)
+    adv = np.stack([co.field_op(0, "to_mont", circ.advice[i]) for i in range(5)])
+    return dict(srs=srs, desc=desc, key=key, rep=rep, adv=adv, s_g2=pr.g2_mul(s, pr.G2), s=s)
+
+
+def test_oracle_proof_of_the_real_witness_is_accepted(pkg, po, co, small_delay_witness):
+    import pairing as pr
+    import plonk_oracle as PO
+    import verifier as V
+    from dehalo2_amd import prover
+
+    (circ, info), _, _ = small_delay_witness
+    c = _oracle_chain(po, co, circ, 14, 8)
+    proof, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 8)
+    assert V.verify_proof(po.BN254, c["desc"], 14, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], proof)
+
+
+@pytest.mark.gpu
+def test_device_proof_of_the_real_pose_enc_witness(pkg, po, co, ctx):
+    """BASELINE configs[0]: PoseidonEncCircuit at K = 11 (benches/pose_enc.rs:127-135, 184)."""
+    import pairing as pr
+    import plonk_oracle as PO
+    import verifier as V
+    from dehalo2_amd import keygen, prover, transcript, witness as W
+
+    circ, info = W.pose_enc_witness(pkg.fields.BN254_FR.p, 11, [0xABCDEF, 0x123456], [42, 43])
+    c = _oracle_chain(po, co, circ, 11, 8)
+    params = keygen.ParamsKZG(ctx, pkg.fields.BN254, 11, c["srs"]["g"], c["srs"]["g_lagrange"])
+    pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
+    tr = transcript.Blake2bWrite(pkg.fields.BN254)
+    prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 8)
+    assert tr.finalize() == want
+    assert V.verify_proof(po.BN254, c["desc"], 11, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
+    params.release()
+
+
+@pytest.mark.gpu
+def test_device_proof_of_the_real_delay_enc_witness(pkg, po, co, ctx):
+    """DelayEncryptCircuit with the reference's checked-in parameters (2048-bit modulus, EXP_LIMB_BITS = 5 -> k = 16,
+    src/lib.rs:122-124, benches/delay_enc.rs:181): real witness -> device proof == CPU restatement's proof, verifier accepts."""
+    import pairing as pr
+    import plonk_oracle as PO
+    import verifier as V
+    from dehalo2_amd import keygen, prover, transcript, witness as W
+
+    v = rsa_vectors()[1]
+    n, x = int(v["n"]), int(v["signature"])
+    circ, info = W.delay_enc_witness(pkg.fields.BN254_FR.p, 16, n, 0b10011, x, 5, [123456789, 987654321])
+    assert info.rsa_result == pow(x, 0b10011, n)
+    c = _oracle_chain(po, co, circ, 16, 16)
+    params = keygen.ParamsKZG(ctx, pkg.fields.BN254, 16, c["srs"]["g"], c["srs"]["g_lagrange"])
+    pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
+    tr = transcript.Blake2bWrite(pkg.fields.BN254)
+    prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 16)
+    assert tr.finalize() == want
+    assert V.verify_proof(po.BN254, c["desc"], 16, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
+    params.release()
