@@ -398,6 +398,7 @@ int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t*
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!bases || !scalars || !out_jacobian) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: null argument");
     if (len > bases->n) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: more scalars than registered bases");
+    if (batch && len > (SIZE_MAX / 32) / batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: batch * len overflows");
     for (size_t b = 0; b < batch; b++)
         if (!scalars[b] && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: null scalar column");
     std::lock_guard<std::recursive_mutex> hold(ctx->mu);   // one critical section per host-buffer call: staging, kernels, download
@@ -460,6 +461,7 @@ int dehalo_to_affine(dehalo_ctx* ctx, int curve, const uint64_t* jacobian, size_
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!jacobian || !affine_xy) && count) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: null argument");
     if (count == 0) return 0;
+    if (count >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "to_affine: too many points");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     TRY(dh_ensure(ctx, ctx->ws_fop[0], count * 96));

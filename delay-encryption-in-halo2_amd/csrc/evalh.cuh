@@ -334,6 +334,7 @@ int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_i
 
 template <class F>
 int perm_h_t(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* d_values, hipStream_t s) {
+    if (log_rows > (uint32_t)F::TWO_ADICITY) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "permutation_h: log_rows exceeds the field's two-adicity");
     const u64 rows = 1ull << log_rows;
     ScopedTimer timer(ctx, s, DEHALO_K_EVAL_H);
     std::vector<fe> sc = {fe_from_u64(in->beta), fe_from_u64(in->gamma), fe_from_u64(in->y), fe_from_u64(in->delta), fe_from_u64(in->beta_zeta)};

@@ -35,7 +35,9 @@
 #define MSM_ACC_THREADS 128
 // (measured: 2 and 3 resident waves per SIMD give the same k_msm_accum0 time -- the loop is
 // VALU-issue-bound -- and capping residency at 2 did not improve multi-stream overlap)
+#ifndef MSM_ACC_WAVES_ATTR
 #define MSM_ACC_WAVES_ATTR
+#endif
 #define MSM_RED_M 4        // buckets per lane in the bucket reduction
 
 struct MsmGeom {

@@ -349,6 +349,7 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
               const uint64_t omega[4], size_t batch, const NttScale& sc, hipStream_t s) {
     if (log_n > (uint32_t)F::TWO_ADICITY) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "log_n exceeds the field's two-adicity");
     if (log_n > 30) return dh_fail(ctx, DEHALO_ERR_INVALID, "log_n > 30");
+    if (batch > 65535) return dh_fail(ctx, DEHALO_ERR_INVALID, "ntt: batch > 65535 (grid.y)");
     if (batch == 0) return 0;
     const fe* tw = nullptr;
     TRY(get_twiddles<F>(ctx, log_n, omega, s, &tw));

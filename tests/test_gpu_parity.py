@@ -63,6 +63,11 @@ def test_poseidon_kats_through_gpu_field_ops(pkg, po, ctx):
     kat = golden("poseidon_kat")[0]
     out = po.poseidon_permute_ref(f, kat["input"], kat["r_f"], kat["r_p"], mul=mul, add=add)
     assert out == [int(x) for x in kat["expected"]]
+    # the same vectors through op 6: the carry-free 9 x 29-bit multiplier (fp29.cuh) that every hot loop uses
+    mul29 = lambda a, b: spec.decode(ctx.field_op(spec.id, "mul29", spec.encode(a).reshape(1, 4), spec.encode(b).reshape(1, 4))[0])
+    for kat in golden("poseidon_kat"):
+        out = po.poseidon_permute_ref(f, kat["input"], kat["r_f"], kat["r_p"], mul=mul29, add=add)
+        assert out == [int(x) for x in kat["expected"]]
 
 
 # ---------------------------------------------------------------- NTT
