@@ -258,19 +258,18 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend):
     st = ProofSetup(pkg, ctx, k, True, min(host_cores(), 256))
     mine = sharding.units_for_rank(total, rank, world)
     st.prove(1000)                                            # warm-up
-    per = 31
-    local = torch.zeros((len(mine), per * 4), dtype=torch.int64)
+    from dehalo2_amd import prover
+    cs = st.circ.cs
+    blobs = []
     fence_all(world)
     t0 = time.perf_counter()
-    for j, p in enumerate(mine):
-        proof = st.prove(1000 + p)                            # every proof its own blinding
-        pts = proof[:32 * 27] + proof[-32 * 4:]               # the 27 commitments before the evaluations + the 4 opening quotients
-        local[j] = torch.frombuffer(bytearray(pts), dtype=torch.int64)
-    dev = local if backend != "nccl" else local.cuda()
-    allc = sharding.all_gather_commitments(dev, total, rank, world)
+    for p in mine:
+        blobs.append(prover.proof_commitments(cs, st.prove(1000 + p)))          # every proof its own blinding
+    allc = sharding.gather_proof_commitments(blobs, total, rank, world, "cuda" if backend == "nccl" else "cpu")
+    per = len(allc[0]) // 32
     fence_all(world)
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
-    assert allc.shape[0] == total
+    assert len(allc) == total and all(len(b) == 32 * per for b in allc)
     st.release()
     return {"k": k, "proofs": total, "n_gpus": world, "proofs_per_s": round(total / elapsed, 2), "ms_per_proof_per_gpu": round(1e3 * elapsed / max(1, len(mine)), 3),
             "gathered": "%d proofs x %d compressed commitments (32 B each) on every rank, one all_gather" % (total, per),

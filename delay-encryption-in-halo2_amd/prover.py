@@ -407,6 +407,21 @@ class Prover:
             rng.scalars(2)
 
 
+def proof_layout(cs: plonk.ConstraintSystem) -> Tuple[int, int]:
+    """(commitments written before the evaluations, evaluations) of a proof of this constraint system; the opening quotients
+    (one per distinct opening point) follow the evaluations."""
+    L, S = len(cs.lookups), cs.num_permutation_sets()
+    head = cs.num_advice + 2 * L + S + L + 1 + (cs.degree() - 1)
+    evals = len(cs.advice_queries) + len(cs.fixed_queries) + 1 + len(cs.permutation_columns) + max(0, 3 * S - 1) + 5 * L
+    return head, evals
+
+
+def proof_commitments(cs: plonk.ConstraintSystem, proof: bytes) -> bytes:
+    """The proof's commitments (32-byte compressed points): what a batch prover all-gathers."""
+    head, evals = proof_layout(cs)
+    return proof[:32 * head] + proof[32 * (head + evals):]
+
+
 def create_proof(params: ParamsKZG, pk: ProvingKey, advice, instances, rng: SeededRng, transcript: Blake2bWrite) -> Blake2bWrite:
     """One-shot form (allocates the proof's device buffers for this call)."""
     return Prover(params, pk).create_proof(advice, instances, rng, transcript)

@@ -32,6 +32,30 @@ def all_gather_commitments(local, units: int, rank: int, world: int):
     return full.contiguous()
 
 
+def gather_proof_commitments(local_blobs, total: int, rank: int, world: int, device="cpu"):
+    """Batch proving (BASELINE configs[4]: proof p -> rank p mod world): every rank hands in the commitment bytes of the proofs it
+    made (prover.proof_commitments, equal lengths), in the order of units_for_rank, and receives all `total` blobs in proof
+    order -- ONE all-gather of total x len bytes (64 proofs x 31 x 32 B = 62 KB: latency-bound over xGMI)."""
+    import torch
+
+    mine = units_for_rank(total, rank, world)
+    if len(local_blobs) != len(mine):
+        raise ValueError("rank %d made %d proofs, its share is %d" % (rank, len(local_blobs), len(mine)))
+    width = len(local_blobs[0]) if local_blobs else 0
+    if world > 1:                                             # ranks without a proof still need the common width
+        import torch.distributed as dist
+        w = torch.tensor([width], dtype=torch.int64, device=device)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        width = int(w.item())
+    if any(len(b) != width for b in local_blobs) or width % 8:
+        raise ValueError("commitment blobs must have one common length, a multiple of 8 bytes")
+    local = torch.zeros((len(mine), width // 8), dtype=torch.int64)
+    for j, b in enumerate(local_blobs):
+        local[j] = torch.frombuffer(bytearray(b), dtype=torch.int64)
+    full = all_gather_commitments(local.to(device), total, rank, world).cpu()
+    return [full[u].numpy().tobytes() for u in range(total)]
+
+
 def max_over_ranks(value: float) -> float:
     import torch
     import torch.distributed as dist

@@ -30,6 +30,17 @@ full = sharding.all_gather_commitments(local, units, rank, world)
 assert full.shape == (units, 12)
 for u in range(units):
     assert int(full[u, 0]) == u + 1 and int(full[u, 11]) == u + 1
+# batch proving: proof p made by rank p mod world, every rank ends with all commitment blobs in proof order
+from dehalo2_amd import plonk, prover
+cs = plonk.maingate_cs(True)
+head, evals = prover.proof_layout(cs)
+assert (head, evals) == (27, 58)
+total = 5
+fake = lambda p: bytes([p + 1]) * (32 * (head + evals + 4))         # a stand-in proof: 27 + 4 points, 58 scalars (2848 bytes, as the real one)
+blobs = [prover.proof_commitments(cs, fake(p)) for p in sharding.units_for_rank(total, rank, world)]
+assert all(len(b) == 32 * 31 for b in blobs)
+got = sharding.gather_proof_commitments(blobs, total, rank, world)
+assert got == [bytes([p + 1]) * (32 * 31) for p in range(total)]
 # max-over-ranks timing helper
 t = sharding.max_over_ranks(float(rank + 1))
 assert t == float(world)
