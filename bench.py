@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--force-device", type=int, default=-1)
     ap.add_argument("--proof-k", type=int, default=17, help="k of the delay_enc-shaped create_proof (0 = skip every proof section)")
     ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 4 per GPU; 0 = skip)")
+    ap.add_argument("--proofs-inflight", type=int, default=3, help="batch mode: proofs in flight per GPU (one context + host thread each)")
     ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
     ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves (0 = library default)")
     ap.add_argument("--inflight", type=int, default=4, help="independent steps in flight, each on its own HIP stream / workspace")
@@ -181,10 +182,10 @@ class ProofSetup:
         ctx.synchronize()
         self.setup_s = {"circuit_and_srs": round(t1 - t0, 2), "params_read_and_tables": round(t2 - t1, 2), "keygen_gpu": round(t3 - t2, 3)}
 
-    def prove(self, seed, timings=None):
+    def prove(self, seed, timings=None, which=None):
         from dehalo2_amd import prover, transcript
         tr = transcript.Blake2bWrite(self.curve)
-        self.prover.create_proof(self.advice, [[]], prover.SeededRng(seed), tr, timings)
+        (which or self.prover).create_proof(self.advice, [[]], prover.SeededRng(seed), tr, timings)
         return tr.finalize()
 
     def release(self):
@@ -250,7 +251,7 @@ def proof_numbers(pkg, co, po, ctx, k, range_lookups, with_cpu, verify, reps=5):
     return out
 
 
-def batch_proofs(pkg, ctx, k, total, rank, world, backend):
+def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight):
     """configs[4]: a batch of delay_enc-shaped proofs dealt round-robin to the ranks (proof p -> rank p mod N, SRS and proving
     key replicated), then ONE all-gather of every proof's commitments (31 x 64 B affine each).  -> dict on every rank."""
     import torch
@@ -259,19 +260,42 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend):
     mine = sharding.units_for_rank(total, rank, world)
     st.prove(1000)                                            # warm-up
     from dehalo2_amd import prover
+    import threading
     cs = st.circ.cs
-    blobs = []
+    # `inflight` proofs at a time on this GPU, each prover on its own context (stream + workspace) and host thread: one proof's
+    # transcript hashing, host gaps and latency-bound kernel tails are covered by the other's kernels
+    extra = [pkg.Context(device) for _ in range(max(1, inflight) - 1)]
+    provers = [st.prover] + [prover.Prover(st.params, st.pk, c) for c in extra]
+    for pv in provers:
+        st.prove(999, which=pv)                               # warm-up of every prover's buffers
+    blobs = [None] * len(mine)
+    errors = []
+
+    def work(t):
+        try:
+            for j in range(t, len(mine), len(provers)):
+                blobs[j] = prover.proof_commitments(cs, st.prove(1000 + mine[j], which=provers[t]))    # every proof its own blinding
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
     fence_all(world)
     t0 = time.perf_counter()
-    for p in mine:
-        blobs.append(prover.proof_commitments(cs, st.prove(1000 + p)))          # every proof its own blinding
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(len(provers))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
     allc = sharding.gather_proof_commitments(blobs, total, rank, world, "cuda" if backend == "nccl" else "cpu")
     per = len(allc[0]) // 32
     fence_all(world)
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
     assert len(allc) == total and all(len(b) == 32 * per for b in allc)
     st.release()
-    return {"k": k, "proofs": total, "n_gpus": world, "proofs_per_s": round(total / elapsed, 2), "ms_per_proof_per_gpu": round(1e3 * elapsed / max(1, len(mine)), 3),
+    for c in extra:
+        c.close()
+    return {"k": k, "proofs": total, "n_gpus": world, "proofs_in_flight_per_gpu": len(provers), "proofs_per_s": round(total / elapsed, 2), "ms_per_proof_per_gpu": round(1e3 * elapsed / max(1, len(mine)), 3),
             "gathered": "%d proofs x %d compressed commitments (32 B each) on every rank, one all_gather" % (total, per),
             "parallelism": "proof p -> rank p mod N; SRS / proving key replicated; no data-path collective"}
 
@@ -402,10 +426,10 @@ def main():
     ctx.timing_enable(False)
     single = collect([ctx]) if rank == 0 else None
 
-    n_proofs = args.proofs if args.proofs >= 0 else 4 * world
+    n_proofs = args.proofs if args.proofs >= 0 else 8 * world
     batch = None
     if args.proof_k > 0 and n_proofs > 0:
-        batch = batch_proofs(pkg, ctx, args.proof_k, n_proofs, rank, world, args.dist_backend)
+        batch = batch_proofs(pkg, ctx, args.proof_k, n_proofs, rank, world, args.dist_backend, local_rank, args.proofs_inflight)
 
     if rank == 0:
         def tsum(kid):

@@ -74,12 +74,13 @@ class CompiledGraph:
 
     def evaluate_device(self, fixed: Sequence[int], advice: Sequence[int], instance: Sequence[int], challenges: Sequence[int], beta: Optional[int],
                         gamma: Optional[int], theta: Optional[int], y: Optional[int], log_rows: int, rot_scale: int, d_previous: int, d_out: int,
-                        stream: int = 0, form_flags: int = 0):
-        """Column arguments are device pointers (extended-domain cosets, 1 << log_rows elements)."""
+                        stream: int = 0, form_flags: int = 0, ctx: Optional[Context] = None):
+        """Column arguments are device pointers (extended-domain cosets, 1 << log_rows elements).  `ctx`: run on another context
+        of the same device (compiled graphs may be shared between contexts, dehalo.h)."""
         e = self.field.encode
         enc = lambda v: None if v is None else e(v)
         ch = self.field.encode_many(list(challenges)) if challenges else None
-        self.ctx.graph_evaluate_device(self.handle, list(fixed), list(advice), list(instance), ch, enc(beta), enc(gamma), enc(theta), enc(y), log_rows, rot_scale,
+        (ctx or self.ctx).graph_evaluate_device(self.handle, list(fixed), list(advice), list(instance), ch, enc(beta), enc(gamma), enc(theta), enc(y), log_rows, rot_scale,
                                        d_previous, d_out, stream, form_flags)
 
     def release(self):

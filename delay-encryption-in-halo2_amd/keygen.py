@@ -95,8 +95,8 @@ class ParamsKZG:
         self.bases_g_lagrange.release()
 
     # commit / commit_lagrange on device-resident columns: `batch` polynomials of `length` <= n coefficients, n apart
-    def commit_device(self, d_polys: int, batch: int, d_out: int, lagrange: bool, length: Optional[int] = None):
-        self.ctx.msm_device(self.bases_g_lagrange if lagrange else self.bases_g, d_polys, self.n if length is None else length, batch, d_out, 0)
+    def commit_device(self, d_polys: int, batch: int, d_out: int, lagrange: bool, length: Optional[int] = None, ctx: Optional[Context] = None):
+        (ctx or self.ctx).msm_device(self.bases_g_lagrange if lagrange else self.bases_g, d_polys, self.n if length is None else length, batch, d_out, 0)
 
     def write(self, fh):
         fh.write(struct.pack("<I", self.k))

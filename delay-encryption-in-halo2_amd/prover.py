@@ -56,15 +56,19 @@ def rotate_omega(domain, x: int, rot: int) -> int:
 class Prover:
     """Owns the device buffers of one proof for a given proving key (allocated once, reused by every create_proof)."""
 
-    def __init__(self, params: ParamsKZG, pk: ProvingKey):
-        with pk.ctx.torch_stream():        # torch's copies and fills go on the context's stream, ordered with the kernels
+    def __init__(self, params: ParamsKZG, pk: ProvingKey, ctx=None):
+        """`ctx`: the context (stream + workspace) this prover runs on; default the key's.  Several provers over one key, each on
+        its own context, may run concurrently from different threads (batch proving): the SRS tables, the key's columns and
+        the compiled programs are shared, the proof buffers are per prover."""
+        self.ctx = ctx if ctx is not None else pk.ctx
+        with self.ctx.torch_stream():      # torch's copies and fills go on the context's stream, ordered with the kernels
             self._init(params, pk)
 
     def _init(self, params: ParamsKZG, pk: ProvingKey):
         import torch
 
         self.torch = torch
-        self.params, self.pk, self.ctx = params, pk, pk.ctx
+        self.params, self.pk = params, pk
         self.cs, self.domain, self.curve = pk.vk.cs, pk.domain, pk.vk.curve
         self.f = self.curve.scalar
         cs, d = self.cs, self.domain
@@ -145,7 +149,7 @@ class Prover:
     def _commit(self, transcript: Blake2bWrite, first: int, count: int, lagrange: bool, src=None):
         """commit `count` consecutive columns, normalise, absorb: the transcript needs affine points on the host."""
         t = self.cols if src is None else src
-        self.params.commit_device(t[first].data_ptr(), count, self.jac.data_ptr(), lagrange)
+        self.params.commit_device(t[first].data_ptr(), count, self.jac.data_ptr(), lagrange, ctx=self.ctx)
         self.ctx.to_affine_device(self.curve.id, self.jac.data_ptr(), count, self.aff.data_ptr(), 0)
         self.ctx.synchronize()
         pts = decode_points(self.curve, to_host(self.aff[:count]))
@@ -223,8 +227,8 @@ class Prover:
         if L:
             for l in range(L):
                 gi, gt = pk.compress_graphs[l]
-                gi.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l].data_ptr(), 0, 0)
-                gt.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l + 1].data_ptr(), 0, 0)
+                gi.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l].data_ptr(), 0, 0, ctx)
+                gt.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l + 1].data_ptr(), 0, 0, ctx)
             # permuted columns are interleaved (input_l, table_l) with a stride of two columns
             base = cols[self.o_perm].data_ptr()
             ctx.permute_expression_pair_batch_device(fid, self.compressed[0].data_ptr(), self.compressed[1].data_ptr(), u, L, 2 * n, base, base + 32 * n, 0)
@@ -243,13 +247,13 @@ class Prover:
         perm_fixed = fixed_v + self._ptrs(pk.perm_values) + [self.omega_col.data_ptr()]
         for s in range(S):
             gd, gn = self.perm_graphs[s]
-            gd.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.den[s].data_ptr(), 0, 0)
-            gn.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.num[s].data_ptr(), 0, 0)
+            gd.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.den[s].data_ptr(), 0, 0, ctx)
+            gn.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.num[s].data_ptr(), 0, 0, ctx)
         for l in range(L):
             gd, gn = self.lookup_product_graphs
             four = [self.compressed[2 * l].data_ptr(), self.compressed[2 * l + 1].data_ptr(), cols[self.o_perm + 2 * l].data_ptr(), cols[self.o_perm + 2 * l + 1].data_ptr()]
-            gd.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.den[S + l].data_ptr(), 0, 0)
-            gn.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.num[S + l].data_ptr(), 0, 0)
+            gd.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.den[S + l].data_ptr(), 0, 0, ctx)
+            gn.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.num[S + l].data_ptr(), 0, 0, ctx)
         if S + L:
             ctx.grand_product_batch_device(fid, self.num.data_ptr(), self.den.data_ptr(), n, S + L, n, cols[self.o_pz].data_ptr(), 0)
         for s in range(1, S):                                    # z_s starts where z_{s-1} ended: z = vec![last_z]
@@ -280,14 +284,14 @@ class Prover:
         FF = ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL
         fixed_c, adv_c, inst_c = self._ptrs(pk.fixed_cosets), self._ptrs(self.ext, self.o_adv, A), self._ptrs(self.ext, nco, self.I)
         l0, l_last, l_active = (pk.l_ext[i].data_ptr() for i in range(3))
-        pk.custom_gates.evaluate_device(fixed_c, adv_c, inst_c, [], None, None, None, y, ek, rot_scale, 0, self.h.data_ptr(), 0, FF)
+        pk.custom_gates.evaluate_device(fixed_c, adv_c, inst_c, [], None, None, None, y, ek, rot_scale, 0, self.h.data_ptr(), 0, FF, ctx)
         if S:
             kindmap = {plonk.ADVICE: adv_c, plonk.FIXED: fixed_c, plonk.INSTANCE: inst_c}
             pcols = [kindmap[ck][ci] for ck, ci in cs.permutation_columns]
             ev.permutation_h_device(ctx, f, self._ptrs(self.ext, self.o_pz, S), pcols, self._ptrs(pk.perm_cosets), cs.permutation_chunk_len(), -(bf + 1), l0, l_last,
                                     l_active, beta, gamma, y, delta, d.g_coset, d.extended_omega, ek, rot_scale, self.h.data_ptr(), 0, FF)
         for l in range(L):
-            pk.lookup_graphs[l].evaluate_device(fixed_c, adv_c, inst_c, [], beta, gamma, theta, None, ek, rot_scale, 0, self.table_value.data_ptr(), 0, FF)
+            pk.lookup_graphs[l].evaluate_device(fixed_c, adv_c, inst_c, [], beta, gamma, theta, None, ek, rot_scale, 0, self.table_value.data_ptr(), 0, FF, ctx)
             ev.lookup_h_device(ctx, f, self.ext[self.o_lz + l].data_ptr(), self.ext[self.o_perm + 2 * l].data_ptr(), self.ext[self.o_perm + 2 * l + 1].data_ptr(),
                                self.table_value.data_ptr(), l0, l_last, l_active, beta, gamma, y, ek, rot_scale, self.h.data_ptr(), 0, FF)
         mark("evaluate_h")
