@@ -11,8 +11,8 @@
 //             repeated row.
 // The blinding rows upstream appends are the caller's (they are random).
 //
-// Upstream: Vec::sort + BTreeMap on one thread.  Here: canonical keys -> four stable LSD passes of
-// rocPRIM's 64-bit radix sort carrying a permutation (rocPRIM is header-only, compiled in; the
+// Upstream: Vec::sort + BTreeMap on one thread.  Here: canonical keys -> one pass of rocPRIM's 64-bit radix sort on the leading
+// bits + a verification of the full order (fallback: four stable LSD passes), carrying a permutation (rocPRIM is header-only, compiled in; the
 // sort is not the prover's hot loop and a hand-written 256-bit radix sort would be the same
 // algorithm), then flag / binary-search / scan / scatter kernels.  Outputs are gathered from the
 // ORIGINAL Montgomery elements, so no value is ever re-encoded.
@@ -99,6 +99,13 @@ __global__ void k_lp_flags(const fe* S, u32 B, u64 n, u32* repeated, u32* consum
     }
     if (lo < n && lp_cmp(f_load(&T[lo]), a) == 0) consumed[(u64)y * n + lo] = 1u;
     else atomicExch(&err[y], 1);
+}
+// bad += 1 for every adjacent pair of one key column that is out of order under the FULL 256-bit comparison (the fast path sorted
+// on the leading bits only)
+__global__ void k_lp_check_sorted(const fe* S, u64 n, u64 total, u32* bad) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || i % n == 0) return;
+    if (lp_cmp(f_load(&S[i - 1]), f_load(&S[i])) > 0) atomicAdd(bad, 1u);
 }
 __global__ void k_lp_not(const u32* consumed, u64 total, u32* leftover) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,19 +196,51 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe
     unsigned long long host_ors[4];
     HIP_TRY(ctx, hipMemcpyAsync(host_ors, ors, sizeof(host_ors), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));          // the pass plan depends on the data (the call synchronises at its end anyway)
-    k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
     u32 *pin = p0, *pout = p1;
-    for (u32 limb = 0; limb <= 4; limb++) {
-        unsigned bits;
-        if (limb < 4) bits = host_ors[limb] ? 64 - (unsigned)__builtin_clzll(host_ors[limb]) : 0;
-        else bits = 2 * B > 1 ? 32 - (unsigned)__builtin_clz(2 * B - 1) : 0;        // last: the column id, stable
-        if (bits == 0) continue;
+    const unsigned col_bits = 2 * B > 1 ? 32 - (unsigned)__builtin_clz(2 * B - 1) : 0;
+    auto sort_pass = [&](u32 limb, unsigned begin_bit, unsigned end_bit) -> int {
         k_lp_limb<<<blocks_total, 256, 0, s>>>(canon, pin, limb, n, total, keys_a);
         size_t bytes = tmp_bytes;
-        HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp, bytes, keys_a, keys_b, pin, pout, total, 0, bits, s));
+        HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp, bytes, keys_a, keys_b, pin, pout, total, begin_bit, end_bit, s));
         std::swap(pin, pout);
+        return 0;
+    };
+    // Fast path: a theta-compressed lookup value is tag * theta + value -- pseudo-random leading bits per tag, a small integer
+    // added at the bottom -- so the low 32 bits and the leading 48 bits of the most significant non-zero limb order them: two
+    // short value passes + the stable column pass (~15 launches instead of ~40), then the whole order is verified with the full
+    // comparison.  Any violation (values that differ only in the bits in between) falls back to the full
+    // least-significant-limb-first sort.
+    int top = 3;
+    while (top > 0 && host_ors[top] == 0) top--;
+    const unsigned top_bits = host_ors[top] ? 64 - (unsigned)__builtin_clzll(host_ors[top]) : 0;
+    bool sorted_ok = false;
+    if (top_bits > 0) {
+        k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
+        const unsigned low_bits = host_ors[0] ? std::min(32u, 64 - (unsigned)__builtin_clzll(host_ors[0])) : 0;
+        if (low_bits && (top > 0 || top_bits > 48)) TRY(sort_pass(0, 0, low_bits));
+        TRY(sort_pass((u32)top, top_bits > 48 ? top_bits - 48 : 0, top_bits));
+        if (col_bits) TRY(sort_pass(4, 0, col_bits));
+        k_lp_gather<<<blocks_total, 256, 0, s>>>(canon, pin, total, S);
+        u32* bad = (u32*)ors;                                  // the limb ORs have been read: reuse the word
+        HIP_TRY(ctx, hipMemsetAsync(bad, 0, sizeof(u32), s));
+        k_lp_check_sorted<<<blocks_total, 256, 0, s>>>(S, n, total, bad);
+        u32 host_bad = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&host_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        sorted_ok = host_bad == 0;
     }
-    k_lp_gather<<<blocks_total, 256, 0, s>>>(canon, pin, total, S);
+    if (!sorted_ok) {
+        pin = p0; pout = p1;
+        k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
+        for (u32 limb = 0; limb <= 4; limb++) {
+            unsigned bits;
+            if (limb < 4) bits = host_ors[limb] ? 64 - (unsigned)__builtin_clzll(host_ors[limb]) : 0;
+            else bits = col_bits;                                 // last: the column id, stable
+            if (bits == 0) continue;
+            TRY(sort_pass(limb, 0, bits));
+        }
+        k_lp_gather<<<blocks_total, 256, 0, s>>>(canon, pin, total, S);
+    }
     HIP_TRY(ctx, hipMemsetAsync(consumed, 0, half * 4, s));
     HIP_TRY(ctx, hipMemsetAsync(err, 0, B * sizeof(int), s));
     HIP_TRY(ctx, hipMemsetAsync(lsrc, 0, half * 4, s));       // a failed lookup leaves gaps: keep every index in range

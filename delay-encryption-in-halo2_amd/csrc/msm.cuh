@@ -898,7 +898,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 4, MSM_HEAVY_THREADS, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 3, merge_lists + 3 * (size_t)merge_cap);
         // bucket reduction
         uint64_t nblocks4 = (uint64_t)per_group * total_groups;       // 4-bucket blocks
-        if (nblocks4 * 4 <= 96 * 1024) {   // <= ~1.5 waves per SIMD even at 4 lanes per block: latency-bound
+        if (nblocks4 * 4 <= 192 * 1024) {   // <= ~3 waves per SIMD at 4 lanes per block (two rounds of resident quads still beat one lane per block: 0.58 -> 0.28 ms for a batch of ten 2^17 MSMs)
             k_msm_reduce_local<CV, true><<<(u32)((nblocks4 * 4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
         } else {
             k_msm_reduce_local<CV, false><<<(u32)((nblocks4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);

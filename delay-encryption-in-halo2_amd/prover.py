@@ -37,9 +37,22 @@ class SeededRng:
         self.gen = np.random.Generator(np.random.PCG64(seed))
 
     def scalars(self, count: int) -> np.ndarray:
-        a = self.gen.integers(0, 1 << 64, size=(count, 4), dtype=np.uint64)
+        a = self.gen.integers(0, 1 << 64, size=(count, 4), dtype=np.uint64)      # one 64-bit output of the generator per word
         a[:, 3] &= np.uint64((1 << 61) - 1)
         return a
+
+    def fork(self, skip: int) -> "SeededRng":
+        """A generator positioned `skip` scalars ahead of this one (which is left where it is): lets a helper thread produce a
+        later, large draw -- the vanishing argument's random polynomial -- while the proof's earlier phases run."""
+        bg = np.random.PCG64()
+        bg.state = self.gen.bit_generator.state
+        bg.advance(4 * skip)
+        out = SeededRng.__new__(SeededRng)
+        out.gen = np.random.Generator(bg)
+        return out
+
+    def skip(self, count: int):
+        self.gen.bit_generator.advance(4 * count)
 
 
 @dataclass
@@ -193,6 +206,19 @@ class Prover:
                 timings.phases_ms[name] = timings.phases_ms.get(name, 0.0) + 1e3 * (now - t_phase)
                 t_phase = now
 
+        # the one large random draw of the proof (the vanishing argument's random polynomial, n scalars, drawn after every
+        # blinding value) is produced and uploaded by a helper thread while the earlier phases run
+        draws_before = A * (n - u) + A + L * (2 * (n - u) + 2) + (S + L) * (bf + 1)
+        prefetch = None
+        if hasattr(rng, "fork"):
+            import threading
+            box = {}
+
+            def _draw(r=rng.fork(draws_before)):
+                with ctx.torch_stream():
+                    box["poly"] = to_device(r.scalars(n))
+            prefetch = threading.Thread(target=_draw)
+            prefetch.start()
         transcript.common_scalar(pk.vk.transcript_repr)          # vk.hash_into
         # -- instance columns: values into the transcript (KZG: QUERY_INSTANCE = false), polynomials on the device
         if len(instances) != self.I:
@@ -258,15 +284,20 @@ class Prover:
             ctx.grand_product_batch_device(fid, self.num.data_ptr(), self.den.data_ptr(), n, S + L, n, cols[self.o_pz].data_ptr(), 0)
         for s in range(1, S):                                    # z_s starts where z_{s-1} ended: z = vec![last_z]
             ctx.scale_device(fid, cols[self.o_pz + s].data_ptr(), n, None, cols[self.o_pz + s - 1][u].data_ptr(), 0)
-        for j in range(S + L):                                   # blinding rows n - bf .. n, then the (unused) commitment blind
-            self._blind_rows(rng, self.o_pz + j, 1, n - bf)
-            rng.scalars(1)
+        if S + L:                                                # per column: bf blinding rows (n - bf .. n), then the (unused) commitment blind
+            vals = rng.scalars((S + L) * (bf + 1)).reshape(S + L, bf + 1, 4)
+            cols[self.o_pz:self.o_pz + S + L, n - bf:] = to_device(np.ascontiguousarray(vals[:, :bf]))
         if S + L:
             self._commit(transcript, self.o_pz, S + L, True)
         mark("grand_products")
 
         # -- vanishing argument: a random polynomial
-        cols[self.o_rand].copy_(to_device(rng.scalars(n)))
+        if prefetch is not None:
+            prefetch.join()
+            cols[self.o_rand].copy_(box["poly"])
+            rng.skip(n)
+        else:
+            cols[self.o_rand].copy_(to_device(rng.scalars(n)))
         rng.scalars(1)
         self._commit(transcript, self.o_rand, 1, False)
         mark("random_poly")
@@ -403,12 +434,11 @@ class Prover:
 
     def _blind_rows_lookup(self, rng):
         """permute_expression_pair's blinding: per lookup, bf + 1 values for the permuted input, then bf + 1 for the permuted
-        table, then the two (unused) commitment blinds."""
-        rows = self.bf + 1
-        for l in range(self.L):
-            vals = rng.scalars(2 * rows).reshape(2, rows, 4)
-            self.cols[self.o_perm + 2 * l:self.o_perm + 2 * l + 2, self.u:] = to_device(vals)
-            rng.scalars(2)
+        table, then the two (unused) commitment blinds -- drawn in that order, uploaded in one piece."""
+        rows, L = self.bf + 1, self.L
+        vals = rng.scalars(L * (2 * rows + 2)).reshape(L, 2 * rows + 2, 4)
+        blind = np.ascontiguousarray(vals[:, :2 * rows]).reshape(2 * L, rows, 4)          # (input_0, table_0, input_1, ...)
+        self.cols[self.o_perm:self.o_perm + 2 * L, self.u:] = to_device(blind)
 
 
 def proof_layout(cs: plonk.ConstraintSystem) -> Tuple[int, int]:

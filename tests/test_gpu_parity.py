@@ -994,3 +994,20 @@ def test_params_ipa_commit_vs_oracle(pkg, co, ctx, cname, k):
     with pytest.raises(ValueError):
         params.commit(poly[:-1], zero)
     params.release()
+
+
+@pytest.mark.gpu
+def test_permute_expression_pair_leading_bit_ties_fall_back(pkg, po, co, ctx):
+    """The lookup sort's fast path orders on the leading 48 bits of the top limb and verifies the full order: values that agree
+    on those bits and differ below must take the full sort and still match upstream's order."""
+    f, of = pkg.fields.BN254_FR, po.BN254_FR
+    n = 3000
+    rng = po.Xoshiro(77)
+    high = 0x1234567890ABCDEF << 190                       # every value shares its leading bits
+    table_vals = [(high + ((i * 7919) % 4096) * (1 << (64 * (i % 3)))) % f.p for i in range(512)]
+    table = [table_vals[i % 512] for i in range(n)]
+    inputs = [table_vals[rng.below(512)] for _ in range(n)]
+    ti, tt = f.encode_many(inputs), f.encode_many(table)
+    got = ctx.permute_expression_pair(f.id, ti, tt, n)
+    want = co.permute_expression_pair(f.id, ti, tt, n)
+    assert want is not None and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

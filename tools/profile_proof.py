@@ -37,4 +37,12 @@ with pkg.Context(0) as ctx:
     for _ in range(reps):
         t = time.perf_counter(); P.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve)); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
     print("no extra syncs: best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
+
+    class PlainRng:                                            # the same stream without fork(): no helper thread
+        def __init__(self, seed): self.r = prover.SeededRng(seed)
+        def scalars(self, c): return self.r.scalars(c)
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); P.create_proof(adv, [[]], PlainRng(7), transcript.Blake2bWrite(curve)); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
+    print("without the random-polynomial helper thread: best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
     params.release()
