@@ -38,6 +38,38 @@ uint32_t choose_window(size_t n) {
     return std::max<uint32_t>(6, l + 1);
 }
 
+// Windows of the signed-digit recoding: the smallest W for which no canonical scalar s < r leaves a carry after window W - 1
+// (msm.cuh for_each_digit drops it).  With top = (r - 1) >> c(W - 1) that holds when top + 1 <= 2^(c-1), and also when top == 2^(c-1)
+// exactly while the c bits of r - 1 just below the top window are all zero (then s with that top digit has a zero digit in window
+// W - 2, which absorbs any carry).  E.g. BN254 Fr, c = 15: 17 windows instead of ceil(256 / 15) = 18; Pasta Fq, c = 17: 15.
+uint32_t signed_windows(const uint32_t r_words[8], uint32_t c) {
+    uint64_t r1[4];                                                  // r - 1 (r is odd)
+    for (int i = 0; i < 4; i++) r1[i] = (uint64_t)r_words[2 * i] | ((uint64_t)r_words[2 * i + 1] << 32);
+    r1[0] -= 1;
+    auto bits_at = [&](uint32_t lo, uint32_t count) -> uint64_t {   // bits [lo, lo + count) of r - 1, count <= 32
+        uint64_t v = 0;
+        for (uint32_t b = 0; b < count; b++) {
+            uint32_t pos = lo + b;
+            if (pos < 256 && ((r1[pos >> 6] >> (pos & 63)) & 1)) v |= 1ull << b;
+        }
+        return v;
+    };
+    for (uint32_t W = (254 + c - 1) / c; W <= (256 + c - 1) / c; W++) {
+        if (W < 2) continue;
+        const uint32_t shift = c * (W - 1);
+        bool above = false;                                          // anything of r - 1 above the top window?
+        for (uint32_t pos = shift + c; pos < 256; pos++) above |= ((r1[pos >> 6] >> (pos & 63)) & 1) != 0;
+        if (above) continue;
+        const uint64_t top = bits_at(shift, c), half = 1ull << (c - 1);
+        if (top + 1 <= half) return W;
+        if (top == half && bits_at(shift - c, c) == 0) return W;
+    }
+    return (256 + c - 1) / c;
+}
+const uint32_t* scalar_modulus_words(int curve) {
+    return curve == DEHALO_CURVE_BN254_G1 ? Bn254Fr::P : curve == DEHALO_CURVE_PALLAS ? PastaFq::P : PastaFp::P;
+}
+
 int do_msm(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, size_t len, size_t batch, jacobian_t* d_out, hipStream_t s) {
     switch (bases->curve) {
         case DEHALO_CURVE_BN254_G1: return run_msm_bn254(ctx, bases, d_scalars, len, batch, d_out, s);
@@ -100,6 +132,11 @@ int do_field_op(dehalo_ctx* ctx, int field, int op, const fe* a, const fe* b, fe
     }
 int do_eval_poly(dehalo_ctx* ctx, int field, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s) {
 #define CALL(N) eval_poly_##N(ctx, c, len, stride, batch, pt, out, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+int do_eval_poly_multi(dehalo_ctx* ctx, int field, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s) {
+#define CALL(N) eval_poly_multi_##N(ctx, polys, count, len, pts, npts, out, s)
     FIELD_SWITCH(ctx, field, CALL)
 #undef CALL
 }
@@ -271,7 +308,7 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return dh_fail(ctx, DEHALO_ERR_INVALID, "window_bits must be 0 or in [4, 16]");
     uint32_t c = window_bits ? (uint32_t)window_bits : choose_window(n);
     if (c < 4) c = 4;
-    uint32_t W = (256 + c - 1) / c;
+    uint32_t W = signed_windows(scalar_modulus_words(curve), c);
     if (precompute && (uint64_t)n * W >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "precomputed table too large");
     // stage the caller's points (standard Montgomery form) on the device, then build the table
     TRY(dh_ensure(ctx, ctx->ws_tmp_bases, n * sizeof(affine_t)));
@@ -649,6 +686,19 @@ int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_eval_poly(ctx, field, (const fe*)d_coeffs, len, stride_elems, batch, point, (fe*)d_out, pick_stream(ctx, stream));
+}
+
+int dehalo_eval_polynomial_multi_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_polys, size_t count, size_t len, const uint64_t* points,
+                                        uint32_t num_points, uint64_t* d_out, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((count && !d_polys) || !points || !d_out) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial_multi: null argument");
+    for (size_t j = 0; j < count; j++)
+        if (!d_polys[j] && len) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial_multi: null polynomial");
+    if (num_points == 0 || num_points > 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial_multi: 1 to 4 points");
+    if (count >= 65536) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial_multi: too many polynomials");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_eval_poly_multi(ctx, field, (const fe* const*)d_polys, count, len, points, num_points, (fe*)d_out, pick_stream(ctx, stream));
 }
 
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]) {

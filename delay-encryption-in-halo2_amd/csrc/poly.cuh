@@ -120,6 +120,79 @@ __global__ __launch_bounds__(POLY_THREADS) void k_poly_eval(const fe* coeffs, u6
     }
 }
 
+// Up to POLY_MP_MAX points at once (the prover opens every column at x, omega x, omega^-1 x and omega^last x), with the block
+// reduction done by ADDITIONS: a tiny kernel first tabulates pw[pt][t] = (x_pt^8)^t, t < 256 (and x_pt^2048 for the next level);
+// a thread then runs the Horner chains of all points over its 8 coefficients together (independent chains), multiplies each
+// by its table entry and the block sums the 256 terms in LDS -- 10 multiplications per 8 coefficients and point instead of the
+// 8 + 16 of k_poly_eval's multiplicative tree, at the same occupancy.  partials[pt][poly][block].
+#define POLY_MP_MAX 4
+struct MultiPoints { fe pt[POLY_MP_MAX]; u32 count; };
+// grid (points, levels): block (ip, l) tabulates level l's powers, whose point is x_ip^(2048^l); pw[l][ip][t], level_points[l][ip]
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_poly_pow_table(MultiPoints P, fe* pw, fe* level_points) {
+    typedef typename f29_of<F>::type F9;
+    const u32 t = threadIdx.x, ip = blockIdx.x, lvl = blockIdx.y;
+    f29 x = f29_from_std<F9>(P.pt[ip]);
+    for (u32 l = 0; l < lvl; l++)
+        for (int q = 0; q < 11; q++) x = f29_sqr<F9>(x);                          // x^2048 per level
+    if (t == 0) poly_store<F9>(&level_points[lvl * POLY_MP_MAX + ip], f29_norm(x));
+    pw += (u64)lvl * POLY_MP_MAX * POLY_THREADS;
+    f29 base = f29_sqr<F9>(f29_sqr<F9>(f29_sqr<F9>(x)));                        // x^8
+    f29 r = f29_one<F9>();
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {                                           // (x^8)^t
+        if ((t >> bit) & 1) r = f29_mul<F9>(r, base);
+        base = f29_sqr<F9>(base);
+    }
+    f_store(&pw[ip * POLY_THREADS + t], f29_to_packed_canon<F9>(f29_norm(r)));   // internal form, canonical, packed
+}
+
+#define POLY_MP_POLYS 96
+struct PolyPtrs { const fe* p[POLY_MP_POLYS]; };
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_poly_eval_multi(PolyPtrs polys, const fe* coeffs, u64 len, u64 stride, u64 point_stride, u32 npts, const fe* point_ptr,
+                                                                  const fe* pw, fe* partials, u64 partial_stride, u64 partial_point_stride) {
+    struct { u32 count; } P{npts};
+    typedef typename f29_of<F>::type F9;
+    __shared__ f29 sh[POLY_THREADS];
+    const u32 t = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * POLY_EVAL_TILE + (u64)t * POLY_EVAL_EPT;
+    f29 x[POLY_MP_MAX], acc[POLY_MP_MAX];
+#pragma unroll
+    for (int ip = 0; ip < POLY_MP_MAX; ip++) {
+        x[ip] = (u32)ip < P.count ? f29_from_std<F9>(f_load(&point_ptr[ip])) : f29_zero();
+        acc[ip] = f29_zero();
+    }
+    const fe* c0 = coeffs ? coeffs + (u64)blockIdx.y * stride : polys.p[blockIdx.y];       // level 0: one device pointer per polynomial
+#pragma unroll
+    for (int j = POLY_EVAL_EPT - 1; j >= 0; j--) {
+        const bool in = base + j < len;
+        // level >= 1: every point has its own partial sums (point_stride apart); level 0: one coefficient array for all points
+        f29 cj = in ? f29_unpack(f_load(&c0[base + j])) : f29_zero();
+#pragma unroll
+        for (int ip = 0; ip < POLY_MP_MAX; ip++) {
+            if (point_stride && ip) cj = in && (u32)ip < P.count ? f29_unpack(f_load(&c0[(u64)ip * point_stride + base + j])) : f29_zero();
+            acc[ip] = f29_add(f29_mul<F9>(acc[ip], x[ip]), cj);
+        }
+    }
+#pragma unroll
+    for (int ip = 0; ip < POLY_MP_MAX; ip++) {
+        if ((u32)ip >= P.count) break;
+        f29 term = f29_mul<F9>(f29_norm(acc[ip]), f29_unpack(f_load(&pw[ip * POLY_THREADS + t])));     // < 2p
+        __syncthreads();                                     // the previous point's sums have been read
+        sh[t] = term;
+        __syncthreads();
+        for (u32 d = POLY_THREADS / 2; d >= 1; d >>= 1) {
+            if (t < d) sh[t] = f29_norm(f29_add(sh[t], sh[t + d]));               // < 512 p << 2^261
+            __syncthreads();
+        }
+        if (t == 0) {
+            f29 r = f29_mul<F9>(sh[0], f29_one<F9>());
+            f_store(&partials[(u64)ip * partial_point_stride + (u64)blockIdx.y * partial_stride + blockIdx.x], f29_pack(f29_cond_sub(r, F9::P)));
+        }
+    }
+}
+
 // ---- batch inversion -----------------------------------------------------------------------------
 // A block owns 1024 elements, four per thread (strided, so the loads coalesce -- Montgomery's
 // trick does not care about order): thread products, block-wide prefix and suffix products in
@@ -424,6 +497,57 @@ int eval_poly_t(dehalo_ctx* ctx, const fe* d_coeffs, uint64_t len, uint64_t stri
     return 0;
 }
 
+// out[pt][poly] = poly_j(points[pt]) for `count` polynomials given by device pointers (len coefficients each) and npts <= POLY_MP_MAX
+// points: one table kernel for every level, then one pass per level
+template <class F>
+int eval_poly_multi_t(dehalo_ctx* ctx, const fe* const* d_polys, size_t count, uint64_t len, const uint64_t* points, uint32_t npts, fe* d_out, hipStream_t s) {
+    if (count == 0 || npts == 0) return 0;
+    if (len == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)npts * count * sizeof(fe), s));
+        return 0;
+    }
+    ScopedTimer timer(ctx, s, DEHALO_K_POLY);
+    uint32_t levels = 1;
+    for (uint64_t l = len; l > POLY_EVAL_TILE; l = (l + POLY_EVAL_TILE - 1) / POLY_EVAL_TILE) levels++;
+    if (levels > 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial_multi: polynomial too long");
+    const uint64_t nb0 = (len + POLY_EVAL_TILE - 1) / POLY_EVAL_TILE;
+    const uint64_t nb1 = (nb0 + POLY_EVAL_TILE - 1) / POLY_EVAL_TILE;
+    TRY(dh_ensure(ctx, ctx->ws_poly[0], std::max<size_t>(64, (size_t)npts * count * nb0 * sizeof(fe))));
+    TRY(dh_ensure(ctx, ctx->ws_poly[1], std::max<size_t>(64, (size_t)npts * count * nb1 * sizeof(fe))));
+    TRY(dh_ensure(ctx, ctx->ws_poly[2], (size_t)4 * (POLY_MP_MAX + POLY_MP_MAX * POLY_THREADS) * sizeof(fe)));
+    fe* bufs[2] = {(fe*)ctx->ws_poly[0].p, (fe*)ctx->ws_poly[1].p};
+    fe* lvl_pts = (fe*)ctx->ws_poly[2].p;                     // [level][point]
+    fe* pw = lvl_pts + 4 * POLY_MP_MAX;                       // [level][point][256]
+    MultiPoints P{};
+    P.count = npts;
+    for (uint32_t i = 0; i < npts; i++) P.pt[i] = fe_from_u64(points + 4 * i);
+    k_poly_pow_table<F><<<dim3(npts, levels), POLY_THREADS, 0, s>>>(P, pw, lvl_pts);
+    uint64_t cur_len = len;
+    const fe* cur = nullptr;
+    for (uint32_t level = 0; level < levels; level++) {
+        const uint64_t nb = (cur_len + POLY_EVAL_TILE - 1) / POLY_EVAL_TILE;
+        const bool last = level + 1 == levels;
+        fe* dst = last ? d_out : bufs[level & 1];
+        const uint64_t dst_pstride = last ? count : count * nb;       // d_out is [pt][poly]; scratch is [pt][poly][block]
+        const fe* lp = lvl_pts + level * POLY_MP_MAX;
+        const fe* lpw = pw + (uint64_t)level * POLY_MP_MAX * POLY_THREADS;
+        if (level == 0) {
+            for (size_t first = 0; first < count; first += POLY_MP_POLYS) {
+                PolyPtrs pp{};
+                const size_t cnt = std::min<size_t>(POLY_MP_POLYS, count - first);
+                for (size_t j = 0; j < cnt; j++) pp.p[j] = d_polys[first + j];
+                k_poly_eval_multi<F><<<dim3((u32)nb, (u32)cnt), POLY_THREADS, 0, s>>>(pp, nullptr, cur_len, 0, 0, npts, lp, lpw, dst + first * (last ? 1 : nb), last ? 1 : nb, dst_pstride);
+            }
+        } else {
+            PolyPtrs pp{};
+            k_poly_eval_multi<F><<<dim3((u32)nb, (u32)count), POLY_THREADS, 0, s>>>(pp, cur, cur_len, cur_len, count * cur_len, npts, lp, lpw, dst, last ? 1 : nb, dst_pstride);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        cur = dst; cur_len = nb;
+    }
+    return 0;
+}
+
 template <class F, bool PACKED>
 int batch_invert_level(dehalo_ctx* ctx, fe* d_v, uint64_t len, fe* scratch, hipStream_t s) {
     const uint64_t nb = (len + POLY_PTILE - 1) / POLY_PTILE;
@@ -547,6 +671,8 @@ int kate_division_t(dehalo_ctx* ctx, const fe* d_a, uint64_t len, const uint64_t
 #define DEFINE_POLY_ENTRY(NAME, F)                                                                                                              \
     int eval_poly_##NAME(dehalo_ctx* ctx, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s) { \
         return eval_poly_t<F>(ctx, c, len, stride, batch, pt, out, s); }                                                                         \
+    int eval_poly_multi_##NAME(dehalo_ctx* ctx, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s) { \
+        return eval_poly_multi_t<F>(ctx, polys, count, len, pts, npts, out, s); }                                                            \
     int batch_invert_##NAME(dehalo_ctx* ctx, fe* v, uint64_t len, hipStream_t s) { return batch_invert_t<F>(ctx, v, len, s); }                    \
     int prefix_product_##NAME(dehalo_ctx* ctx, const fe* in, uint64_t len, fe* out, hipStream_t s) {                                             \
         return prefix_product_t<F>(ctx, in, len, nullptr, 0, len, 1, out, len, s); }                                                             \

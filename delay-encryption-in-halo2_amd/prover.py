@@ -341,14 +341,16 @@ class Prover:
         point = {r: rotate_omega(d, x, r) for r in rots}
         nfix, off = cs.num_fixed, 0
         slots: Dict[Tuple[str, int], int] = {}
-        for r in rots:                                           # evals[slots[(buffer, r)] + column]
-            for name, t, first, cnt in (("cols", cols, 0, self.NC), ("fixed", pk.fixed_polys, 0, nfix), ("sigma", pk.perm_polys, 0, npc)):
-                need = (name == "cols") or (name == "fixed" and any(rr == r for _, rr in cs.fixed_queries)) or (name == "sigma" and r == 0)
-                if not need or cnt == 0:
-                    continue
-                slots[(name, r)] = off
-                ctx.eval_polynomial_device(fid, t[first].data_ptr(), n, n, cnt, enc(point[r]), self.evals[off].data_ptr(), 0)
-                off += cnt
+        # every opened polynomial (committed columns, fixed, sigma) at every rotation in ONE call: evals[slot[(buffer, r)] + column]
+        rots4 = rots[:4]
+        if len(rots) > 4:
+            raise ValueError("more than four distinct opening rotations")
+        plist = self._ptrs(cols, 0, self.NC) + self._ptrs(pk.fixed_polys) + self._ptrs(pk.perm_polys)
+        ntot = len(plist)
+        for j, r in enumerate(rots4):
+            slots[("cols", r)], slots[("fixed", r)], slots[("sigma", r)] = off + j * ntot, off + j * ntot + self.NC, off + j * ntot + self.NC + nfix
+        ctx.eval_polynomial_multi_device(fid, plist, n, f.encode_many([point[r] for r in rots4]), self.evals[off].data_ptr(), 0)
+        off += len(rots4) * ntot
         # the folded quotient  h(X) = sum_i x^(n i) h_i(X)  and its value at x
         hp = self.h.view(m // n, n, 4)
         xs, cur = [], 1
@@ -359,7 +361,9 @@ class Prover:
         slots[("hfold", 0)] = off
         ctx.eval_polynomial_device(fid, self.hfold.data_ptr(), n, n, 1, enc(x), self.evals[off].data_ptr(), 0)
         off += 1
+        mark("evaluations_launch")
         ctx.synchronize()
+        mark("evaluations_device")
         ev_host = array_to_ints(to_host(self.evals[:off]))
         rinv = pow(1 << 256, -1, p)
         val = lambda name, col, r: ev_host[slots[(name, r)] + col] * rinv % p

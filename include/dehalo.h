@@ -188,6 +188,11 @@ int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, cons
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]);
 int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
                                   const uint64_t point[4], uint64_t* d_out, void* stream);
+/* `count` polynomials (d_polys: HOST array of DEVICE pointers, len coefficients each) at 1..4 points in one pass over the coefficients
+ * (create_proof opens its columns at x, omega x, omega^-1 x and omega^last x): points = num_points x 4 u64 (host),
+ * d_out[point][polynomial][4]. */
+int dehalo_eval_polynomial_multi_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_polys, size_t count, size_t len, const uint64_t* points,
+                                        uint32_t num_points, uint64_t* d_out, void* stream);
 int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len);
 int dehalo_batch_invert_device(dehalo_ctx* ctx, int field, uint64_t* d_values, size_t len, void* stream);
 int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, size_t len, uint64_t* d_out, void* stream);

@@ -297,6 +297,27 @@ def test_kate_division_vs_oracle(pkg, co, ctx, fname, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 9, 2048, 2049, 70000, 1 << 17])
+def test_eval_polynomial_multi_vs_oracle(pkg, co, ctx, n):
+    import torch
+
+    f = pkg.fields.BN254_FR
+    batch = 5
+    cols = np.stack([co.fill_scalars(f.id, "uniform", n, 300 + i) for i in range(batch)])
+    pts = co.fill_scalars(f.id, "uniform", 4, 17)
+    d = torch.from_numpy(cols.view(np.int64)).cuda()
+    for npts in (1, 3, 4):
+        out = torch.zeros((npts, batch, 4), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.eval_polynomial_multi_device(f.id, [d[b].data_ptr() for b in range(batch)], n, pts[:npts], out.data_ptr())
+        ctx.synchronize()
+        got = out.cpu().numpy().view(np.uint64)
+        for i in range(npts):
+            for b in range(batch):
+                assert np.array_equal(got[i, b], co.eval_polynomial(f.id, cols[b], pts[i], 2)), (n, npts, i, b)
+
+
+@pytest.mark.gpu
 def test_lincomb_and_scale_vs_oracle(pkg, co, ctx):
     import torch
 
