@@ -148,6 +148,11 @@ def real_witness(p, k, range_lookups):
     return circ, desc
 
 
+def ctx_device(ctx):
+    import torch
+    return torch.cuda.current_device()
+
+
 class ProofSetup:
     """Circuit, SRS, proving key and a Prover for one (k, shape): the one-time work the reference caches on disk
     (benches/delay_enc.rs:41-54, 84-115).  The SRS travels through ParamsKZG's RawBytes format, as the reference's does."""
@@ -175,7 +180,8 @@ class ProofSetup:
         self.pk = keygen.keygen(ctx, self.params, self.circ.cs, self.circ.fixed, self.circ.assembly, self.circ.selectors)
         ctx.synchronize()
         t3 = time.time()
-        self.prover = prover.Prover(self.params, self.pk)
+        self.side = pkg.Context(ctx_device(ctx))                      # NTTs and the random commitment run beside the commitment phases
+        self.prover = prover.Prover(self.params, self.pk, ctx, self.side)
         with ctx.torch_stream():
             self.advice = keygen.to_device(self.circ.advice)          # the witness, resident in HBM (Montgomery form)
             ctx.field_op_device(self.curve.scalar.id, "to_mont", self.advice.data_ptr(), 0, self.advice.data_ptr(), self.advice.numel() // 4, 0)
@@ -190,6 +196,7 @@ class ProofSetup:
 
     def release(self):
         self.params.release()
+        self.side.close()
 
 
 def proof_numbers(pkg, co, po, ctx, k, range_lookups, with_cpu, verify, reps=5):

@@ -203,6 +203,11 @@ class Context:
     def set_tuning(self, key: str, value: int):
         self._check(self.lib.dehalo_ctx_set_tuning(self.handle, key.encode(), value))
 
+    def torch_stream_obj(self):
+        """The context's stream as a torch.cuda.ExternalStream (for events: record on one context, wait on another)."""
+        self.torch_stream()
+        return self._tstream
+
     def torch_stream(self):
         """The context's stream as a torch stream: `with torch.cuda.stream(ctx.torch_stream()):` puts torch's own copies and
         fills on the stream the library's kernels run on, so they are ordered with them (the context's stream is

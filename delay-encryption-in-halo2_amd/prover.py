@@ -69,11 +69,15 @@ def rotate_omega(domain, x: int, rot: int) -> int:
 class Prover:
     """Owns the device buffers of one proof for a given proving key (allocated once, reused by every create_proof)."""
 
-    def __init__(self, params: ParamsKZG, pk: ProvingKey, ctx=None):
+    def __init__(self, params: ParamsKZG, pk: ProvingKey, ctx=None, side_ctx=None):
         """`ctx`: the context (stream + workspace) this prover runs on; default the key's.  Several provers over one key, each on
         its own context, may run concurrently from different threads (batch proving): the SRS tables, the key's columns and
-        the compiled programs are shared, the proof buffers are per prover."""
+        the compiled programs are shared, the proof buffers are per prover.
+        `side_ctx`: a second context of the same device.  Work that no transcript challenge waits for -- lagrange_to_coeff and
+        coeff_to_extended of a phase's columns, the random polynomial's commitment -- is then queued there as soon as its inputs
+        exist and runs beside the main context's commitment phases (ordered by events), instead of after y."""
         self.ctx = ctx if ctx is not None else pk.ctx
+        self.side = side_ctx
         with self.ctx.torch_stream():      # torch's copies and fills go on the context's stream, ordered with the kernels
             self._init(params, pk)
 
@@ -95,6 +99,7 @@ class Prover:
         # committed columns, one contiguous block: [advice | permuted (input_0, table_0, input_1, ...) | perm z | lookup z | random]
         self.NC = A + 2 * L + S + L + 1
         self.cols = z(self.NC, n, 4)
+        self.polys = z(self.NC, n, 4) if self.side is not None else self.cols    # coefficient forms (in place without a side context)
         self.o_adv, self.o_perm, self.o_pz, self.o_lz, self.o_rand = 0, A, A + 2 * L, A + 2 * L + S, A + 2 * L + S + L
         self.instance = z(max(self.I, 1), n, 4)
         self.compressed = z(max(2 * L, 1), n, 4)                # theta-compressed (input_l, table_l)
@@ -106,6 +111,7 @@ class Prover:
         self.hfold = z(n, 4)
         self.qbuf = z(4, n, 4)                                  # per opening point: the batched polynomial
         self.wbuf = z(8, n, 4)                                  # ... and its quotient (last coefficient zero)
+        self.jac_side, self.aff_side = z(1, 12), z(1, 8)
         self.jac = z(max(self.NC, 8), 12)
         self.aff = z(max(self.NC, 8), 8)
         self.evals = z(64 + 4 * (self.NC + cs.num_fixed + len(cs.permutation_columns)), 4)
@@ -215,10 +221,31 @@ class Prover:
             box = {}
 
             def _draw(r=rng.fork(draws_before)):
-                with ctx.torch_stream():
-                    box["poly"] = to_device(r.scalars(n))
+                if self.side is None:
+                    with ctx.torch_stream():
+                        box["poly"] = to_device(r.scalars(n))
+                    return
+                # with a side context the random polynomial is also COMMITTED there, long before its phase
+                with self.side.torch_stream():
+                    self.polys[self.o_rand].copy_(to_device(r.scalars(n)))
+                    self.params.commit_device(self.polys[self.o_rand].data_ptr(), 1, self.jac_side.data_ptr(), False, ctx=self.side)
+                    self.side.to_affine_device(self.curve.id, self.jac_side.data_ptr(), 1, self.aff_side.data_ptr(), 0)
+                    self.side.synchronize()
+                    box["point"] = decode_points(self.curve, to_host(self.aff_side[:1]))[0]
             prefetch = threading.Thread(target=_draw)
             prefetch.start()
+
+        def side_ntt(first, count):
+            """polys[first : first + count] = lagrange_to_coeff(cols[...]), ext[...] = coeff_to_extended(...) on the side context, after
+            everything queued so far on the main one (the columns and their blinding rows)."""
+            e = torch.cuda.Event()
+            e.record(ctx.torch_stream_obj())
+            sb = self.side.torch_stream_obj()
+            sb.wait_event(e)
+            with torch.cuda.stream(sb):
+                self.polys[first:first + count].copy_(cols[first:first + count])
+            self.side.intt_scaled_device(fid, self.polys[first].data_ptr(), k, c["omega_inv"], c["ifft"], count, 0)
+            self.side.coset_ntt_form_device(fid, self.polys[first].data_ptr(), k, self.ext[first].data_ptr(), ek, c["ext_omega"], c["zeta"], count, ev.FORM_OUT_INTERNAL, 0)
         transcript.common_scalar(pk.vk.transcript_repr)          # vk.hash_into
         # -- instance columns: values into the transcript (KZG: QUERY_INSTANCE = false), polynomials on the device
         if len(instances) != self.I:
@@ -241,6 +268,8 @@ class Prover:
             raise ValueError("advice must be num_advice x n x 4")
         cols[self.o_adv:self.o_adv + A].copy_(adv)
         self._blind_rows(rng, self.o_adv, A, u)
+        if self.side is not None:
+            side_ntt(self.o_adv, A)
         rng.scalars(A)                                           # the commitments' blinds: drawn, unused by KZG
         self._commit(transcript, self.o_adv, A, True)
         mark("advice")
@@ -259,6 +288,8 @@ class Prover:
             base = cols[self.o_perm].data_ptr()
             ctx.permute_expression_pair_batch_device(fid, self.compressed[0].data_ptr(), self.compressed[1].data_ptr(), u, L, 2 * n, base, base + 32 * n, 0)
             self._blind_rows_lookup(rng)
+            if self.side is not None:
+                side_ntt(self.o_perm, 2 * L)
             self._commit(transcript, self.o_perm, 2 * L, True)
         mark("lookup_permuted")
         beta = transcript.squeeze_challenge_scalar()
@@ -288,25 +319,37 @@ class Prover:
             vals = rng.scalars((S + L) * (bf + 1)).reshape(S + L, bf + 1, 4)
             cols[self.o_pz:self.o_pz + S + L, n - bf:] = to_device(np.ascontiguousarray(vals[:, :bf]))
         if S + L:
+            if self.side is not None:
+                side_ntt(self.o_pz, S + L)
             self._commit(transcript, self.o_pz, S + L, True)
         mark("grand_products")
 
         # -- vanishing argument: a random polynomial
+        polys = self.polys
         if prefetch is not None:
             prefetch.join()
-            cols[self.o_rand].copy_(box["poly"])
             rng.skip(n)
+        if self.side is not None and prefetch is not None:
+            rng.scalars(1)
+            transcript.write_point(box["point"])                 # committed on the side context while the earlier phases ran
         else:
-            cols[self.o_rand].copy_(to_device(rng.scalars(n)))
-        rng.scalars(1)
-        self._commit(transcript, self.o_rand, 1, False)
+            cols[self.o_rand].copy_(box["poly"] if prefetch is not None else to_device(rng.scalars(n)))
+            if self.side is not None:
+                polys[self.o_rand].copy_(cols[self.o_rand])
+            rng.scalars(1)
+            self._commit(transcript, self.o_rand, 1, False)
         mark("random_poly")
         y = transcript.squeeze_challenge_scalar()
 
         # -- coefficient forms and cosets of everything committed so far
         nco = self.NC - 1
-        ctx.intt_scaled_device(fid, cols.data_ptr(), k, c["omega_inv"], c["ifft"], nco, 0)
-        ctx.coset_ntt_form_device(fid, cols.data_ptr(), k, self.ext.data_ptr(), ek, c["ext_omega"], c["zeta"], nco, ev.FORM_OUT_INTERNAL, 0)
+        if self.side is None:
+            ctx.intt_scaled_device(fid, cols.data_ptr(), k, c["omega_inv"], c["ifft"], nco, 0)
+            ctx.coset_ntt_form_device(fid, cols.data_ptr(), k, self.ext.data_ptr(), ek, c["ext_omega"], c["zeta"], nco, ev.FORM_OUT_INTERNAL, 0)
+        else:                                                    # queued phase by phase on the side context: wait for it
+            e = torch.cuda.Event()
+            e.record(self.side.torch_stream_obj())
+            ctx.torch_stream_obj().wait_event(e)
         if self.I:
             ctx.coset_ntt_form_device(fid, self.instance.data_ptr(), k, self.ext[nco].data_ptr(), ek, c["ext_omega"], c["zeta"], self.I, ev.FORM_OUT_INTERNAL, 0)
         mark("ntt")
@@ -345,7 +388,7 @@ class Prover:
         rots4 = rots[:4]
         if len(rots) > 4:
             raise ValueError("more than four distinct opening rotations")
-        plist = self._ptrs(cols, 0, self.NC) + self._ptrs(pk.fixed_polys) + self._ptrs(pk.perm_polys)
+        plist = self._ptrs(polys, 0, self.NC) + self._ptrs(pk.fixed_polys) + self._ptrs(pk.perm_polys)
         ntot = len(plist)
         for j, r in enumerate(rots4):
             slots[("cols", r)], slots[("fixed", r)], slots[("sigma", r)] = off + j * ntot, off + j * ntot + self.NC, off + j * ntot + self.NC + nfix
@@ -390,24 +433,24 @@ class Prover:
         # -- queries (point rotation, device polynomial, evaluation), in upstream's order
         Q: List[Tuple[int, int, int]] = []
         for col, r in cs.advice_queries:
-            Q.append((r, cols[self.o_adv + col].data_ptr(), val("cols", self.o_adv + col, r)))
+            Q.append((r, polys[self.o_adv + col].data_ptr(), val("cols", self.o_adv + col, r)))
         for s in range(S):                                                       # permutation::Constructed::open
             zc = self.o_pz + s
-            Q.append((0, cols[zc].data_ptr(), val("cols", zc, 0)))
-            Q.append((1, cols[zc].data_ptr(), val("cols", zc, 1)))
+            Q.append((0, polys[zc].data_ptr(), val("cols", zc, 0)))
+            Q.append((1, polys[zc].data_ptr(), val("cols", zc, 1)))
         for s in range(S - 1):
             zc = self.o_pz + s
-            Q.append((last, cols[zc].data_ptr(), val("cols", zc, last)))
+            Q.append((last, polys[zc].data_ptr(), val("cols", zc, last)))
         for l in range(L):                                                       # lookup::Evaluated::open
             zc, ai, ti = self.o_lz + l, self.o_perm + 2 * l, self.o_perm + 2 * l + 1
             for colr in ((zc, 0), (ai, 0), (ti, 0), (ai, -1), (zc, 1)):
-                Q.append((colr[1], cols[colr[0]].data_ptr(), val("cols", *colr)))
+                Q.append((colr[1], polys[colr[0]].data_ptr(), val("cols", *colr)))
         for col, r in cs.fixed_queries:
             Q.append((r, pk.fixed_polys[col].data_ptr(), val("fixed", col, r)))
         for j in range(npc):                                                     # pk.permutation.open
             Q.append((0, pk.perm_polys[j].data_ptr(), val("sigma", j, 0)))
         Q.append((0, self.hfold.data_ptr(), val("hfold", 0, 0)))                 # vanishing::Evaluated::open
-        Q.append((0, cols[self.o_rand].data_ptr(), val("cols", self.o_rand, 0)))
+        Q.append((0, polys[self.o_rand].data_ptr(), val("cols", self.o_rand, 0)))
 
         # -- ProverGWC::create_proof: one witness polynomial per distinct point, in order of first appearance
         v = transcript.squeeze_challenge_scalar()

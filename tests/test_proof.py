@@ -235,6 +235,24 @@ def test_device_proof_matches_oracle_and_verifies(pkg, po, ctx, chain, device_ch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,rl", [(9, True), (11, False)])
+def test_side_context_prover_makes_the_same_proof(pkg, po, ctx, chain, device_chain, k, rl):
+    """Prover(side_ctx=...): the NTTs of each phase's columns and the random polynomial's commitment run on a second context
+    beside the commitment phases; the proof bytes do not change."""
+    from dehalo2_amd import prover, transcript
+
+    c, d = chain(k, rl), device_chain(k, rl)
+    want, _ = oracle_proof(po, c)
+    side = pkg.Context(0)
+    P2 = prover.Prover(d["params"], d["pk"], ctx, side)
+    for _ in range(3):
+        tr = transcript.Blake2bWrite(pkg.fields.BN254)
+        P2.create_proof(c["adv"], [[]], prover.SeededRng(7), tr)
+        assert tr.finalize() == want
+    side.close()
+
+
+@pytest.mark.gpu
 def test_device_proof_unsatisfied_witness_is_rejected(pkg, po, ctx, chain, device_chain):
     from dehalo2_amd import prover, transcript
 

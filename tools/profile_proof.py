@@ -45,4 +45,17 @@ with pkg.Context(0) as ctx:
     for _ in range(reps):
         t = time.perf_counter(); P.create_proof(adv, [[]], PlainRng(7), transcript.Blake2bWrite(curve)); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
     print("without the random-polynomial helper thread: best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
+    side = pkg.Context(0)
+    P2 = prover.Prover(params, pk, ctx, side)
+    want = transcript.Blake2bWrite(curve); P.create_proof(adv, [[]], prover.SeededRng(7), want)
+    ts = []
+    for _ in range(reps + 2):
+        tr = transcript.Blake2bWrite(curve)
+        t = time.perf_counter(); P2.create_proof(adv, [[]], prover.SeededRng(7), tr); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
+        assert tr.finalize() == want.finalize(), "side-context proof differs"
+    ts = ts[2:]
+    print("with a side context (NTTs and the random commitment beside the commitment phases): best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
+    tm = prover.ProofTimings(); P2.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve), tm)
+    print("   phases", {a: round(b, 2) for a, b in tm.phases_ms.items()})
+    side.close()
     params.release()
