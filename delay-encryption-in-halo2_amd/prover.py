@@ -165,11 +165,14 @@ class Prover:
         return gd.compile(self.ctx, self.f), gn.compile(self.ctx, self.f)
 
     # ---- helpers ----
-    def _commit(self, transcript: Blake2bWrite, first: int, count: int, lagrange: bool, src=None):
-        """commit `count` consecutive columns, normalise, absorb: the transcript needs affine points on the host."""
+    def _commit(self, transcript: Blake2bWrite, first: int, count: int, lagrange: bool, src=None, before_sync=None):
+        """commit `count` consecutive columns, normalise, absorb: the transcript needs affine points on the host.
+        `before_sync()` runs once the launches are queued, just before this thread blocks on them."""
         t = self.cols if src is None else src
         self.params.commit_device(t[first].data_ptr(), count, self.jac.data_ptr(), lagrange, ctx=self.ctx)
         self.ctx.to_affine_device(self.curve.id, self.jac.data_ptr(), count, self.aff.data_ptr(), 0)
+        if before_sync is not None:
+            before_sync()
         self.ctx.synchronize()
         pts = decode_points(self.curve, to_host(self.aff[:count]))
         for P in pts:
@@ -232,8 +235,7 @@ class Prover:
                     self.side.to_affine_device(self.curve.id, self.jac_side.data_ptr(), 1, self.aff_side.data_ptr(), 0)
                     self.side.synchronize()
                     box["point"] = decode_points(self.curve, to_host(self.aff_side[:1]))[0]
-            prefetch = threading.Thread(target=_draw)
-            prefetch.start()
+            prefetch = threading.Thread(target=_draw)      # started when the advice commitments are queued (below): the host is idle then
 
         def side_ntt(first, count):
             """polys[first : first + count] = lagrange_to_coeff(cols[...]), ext[...] = coeff_to_extended(...) on the side context, after
@@ -271,7 +273,7 @@ class Prover:
         if self.side is not None:
             side_ntt(self.o_adv, A)
         rng.scalars(A)                                           # the commitments' blinds: drawn, unused by KZG
-        self._commit(transcript, self.o_adv, A, True)
+        self._commit(transcript, self.o_adv, A, True, before_sync=prefetch.start if prefetch is not None else None)
         mark("advice")
         theta = transcript.squeeze_challenge_scalar()
 
