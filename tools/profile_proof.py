@@ -14,7 +14,9 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 rl = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 curve = pkg.fields.BN254
-circ = circuits.synthesize(curve.scalar.p, k, rl, seed=3)
+import bench                                            # the bench's witness: the real DelayEncryptCircuit / PoseidonEncCircuit values
+circ, desc = bench.real_witness(curve.scalar.p, k, rl)
+print(desc)
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 with pkg.Context(0) as ctx:
     params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"])
