@@ -195,7 +195,11 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u
 }
 
 // single block: exclusive scan of the block sums in place (nblocks <= a few thousand)
-static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks) {
+// It also fixes the accumulation's points per lane from the ACTUAL number of sorted points M (zero digits are never sorted: a
+// witness column of small values has a fraction of batch * n * W): geo[0] = L = ceil(M / (rounds * resident)) with
+// rounds = ceil(M / (resident * lmax)), at least 4; geo[1] = M.  (Sized from the upper bound on the host, a sparse column left most
+// lanes idle and the rest with full-length chains: advice columns took half the time of dense ones with a fifth of the points.)
+static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident, u32 lmax) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     __shared__ u32 carry_i, carry_t;
     if (threadIdx.x == 0) { carry_i = 0; carry_t = 0; }
@@ -216,15 +220,24 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_item
         if (threadIdx.x == SCAN_THREADS - 1) { carry_i += s_i[threadIdx.x]; carry_t += s_t[threadIdx.x]; }
         __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        const u64 M = carry_i;
+        const u64 rounds = max((u64)1, (M + (u64)resident * lmax - 1) / ((u64)resident * lmax));
+        u64 L = (M + rounds * resident - 1) / (rounds * resident);
+        L = min((u64)lmax, max((u64)4, L));
+        geo[0] = (u32)L;
+        geo[1] = (u32)M;
+    }
 }
 
 // off[b] = points before bucket b.  The accumulation cuts the sorted list into ranges of L points,
 // one per lane, regardless of bucket boundaries; lane g writes one partial sum per bucket its
 // range touches, at record  g + (number of non-empty buckets before that bucket)  -- consecutive
 // for the lanes of one bucket.  rbeg/rend[b] = that bucket's record range (equal when empty).
-static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32 total, u32 L, const u32* bsum_items, const u32* bsum_tasks,
+static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32 total, const u32* geo, const u32* bsum_items, const u32* bsum_tasks,
                                                                     u32* off, u32* nrank, u32* rbeg, u32* rend) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
+    const u32 L = geo[0];
     u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
     u32 vi[SCAN_PER_THREAD], vt[SCAN_PER_THREAD];
     u32 si = 0, st = 0;
@@ -465,14 +478,15 @@ FP_DEV aff29 load_point(const affine_t* table, u32 e, bool& is_id) {
 // bucket's; L0 is chosen on the host so that the lanes fill the chip a whole number of times.
 template <class CV>
 __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* nrank,
-                                                               const affine_t* table, xyzz29_rec* partial) {
+                                                               const affine_t* table, xyzz29_rec* partial, const u32* geo) {
     typedef typename f29_of<typename CV::Base>::type F;
     const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 M = off[total_buckets];
-    const u64 beg64 = (u64)lane * g.L0;
+    const u32 L0 = geo[0];                                      // points per lane, fixed by the scan from the actual M
+    const u64 beg64 = (u64)lane * L0;
     if (beg64 >= M) return;
     const u32 beg = (u32)beg64;
-    const u32 end = (u32)min((u64)M, beg64 + g.L0);
+    const u32 end = (u32)min((u64)M, beg64 + L0);
     u32 b = find_segment(off, total_buckets, beg);      // the (non-empty) bucket holding point `beg`
     u32 next = off[b + 1];
     u32 rec = lane + nrank[b];
@@ -786,14 +800,14 @@ __global__ void k_jac_to_affine(const jacobian_t* in, affine_t* out, u32 count) 
 // ==========================================================================================
 // host driver (instantiated once per curve in msm_<curve>.hip)
 // ==========================================================================================
-static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32 L, u32* off, u32* nrank, u32* rbeg, u32* rend, hipStream_t s) {
+static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32* geo, u32 resident, u32 lmax, u32* off, u32* nrank, u32* rbeg, u32* rend, hipStream_t s) {
     u32 nblocks = (total + SCAN_BLOCK - 1) / SCAN_BLOCK;
     TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)nblocks * 2 * sizeof(u32)));
     u32* bs_i = (u32*)ctx->ws_bsum.p;
     u32* bs_t = bs_i + nblocks;
-    k_scan_block_sums<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, L, bs_i, bs_t);
-    k_scan_top<<<1, SCAN_THREADS, 0, s>>>(bs_i, bs_t, nblocks);
-    k_scan_apply<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, L, bs_i, bs_t, off, nrank, rbeg, rend);
+    k_scan_block_sums<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, 0, bs_i, bs_t);
+    k_scan_top<<<1, SCAN_THREADS, 0, s>>>(bs_i, bs_t, nblocks, geo, resident, lmax);
+    k_scan_apply<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, geo, bs_i, bs_t, off, nrank, rbeg, rend);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -816,21 +830,19 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const uint64_t Mmax = (uint64_t)batch * len * g.W;
     if (Mmax >= (1ull << 32) || total_buckets >= (1ull << 31))
         return dh_fail(ctx, DEHALO_ERR_INVALID, "batch * len * windows too large for one launch");
-    {   // points per lane: the lanes fill the chip (4 waves per SIMD of k_msm_accum0) a whole number of times
-        const uint64_t resident = (uint64_t)ctx->num_cus * 4 * (uint64_t)ctx->msm_acc_waves * 64;
-        const uint64_t lmax = 64 * 4 / (uint64_t)ctx->msm_acc_waves;
-        const uint64_t rounds = std::max<uint64_t>(1, (Mmax + resident * lmax - 1) / (resident * lmax));
-        uint64_t L0 = (Mmax + rounds * resident - 1) / (rounds * resident);
-        L0 = std::min<uint64_t>(lmax, std::max<uint64_t>(4, L0));
-        g.L0 = (u32)L0;
-    }
-    const uint64_t lanes_max = (Mmax + g.L0 - 1) / g.L0;
+    // points per lane: the lanes fill the chip (msm_acc_waves waves per SIMD of k_msm_accum0) a whole number of times.  The value is
+    // fixed ON THE DEVICE from the number of points actually sorted (k_scan_top); the host only bounds the lane count.
+    const uint64_t resident = (uint64_t)ctx->num_cus * 4 * (uint64_t)ctx->msm_acc_waves * 64;
+    const uint64_t lmax = 64 * 4 / (uint64_t)ctx->msm_acc_waves;
+    const uint64_t rounds_max = std::max<uint64_t>(1, (Mmax + resident * lmax - 1) / (resident * lmax));
+    g.L0 = 0;
+    const uint64_t lanes_max = rounds_max * resident + MSM_ACC_THREADS;
     const uint64_t nt0_max = lanes_max + total_buckets;        // records: one per lane + one per non-empty bucket (upper bound)
     const u32 per_group = (g.nb + MSM_RED_M - 1) / MSM_RED_M;
     const size_t REC = sizeof(xyzz29_rec);
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
-    TRY(dh_ensure(ctx, ctx->ws_counters, 16));                                   // 4 merge-class counters
+    TRY(dh_ensure(ctx, ctx->ws_counters, 32));                                   // 4 merge-class counters | L0 | M
     TRY(dh_ensure(ctx, ctx->ws_bhist, total_buckets * (size_t)g.slices * 4));   // per-block histograms
     const u32 sub_bits = g.c - 1 < 8 ? g.c - 1 : 8, P = g.nb >> sub_bits;
     TRY(dh_ensure(ctx, ctx->ws_pcount, total_groups * (size_t)g.slices * P * 4));   // per-(slice, partition) counts
@@ -877,7 +889,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, bh, pc);
         k_msm_colscan<<<(tb + 255) / 256, 256, 0, s>>>(g.nb, g.slices, tb, bh, count);
         k_msm_colscan<<<((u32)total_groups * P + 255) / 256, 256, 0, s>>>(P, g.slices, (u32)total_groups * P, pc, nullptr);
-        TRY(run_scan(ctx, count, tb, g.L0, off, nrank, rbeg, rend, s));
+        TRY(run_scan(ctx, count, tb, cursor + 4, (u32)resident, (u32)lmax, off, nrank, rbeg, rend, s));
         k_msm_part<FS><<<grid, MSM_SORT_THREADS, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, 0, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
         HIP_TRY(ctx, hipGetLastError());
@@ -885,7 +897,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_ACCUMULATE);
         u32 blocks = (u32)((lanes_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
-        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, 0, s>>>(g, tb, idx, off, nrank, bases->table, partial0);
+        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, 0, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + 4);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
