@@ -22,7 +22,7 @@ SYMBOLS = [
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device",
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
-    "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device",
+    "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device", "dehalo_kate_division_batch_device",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
@@ -130,6 +130,7 @@ def load_library():
     lib.dehalo_scale_device.argtypes = [P, C.c_int, u64p, sz, u64p, u32, u64p, P]
     lib.dehalo_kate_division.argtypes = [P, C.c_int, u64p, sz, u64p, u64p]
     lib.dehalo_kate_division_device.argtypes = [P, C.c_int, u64p, sz, u64p, u64p, P]
+    lib.dehalo_kate_division_batch_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), sz, u64p, C.POINTER(C.c_void_p), sz, P]
     lib.dehalo_convert_form_device.argtypes = [P, C.c_int, u64p, u64p, sz, C.c_int, P]
     lib.dehalo_coset_ntt_form_device.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p, sz, u32, P]
     lib.dehalo_coset_intt_form_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p, sz, u32, P]
@@ -398,6 +399,11 @@ class Context:
         q = np.zeros((a.shape[0] - 1, 4), dtype=np.uint64)
         self._check(self.lib.dehalo_kate_division(self.handle, field, _ptr(a), a.shape[0], _ptr(_u64(point, 4)), _ptr(q) if q.shape[0] else None))
         return q
+
+    def kate_division_batch_device(self, field: int, d_a: Sequence[int], length: int, points, d_q: Sequence[int], stream: int = 0):
+        pts = _u64(points, 4)
+        ta, tq = (C.c_void_p * max(1, len(d_a)))(*d_a), (C.c_void_p * max(1, len(d_q)))(*d_q)
+        self._check(self.lib.dehalo_kate_division_batch_device(self.handle, field, ta, length, _ptr(pts), tq, len(d_a), stream or None))
 
     def kate_division_device(self, field: int, d_a: int, length: int, point, d_q: int, stream: int = 0):
         self._check(self.lib.dehalo_kate_division_device(self.handle, field, d_a, length, _ptr(_u64(point, 4)), d_q, stream or None))

@@ -172,6 +172,12 @@ int do_kate_division(dehalo_ctx* ctx, int field, const fe* a, uint64_t len, cons
 #undef CALL
 }
 
+int do_kate_division_batch(dehalo_ctx* ctx, int field, const fe* const* a, uint64_t len, const uint64_t* pts, fe* const* q, size_t count, hipStream_t s) {
+#define CALL(N) kate_division_batch_##N(ctx, a, len, pts, q, count, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+
 int do_convert_form(dehalo_ctx* ctx, int field, const fe* in, fe* out, uint64_t n, int to_internal, hipStream_t s) {
 #define CALL(N) convert_form_##N(ctx, in, out, n, to_internal, s)
     FIELD_SWITCH(ctx, field, CALL)
@@ -818,6 +824,21 @@ int dehalo_kate_division_device(dehalo_ctx* ctx, int field, const uint64_t* d_a,
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_kate_division(ctx, field, (const fe*)d_a, len, point, (fe*)d_q, pick_stream(ctx, stream));
+}
+
+int dehalo_kate_division_batch_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_a, size_t len, const uint64_t* points, uint64_t* const* d_q,
+                                      size_t count, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (count && (!d_a || !d_q || !points)) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division_batch: null argument");
+    if (count > 8) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division_batch: at most 8 divisions per call");
+    if (len > (1ull << 22)) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division_batch: polynomials of at most 2^22 coefficients");
+    for (size_t y = 0; y < count; y++) {
+        if ((!d_a[y] || !d_q[y]) && len > 1) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division_batch: null polynomial");
+        if (d_a[y] == d_q[y]) return dh_fail(ctx, DEHALO_ERR_INVALID, "kate_division_batch: a and q may not alias");
+    }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_kate_division_batch(ctx, field, (const fe* const*)d_a, len, points, (fe* const*)d_q, count, pick_stream(ctx, stream));
 }
 
 int dehalo_kate_division(dehalo_ctx* ctx, int field, const uint64_t* a, size_t len, const uint64_t point[4], uint64_t* q) {

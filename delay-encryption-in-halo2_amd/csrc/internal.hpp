@@ -163,7 +163,8 @@ DECL_NTT(pasta_fq)
     int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, size_t batch, uint64_t stride, fe* z, hipStream_t s); \
     int lincomb_##NAME(dehalo_ctx* ctx, const fe* const* cols, const uint64_t* coefs, size_t count, uint64_t len, fe* out, const uint64_t* sub0, hipStream_t s); \
     int scale_##NAME(dehalo_ctx* ctx, fe* a, uint64_t len, const uint64_t* pattern, uint32_t period, const fe* d_factor, hipStream_t s);    \
-    int kate_division_##NAME(dehalo_ctx* ctx, const fe* a, uint64_t len, const uint64_t pt[4], fe* q, hipStream_t s);
+    int kate_division_##NAME(dehalo_ctx* ctx, const fe* a, uint64_t len, const uint64_t pt[4], fe* q, hipStream_t s);                       \
+    int kate_division_batch_##NAME(dehalo_ctx* ctx, const fe* const* a, uint64_t len, const uint64_t* pts, fe* const* q, size_t count, hipStream_t s);
 DECL_POLY(bn254_fr)
 DECL_POLY(bn254_fq)
 DECL_POLY(pasta_fp)

@@ -382,17 +382,29 @@ __global__ __launch_bounds__(POLY_THREADS) void k_lincomb(LincombArgs A, u64 len
     if (t < A.count) cf[t] = f29_from_std<F9>(A.coef[t]);
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * (POLY_THREADS * POLY_LC_EPT) + t;
+    // the thread's POLY_LC_EPT elements advance together: that many independent loads and multiplications per column
+    f29 acc[POLY_LC_EPT];
+#pragma unroll
+    for (int e = 0; e < POLY_LC_EPT; e++) {
+        const u64 i = i0 + (u64)e * POLY_THREADS;
+        acc[e] = accumulate && i < len ? f29_unpack(f_load(&out[i])) : f29_zero();
+    }
+    for (u32 j = 0; j < A.count; j++) {
+        const fe* col = A.cols[j];
+        const f29 cj = cf[j];
+#pragma unroll
+        for (int e = 0; e < POLY_LC_EPT; e++) {
+            const u64 i = i0 + (u64)e * POLY_THREADS;
+            if (i < len) acc[e] = f29_norm(f29_add(acc[e], f29_mul<F9>(cj, f29_unpack(f_load(&col[i])))));     // < (1 + 2 * 40) p  << 2^261
+        }
+    }
 #pragma unroll
     for (int e = 0; e < POLY_LC_EPT; e++) {
         const u64 i = i0 + (u64)e * POLY_THREADS;
         if (i >= len) continue;
-        f29 acc = accumulate ? f29_unpack(f_load(&out[i])) : f29_zero();
-        for (u32 j = 0; j < A.count; j++) {
-            f29 pr = f29_mul<F9>(cf[j], f29_unpack(f_load(&A.cols[j][i])));      // < 2p
-            acc = f29_norm(f29_add(acc, pr));                                     // < (1 + 2 * 40) p  << 2^261
-        }
-        if (has_sub0 && i == 0) acc = f29_norm(f29_sub(acc, f29_unpack(sub0), F9::KM));
-        f29 r = f29_mul<F9>(acc, f29_one<F9>());                                  // value * 2^261 * 2^256 / 2^261: standard form, < 2p
+        f29 a = acc[e];
+        if (has_sub0 && i == 0) a = f29_norm(f29_sub(a, f29_unpack(sub0), F9::KM));
+        f29 r = f29_mul<F9>(a, f29_one<F9>());                                    // value * 2^261 * 2^256 / 2^261: standard form, < 2p
         f_store(&out[i], f29_pack(f29_cond_sub(r, F9::P)));
     }
 }
@@ -424,11 +436,11 @@ __global__ __launch_bounds__(POLY_THREADS) void k_scale(fe* a, u64 len, ScaleArg
 //   (3) k_kate_apply: a thread's 8 coefficients, a 257-slot Hillis-Steele suffix scan in LDS (slot 256 = C_b),
 //       then Horner down the thread's coefficients, storing E(i) to q[i-1].
 template <class F>
-__global__ __launch_bounds__(POLY_THREADS) void k_kate_apply(const fe* a, u64 len, fe point_val, const fe* point_ptr, const fe* carries, fe* q) {
+FP_DEV void kate_apply_body(const fe* a, u64 len, const fe& point, const fe* carries, fe* q) {
     typedef typename f29_of<F>::type F9;
     __shared__ f29 sh[POLY_THREADS + 1];
     const u32 t = threadIdx.x;
-    const f29 x = f29_from_std<F9>(point_ptr ? f_load(point_ptr) : point_val);
+    const f29 x = f29_from_std<F9>(point);
     const u64 base = (u64)blockIdx.x * POLY_EVAL_TILE + (u64)t * POLY_EVAL_EPT;
     f29 c[POLY_EVAL_EPT];
     f29 acc = f29_zero();
@@ -459,6 +471,48 @@ __global__ __launch_bounds__(POLY_THREADS) void k_kate_apply(const fe* a, u64 le
             f29 r = f29_mul<F9>(e, f29_one<F9>());
             f_store(&q[i - 1], f29_pack(f29_cond_sub(r, F9::P)));
         }
+    }
+}
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_kate_apply(const fe* a, u64 len, fe point_val, const fe* point_ptr, const fe* carries, fe* q) {
+    kate_apply_body<F>(a, len, point_ptr ? f_load(point_ptr) : point_val, carries, q);
+}
+// Several (polynomial, point) pairs in one launch (blockIdx.y): ProverGWC opens at up to four points, and every launch of
+// this latency-bound chain costs the same whether it carries one division or four.
+#define POLY_KATE_MAX 8
+struct KateBatch { const fe* a[POLY_KATE_MAX]; fe* q[POLY_KATE_MAX]; fe pt[POLY_KATE_MAX]; };
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_kate_apply_batch(KateBatch B, u64 len, const fe* pt_dev, const fe* carries, u64 carries_stride) {
+    const u32 y = blockIdx.y;
+    kate_apply_body<F>(B.a[y], len, pt_dev ? f_load(&pt_dev[y]) : B.pt[y], carries ? carries + (u64)y * carries_stride : nullptr, B.q[y]);
+}
+// block sums S[y][b] = sum_j a_y[2048 b + j] z_y^j and z_y^2048 (the k_poly_eval tree with a point per polynomial)
+template <class F>
+__global__ __launch_bounds__(POLY_THREADS) void k_kate_sums_batch(KateBatch B, u64 len, fe* S, u64 s_stride, fe* next_pt) {
+    typedef typename f29_of<F>::type F9;
+    __shared__ f29 sh[POLY_THREADS];
+    const u32 t = threadIdx.x, y = blockIdx.y;
+    const fe* c = B.a[y];
+    const f29 x = f29_from_std<F9>(B.pt[y]);
+    const u64 base = (u64)blockIdx.x * POLY_EVAL_TILE + (u64)t * POLY_EVAL_EPT;
+    f29 acc = f29_zero();
+#pragma unroll
+    for (int j = POLY_EVAL_EPT - 1; j >= 0; j--) {
+        f29 cj = base + j < len ? f29_unpack(f_load(&c[base + j])) : f29_zero();
+        acc = f29_add(f29_mul<F9>(acc, x), cj);
+    }
+    f29 X = f29_sqr<F9>(f29_sqr<F9>(f29_sqr<F9>(x)));
+    sh[t] = f29_norm(acc);
+    __syncthreads();
+    for (u32 d = 1; d < POLY_THREADS; d <<= 1) {
+        if ((t & (2 * d - 1)) == 0) sh[t] = f29_norm(f29_add(sh[t], f29_mul<F9>(sh[t + d], X)));
+        X = f29_sqr<F9>(X);
+        __syncthreads();
+    }
+    if (t == 0) {
+        f29 r = f29_mul<F9>(sh[0], f29_one<F9>());
+        f_store(&S[(u64)y * s_stride + blockIdx.x], f29_pack(f29_cond_sub(r, F9::P)));
+        if (blockIdx.x == 0) poly_store<F9>(&next_pt[y], X);
     }
 }
 
@@ -657,6 +711,33 @@ int kate_level(dehalo_ctx* ctx, const fe* d_a, uint64_t len, fe point_val, const
     return 0;
 }
 
+// `count` <= POLY_KATE_MAX divisions of equal length in three launches (sums, carries, apply); len <= 2048^2
+template <class F>
+int kate_division_batch_t(dehalo_ctx* ctx, const fe* const* d_a, uint64_t len, const uint64_t* points, fe* const* d_q, size_t count, hipStream_t s) {
+    if (len <= 1 || count == 0) return 0;
+    ScopedTimer timer(ctx, s, DEHALO_K_POLY);
+    const uint64_t nb = (len + POLY_EVAL_TILE - 1) / POLY_EVAL_TILE;
+    KateBatch B{};
+    for (size_t y = 0; y < count; y++) { B.a[y] = d_a[y]; B.q[y] = d_q[y]; B.pt[y] = fe_from_u64(points + 4 * y); }
+    if (nb == 1) {
+        k_kate_apply_batch<F><<<dim3(1, (u32)count), POLY_THREADS, 0, s>>>(B, len, nullptr, nullptr, 0);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
+    TRY(dh_ensure(ctx, ctx->ws_poly[0], (2 * nb + 2) * POLY_KATE_MAX * sizeof(fe) + 4096));
+    fe* S = (fe*)ctx->ws_poly[0].p;                       // [y][nb]
+    fe* C = S + POLY_KATE_MAX * nb;                       // [y][nb]; C[y][nb - 1] = 0: nothing above the last block
+    fe* pt2 = C + POLY_KATE_MAX * nb;                     // [y]: z_y^2048
+    k_kate_sums_batch<F><<<dim3((u32)nb, (u32)count), POLY_THREADS, 0, s>>>(B, len, S, nb, pt2);
+    HIP_TRY(ctx, hipMemsetAsync(C, 0, POLY_KATE_MAX * nb * sizeof(fe), s));
+    KateBatch B2{};
+    for (size_t y = 0; y < count; y++) { B2.a[y] = S + y * nb; B2.q[y] = C + y * nb; }
+    k_kate_apply_batch<F><<<dim3(1, (u32)count), POLY_THREADS, 0, s>>>(B2, nb, pt2, nullptr, 0);       // C[y][b] = E_S(b + 1), b < nb - 1
+    k_kate_apply_batch<F><<<dim3((u32)nb, (u32)count), POLY_THREADS, 0, s>>>(B, len, nullptr, C, nb);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 template <class F>
 int kate_division_t(dehalo_ctx* ctx, const fe* d_a, uint64_t len, const uint64_t point[4], fe* d_q, hipStream_t s) {
     if (len <= 1) return 0;
@@ -683,4 +764,6 @@ int kate_division_t(dehalo_ctx* ctx, const fe* d_a, uint64_t len, const uint64_t
     int scale_##NAME(dehalo_ctx* ctx, fe* a, uint64_t len, const uint64_t* pattern, uint32_t period, const fe* d_factor, hipStream_t s) {        \
         return scale_t<F>(ctx, a, len, pattern, period, d_factor, s); }                                                                          \
     int kate_division_##NAME(dehalo_ctx* ctx, const fe* a, uint64_t len, const uint64_t pt[4], fe* q, hipStream_t s) {                           \
-        return kate_division_t<F>(ctx, a, len, pt, q, s); }
+        return kate_division_t<F>(ctx, a, len, pt, q, s); }                                                                                      \
+    int kate_division_batch_##NAME(dehalo_ctx* ctx, const fe* const* a, uint64_t len, const uint64_t* pts, fe* const* q, size_t count, hipStream_t s) { \
+        return kate_division_batch_t<F>(ctx, a, len, pts, q, count, s); }

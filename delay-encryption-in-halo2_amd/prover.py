@@ -474,7 +474,7 @@ class Prover:
                 eval_batch = (eval_batch + pw * e) % p
                 pw = pw * v % p
             ctx.lincomb_device(fid, ptrs, f.encode_many(coefs), n, self.qbuf[gi].data_ptr(), enc(eval_batch), 0)
-            ctx.kate_division_device(fid, self.qbuf[gi].data_ptr(), n, enc(point[r]), self.wbuf[gi].data_ptr(), 0)
+        ctx.kate_division_batch_device(fid, self._ptrs(self.qbuf, 0, len(order)), n, f.encode_many([point[r] for r in order]), self._ptrs(self.wbuf, 0, len(order)), 0)
         self._commit(transcript, 0, len(order), False, src=self.wbuf)
         mark("openings")
         if timings is not None:

@@ -219,6 +219,10 @@ int dehalo_lincomb_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_c
 int dehalo_scale_device(dehalo_ctx* ctx, int field, uint64_t* d_a, size_t len, const uint64_t* pattern, uint32_t period, const uint64_t* d_factor, void* stream);
 int dehalo_kate_division(dehalo_ctx* ctx, int field, const uint64_t* a, size_t len, const uint64_t point[4], uint64_t* q);
 int dehalo_kate_division_device(dehalo_ctx* ctx, int field, const uint64_t* d_a, size_t len, const uint64_t point[4], uint64_t* d_q, void* stream);
+/* up to 8 divisions of equal length (<= 2^22 coefficients) in one set of launches: d_a / d_q = HOST arrays of DEVICE pointers,
+ * points = count x 4 u64 (ProverGWC::create_proof: one division per distinct opening point) */
+int dehalo_kate_division_batch_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_a, size_t len, const uint64_t* points, uint64_t* const* d_q,
+                                      size_t count, void* stream);
 
 /* ---- quotient numerator: evaluate_h --------------------------------------
  * The row loops of halo2_proofs/src/plonk/evaluation.rs @ v2023_04_20 on device-resident

@@ -336,6 +336,26 @@ def test_eval_polynomial_multi_vs_oracle(pkg, co, ctx, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 2048, 2049, 1 << 17, (1 << 18) + 5])
+def test_kate_division_batch_vs_oracle(pkg, co, ctx, n):
+    import torch
+
+    f = pkg.fields.BN254_FR
+    cnt = 4
+    a = np.stack([co.fill_scalars(f.id, "uniform", n, 900 + i) for i in range(cnt)])
+    pts = co.fill_scalars(f.id, "uniform", cnt, 23)
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    dq = torch.zeros((cnt, n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.kate_division_batch_device(f.id, [da[i].data_ptr() for i in range(cnt)], n, pts, [dq[i].data_ptr() for i in range(cnt)])
+    ctx.synchronize()
+    got = dq.cpu().numpy().view(np.uint64)
+    for i in range(cnt):
+        assert np.array_equal(got[i, :n - 1], co.kate_division(f.id, a[i], pts[i])), (n, i)
+        assert not got[i, n - 1].any()
+
+
+@pytest.mark.gpu
 def test_lincomb_and_scale_vs_oracle(pkg, co, ctx):
     import torch
 
