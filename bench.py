@@ -102,6 +102,63 @@ def cpu_baseline(co, po, curve, field, log_n, bases, scalars, a):
     }, co.to_affine(curve.id, msm_res), ntt_res
 
 
+def secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n):
+    """What the headline does not show: the cost of building the resident SRS table, the same MSM over a single-row table
+    (no precomputed window multiples) and the literal drop-in `best_multiexp(coeffs, bases)` over host buffers that are not
+    registered (upload + one-row table + MSM + download: PCIe-inclusive)."""
+    import numpy as np
+    import torch
+    n = 1 << log_n
+    out = {}
+    t = time.perf_counter(); b = ctx.register_bases(curve.id, bases_h, 0, True); out["table_build_ms_precomputed"] = round(1e3 * (time.perf_counter() - t), 2)
+    out["table_windows"], out["table_bytes"] = b.windows, b.windows * n * 64
+    b.release()
+    t = time.perf_counter(); b1 = ctx.register_bases(curve.id, bases_h, 0, False); out["table_build_ms_single_row"] = round(1e3 * (time.perf_counter() - t), 2)
+    d_s = torch.from_numpy(scalars_h.view(np.int64)).cuda()
+    d_o = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(4):
+        t = time.perf_counter(); ctx.msm_device(b1, d_s.data_ptr(), n, 1, d_o.data_ptr(), 0); ctx.synchronize(); ts.append(time.perf_counter() - t)
+    out["msm_single_row_device_ms"] = round(1e3 * min(ts[1:]), 3)
+    b1.release()
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter(); ctx.best_multiexp(curve.id, scalars_h, bases_h); ts.append(time.perf_counter() - t)
+    out["best_multiexp_host_buffers_ms"] = round(1e3 * min(ts[1:]), 3)
+    out["best_multiexp_host_buffers_mpoints_per_s"] = round(n / min(ts[1:]) / 1e6, 1)
+    return out
+
+
+def real_witness(p, k, range_lookups):
+    """The reference's circuits with real witnesses (dehalo2_amd/witness.py): DelayEncryptCircuit over a 2048-bit modulus with as many
+    exponent bits as 2^k rows hold (15 bits at k = 17: the north-star shape, benches/README.md:59-60), or PoseidonEncCircuit."""
+    import random
+    from dehalo2_amd import circuits, witness as W
+    rnd = random.Random(0x64656C6179)
+    n_big = rnd.getrandbits(2048) | (1 << 2047) | 1
+    x = rnd.getrandbits(2040)
+    message = [rnd.getrandbits(250), rnd.getrandbits(250)]
+    if not range_lookups:
+        circ, info = W.pose_enc_witness(p, k, [rnd.getrandbits(250), rnd.getrandbits(250)], message)
+        return circ, "PoseidonEncCircuit (benches/pose_enc.rs), %d rows" % info.total_rows
+    kk = min(k, 17)
+    bits = max(1, min(15, ((1 << kk) - 6 - 6500) // 7100))
+    e = rnd.getrandbits(bits) | (1 << (bits - 1))
+    circ, info = W.delay_enc_witness(p, kk, n_big, e, x, bits, message)
+    assert info.rsa_result == pow(x, e, n_big)
+    desc = "DelayEncryptCircuit (src/lib.rs), 2048-bit modulus, %d-bit exponent: %d RSA rows + %d hash / cipher rows" % (bits, info.rsa_rows, info.total_rows - info.rsa_rows)
+    if k > kk:
+        circ = circuits._tile(circ, k)
+        desc += ", stacked %d times" % (1 << (k - kk))
+    return circ, desc
+
+
+def ctx_device(ctx):
+    import torch
+    return torch.cuda.current_device()
+
+
 class ProofSetup:
     """Circuit, SRS, proving key and a Prover for one (k, shape): the one-time work the reference caches on disk
     (benches/delay_enc.rs:41-54, 84-115).  The SRS travels through ParamsKZG's RawBytes format, as the reference's does."""
