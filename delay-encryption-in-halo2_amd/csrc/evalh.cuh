@@ -27,8 +27,8 @@ struct EvhArgs {
     const DevCalc* calcs;
     const DevSrc* parts;
     const fe* scalars;            // [beta, gamma, theta, y, constants..., challenges...] internal packed
-    const fe* const* columns;     // [fixed..., advice..., instance...] device pointers (table in HBM), or null:
-    const fe* colv[EVH_ARG_COLS]; // ... the same table carried in the kernel arguments (no staging launch) when it fits
+    const fe* const* columns;     // [fixed..., advice..., instance...] device pointers (table in HBM: a table carried in the kernel
+                                  // arguments and indexed dynamically is demoted to scratch memory -- measured 40 % slower)
     u32 num_calcs, fixed_base, advice_base, instance_base;
     u32 rows_mask, rot_scale;
     const fe* previous;
@@ -73,7 +73,7 @@ FP_DEV f29 evh_fetch(const EvhArgs& A, const EvhLds& L, const DevSrc& s, u64 row
             return A.vals_internal ? f29_unpack(f_load(&A.previous[row])) : f29_from_std<F9>(f_load(&A.previous[row]));
         default: {
             u32 base = s.kind == EVS_FIXED ? A.fixed_base : (s.kind == EVS_ADVICE ? A.advice_base : A.instance_base);
-            const fe* col = A.columns ? A.columns[base + s.index] : A.colv[base + s.index];
+            const fe* col = A.columns[base + s.index];
             u32 r = ((u32)row + (u32)(s.rot * (int32_t)A.rot_scale)) & A.rows_mask;    // rem_euclid for a power of two
             return A.cols_internal ? f29_unpack(f_load(&col[r])) : f29_from_std<F9>(f_load(&col[r]));
         }
@@ -137,11 +137,18 @@ __global__ void k_evh_scalars_val(FeBatch b, fe* out, u32 n) {
     if (i < n) f_store(&out[i], f29_to_packed_canon<F9>(f29_from_std<F9>(b.v[i])));
 }
 // the whole scalar table of one graph evaluation in ONE launch: [beta, gamma, theta, y | constants (already internal) | challenges]
-struct EvhStage { fe v[16]; const fe* constants; u32 nconst, nchal; };
+// and the column pointer table
+struct EvhStage { fe v[16]; const fe* constants; u32 nconst, nchal; const void* cols[EVH_ARG_COLS]; u32 ncols; };
 template <class F>
-__global__ void k_evh_stage(EvhStage st, fe* table) {
+__global__ void k_evh_stage(EvhStage st, fe* table, const void** ptr_table) {
     typedef typename f29_of<F>::type F9;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x, total = 4 + st.nconst + st.nchal;
+    if (i < st.ncols) {                                       // (static unrolled select: no dynamic indexing of the argument array)
+        const void* p = nullptr;
+#pragma unroll
+        for (u32 j = 0; j < EVH_ARG_COLS; j++) if (j == i) p = st.cols[j];
+        ptr_table[i] = p;
+    }
     if (i >= total) return;
     if (i < 4) f_store(&table[i], f29_to_packed_canon<F9>(f29_from_std<F9>(st.v[i])));
     else if (i < 4 + st.nconst) f_store(&table[i], f_load(&st.constants[i - 4]));
@@ -316,12 +323,21 @@ int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_i
     TRY(dh_ensure(ctx, ctx->ws_evh[0], (size_t)(nsc + 8) * sizeof(fe)));
     fe* table = (fe*)ctx->ws_evh[0].p;
     const uint64_t* four[4] = {in->beta, in->gamma, in->theta, in->y};
-    if (in->num_challenges <= 12) {
+    const u32 ncol = in->num_fixed + in->num_advice + in->num_instance;
+    std::vector<const fe*> cols(ncol, nullptr);
+    for (u32 i = 0; i < in->num_fixed; i++) cols[i] = (const fe*)in->fixed[i];
+    for (u32 i = 0; i < in->num_advice; i++) cols[in->num_fixed + i] = (const fe*)in->advice[i];
+    for (u32 i = 0; i < in->num_instance; i++) cols[in->num_fixed + in->num_advice + i] = (const fe*)in->instance[i];
+    TRY(dh_ensure(ctx, ctx->ws_evh[2], (cols.size() + 1) * sizeof(void*)));
+    if (in->num_challenges <= 12 && ncol <= EVH_ARG_COLS) {   // the common case: scalars, constants and column pointers staged by ONE launch
         EvhStage st{};
         for (int i = 0; i < 4; i++) st.v[i] = four[i] ? fe_from_u64(four[i]) : fe{};
         for (u32 i = 0; i < in->num_challenges; i++) st.v[4 + i] = fe_from_u64(in->challenges + 4 * (size_t)i);
         st.constants = g->d_constants; st.nconst = g->num_constants; st.nchal = in->num_challenges;
-        k_evh_stage<F><<<(nsc + 63) / 64, 64, 0, s>>>(st, table);
+        st.ncols = ncol;
+        for (u32 i = 0; i < ncol; i++) st.cols[i] = cols[i];
+        const u32 work = std::max<u32>(nsc, ncol);
+        k_evh_stage<F><<<(work + 63) / 64, 64, 0, s>>>(st, table, (const void**)ctx->ws_evh[2].p);
     } else {
         std::vector<fe> head(4), chal(in->num_challenges);
         for (int i = 0; i < 4; i++) head[i] = four[i] ? fe_from_u64(four[i]) : fe{};
@@ -329,22 +345,10 @@ int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_i
         TRY(evh_stage_scalars<F>(ctx, head, table, s));
         if (g->num_constants) HIP_TRY(ctx, hipMemcpyAsync(table + 4, g->d_constants, (size_t)g->num_constants * sizeof(fe), hipMemcpyDeviceToDevice, s));
         TRY(evh_stage_scalars<F>(ctx, chal, table + 4 + g->num_constants, s));
-    }
-    // column pointer table: in the kernel arguments when it fits, else staged in HBM
-    const u32 ncol = in->num_fixed + in->num_advice + in->num_instance;
-    std::vector<const fe*> cols(ncol, nullptr);
-    for (u32 i = 0; i < in->num_fixed; i++) cols[i] = (const fe*)in->fixed[i];
-    for (u32 i = 0; i < in->num_advice; i++) cols[in->num_fixed + i] = (const fe*)in->advice[i];
-    for (u32 i = 0; i < in->num_instance; i++) cols[in->num_fixed + in->num_advice + i] = (const fe*)in->instance[i];
-    EvhArgs A{};
-    if (ncol <= EVH_ARG_COLS) {
-        A.columns = nullptr;
-        for (u32 i = 0; i < ncol; i++) A.colv[i] = cols[i];
-    } else {
-        TRY(dh_ensure(ctx, ctx->ws_evh[2], (cols.size() + 1) * sizeof(void*)));
         TRY(evh_stage_ptrs(ctx, cols, (const void**)ctx->ws_evh[2].p, s));
-        A.columns = (const fe* const*)ctx->ws_evh[2].p;
     }
+    EvhArgs A{};
+    A.columns = (const fe* const*)ctx->ws_evh[2].p;
     if (g->hbm_slots) TRY(dh_ensure(ctx, ctx->ws_evh[3], (size_t)g->hbm_slots * rows * sizeof(fe)));
     A.calcs = g->d_calcs; A.parts = g->d_parts; A.scalars = table;
     A.num_calcs = g->num_calcs; A.fixed_base = 0; A.advice_base = in->num_fixed; A.instance_base = in->num_fixed + in->num_advice;
