@@ -323,6 +323,7 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     size_t rows = precompute ? W : 1;
     hipError_t e = hipMalloc((void**)&b->table, rows * n * sizeof(affine_t));
     if (e != hipSuccess) { delete b; return dh_fail(ctx, DEHALO_ERR_OOM, std::string("bases table: ") + hipGetErrorString(e)); }
+    HostPin pin_bases(affine_xy, n * stride_bytes);         // 64 MiB of SRS points at 2^20: DMA straight from the caller's pages
     e = hipMemcpy2DAsync(ctx->ws_tmp_bases.p, 64, affine_xy, stride_bytes, 64, n, hipMemcpyHostToDevice, ctx->stream);
     int rc = 0;
     if (e == hipSuccess) rc = do_build_table(ctx, b, (const affine_t*)ctx->ws_tmp_bases.p, ctx->stream);
