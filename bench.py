@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--force-device", type=int, default=-1)
     ap.add_argument("--proof-k", type=int, default=17, help="k of the delay_enc-shaped create_proof (0 = skip every proof section)")
     ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 4 per GPU; 0 = skip)")
-    ap.add_argument("--proofs-inflight", type=int, default=3, help="batch mode: proofs in flight per GPU (one context + host thread each)")
+    ap.add_argument("--proofs-inflight", type=int, default=4, help="batch mode: proofs in flight per GPU (one context + host thread each)")
     ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
     ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves (0 = library default)")
     ap.add_argument("--inflight", type=int, default=4, help="independent steps in flight, each on its own HIP stream / workspace")
