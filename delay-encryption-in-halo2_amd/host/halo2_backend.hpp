@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/dehalo.h"
@@ -59,6 +60,22 @@ class Backend {
         std::vector<Fe> z(num.size());
         if (!num.empty()) check(dehalo_grand_product(ctx_, field, num[0].data(), den[0].data(), num.size(), z[0].data()));
         return z;
+    }
+    // arithmetic::kate_division(a, point) -> (a(X) - a(point)) / (X - point), a.len() - 1 coefficients
+    std::vector<Fe> kate_division(dehalo_field field, const std::vector<Fe>& a, const Fe& point) const {
+        if (a.empty()) throw std::invalid_argument("kate_division: empty polynomial");
+        std::vector<Fe> q(a.size() - 1);
+        check(dehalo_kate_division(ctx_, field, a[0].data(), a.size(), point.data(), q.empty() ? nullptr : q[0].data()));
+        return q;
+    }
+    // plonk::lookup::prover::permute_expression_pair over the first `usable_rows` values (the caller appends the blinding rows);
+    // Err(ConstraintSystemFailure) -> std::runtime_error carrying DEHALO_ERR_NOT_IN_TABLE
+    std::pair<std::vector<Fe>, std::vector<Fe>> permute_expression_pair(dehalo_field field, const std::vector<Fe>& input, const std::vector<Fe>& table,
+                                                                        size_t usable_rows) const {
+        if (input.size() < usable_rows || table.size() < usable_rows) throw std::invalid_argument("permute_expression_pair: fewer than usable_rows values");
+        std::vector<Fe> pi(usable_rows), pt(usable_rows);
+        if (usable_rows) check(dehalo_permute_expression_pair(ctx_, field, input[0].data(), table[0].data(), usable_rows, pi[0].data(), pt[0].data()));
+        return {pi, pt};
     }
     void check(int rc) const {
         if (rc != 0) throw std::runtime_error(std::string("dehalo error ") + std::to_string(rc) + ": " + dehalo_last_error(ctx_));
@@ -117,6 +134,37 @@ class Params {
         return out;
     }
     const Backend& be_;
+    dehalo_bases* g_ = nullptr;
+    dehalo_bases* gl_ = nullptr;
+};
+
+// ParamsIPA::{commit, commit_lagrange}(poly, r) = <poly, g> + r * w: tables registered over g || w (n + 1 points)
+class ParamsIPA {
+  public:
+    ParamsIPA(const Backend& be, dehalo_curve curve, std::vector<Affine> g, std::vector<Affine> g_lagrange, const Affine& w) : be_(be), n_(g.size()) {
+        if (g_lagrange.size() != n_) throw std::invalid_argument("ParamsIPA: g and g_lagrange differ in length");
+        g.push_back(w);
+        g_lagrange.push_back(w);
+        be_.check(dehalo_bases_register(be_.raw(), curve, g[0].data(), g.size(), 64, 0, 1, &g_));
+        be_.check(dehalo_bases_register(be_.raw(), curve, g_lagrange[0].data(), g_lagrange.size(), 64, 0, 1, &gl_));
+    }
+    ~ParamsIPA() {
+        if (g_) dehalo_bases_release(be_.raw(), g_);
+        if (gl_) dehalo_bases_release(be_.raw(), gl_);
+    }
+    Projective commit(const std::vector<Fe>& poly, const Fe& blind) const { return msm(g_, poly, blind); }
+    Projective commit_lagrange(const std::vector<Fe>& poly, const Fe& blind) const { return msm(gl_, poly, blind); }
+
+  private:
+    Projective msm(dehalo_bases* b, std::vector<Fe> poly, const Fe& blind) const {
+        if (poly.size() != n_) throw std::invalid_argument("commit: poly.len() != params.n");   // upstream: assert_eq!
+        poly.push_back(blind);
+        Projective out{};
+        be_.check(dehalo_msm(be_.raw(), b, poly[0].data(), poly.size(), out.data()));
+        return out;
+    }
+    const Backend& be_;
+    size_t n_;
     dehalo_bases* g_ = nullptr;
     dehalo_bases* gl_ = nullptr;
 };
