@@ -315,11 +315,12 @@ def test_kate_division_vs_oracle(pkg, co, ctx, fname, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fname", ["bn254_fr", "pasta_fq"])
 @pytest.mark.parametrize("n", [1, 9, 2048, 2049, 70000, 1 << 17])
-def test_eval_polynomial_multi_vs_oracle(pkg, co, ctx, n):
+def test_eval_polynomial_multi_vs_oracle(pkg, co, ctx, n, fname):
     import torch
 
-    f = pkg.fields.BN254_FR
+    f = pkg.fields.FIELDS[fname]
     batch = 5
     cols = np.stack([co.fill_scalars(f.id, "uniform", n, 300 + i) for i in range(batch)])
     pts = co.fill_scalars(f.id, "uniform", 4, 17)
@@ -336,11 +337,12 @@ def test_eval_polynomial_multi_vs_oracle(pkg, co, ctx, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fname", ["bn254_fr", "pasta_fp"])
 @pytest.mark.parametrize("n", [2, 2048, 2049, 1 << 17, (1 << 18) + 5])
-def test_kate_division_batch_vs_oracle(pkg, co, ctx, n):
+def test_kate_division_batch_vs_oracle(pkg, co, ctx, n, fname):
     import torch
 
-    f = pkg.fields.BN254_FR
+    f = pkg.fields.FIELDS[fname]
     cnt = 4
     a = np.stack([co.fill_scalars(f.id, "uniform", n, 900 + i) for i in range(cnt)])
     pts = co.fill_scalars(f.id, "uniform", cnt, 23)
@@ -356,10 +358,11 @@ def test_kate_division_batch_vs_oracle(pkg, co, ctx, n):
 
 
 @pytest.mark.gpu
-def test_lincomb_and_scale_vs_oracle(pkg, co, ctx):
+@pytest.mark.parametrize("fname", ["bn254_fr", "pasta_fp"])
+def test_lincomb_and_scale_vs_oracle(pkg, co, ctx, fname):
     import torch
 
-    f = pkg.fields.BN254_FR
+    f = pkg.fields.FIELDS[fname]
     n = 5000
     for count in (1, 3, 40, 41, 97):
         cols = [co.fill_scalars(f.id, "uniform", n, 100 + i) for i in range(count)]
