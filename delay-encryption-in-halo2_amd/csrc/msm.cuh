@@ -522,15 +522,21 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 
 // ---- merging the partial sums of each bucket ---------------------------------------------
 // Signed-digit carries of small witness values pile thousands of points into bucket 0 (digit
-// +-1) and 0/1 columns put half the column into one bucket, so the number S of partial sums per
-// bucket spans 0 .. 10^5.  Buckets are classed by S and merged by a lane group sized to it:
-//   S <= 24: one lane or quad | S <= 128: 32 lanes | S <= 2048: one wave | larger: a 512-thread block;
-// chain length <= S/g + log2 g group additions instead of S.
-#define MSM_C0_MAX 24
+// +-1), 0/1 columns put half the column into one bucket and a grand-product column that stays
+// constant over unused rows repeats one scalar thousands of times, so the number S of partial sums
+// per bucket spans 0 .. 10^5.  Buckets are classed by S and merged by a lane group sized to it:
+//   S <= c0: one lane or quad | S <= 128: 32 lanes | S <= 512: one wave | larger: a 512-thread block;
+// chain length <= S/g + log2 g group additions instead of S.  All four classes run in ONE launch
+// (k_msm_merge_all: sections of the grid, longest chains first): these are latency-bound chains
+// on short lists, and as four launches their times added up (0.33-0.43 ms of a proof's skewed
+// commitments; one launch: the longest of the four).
 #define MSM_C1_MAX 128
-#define MSM_C2_MAX 2048
-#define MSM_HEAVY_THREADS 512    // 2 waves per SIMD: room for the ~170 VGPRs of a group addition (1024 threads would spill)
-#define MSM_MERGE_BLOCKS 1024
+#define MSM_C2_MAX 512
+#define MSM_MERGE_THREADS 512    // 2 waves per SIMD: room for the ~170 VGPRs of a group addition (1024 threads would spill)
+#define MSM_MERGE_BLOCKS_LIGHT 512
+#define MSM_MERGE_BLOCKS_G32 512
+#define MSM_MERGE_BLOCKS_G64 512
+#define MSM_MERGE_BLOCKS_HEAVY 256
 #ifndef MSM_LIGHT_QUAD_MAX
 #define MSM_LIGHT_QUAD_MAX 65536   // listed buckets up to which the light class runs one quad per bucket (2 waves per SIMD of quads)
 #endif
@@ -540,12 +546,12 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 // lists: [light | class 1 | class 2 | class 3], each with `cap` slots; counters[4].
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
-                                                           u32* counters, u32* lists, u32 cap) {
+                                                           u32* counters, u32* lists, u32 cap, u32 c0max) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total_buckets) return;
     u32 beg = rbeg[b], end = rend[b];
     u32 S = end - beg;
-    const u32 cls = S <= 1 ? 4u : (S <= MSM_C0_MAX ? 0u : (S <= MSM_C1_MAX ? 1u : (S <= MSM_C2_MAX ? 2u : 3u)));
+    const u32 cls = S <= 1 ? 4u : (S <= c0max ? 0u : (S <= MSM_C1_MAX ? 1u : (S <= MSM_C2_MAX ? 2u : 3u)));
     const u32 lane = threadIdx.x & 63;
     for (u32 c = 0; c < 4; c++) {
         unsigned long long mask = __ballot(cls == c);
@@ -566,16 +572,14 @@ __global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, c
     buckets[b] = rec;
 }
 
-// light class (2 .. MSM_C0_MAX partials).  Few listed buckets (latency-bound): one QUAD per bucket,
+// light class (2 .. c0 partials).  Few listed buckets (latency-bound): one QUAD per bucket,
 // quad-cooperative additions; many (throughput-bound, e.g. every bucket of a large uniform MSM):
 // one lane per bucket.  The choice is made on the device from the list length.
-template <class CV>
-__global__ __launch_bounds__(256) void k_msm_merge_light(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter, const u32* list) {
-    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    const u32 count = *counter;
+template <class F>
+FP_DEV void merge_light_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list) {
     if (count <= MSM_LIGHT_QUAD_MAX) {
         const u32 role = threadIdx.x & 3;
-        for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < count; i += (gridDim.x * blockDim.x) >> 2) {
+        for (u32 i = (blk * MSM_MERGE_THREADS + threadIdx.x) >> 2; i < count; i += (nblk * MSM_MERGE_THREADS) >> 2) {
             u32 b = list[i];
             u32 beg = rbeg[b], end = rend[b];
             xyzz29 acc = x29_load(&partial[beg]);
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* rbeg, const 
             if (role == 0) x29_store(&buckets[b], acc);
         }
     } else {
-        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        for (u32 i = blk * MSM_MERGE_THREADS + threadIdx.x; i < count; i += nblk * MSM_MERGE_THREADS) {
             u32 b = list[i];
             u32 beg = rbeg[b], end = rend[b];
             xyzz29 acc = x29_load(&partial[beg]);
@@ -593,15 +597,12 @@ __global__ __launch_bounds__(256) void k_msm_merge_light(const u32* rbeg, const 
     }
 }
 
-// groups of G lanes (8 or 64) walk a class list: strided lane sums, then a shuffle reduction
-template <class CV, int G>
-__global__ __launch_bounds__(256) void k_msm_merge_group(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counter,
-                                                        const u32* list) {
-    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    const u32 count = *counter;
-    const u32 groups_per_block = 256 / G;
+// groups of G lanes (32 or 64) walk a class list: strided lane sums, then a shuffle reduction
+template <class F, int G>
+FP_DEV void merge_group_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list) {
+    const u32 groups_per_block = MSM_MERGE_THREADS / G;
     const u32 gl = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    for (u32 i = blockIdx.x * groups_per_block + grp; i < count; i += gridDim.x * groups_per_block) {
+    for (u32 i = blk * groups_per_block + grp; i < count; i += nblk * groups_per_block) {
         u32 b = list[i];
         u32 beg = rbeg[b], end = rend[b];
         xyzz29 acc = x29_identity();
@@ -615,34 +616,57 @@ __global__ __launch_bounds__(256) void k_msm_merge_group(const u32* rbeg, const 
     }
 }
 
-// 512-thread blocks walk the heaviest class: strided lane sums, shuffle reduction per wave,
-// 16 wave results through LDS, shuffle reduction again.  Chain: ceil(S / 1024) + 10 adds.
-template <class CV>
-__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
-                                                                     const u32* counter, const u32* list) {
-    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    __shared__ xyzz29_rec sh[MSM_HEAVY_THREADS / 64];
-    const u32 count = *counter;
+// whole blocks walk the heaviest class: strided lane sums, shuffle reduction per wave, the wave
+// results through LDS, shuffle reduction again.  Chain: ceil(S / 512) + 9 adds.
+template <class F>
+FP_DEV void merge_heavy_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list,
+                                xyzz29_rec* sh) {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
+    for (u32 i = blk; i < count; i += nblk) {
         u32 b = list[i];
         u32 beg = rbeg[b], end = rend[b];
         xyzz29 acc = x29_identity();
         u32 p = beg + threadIdx.x;
         if (p < end) {
             acc = x29_load(&partial[p]);
-            for (p += MSM_HEAVY_THREADS; p < end; p += MSM_HEAVY_THREADS) acc = x29_add<F>(acc, x29_load(&partial[p]));
+            for (p += MSM_MERGE_THREADS; p < end; p += MSM_MERGE_THREADS) acc = x29_add<F>(acc, x29_load(&partial[p]));
         }
         acc = x29_group_reduce<F, 64>(acc);
         if (lane == 0) x29_store(&sh[wave], acc);
         __syncthreads();
         if (wave == 0) {
-            xyzz29 v = lane < MSM_HEAVY_THREADS / 64 ? x29_load(&sh[lane]) : x29_identity();
-            v = x29_group_reduce<F, MSM_HEAVY_THREADS / 64>(v);
+            xyzz29 v = lane < MSM_MERGE_THREADS / 64 ? x29_load(&sh[lane]) : x29_identity();
+            v = x29_group_reduce<F, MSM_MERGE_THREADS / 64>(v);
             if (lane == 0) x29_store(&buckets[b], v);
         }
         __syncthreads();
     }
+}
+
+// grid = [heavy | 64-lane groups | 32-lane groups | light] sections; a block whose section's list is
+// shorter than its position leaves at once, so the sections run side by side on short lists
+template <class CV>
+__global__ __launch_bounds__(MSM_MERGE_THREADS) void k_msm_merge_all(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters,
+                                                                    const u32* lists, u32 cap) {
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
+    __shared__ xyzz29_rec sh[MSM_MERGE_THREADS / 64];
+    u32 blk = blockIdx.x;
+    if (blk < MSM_MERGE_BLOCKS_HEAVY) {
+        merge_heavy_section<F>(blk, MSM_MERGE_BLOCKS_HEAVY, rbeg, rend, partial, buckets, counters[3], lists + 3 * (size_t)cap, sh);
+        return;
+    }
+    blk -= MSM_MERGE_BLOCKS_HEAVY;
+    if (blk < MSM_MERGE_BLOCKS_G64) {
+        merge_group_section<F, 64>(blk, MSM_MERGE_BLOCKS_G64, rbeg, rend, partial, buckets, counters[2], lists + 2 * (size_t)cap);
+        return;
+    }
+    blk -= MSM_MERGE_BLOCKS_G64;
+    if (blk < MSM_MERGE_BLOCKS_G32) {
+        merge_group_section<F, 32>(blk, MSM_MERGE_BLOCKS_G32, rbeg, rend, partial, buckets, counters[1], lists + 1 * (size_t)cap);
+        return;
+    }
+    blk -= MSM_MERGE_BLOCKS_G32;
+    merge_light_section<F>(blk, MSM_MERGE_BLOCKS_LIGHT, rbeg, rend, partial, buckets, counters[0], lists);
 }
 
 // ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
@@ -903,11 +927,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_REDUCE);
         // partial sums -> one point per bucket (by size class)
-        k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
-        k_msm_merge_light<CV><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 0, merge_lists + 0 * (size_t)merge_cap);
-        k_msm_merge_group<CV, 32><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 1, merge_lists + 1 * (size_t)merge_cap);
-        k_msm_merge_group<CV, 64><<<MSM_MERGE_BLOCKS, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 2, merge_lists + 2 * (size_t)merge_cap);
-        k_msm_merge_heavy<CV><<<MSM_MERGE_BLOCKS / 4, MSM_HEAVY_THREADS, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters + 3, merge_lists + 3 * (size_t)merge_cap);
+        // (a list of <= MSM_LIGHT_QUAD_MAX buckets runs one quad per bucket, where 23 additions are still a short chain; a longer
+        // list runs one LANE per bucket and is kept to 11 full-width additions)
+        const u32 c0max = tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
+        k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
+        k_msm_merge_all<CV><<<MSM_MERGE_BLOCKS_HEAVY + MSM_MERGE_BLOCKS_G64 + MSM_MERGE_BLOCKS_G32 + MSM_MERGE_BLOCKS_LIGHT, MSM_MERGE_THREADS, 0, s>>>(
+            rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
         // bucket reduction
         uint64_t nblocks4 = (uint64_t)per_group * total_groups;       // 4-bucket blocks
         if (nblocks4 * 4 <= 192 * 1024) {   // <= ~3 waves per SIMD at 4 lanes per block (two rounds of resident quads still beat one lane per block: 0.58 -> 0.28 ms for a batch of ten 2^17 MSMs)

@@ -32,7 +32,9 @@
 #include "fp29.cuh"
 #include "internal.hpp"
 
+#ifndef NTT_TILE_LOG
 #define NTT_TILE_LOG 11
+#endif
 #define NTT_TILE (1 << NTT_TILE_LOG)
 #define NTT_MAX_PASSES 4
 
@@ -80,7 +82,9 @@ FP_DEV fe tw_lookup(const fe* tw, u64 e, u32 log_n) {
 // standard form (x * 2^256); twiddles are w * 2^261, so products stay in that form, and the
 // multiplication every element needs on the way out (inter-pass twiddle, post-scale, or 1)
 // brings it back below 2p for one conditional subtraction.
+#ifndef NTT_THREADS
 #define NTT_THREADS 512
+#endif
 
 struct Lds29 {
     u64* p01; u64* p23; u64* p45; u64* p67; u32* p8;
