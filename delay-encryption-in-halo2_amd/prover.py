@@ -115,6 +115,12 @@ class Prover:
         self.jac = z(max(self.NC, 8), 12)
         self.aff = z(max(self.NC, 8), 8)
         self.evals = z(64 + 4 * (self.NC + cs.num_fixed + len(cs.permutation_columns)), 4)
+        # every blinding value of a proof but the random polynomial: drawn at the start (program order), uploaded once, copied into
+        # the columns on the device phase by phase (a pinned torch staging buffer is not used: torch's host allocator would touch
+        # the context's stream again when the buffer is freed, possibly after the context is gone)
+        rows = self.n - self.u
+        self.blind_counts = (A * rows, A, L * (2 * rows + 2), (S + L) * (self.bf + 1))
+        self.blind_dev = z(max(1, sum(self.blind_counts)), 4)
         self.omega_col = omega_powers_device(self.ctx, d)
         e = self.f.encode
         self._c = dict(omega_inv=e(d.omega_inv), ifft=e(d.ifft_divisor), ext_omega=e(d.extended_omega), ext_omega_inv=e(d.extended_omega_inv),
@@ -179,11 +185,18 @@ class Prover:
             transcript.write_point(P)
         return pts
 
-    def _blind_rows(self, rng, first_col: int, count: int, first_row: int):
-        """random values into rows [first_row, n) of `count` consecutive columns (column after column, as upstream draws them)."""
-        rows = self.n - first_row
-        vals = rng.scalars(count * rows).reshape(count, rows, 4)
-        self.cols[first_col:first_col + count, first_row:] = to_device(vals)
+    def _draw_blinds(self, rng):
+        """advice blinding rows (column after column), the advice commitments' blinds (unused by KZG), per lookup (bf + 1 rows
+        for the permuted input, bf + 1 for the permuted table, two unused blinds), per grand product (bf rows + one unused
+        blind): upstream's draws up to the random polynomial, in its order; one upload."""
+        total = sum(self.blind_counts)
+        if total == 0:
+            return
+        self.blind_dev[:total].copy_(self.torch.from_numpy(rng.scalars(total).view(np.int64)))
+
+    def _blind_slice(self, which: int):
+        off = sum(self.blind_counts[:which])
+        return self.blind_dev[off:off + self.blind_counts[which]]
 
     def _ptrs(self, t, first=0, count=None):
         count = t.shape[0] - first if count is None else count
@@ -269,10 +282,10 @@ class Prover:
         if tuple(adv.shape) != (A, n, 4):
             raise ValueError("advice must be num_advice x n x 4")
         cols[self.o_adv:self.o_adv + A].copy_(adv)
-        self._blind_rows(rng, self.o_adv, A, u)
+        self._draw_blinds(rng)
+        cols[self.o_adv:self.o_adv + A, u:] = self._blind_slice(0).view(A, n - u, 4)
         if self.side is not None:
             side_ntt(self.o_adv, A)
-        rng.scalars(A)                                           # the commitments' blinds: drawn, unused by KZG
         self._commit(transcript, self.o_adv, A, True, before_sync=prefetch.start if prefetch is not None else None)
         mark("advice")
         theta = transcript.squeeze_challenge_scalar()
@@ -289,7 +302,8 @@ class Prover:
             # permuted columns are interleaved (input_l, table_l) with a stride of two columns
             base = cols[self.o_perm].data_ptr()
             ctx.permute_expression_pair_batch_device(fid, self.compressed[0].data_ptr(), self.compressed[1].data_ptr(), u, L, 2 * n, base, base + 32 * n, 0)
-            self._blind_rows_lookup(rng)
+            rows = n - u                                         # (input_0, table_0, input_1, ...): bf + 1 rows each
+            cols[self.o_perm:self.o_perm + 2 * L, u:] = self._blind_slice(2).view(L, 2 * rows + 2, 4)[:, :2 * rows].reshape(2 * L, rows, 4)
             if self.side is not None:
                 side_ntt(self.o_perm, 2 * L)
             self._commit(transcript, self.o_perm, 2 * L, True)
@@ -318,8 +332,7 @@ class Prover:
         for s in range(1, S):                                    # z_s starts where z_{s-1} ended: z = vec![last_z]
             ctx.scale_device(fid, cols[self.o_pz + s].data_ptr(), n, None, cols[self.o_pz + s - 1][u].data_ptr(), 0)
         if S + L:                                                # per column: bf blinding rows (n - bf .. n), then the (unused) commitment blind
-            vals = rng.scalars((S + L) * (bf + 1)).reshape(S + L, bf + 1, 4)
-            cols[self.o_pz:self.o_pz + S + L, n - bf:] = to_device(np.ascontiguousarray(vals[:, :bf]))
+            cols[self.o_pz:self.o_pz + S + L, n - bf:] = self._blind_slice(3).view(S + L, bf + 1, 4)[:, :bf]
         if S + L:
             if self.side is not None:
                 side_ntt(self.o_pz, S + L)
@@ -480,15 +493,6 @@ class Prover:
         if timings is not None:
             timings.total_ms = 1e3 * (time.perf_counter() - t_start)
         return transcript
-
-    def _blind_rows_lookup(self, rng):
-        """permute_expression_pair's blinding: per lookup, bf + 1 values for the permuted input, then bf + 1 for the permuted
-        table, then the two (unused) commitment blinds -- drawn in that order, uploaded in one piece."""
-        rows, L = self.bf + 1, self.L
-        vals = rng.scalars(L * (2 * rows + 2)).reshape(L, 2 * rows + 2, 4)
-        blind = np.ascontiguousarray(vals[:, :2 * rows]).reshape(2 * L, rows, 4)          # (input_0, table_0, input_1, ...)
-        self.cols[self.o_perm:self.o_perm + 2 * L, self.u:] = to_device(blind)
-
 
 def proof_layout(cs: plonk.ConstraintSystem) -> Tuple[int, int]:
     """(commitments written before the evaluations, evaluations) of a proof of this constraint system; the opening quotients
