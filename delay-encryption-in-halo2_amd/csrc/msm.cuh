@@ -36,7 +36,16 @@
 // (measured: 2 and 3 resident waves per SIMD give the same k_msm_accum0 time -- the loop is
 // VALU-issue-bound -- and capping residency at 2 did not improve multi-stream overlap)
 #ifndef MSM_ACC_WAVES_ATTR
+#ifdef MSM_ACC_CAP
+#define MSM_ACC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MSM_ACC_CAP, MSM_ACC_CAP)))
+#else
 #define MSM_ACC_WAVES_ATTR
+#endif
+#endif
+#ifdef MSM_HIST_VGPR64
+#define MSM_HIST_ATTR __attribute__((amdgpu_num_vgpr(64)))
+#else
+#define MSM_HIST_ATTR
 #endif
 #define MSM_RED_M 4        // buckets per lane in the bucket reduction
 
@@ -104,7 +113,7 @@ FP_DEV u32 msm_sub_bits(u32 c) { return c - 1 < 8 ? c - 1 : 8; }
 // (plain coalesced stores): bh[group][slice][bucket].  No global atomics anywhere in the sort:
 // 256 blocks claiming runs in the same 2^15 counters with returning atomics cost 0.2 ms.
 template <class FS>
-__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_hist(MsmGeom g, const fe* scalars, u32* bh, u32* pc) {
+__global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(MsmGeom g, const fe* scalars, u32* bh, u32* pc) {
     extern __shared__ u32 lhist[];
     for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) lhist[b] = 0;
     __syncthreads();

@@ -259,6 +259,36 @@ def test_msm_skewed_buckets(pkg, co, ctx):
     h.release()
 
 
+def test_msm_every_merge_class(pkg, co, ctx):
+    """Repeated scalars put 1 .. 6000 points into single buckets: every class of the partial-sum merge (one lane / quad, 32 lanes,
+    one wave, a whole block) and the single-record copy, alone (quad mode) and in a batch whose bucket count selects lane mode."""
+    spec = pkg.fields.BN254
+    n = 1 << 15
+    bases = co.synth_bases(spec.id, n)
+    h = ctx.register_bases(spec.id, bases, 0, True)
+    rng = np.random.default_rng(11)
+
+    def column(seed_val, mults):
+        col = np.zeros((n, 4), np.uint64)
+        i, v = 0, seed_val
+        for m in mults:
+            col[i:i + m] = spec.scalar.encode(v)          # one small value: one non-zero digit, m points in its bucket
+            i, v = i + m, v + 1
+        return col[rng.permutation(n)]                     # positions do not matter to the sort, only multiplicities
+
+    cols = [column(3, [6000, 2500, 1200, 700, 300, 200, 90, 60, 33, 17, 9, 5, 3, 2, 1, 1]),
+            column(1000, [40] * 300 + [7] * 500), column(5000, [130] * 100), column(9000, [2] * 9000), column(1, [n]),
+            co.fill_scalars(spec.scalar.id, "uniform", n, 5)]
+    want = [co.to_affine(spec.id, co.best_multiexp(spec.id, c, bases, 8)) for c in cols]
+    for c, w in zip(cols, want):
+        assert np.array_equal(ctx.to_affine(spec.id, ctx.msm(h, c))[0], w)
+    assert len(cols) * (1 << (h.window_bits - 1)) > 65536 or h.window_bits < 15     # the batch is past the quad-mode bound at c = 15
+    got = ctx.to_affine(spec.id, ctx.msm_batch(h, cols))
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    h.release()
+
+
 @pytest.mark.parametrize("cname", ["pallas", "bn254"])
 def test_msm_full_size_2_20(pkg, co, ctx, cname):
     """BASELINE config #2: 2^20 points.  Direct comparison with the C restatement of
