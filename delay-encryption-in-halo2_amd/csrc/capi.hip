@@ -38,6 +38,16 @@ uint32_t choose_window(size_t n) {
     return std::max<uint32_t>(6, l + 1);
 }
 
+// Single-row tables (the one-shot, unregistered path: every window keeps its own buckets and the window sums are combined by
+// c (W - 1) doublings): fewer buckets per window pay for the extra windows.  Measured on MI355X (tools/sweep_single_row.py, Pallas,
+// uniform scalars, device time): 2^14 c = 10 0.81 ms (13: 0.95, 16: 1.12); 2^17 c = 13 1.15 (10: 1.21, 15: 1.39); 2^20 c = 13 3.13 (16: 3.51).
+uint32_t choose_window_single(size_t n) {
+    uint32_t l = log2_ceil(n ? n : 1);
+    if (l >= 16) return 13;
+    if (l >= 12) return 10;
+    return choose_window(n);
+}
+
 // Windows of the signed-digit recoding: the smallest W for which no canonical scalar s < r leaves a carry after window W - 1
 // (msm.cuh for_each_digit drops it).  With top = (r - 1) >> c(W - 1) that holds when top + 1 <= 2^(c-1), and also when top == 2^(c-1)
 // exactly while the c bits of r - 1 just below the top window are all zero (then s with that top digit has a zero digit in window
@@ -312,7 +322,7 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
                   dehalo_bases** out) {
     if (!affine_xy || !out || n == 0 || stride_bytes < 64 || n >= (1ull << 30)) return dh_fail(ctx, DEHALO_ERR_INVALID, "bases_register: bad argument");
     if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return dh_fail(ctx, DEHALO_ERR_INVALID, "window_bits must be 0 or in [4, 16]");
-    uint32_t c = window_bits ? (uint32_t)window_bits : choose_window(n);
+    uint32_t c = window_bits ? (uint32_t)window_bits : (precompute ? choose_window(n) : choose_window_single(n));
     if (c < 4) c = 4;
     uint32_t W = signed_windows(scalar_modulus_words(curve), c);
     if (precompute && (uint64_t)n * W >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "precomputed table too large");

@@ -746,39 +746,36 @@ __global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 
 }
 
 // ---- final: window sums -> one Jacobian point per MSM -------------------------------------
-// G == 1: convert.  G == W: result = sum_w 2^(c*w) S_w; lane w doubles S_w c*w times, then an
-// LDS tree (the one-shot, unregistered-bases path only).
+// G == 1: convert.  G == W: result = sum_w 2^(c*w) S_w; QUAD w doubles S_w c*w times (a chain of up to c (W - 1) ~ 240 doublings
+// whatever the size of the MSM: quad-cooperative, it is 2.4x shorter), then an LDS tree of quad additions (the one-shot,
+// unregistered-bases path only).  256 threads = 64 quads >= W.
 template <class CV>
-__global__ __launch_bounds__(64) void k_msm_final(MsmGeom g, const xyzz29_rec* group_sums, jacobian_t* out) {
+__global__ __launch_bounds__(256) void k_msm_final(MsmGeom g, const xyzz29_rec* group_sums, jacobian_t* out) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[64];
-    u32 bat = blockIdx.x;
-    u32 w = threadIdx.x;
+    const u32 bat = blockIdx.x;
+    const u32 w = threadIdx.x >> 2, role = threadIdx.x & 3;
     if (g.G == 1) {  // precomputed tables: nothing to combine
-        if (w == 0) {
+        if (threadIdx.x == 0) {
             jacobian_t j = x29_to_jacobian_std<F>(x29_load(&group_sums[bat]));
             f_store(&out[bat].x, j.x); f_store(&out[bat].y, j.y); f_store(&out[bat].z, j.z);
         }
         return;
     }
     xyzz29 s = x29_identity();
-    if (w < g.G) {
-        s = x29_load(&group_sums[(u64)bat * g.G + w]);
-        if (g.G > 1) {
-            u32 nd = g.c * w;
-            for (u32 i = 0; i < nd; i++) s = x29_double<F>(s);
-        }
-    }
-    x29_store(&sh[w], s);
+    if (w < g.G) s = x29_load(&group_sums[(u64)bat * g.G + w]);
+    const u32 nd = w < g.G ? g.c * w : 0;
+    for (u32 i = 0; i < nd; i++) s = x29_double_quad<F>(s);        // (uniform within a quad)
+    if (role == 0) x29_store(&sh[w], s);
     __syncthreads();
     for (u32 d = 32; d > 0; d >>= 1) {
         if (w < d) {
-            xyzz29 x = x29_add<F>(x29_load(&sh[w]), x29_load(&sh[w + d]));
-            x29_store(&sh[w], x);
+            xyzz29 x = x29_add_quad<F>(x29_load(&sh[w]), x29_load(&sh[w + d]));
+            if (role == 0) x29_store(&sh[w], x);
         }
         __syncthreads();
     }
-    if (w == 0) {
+    if (threadIdx.x == 0) {
         jacobian_t j = x29_to_jacobian_std<F>(x29_load(&sh[0]));
         f_store(&out[bat].x, j.x); f_store(&out[bat].y, j.y); f_store(&out[bat].z, j.z);
     }
@@ -961,7 +958,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
             cur = o; cnt = out_cnt; which ^= 1;
         }
         if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));
-        k_msm_final<CV><<<(u32)batch, 64, 0, s>>>(g, gsums, d_out);
+        k_msm_final<CV><<<(u32)batch, 256, 0, s>>>(g, gsums, d_out);
         HIP_TRY(ctx, hipGetLastError());
     }
     return 0;
