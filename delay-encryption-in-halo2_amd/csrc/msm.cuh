@@ -59,6 +59,7 @@ struct MsmGeom {
     u32 batch;      // independent MSMs in this launch
     u32 slices;     // sort blocks per (group, batch)
     u32 L0;         // points per lane of k_msm_accum0
+    u32 wb;         // G == W only: windows (= bucket groups) one sort block covers; the sort's grid.y = ceil(G / wb)
 };
 
 // ---- scalar -> signed digits -------------------------------------------------------------
@@ -115,13 +116,17 @@ FP_DEV u32 msm_sub_bits(u32 c) { return c - 1 < 8 ? c - 1 : 8; }
 template <class FS>
 __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(MsmGeom g, const fe* scalars, u32* bh, u32* pc) {
     extern __shared__ u32 lhist[];
-    for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) lhist[b] = 0;
+    // G == 1: the block counts every window into the one bucket set.  G == W: it covers windows [w_lo, w_hi), one bucket set each
+    // (a scalar is decoded once per block, not once per window: ceil(W / wb) passes over the scalars instead of W).
+    const u32 bat = blockIdx.z;
+    const u32 w_lo = g.G == 1 ? 0 : blockIdx.y * g.wb, w_hi = g.G == 1 ? g.W : min(g.W, w_lo + g.wb);
+    const u32 ng = g.G == 1 ? 1 : w_hi - w_lo, grp0 = g.G == 1 ? 0 : w_lo;
+    for (u32 b = threadIdx.x; b < ng * g.nb; b += blockDim.x) lhist[b] = 0;
     __syncthreads();
-    const u32 grp = blockIdx.y, bat = blockIdx.z;
-    const u32 w_lo = g.G == 1 ? 0 : grp, w_hi = g.G == 1 ? g.W : grp + 1;
     const fe* sc = scalars + (u64)bat * g.n;
     const u32 per = (g.n + g.slices - 1) / g.slices;
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
+    const bool one = g.G == 1;
     for (u32 i0 = beg + threadIdx.x; i0 < end; i0 += 4 * blockDim.x) {      // four scalar loads in flight per lane
         fe s4[4];
 #pragma unroll
@@ -130,24 +135,28 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (i0 + j * blockDim.x < end)
-                for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32, u32 bucket, bool) { atomicAdd(&lhist[bucket], 1u); });
+                for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool) { atomicAdd(&lhist[(one ? 0u : (w - w_lo) * g.nb) + bucket], 1u); });
     }
     __syncthreads();
-    u32* out = bh + (((u64)bat * g.G + grp) * g.slices + blockIdx.x) * g.nb;
-    for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) out[b] = lhist[b];
-    // partition = the bucket's top bits; its count for this slice (second sort level, see k_msm_part)
     const u32 sub = msm_sub_bits(g.c), P = g.nb >> sub;
-    u32* pout = pc + (((u64)bat * g.G + grp) * g.slices + blockIdx.x) * P;
     const u32 ways = sub >= 3 ? 8 : 1, chunk = (1u << sub) / ways;   // 8 lanes share a partition's 2^sub counters
-    for (u32 t = threadIdx.x; t < P * ways; t += blockDim.x) {
-        u32 q = t / ways, part = t % ways, sum = 0;
-        for (u32 j = 0; j < chunk; j++) sum += lhist[(q << sub) + part * chunk + j];
-        if (ways == 8) {
-            sum += __shfl_down(sum, 4, 8);
-            sum += __shfl_down(sum, 2, 8);
-            sum += __shfl_down(sum, 1, 8);
+    for (u32 gi = 0; gi < ng; gi++) {
+        const u64 gidx = (u64)bat * g.G + grp0 + gi;
+        const u32* lh = lhist + gi * g.nb;
+        u32* out = bh + (gidx * g.slices + blockIdx.x) * g.nb;
+        for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) out[b] = lh[b];
+        // partition = the bucket's top bits; its count for this slice (second sort level, see k_msm_part)
+        u32* pout = pc + (gidx * g.slices + blockIdx.x) * P;
+        for (u32 t = threadIdx.x; t < P * ways; t += blockDim.x) {
+            u32 q = t / ways, part = t % ways, sum = 0;
+            for (u32 j = 0; j < chunk; j++) sum += lh[(q << sub) + part * chunk + j];
+            if (ways == 8) {
+                sum += __shfl_down(sum, 4, 8);
+                sum += __shfl_down(sum, 2, 8);
+                sum += __shfl_down(sum, 1, 8);
+            }
+            if (part == 0) pout[q] = sum;
         }
-        if (part == 0) pout[q] = sum;
     }
 }
 
@@ -300,9 +309,13 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* c
 template <class FS>
 __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const fe* scalars, const u32* off, const u32* pc, unsigned long long* pairs) {
     extern __shared__ __align__(8) unsigned char part_smem[];
-    const u32 grp = blockIdx.y, bat = blockIdx.z;
-    const u64 gidx = (u64)bat * g.G + grp;
+    const u32 bat = blockIdx.z;
     const u32 sub = msm_sub_bits(g.c), P = g.nb >> sub, submask = (1u << sub) - 1;
+    // windows [w_lo, w_hi) of this block and their bucket groups (k_msm_hist): the runs of (group, partition) pairs, PT <= 128 of them
+    const u32 w_lo = g.G == 1 ? 0 : blockIdx.y * g.wb, w_hi = g.G == 1 ? g.W : min(g.W, w_lo + g.wb);
+    const u32 ng = g.G == 1 ? 1 : w_hi - w_lo, grp0 = g.G == 1 ? 0 : w_lo;
+    const u32 PT = ng * P;
+    const bool one = g.G == 1;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     u32* pcur = reinterpret_cast<u32*>(part_smem);                               // block-shared run cursors [128]
     unsigned char* wbase = part_smem + 512 + (size_t)wave * MSM_PART_WAVE_LDS;  // this wave's slice
@@ -312,11 +325,12 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
     u32* lcur = lbase + 128;                                                     // placement cursor
     u32* gbase = lcur + 128;                                                     // reserved global position
     unsigned short* stageq = reinterpret_cast<unsigned short*>(gbase + 128);     // [512] partition of a staged pair
-    const u32* prel = pc + (gidx * g.slices + blockIdx.x) * P;
-    const u32* goff = off + gidx * g.nb;
-    for (u32 q = threadIdx.x; q < P; q += blockDim.x) pcur[q] = goff[q << sub] + prel[q];
+    for (u32 qq = threadIdx.x; qq < PT; qq += blockDim.x) {
+        const u32 gi = qq / P, q = qq - gi * P;
+        const u64 gidx = (u64)bat * g.G + grp0 + gi;
+        pcur[qq] = off[gidx * g.nb + (q << sub)] + pc[(gidx * g.slices + blockIdx.x) * P + q];
+    }
     __syncthreads();
-    const u32 w_lo = g.G == 1 ? 0 : grp, w_hi = g.G == 1 ? g.W : grp + 1;
     const fe* sc = scalars + (u64)bat * g.n;
     const u32 per = (g.n + g.slices - 1) / g.slices;
     const u32 beg = blockIdx.x * per, end = min(beg + per, g.n);
@@ -332,31 +346,32 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
         if (have) ds.template init<FS>(s_cur, g.c);
         for (u32 w0 = 0; w0 < w_hi; w0 += 8) {
             u32 bk[8];
-            bool ng[8];
+            bool ng8[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                bk[j] = 0xffffffffu; ng[j] = false;
+                bk[j] = 0xffffffffu; ng8[j] = false;
                 if (have && w0 + j < w_hi) {
-                    ds.next(bk[j], ng[j]);
+                    ds.next(bk[j], ng8[j]);
                     if (w0 + j < w_lo) bk[j] = 0xffffffffu;
                 }
             }
+            if (w0 + 8 <= w_lo) continue;                                // (uniform) nothing of this block's windows yet
             // count
-            for (u32 q = lane; q < P; q += 64) lcnt[q] = 0;
+            for (u32 q = lane; q < PT; q += 64) lcnt[q] = 0;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if (bk[j] != 0xffffffffu) atomicAdd(&lcnt[bk[j] >> sub], 1u);
+                if (bk[j] != 0xffffffffu) atomicAdd(&lcnt[(one ? 0u : (w0 + j - w_lo) * P) + (bk[j] >> sub)], 1u);
             __builtin_amdgcn_wave_barrier();
-            // scan (P <= 128: two entries per lane) and reservation in the partition runs
+            // scan (PT <= 128: two entries per lane) and reservation in the partition runs
             u32 run = 0;
-            for (u32 q0 = 0; q0 < P; q0 += 64) {
+            for (u32 q0 = 0; q0 < PT; q0 += 64) {
                 const u32 q = q0 + lane;
-                const u32 v = q < P ? lcnt[q] : 0;
+                const u32 v = q < PT ? lcnt[q] : 0;
                 u32 x = v;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
-                if (q < P) {
+                if (q < PT) {
                     lbase[q] = run + x - v; lcur[q] = run + x - v;
                     gbase[q] = v ? atomicAdd(&pcur[q], v) : 0u;
                 }
@@ -367,10 +382,10 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 if (bk[j] != 0xffffffffu) {
-                    const u32 q = bk[j] >> sub;
+                    const u32 q = (one ? 0u : (w0 + j - w_lo) * P) + (bk[j] >> sub);
                     const u32 pos = atomicAdd(&lcur[q], 1u);
-                    const u32 tidx = g.G == 1 ? (w0 + j) * g.table_n + i : i;
-                    stage[pos] = ((unsigned long long)(bk[j] & submask) << 32) | (tidx | (ng[j] ? 0x80000000u : 0u));
+                    const u32 tidx = one ? (w0 + j) * g.table_n + i : i;
+                    stage[pos] = ((unsigned long long)(bk[j] & submask) << 32) | (tidx | (ng8[j] ? 0x80000000u : 0u));
                     stageq[pos] = (unsigned short)q;
                 }
             __builtin_amdgcn_wave_barrier();
@@ -855,6 +870,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     g.G = bases->precomp ? 1 : g.W;
     g.batch = (u32)batch;
     g.slices = (u32)std::min<size_t>(256, std::max<size_t>(1, len / 2048));
+    {   // single-row tables: windows per sort block -- the block's histograms fit 128 KiB of LDS and its (group, partition) runs the 128 staging lists
+        const u32 sb = g.c - 1 < 8 ? g.c - 1 : 8, Pg = g.nb >> sb;
+        const u32 fit = std::min<u32>(std::min<u32>(g.W, 128 / Pg), (128u * 1024 / 4) / g.nb);
+        const u32 fill = (u32)((uint64_t)g.W * g.slices * batch / 256);        // ... while the grid keeps >= 256 blocks (2^14: one window per block as before)
+        g.wb = g.G == 1 ? g.W : std::max<u32>(1, std::min<u32>(fit, fill));
+    }
     const uint64_t total_groups = (uint64_t)batch * g.G;
     const uint64_t total_buckets = total_groups * g.nb;
     const uint64_t Mmax = (uint64_t)batch * len * g.W;
@@ -905,7 +926,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     xyzz29_rec* tree = (xyzz29_rec*)ctx->ws_tree.p;
     xyzz29_rec* gsums = (xyzz29_rec*)ctx->ws_gsums.p;
 
-    const size_t lds_hist = (size_t)g.nb * 4;
+    const size_t lds_hist = (size_t)g.nb * 4 * (g.G == 1 ? 1 : g.wb);
     if (lds_hist > 48 * 1024) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_hist<FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
     }
@@ -915,7 +936,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
         HIP_TRY(ctx, hipMemsetAsync(merge_counters, 0, 16, s));
-        dim3 grid(g.slices, g.G, (u32)batch);
+        dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
         k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, bh, pc);
         k_msm_colscan<<<(tb + 255) / 256, 256, 0, s>>>(g.nb, g.slices, tb, bh, count);
         k_msm_colscan<<<((u32)total_groups * P + 255) / 256, 256, 0, s>>>(P, g.slices, (u32)total_groups * P, pc, nullptr);
