@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 4 per GPU; 0 = skip)")
     ap.add_argument("--proofs-inflight", type=int, default=4, help="batch mode: proofs in flight per GPU (one context + host thread each)")
     ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
-    ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves (0 = library default)")
+    ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves with the whole-rounds rule (0 = library default: msm_acc_points)")
     ap.add_argument("--inflight", type=int, default=4, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
 
@@ -361,6 +361,7 @@ def main():
     ctx = ctxs[0]
     if args.acc_waves:
         for c in ctxs:
+            c.set_tuning("msm_acc_points", 0)
             c.set_tuning("msm_acc_waves", args.acc_waves)
     # synthetic SRS and witnesses; every rank gets its own scalar column
     bases_h = co.synth_bases(curve.id, n)

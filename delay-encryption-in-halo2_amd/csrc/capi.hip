@@ -369,6 +369,7 @@ int dehalo_ctx_create(int device, dehalo_ctx** out) {
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
+    if (const char* e = getenv("DEHALO_MSM_ACC_POINTS")) ctx->msm_acc_points = std::max(0, std::min(4096, atoi(e)));   // launch geometry only (dehalo_ctx_set_tuning)
     *out = ctx;
     return 0;
 }
@@ -395,6 +396,11 @@ const char* dehalo_last_error(const dehalo_ctx* ctx) { return ctx ? ctx->err.c_s
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return DEHALO_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!strcmp(key, "msm_acc_points")) {
+        if (value < 0 || value > 4096) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_acc_points must be in [0, 4096]");
+        ctx->msm_acc_points = value;
+        return 0;
+    }
     if (!strcmp(key, "msm_acc_waves")) {
         if (value < 1 || value > 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_acc_waves must be in [1, 4]");
         ctx->msm_acc_waves = value;

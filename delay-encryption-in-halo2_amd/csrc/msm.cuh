@@ -217,7 +217,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u
 // witness column of small values has a fraction of batch * n * W): geo[0] = L = ceil(M / (rounds * resident)) with
 // rounds = ceil(M / (resident * lmax)), at least 4; geo[1] = M.  (Sized from the upper bound on the host, a sparse column left most
 // lanes idle and the rest with full-length chains: advice columns took half the time of dense ones with a fifth of the points.)
-static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident, u32 lmax) {
+static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident, u32 lmax, u32 lcap) {
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     __shared__ u32 carry_i, carry_t;
     if (threadIdx.x == 0) { carry_i = 0; carry_t = 0; }
@@ -240,9 +240,16 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_item
     }
     if (threadIdx.x == 0) {
         const u64 M = carry_i;
-        const u64 rounds = max((u64)1, (M + (u64)resident * lmax - 1) / ((u64)resident * lmax));
-        u64 L = (M + rounds * resident - 1) / (rounds * resident);
-        L = min((u64)lmax, max((u64)4, L));
+        u64 L;
+        if (lcap) {   // layers of one wave per SIMD (`resident` lanes each): 4 (a full chip), 6, 8, ... until a lane has <= lcap points
+            u64 k = 4;
+            while (M > k * resident * lcap) k += 2;
+            L = max((u64)4, (M + k * resident - 1) / (k * resident));
+        } else {
+            const u64 rounds = max((u64)1, (M + (u64)resident * lmax - 1) / ((u64)resident * lmax));
+            L = (M + rounds * resident - 1) / (rounds * resident);
+            L = min((u64)lmax, max((u64)4, L));
+        }
         geo[0] = (u32)L;
         geo[1] = (u32)M;
     }
@@ -845,13 +852,13 @@ __global__ void k_jac_to_affine(const jacobian_t* in, affine_t* out, u32 count) 
 // ==========================================================================================
 // host driver (instantiated once per curve in msm_<curve>.hip)
 // ==========================================================================================
-static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32* geo, u32 resident, u32 lmax, u32* off, u32* nrank, u32* rbeg, u32* rend, hipStream_t s) {
+static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32* geo, u32 resident, u32 lmax, u32 lcap, u32* off, u32* nrank, u32* rbeg, u32* rend, hipStream_t s) {
     u32 nblocks = (total + SCAN_BLOCK - 1) / SCAN_BLOCK;
     TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)nblocks * 2 * sizeof(u32)));
     u32* bs_i = (u32*)ctx->ws_bsum.p;
     u32* bs_t = bs_i + nblocks;
     k_scan_block_sums<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, 0, bs_i, bs_t);
-    k_scan_top<<<1, SCAN_THREADS, 0, s>>>(bs_i, bs_t, nblocks, geo, resident, lmax);
+    k_scan_top<<<1, SCAN_THREADS, 0, s>>>(bs_i, bs_t, nblocks, geo, resident, lmax, lcap);
     k_scan_apply<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, geo, bs_i, bs_t, off, nrank, rbeg, rend);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -883,11 +890,19 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         return dh_fail(ctx, DEHALO_ERR_INVALID, "batch * len * windows too large for one launch");
     // points per lane: the lanes fill the chip (msm_acc_waves waves per SIMD of k_msm_accum0) a whole number of times.  The value is
     // fixed ON THE DEVICE from the number of points actually sorted (k_scan_top); the host only bounds the lane count.
-    const uint64_t resident = (uint64_t)ctx->num_cus * 4 * (uint64_t)ctx->msm_acc_waves * 64;
+    const uint32_t lcap = (uint32_t)ctx->msm_acc_points;
+    const uint64_t resident = (uint64_t)ctx->num_cus * 4 * (lcap ? 1 : (uint64_t)ctx->msm_acc_waves) * 64;
     const uint64_t lmax = 64 * 4 / (uint64_t)ctx->msm_acc_waves;
-    const uint64_t rounds_max = std::max<uint64_t>(1, (Mmax + resident * lmax - 1) / (resident * lmax));
     g.L0 = 0;
-    const uint64_t lanes_max = rounds_max * resident + MSM_ACC_THREADS;
+    uint64_t lanes_max;
+    if (lcap) {
+        uint64_t k = 4;
+        while (Mmax > k * resident * lcap) k += 2;
+        lanes_max = k * resident + MSM_ACC_THREADS;
+    } else {
+        const uint64_t rounds_max = std::max<uint64_t>(1, (Mmax + resident * lmax - 1) / (resident * lmax));
+        lanes_max = rounds_max * resident + MSM_ACC_THREADS;
+    }
     const uint64_t nt0_max = lanes_max + total_buckets;        // records: one per lane + one per non-empty bucket (upper bound)
     const u32 per_group = (g.nb + MSM_RED_M - 1) / MSM_RED_M;
     const size_t REC = sizeof(xyzz29_rec);
@@ -940,7 +955,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, bh, pc);
         k_msm_colscan<<<(tb + 255) / 256, 256, 0, s>>>(g.nb, g.slices, tb, bh, count);
         k_msm_colscan<<<((u32)total_groups * P + 255) / 256, 256, 0, s>>>(P, g.slices, (u32)total_groups * P, pc, nullptr);
-        TRY(run_scan(ctx, count, tb, cursor + 4, (u32)resident, (u32)lmax, off, nrank, rbeg, rend, s));
+        TRY(run_scan(ctx, count, tb, cursor + 4, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend, s));
         k_msm_part<FS><<<grid, MSM_SORT_THREADS, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, 0, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
         HIP_TRY(ctx, hipGetLastError());

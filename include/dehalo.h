@@ -61,9 +61,10 @@ int dehalo_ctx_create(int device, dehalo_ctx** out);
 void dehalo_ctx_destroy(dehalo_ctx* ctx);
 /* Human-readable text of the last error on this context (valid until the next call). */
 const char* dehalo_last_error(const dehalo_ctx* ctx);
-/* Launch-geometry knobs (results never depend on them).  "msm_acc_waves" in [1, 4]: waves per SIMD the bucket-accumulation grid of
- * an MSM is sized for; below 4 the kernel leaves wave slots and registers free, so that the latency-bound kernels of OTHER contexts
- * (sort, bucket reduction of a neighbouring column) run beside it instead of behind it. */
+/* Launch-geometry knobs (results never depend on them).  "msm_acc_points" (default 48; also the environment variable
+ * DEHALO_MSM_ACC_POINTS at context creation): the bucket-accumulation grid of an MSM is 4, 6, 8, ... layers of one wave per SIMD,
+ * the fewest that leave a lane at most this many points; 0 selects the older rule, whole rounds of "msm_acc_waves" in [1, 4]
+ * waves per SIMD (below 4 the kernel leaves wave slots and registers free for the latency-bound kernels of other contexts). */
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
  * kernels by enqueueing it on the same stream. */
