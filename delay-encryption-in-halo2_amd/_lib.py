@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SYMBOLS = [
-    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
+    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
     "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
@@ -89,6 +89,7 @@ def load_library():
     lib.dehalo_ctx_destroy.argtypes = [P]
     lib.dehalo_ctx_destroy.restype = None
     lib.dehalo_ctx_synchronize.argtypes = [P]
+    lib.dehalo_download.argtypes = [P, P, C.c_size_t, P]
     lib.dehalo_ctx_set_tuning.argtypes = [P, C.c_char_p, C.c_int]
     lib.dehalo_ctx_stream.argtypes = [P]
     lib.dehalo_ctx_stream.restype = C.c_void_p
@@ -200,6 +201,12 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.dehalo_ctx_synchronize(self.handle))
+
+    def download(self, d_src: int, count: int, width: int = 4) -> np.ndarray:
+        """(count, width) u64 from device memory, after everything queued on the context's stream (one call: copy + wait)."""
+        out = np.empty((count, width), dtype=np.uint64)
+        self._check(self.lib.dehalo_download(self.handle, d_src, out.nbytes, out.ctypes.data))
+        return out
 
     def set_tuning(self, key: str, value: int):
         self._check(self.lib.dehalo_ctx_set_tuning(self.handle, key.encode(), value))

@@ -417,6 +417,15 @@ int dehalo_ctx_synchronize(dehalo_ctx* ctx) {
     return 0;
 }
 
+int dehalo_download(dehalo_ctx* ctx, const void* d_src, size_t bytes, void* host_dst) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_src || !host_dst) && bytes) return dh_fail(ctx, DEHALO_ERR_INVALID, "download: null argument");
+    (void)hipSetDevice(ctx->device);
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes, int window_bits, int precompute,
                           dehalo_bases** out) {
     if (!ctx) return DEHALO_ERR_INVALID;

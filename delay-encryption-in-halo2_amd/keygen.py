@@ -55,11 +55,20 @@ def to_host(t) -> np.ndarray:
     return t.cpu().numpy().view(np.uint64)
 
 
+_RINV: dict = {}
+
+
+def _rinv(p: int) -> int:
+    if p not in _RINV:
+        _RINV[p] = pow(1 << 256, -1, p)
+    return _RINV[p]
+
+
 def decode_points(curve: CurveSpec, xy) -> list:
     """(count, 8) u64 Montgomery affine -> [(x, y) | None] canonical."""
     out = []
     f = curve.base
-    rinv = pow(1 << 256, -1, f.p)
+    rinv = _rinv(f.p)
     vals = array_to_ints(np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 4))
     for i in range(0, len(vals), 2):
         x, y = vals[i], vals[i + 1]

@@ -59,6 +59,12 @@ class SeededRng:
 class ProofTimings:
     phases_ms: Dict[str, float] = dc_field(default_factory=dict)
     total_ms: float = 0.0
+    fine: bool = False                                     # also record host timestamps inside the phases (no extra syncs)
+    ticks: List[Tuple[str, float]] = dc_field(default_factory=list)
+
+    def tick(self, label: str):
+        if self.fine:
+            self.ticks.append((label, time.perf_counter()))
 
 
 def rotate_omega(domain, x: int, rot: int) -> int:
@@ -78,6 +84,7 @@ class Prover:
         exist and runs beside the main context's commitment phases (ordered by events), instead of after y."""
         self.ctx = ctx if ctx is not None else pk.ctx
         self.side = side_ctx
+        self._timings = None
         with self.ctx.torch_stream():      # torch's copies and fills go on the context's stream, ordered with the kernels
             self._init(params, pk)
 
@@ -173,16 +180,21 @@ class Prover:
     # ---- helpers ----
     def _commit(self, transcript: Blake2bWrite, first: int, count: int, lagrange: bool, src=None, before_sync=None):
         """commit `count` consecutive columns, normalise, absorb: the transcript needs affine points on the host.
-        `before_sync()` runs once the launches are queued, just before this thread blocks on them."""
+        `before_sync()` runs once the launches are queued, just before this thread blocks on them (work for the side context,
+        the helper thread's start: nothing the commitment waits for)."""
         t = self.cols if src is None else src
         self.params.commit_device(t[first].data_ptr(), count, self.jac.data_ptr(), lagrange, ctx=self.ctx)
         self.ctx.to_affine_device(self.curve.id, self.jac.data_ptr(), count, self.aff.data_ptr(), 0)
+        tk = self._tick
+        tk("commit queued")
         if before_sync is not None:
             before_sync()
-        self.ctx.synchronize()
-        pts = decode_points(self.curve, to_host(self.aff[:count]))
+        host = self.ctx.download(self.aff.data_ptr(), count, 8)      # waits for the commitment, then copies: one call
+        tk("points on host")
+        pts = decode_points(self.curve, host)
         for P in pts:
             transcript.write_point(P)
+        tk("points in transcript")
         return pts
 
     def _draw_blinds(self, rng):
@@ -198,6 +210,10 @@ class Prover:
         off = sum(self.blind_counts[:which])
         return self.blind_dev[off:off + self.blind_counts[which]]
 
+    def _tick(self, label: str):
+        if self._timings is not None:
+            self._timings.tick(label)
+
     def _ptrs(self, t, first=0, count=None):
         count = t.shape[0] - first if count is None else count
         return [t[first + i].data_ptr() for i in range(count)]
@@ -205,6 +221,7 @@ class Prover:
     # ---- the proof ----
     def create_proof(self, advice, instances: Sequence[Sequence[int]], rng: SeededRng, transcript: Blake2bWrite,
                      timings: Optional[ProofTimings] = None):
+        self._timings = timings
         with self.ctx.torch_stream():
             return self._create_proof(advice, instances, rng, transcript, timings)
 
@@ -222,7 +239,9 @@ class Prover:
 
         def mark(name):
             nonlocal t_phase
-            if timings is not None:
+            if timings is not None and timings.fine:
+                timings.tick("== " + name)
+            elif timings is not None:
                 ctx.synchronize()
                 now = time.perf_counter()
                 timings.phases_ms[name] = timings.phases_ms.get(name, 0.0) + 1e3 * (now - t_phase)
@@ -250,11 +269,18 @@ class Prover:
                     box["point"] = decode_points(self.curve, to_host(self.aff_side[:1]))[0]
             prefetch = threading.Thread(target=_draw)      # started when the advice commitments are queued (below): the host is idle then
 
-        def side_ntt(first, count):
-            """polys[first : first + count] = lagrange_to_coeff(cols[...]), ext[...] = coeff_to_extended(...) on the side context, after
-            everything queued so far on the main one (the columns and their blinding rows)."""
+        def columns_ready():
+            """an event after everything queued so far on the main context (a phase's columns and their blinding rows)"""
+            if self.side is None:
+                return None
             e = torch.cuda.Event()
             e.record(ctx.torch_stream_obj())
+            return e
+
+        def side_ntt(first, count, e):
+            """polys[first : first + count] = lagrange_to_coeff(cols[...]), ext[...] = coeff_to_extended(...) on the side context, once
+            the event `e` (recorded BEFORE the phase's commitment was queued) has passed: the launches themselves are made after the
+            commitment's, while this thread would otherwise only wait."""
             sb = self.side.torch_stream_obj()
             sb.wait_event(e)
             with torch.cuda.stream(sb):
@@ -284,11 +310,17 @@ class Prover:
         cols[self.o_adv:self.o_adv + A].copy_(adv)
         self._draw_blinds(rng)
         cols[self.o_adv:self.o_adv + A, u:] = self._blind_slice(0).view(A, n - u, 4)
-        if self.side is not None:
-            side_ntt(self.o_adv, A)
-        self._commit(transcript, self.o_adv, A, True, before_sync=prefetch.start if prefetch is not None else None)
+        ready = columns_ready()
+
+        def after_advice_queued():
+            if self.side is not None:
+                side_ntt(self.o_adv, A, ready)
+            if prefetch is not None:
+                prefetch.start()
+        self._commit(transcript, self.o_adv, A, True, before_sync=after_advice_queued)
         mark("advice")
         theta = transcript.squeeze_challenge_scalar()
+        self._tick("theta")
 
         # -- lookups: compress, permute, blind, commit
         fixed_v = self._ptrs(pk.fixed_values)
@@ -301,15 +333,18 @@ class Prover:
                 gt.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l + 1].data_ptr(), 0, 0, ctx)
             # permuted columns are interleaved (input_l, table_l) with a stride of two columns
             base = cols[self.o_perm].data_ptr()
+            self._tick("compress queued")
             ctx.permute_expression_pair_batch_device(fid, self.compressed[0].data_ptr(), self.compressed[1].data_ptr(), u, L, 2 * n, base, base + 32 * n, 0)
+            self._tick("permute returned")
             rows = n - u                                         # (input_0, table_0, input_1, ...): bf + 1 rows each
             cols[self.o_perm:self.o_perm + 2 * L, u:] = self._blind_slice(2).view(L, 2 * rows + 2, 4)[:, :2 * rows].reshape(2 * L, rows, 4)
-            if self.side is not None:
-                side_ntt(self.o_perm, 2 * L)
-            self._commit(transcript, self.o_perm, 2 * L, True)
+            self._tick("blinds copied")
+            ready = columns_ready()
+            self._commit(transcript, self.o_perm, 2 * L, True, before_sync=(lambda: side_ntt(self.o_perm, 2 * L, ready)) if self.side is not None else None)
         mark("lookup_permuted")
         beta = transcript.squeeze_challenge_scalar()
         gamma = transcript.squeeze_challenge_scalar()
+        self._tick("beta gamma")
 
         # -- grand products: permutation sets, then lookups; one batched inversion
         npc = len(cs.permutation_columns)
@@ -327,6 +362,7 @@ class Prover:
             four = [self.compressed[2 * l].data_ptr(), self.compressed[2 * l + 1].data_ptr(), cols[self.o_perm + 2 * l].data_ptr(), cols[self.o_perm + 2 * l + 1].data_ptr()]
             gd.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.den[S + l].data_ptr(), 0, 0, ctx)
             gn.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.num[S + l].data_ptr(), 0, 0, ctx)
+        self._tick("product graphs queued")
         if S + L:
             ctx.grand_product_batch_device(fid, self.num.data_ptr(), self.den.data_ptr(), n, S + L, n, cols[self.o_pz].data_ptr(), 0)
         for s in range(1, S):                                    # z_s starts where z_{s-1} ended: z = vec![last_z]
@@ -334,9 +370,8 @@ class Prover:
         if S + L:                                                # per column: bf blinding rows (n - bf .. n), then the (unused) commitment blind
             cols[self.o_pz:self.o_pz + S + L, n - bf:] = self._blind_slice(3).view(S + L, bf + 1, 4)[:, :bf]
         if S + L:
-            if self.side is not None:
-                side_ntt(self.o_pz, S + L)
-            self._commit(transcript, self.o_pz, S + L, True)
+            ready = columns_ready()
+            self._commit(transcript, self.o_pz, S + L, True, before_sync=(lambda: side_ntt(self.o_pz, S + L, ready)) if self.side is not None else None)
         mark("grand_products")
 
         # -- vanishing argument: a random polynomial
@@ -355,6 +390,7 @@ class Prover:
             self._commit(transcript, self.o_rand, 1, False)
         mark("random_poly")
         y = transcript.squeeze_challenge_scalar()
+        self._tick("y")
 
         # -- coefficient forms and cosets of everything committed so far
         nco = self.NC - 1
@@ -392,6 +428,7 @@ class Prover:
         mark("h_pieces")
         x = transcript.squeeze_challenge_scalar()
         xn = pow(x, n, p)
+        self._tick("x")
 
         # -- evaluations, in upstream's order.  Every coefficient-form column is evaluated at every rotation it is opened at
         # with one batched launch per (buffer, point).
@@ -469,6 +506,7 @@ class Prover:
 
         # -- ProverGWC::create_proof: one witness polynomial per distinct point, in order of first appearance
         v = transcript.squeeze_challenge_scalar()
+        self._tick("v")
         order: List[int] = []
         groups: Dict[int, List[Tuple[int, int]]] = {}
         for r, ptr, e in Q:
@@ -487,6 +525,7 @@ class Prover:
                 eval_batch = (eval_batch + pw * e) % p
                 pw = pw * v % p
             ctx.lincomb_device(fid, ptrs, f.encode_many(coefs), n, self.qbuf[gi].data_ptr(), enc(eval_batch), 0)
+        self._tick("lincombs queued")
         ctx.kate_division_batch_device(fid, self._ptrs(self.qbuf, 0, len(order)), n, f.encode_many([point[r] for r in order]), self._ptrs(self.wbuf, 0, len(order)), 0)
         self._commit(transcript, 0, len(order), False, src=self.wbuf)
         mark("openings")

@@ -71,6 +71,10 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
 void* dehalo_ctx_stream(dehalo_ctx* ctx);
 /* Blocks until everything queued on the context's own stream has finished. */
 int dehalo_ctx_synchronize(dehalo_ctx* ctx);
+/* Copies `bytes` from device memory to the host after everything queued on the context's own stream, and waits for it: the read-back
+ * of a phase's commitments / evaluations (what Blake2bWrite::write_point needs on the host, halo2_proofs/src/transcript.rs) in one
+ * call instead of a synchronize followed by a separate copy. */
+int dehalo_download(dehalo_ctx* ctx, const void* d_src, size_t bytes, void* host_dst);
 
 /* ---- SRS / bases ------------------------------------------------------------------------
  * Replaces the `g` / `g_lagrange` vectors of ParamsKZG / ParamsIPA
