@@ -85,6 +85,7 @@ class Prover:
         self.ctx = ctx if ctx is not None else pk.ctx
         self.side = side_ctx
         self._timings = None
+        self._rinv = pow(1 << 256, -1, pk.vk.curve.scalar.p)
         with self.ctx.torch_stream():      # torch's copies and fills go on the context's stream, ordered with the kernels
             self._init(params, pk)
 
@@ -215,8 +216,12 @@ class Prover:
             self._timings.tick(label)
 
     def _ptrs(self, t, first=0, count=None):
+        """device pointers of t[first], t[first + 1], ... (pointer arithmetic: indexing a tensor costs a microsecond per row)"""
         count = t.shape[0] - first if count is None else count
-        return [t[first + i].data_ptr() for i in range(count)]
+        if count <= 0:
+            return []
+        base, pitch = t.data_ptr(), t.stride(0) * t.element_size()
+        return [base + (first + i) * pitch for i in range(count)]
 
     # ---- the proof ----
     def create_proof(self, advice, instances: Sequence[Sequence[int]], rng: SeededRng, transcript: Blake2bWrite,
@@ -457,10 +462,8 @@ class Prover:
         ctx.eval_polynomial_device(fid, self.hfold.data_ptr(), n, n, 1, enc(x), self.evals[off].data_ptr(), 0)
         off += 1
         mark("evaluations_launch")
-        ctx.synchronize()
-        mark("evaluations_device")
-        ev_host = array_to_ints(to_host(self.evals[:off]))
-        rinv = pow(1 << 256, -1, p)
+        ev_host = array_to_ints(ctx.download(self.evals.data_ptr(), off, 4))
+        rinv = self._rinv
         val = lambda name, col, r: ev_host[slots[(name, r)] + col] * rinv % p
 
         for col, r in cs.advice_queries:
