@@ -401,6 +401,24 @@ def test_msm_randomised_configurations(pkg, co, ctx):
             assert np.array_equal(got[j], want), (trial, spec.name, n, m, c, precompute, batch, j)
 
 
+def test_msm_single_row_sort_blocks_cover_several_windows(pkg, co, ctx):
+    """Unregistered-style (single-row) tables at 2^17: every window keeps its own buckets and a sort block covers eight of them;
+    batch of three, prefix lengths that leave ragged last slices, and the one-shot best_multiexp entry point."""
+    spec = pkg.fields.BN254
+    n = 1 << 17
+    bases = co.synth_bases(spec.id, n)
+    h = ctx.register_bases(spec.id, bases, 0, False)
+    assert not h.precomputed and h.windows > 8
+    cols = [co.fill_scalars(spec.scalar.id, d, n, 31 + j) for j, d in enumerate(("uniform", "witness", "lookup"))]
+    for m in (n, n - 1, 100001):
+        got = ctx.to_affine(spec.id, ctx.msm_batch(h, [c[:m] for c in cols]))
+        for j, c in enumerate(cols):
+            assert np.array_equal(got[j], co.to_affine(spec.id, co.best_multiexp(spec.id, c[:m], bases[:m], 8))), (m, j)
+    h.release()
+    got = ctx.to_affine(spec.id, ctx.best_multiexp(spec.id, cols[0], bases))[0]
+    assert np.array_equal(got, co.to_affine(spec.id, co.best_multiexp(spec.id, cols[0], bases, 8)))
+
+
 def test_ntt_batched_device_entry_points(pkg, po, co, ctx):
     """ntt_device / intt_scaled_device with batch > 1 (the prover runs its columns batched)."""
     import torch
