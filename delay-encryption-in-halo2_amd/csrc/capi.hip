@@ -465,6 +465,26 @@ int dehalo_msm_device(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t
     return do_msm(ctx, bases, (const fe*)d_scalars, len, batch, (jacobian_t*)d_out_jacobian, pick_stream(ctx, stream));
 }
 
+int dehalo_msm_device_affine(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* d_scalars, size_t len, size_t batch, uint64_t* d_out_jacobian,
+                             uint64_t* d_out_affine, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!bases || (!d_scalars && len) || !d_out_affine) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: null argument");
+    if (len > bases->n) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: more scalars than registered bases");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = pick_stream(ctx, stream);
+    if (len == 0 || batch == 0) {   // the empty sum: identity = (0, 0)
+        if (batch) HIP_TRY(ctx, hipMemsetAsync(d_out_affine, 0, batch * sizeof(affine_t), s));
+        if (batch && d_out_jacobian) HIP_TRY(ctx, hipMemsetAsync(d_out_jacobian, 0, batch * sizeof(jacobian_t), s));
+        return 0;
+    }
+    ctx->msm_affine_out = (affine_t*)d_out_affine;
+    // (without a Jacobian destination the kernel skips that form; run_msm_t only passes the pointer on)
+    int rc = do_msm(ctx, bases, (const fe*)d_scalars, len, batch, (jacobian_t*)d_out_jacobian, s);
+    ctx->msm_affine_out = nullptr;
+    return rc;
+}
+
 int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* const* scalars, size_t len, size_t batch, uint64_t* out_jacobian) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if (!bases || !scalars || !out_jacobian) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: null argument");

@@ -39,6 +39,7 @@ struct dehalo_ctx {
     DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_records, ws_merge_lists, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
         ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[5], ws_poly_io[3], ws_evh[4], ws_lookup;
     std::vector<TwiddleEntry> twiddles;
+    affine_t* msm_affine_out = nullptr;   // set for the duration of dehalo_msm_device_affine (under mu): k_msm_final also writes affine points
     int msm_acc_points = 48; // > 0: the accumulation's grid is 4, 6, 8, ... layers of one wave per SIMD, the fewest that leave a lane <= this many
                              // points (2^20 x 16: 6 layers of 43; four dense 2^17 columns: 4 of 34, where whole rounds of 3 waves gave one round of 46
                              // on three quarters of the wave slots -- k = 17 proof 12.6 -> 12.05 ms); 0: rounds of msm_acc_waves waves per SIMD

@@ -772,16 +772,31 @@ __global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 
 // whatever the size of the MSM: quad-cooperative, it is 2.4x shorter), then an LDS tree of quad additions (the one-shot,
 // unregistered-bases path only).  256 threads = 64 quads >= W.
 template <class CV>
-__global__ __launch_bounds__(256) void k_msm_final(MsmGeom g, const xyzz29_rec* group_sums, jacobian_t* out) {
+__global__ __launch_bounds__(256) void k_msm_final(MsmGeom g, const xyzz29_rec* group_sums, jacobian_t* out, affine_t* out_affine) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[64];
     const u32 bat = blockIdx.x;
     const u32 w = threadIdx.x >> 2, role = threadIdx.x & 3;
-    if (g.G == 1) {  // precomputed tables: nothing to combine
-        if (threadIdx.x == 0) {
-            jacobian_t j = x29_to_jacobian_std<F>(x29_load(&group_sums[bat]));
+    // the result leaves as upstream's Jacobian {x, y, z} and / or, for a caller that feeds the transcript (dehalo_msm_device_affine),
+    // as the affine point: x = X / ZZ, y = Y / ZZZ with one inversion of ZZ * ZZZ -- no second kernel, no detour through Jacobian
+    auto emit = [&](const xyzz29& p) __attribute__((always_inline)) {
+        if (out) {
+            jacobian_t j = x29_to_jacobian_std<F>(p);
             f_store(&out[bat].x, j.x); f_store(&out[bat].y, j.y); f_store(&out[bat].z, j.z);
         }
+        if (out_affine) {
+            affine_t a;
+            if (f29_is_zero_slow<F>(p.zz)) { a.x = f_zero(); a.y = f_zero(); }
+            else {
+                f29 ti = f29_inv_safegcd<F>(f29_mul<F>(p.zz, p.zzz));
+                a.x = f29_to_std<F>(f29_mul<F>(p.x, f29_mul<F>(ti, p.zzz)));
+                a.y = f29_to_std<F>(f29_mul<F>(p.y, f29_mul<F>(ti, p.zz)));
+            }
+            aff_store(&out_affine[bat], a);
+        }
+    };
+    if (g.G == 1) {  // precomputed tables: nothing to combine
+        if (threadIdx.x == 0) emit(x29_load(&group_sums[bat]));
         return;
     }
     xyzz29 s = x29_identity();
@@ -797,10 +812,7 @@ __global__ __launch_bounds__(256) void k_msm_final(MsmGeom g, const xyzz29_rec* 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        jacobian_t j = x29_to_jacobian_std<F>(x29_load(&sh[0]));
-        f_store(&out[bat].x, j.x); f_store(&out[bat].y, j.y); f_store(&out[bat].z, j.z);
-    }
+    if (threadIdx.x == 0) emit(x29_load(&sh[0]));
 }
 
 // ---- SRS table: table[w][i] = [2^(c*w)] P_i, affine, internal canonical packed form ---------
@@ -994,7 +1006,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
             cur = o; cnt = out_cnt; which ^= 1;
         }
         if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));
-        k_msm_final<CV><<<(u32)batch, 256, 0, s>>>(g, gsums, d_out);
+        k_msm_final<CV><<<(u32)batch, 256, 0, s>>>(g, gsums, d_out, ctx->msm_affine_out);
         HIP_TRY(ctx, hipGetLastError());
     }
     return 0;

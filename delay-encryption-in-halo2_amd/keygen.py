@@ -107,6 +107,11 @@ class ParamsKZG:
     def commit_device(self, d_polys: int, batch: int, d_out: int, lagrange: bool, length: Optional[int] = None, ctx: Optional[Context] = None):
         (ctx or self.ctx).msm_device(self.bases_g_lagrange if lagrange else self.bases_g, d_polys, self.n if length is None else length, batch, d_out, 0)
 
+    def commit_affine_device(self, d_polys: int, batch: int, d_out_affine: int, lagrange: bool, length: Optional[int] = None, ctx: Optional[Context] = None):
+        """commit(..).to_affine() of `batch` columns in one call: the points the transcript absorbs."""
+        (ctx or self.ctx).msm_device_affine(self.bases_g_lagrange if lagrange else self.bases_g, d_polys, self.n if length is None else length, batch, 0,
+                                            d_out_affine, 0)
+
     def write(self, fh):
         fh.write(struct.pack("<I", self.k))
         fh.write(self.g.tobytes())

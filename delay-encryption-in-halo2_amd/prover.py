@@ -184,8 +184,7 @@ class Prover:
         `before_sync()` runs once the launches are queued, just before this thread blocks on them (work for the side context,
         the helper thread's start: nothing the commitment waits for)."""
         t = self.cols if src is None else src
-        self.params.commit_device(t[first].data_ptr(), count, self.jac.data_ptr(), lagrange, ctx=self.ctx)
-        self.ctx.to_affine_device(self.curve.id, self.jac.data_ptr(), count, self.aff.data_ptr(), 0)
+        self.params.commit_affine_device(t[first].data_ptr(), count, self.aff.data_ptr(), lagrange, ctx=self.ctx)
         tk = self._tick
         tk("commit queued")
         if before_sync is not None:
@@ -268,8 +267,7 @@ class Prover:
                 # with a side context the random polynomial is also COMMITTED there, long before its phase
                 with self.side.torch_stream():
                     self.polys[self.o_rand].copy_(to_device(r.scalars(n)))
-                    self.params.commit_device(self.polys[self.o_rand].data_ptr(), 1, self.jac_side.data_ptr(), False, ctx=self.side)
-                    self.side.to_affine_device(self.curve.id, self.jac_side.data_ptr(), 1, self.aff_side.data_ptr(), 0)
+                    self.params.commit_affine_device(self.polys[self.o_rand].data_ptr(), 1, self.aff_side.data_ptr(), False, ctx=self.side)
                     self.side.synchronize()
                     box["point"] = decode_points(self.curve, to_host(self.aff_side[:1]))[0]
             prefetch = threading.Thread(target=_draw)      # started when the advice commitments are queued (below): the host is idle then

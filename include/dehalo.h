@@ -108,6 +108,11 @@ int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t*
 /* Device-resident form: d_scalars = batch x len x 4 u64 contiguous in HBM, d_out = batch x 12 u64 in HBM. */
 int dehalo_msm_device(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* d_scalars, size_t len, size_t batch,
                       uint64_t* d_out_jacobian, void* stream);
+/* The same MSMs with the results ALSO (d_out_jacobian may be null: only) written as affine points {x, y} (64 B each, identity =
+ * (0, 0), standard Montgomery form): what Blake2bWrite::write_point needs after ParamsKZG::commit_lagrange(..).to_affine()
+ * [UPSTREAM halo2_proofs/src/plonk/prover.rs: `C::Curve::batch_normalize`] -- normalised by the kernel that finishes the MSM. */
+int dehalo_msm_device_affine(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t* d_scalars, size_t len, size_t batch, uint64_t* d_out_jacobian,
+                             uint64_t* d_out_affine, void* stream);
 /* One-shot best_multiexp over bases that are not registered (uploaded, used, dropped). */
 int dehalo_best_multiexp(dehalo_ctx* ctx, int curve, const uint64_t* scalars, const uint64_t* affine_xy, size_t len,
                          uint64_t out_jacobian[12]);

@@ -401,6 +401,33 @@ def test_msm_randomised_configurations(pkg, co, ctx):
             assert np.array_equal(got[j], want), (trial, spec.name, n, m, c, precompute, batch, j)
 
 
+@pytest.mark.parametrize("precompute", [True, False])
+def test_msm_device_affine_matches_msm_then_to_affine(pkg, co, ctx, precompute):
+    """dehalo_msm_device_affine: the points the transcript absorbs, normalised by the kernel that finishes the MSM -- equal to
+    msm_device + to_affine and to the oracle, identity columns and the Jacobian output included."""
+    import torch
+    spec = pkg.fields.BN254
+    n = 1 << 12
+    bases = co.synth_bases(spec.id, n)
+    h = ctx.register_bases(spec.id, bases, 0, precompute)
+    cols = np.stack([co.fill_scalars(spec.scalar.id, "uniform", n, 77), np.zeros((n, 4), np.uint64), co.fill_scalars(spec.scalar.id, "witness", n, 78)])
+    with ctx.torch_stream():
+        d = torch.from_numpy(cols.view(np.int64)).cuda()
+        jac = torch.zeros((3, 12), dtype=torch.int64, device="cuda")
+        aff = torch.full((3, 8), -1, dtype=torch.int64, device="cuda")
+        aff_only = torch.full((3, 8), -1, dtype=torch.int64, device="cuda")
+        ctx.msm_device_affine(h, d.data_ptr(), n, 3, jac.data_ptr(), aff.data_ptr(), 0)
+        ctx.msm_device_affine(h, d.data_ptr(), n, 3, 0, aff_only.data_ptr(), 0)
+        ctx.synchronize()
+        got, got_only, got_jac = aff.cpu().numpy().view(np.uint64), aff_only.cpu().numpy().view(np.uint64), jac.cpu().numpy().view(np.uint64)
+    for j in range(3):
+        want = co.to_affine(spec.id, co.best_multiexp(spec.id, cols[j], bases, 4))
+        assert np.array_equal(got[j], want) and np.array_equal(got_only[j], want), j
+        assert np.array_equal(co.to_affine(spec.id, got_jac[j]), want), j
+    assert not got[1].any()                                   # the empty commitment: identity = (0, 0)
+    h.release()
+
+
 def test_msm_single_row_sort_blocks_cover_several_windows(pkg, co, ctx):
     """Unregistered-style (single-row) tables at 2^17: every window keeps its own buckets and a sort block covers eight of them;
     batch of three, prefix lengths that leave ragged last slices, and the one-shot best_multiexp entry point."""
