@@ -742,10 +742,31 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u3
     if (!QUAD || (threadIdx.x & 3) == 0) x29_store(&contrib[gid], acc);
 }
 
-// tree sum: in[groups][cnt] -> out[groups][ceil(cnt / MSM_TREE_ITEMS)]; 64 quads per block
+// An MSM's result leaves as upstream's Jacobian {x, y, z} and / or, for a caller that feeds the transcript (dehalo_msm_device_affine),
+// as the affine point: x = X / ZZ, y = Y / ZZZ with one inversion of ZZ * ZZZ -- no second kernel, no detour through Jacobian.
+template <class F>
+FP_DEV void msm_emit(const xyzz29& p, jacobian_t* out, affine_t* out_affine) {
+    if (out) {
+        jacobian_t j = x29_to_jacobian_std<F>(p);
+        f_store(&out->x, j.x); f_store(&out->y, j.y); f_store(&out->z, j.z);
+    }
+    if (out_affine) {
+        affine_t a;
+        if (f29_is_zero_slow<F>(p.zz)) { a.x = f_zero(); a.y = f_zero(); }
+        else {
+            f29 ti = f29_inv_safegcd<F>(f29_mul<F>(p.zz, p.zzz));
+            a.x = f29_to_std<F>(f29_mul<F>(p.x, f29_mul<F>(ti, p.zzz)));
+            a.y = f29_to_std<F>(f29_mul<F>(p.y, f29_mul<F>(ti, p.zz)));
+        }
+        aff_store(out_affine, a);
+    }
+}
+
+// tree sum: in[groups][cnt] -> out[groups][ceil(cnt / MSM_TREE_ITEMS)]; 64 quads per block.  The launch that leaves one sum per
+// MSM of a precomputed-table batch (fin_out / fin_affine given) writes the results itself instead of a k_msm_final launch.
 #define MSM_TREE_ITEMS 128
 template <class CV>
-__global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 cnt, xyzz29_rec* out, u32 out_cnt) {
+__global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 cnt, xyzz29_rec* out, u32 out_cnt, jacobian_t* fin_out, affine_t* fin_affine) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[64];
     const u32 qd = threadIdx.x >> 2, role = threadIdx.x & 3;
@@ -764,7 +785,10 @@ __global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(u64)grp * out_cnt + blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) {
+        if (fin_out || fin_affine) msm_emit<F>(x29_load(&sh[0]), fin_out ? fin_out + grp : nullptr, fin_affine ? fin_affine + grp : nullptr);
+        else out[(u64)grp * out_cnt + blockIdx.x] = sh[0];
+    }
 }
 
 // ---- final: window sums -> one Jacobian point per MSM -------------------------------------
@@ -777,26 +801,8 @@ __global__ __launch_bounds__(256) void k_msm_final(MsmGeom g, const xyzz29_rec* 
     __shared__ xyzz29_rec sh[64];
     const u32 bat = blockIdx.x;
     const u32 w = threadIdx.x >> 2, role = threadIdx.x & 3;
-    // the result leaves as upstream's Jacobian {x, y, z} and / or, for a caller that feeds the transcript (dehalo_msm_device_affine),
-    // as the affine point: x = X / ZZ, y = Y / ZZZ with one inversion of ZZ * ZZZ -- no second kernel, no detour through Jacobian
-    auto emit = [&](const xyzz29& p) __attribute__((always_inline)) {
-        if (out) {
-            jacobian_t j = x29_to_jacobian_std<F>(p);
-            f_store(&out[bat].x, j.x); f_store(&out[bat].y, j.y); f_store(&out[bat].z, j.z);
-        }
-        if (out_affine) {
-            affine_t a;
-            if (f29_is_zero_slow<F>(p.zz)) { a.x = f_zero(); a.y = f_zero(); }
-            else {
-                f29 ti = f29_inv_safegcd<F>(f29_mul<F>(p.zz, p.zzz));
-                a.x = f29_to_std<F>(f29_mul<F>(p.x, f29_mul<F>(ti, p.zzz)));
-                a.y = f29_to_std<F>(f29_mul<F>(p.y, f29_mul<F>(ti, p.zz)));
-            }
-            aff_store(&out_affine[bat], a);
-        }
-    };
     if (g.G == 1) {  // precomputed tables: nothing to combine
-        if (threadIdx.x == 0) emit(x29_load(&group_sums[bat]));
+        if (threadIdx.x == 0) msm_emit<F>(x29_load(&group_sums[bat]), out ? out + bat : nullptr, out_affine ? out_affine + bat : nullptr);
         return;
     }
     xyzz29 s = x29_identity();
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(256) void k_msm_final(MsmGeom g, const xyzz29_rec* 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) emit(x29_load(&sh[0]));
+    if (threadIdx.x == 0) msm_emit<F>(x29_load(&sh[0]), out ? out + bat : nullptr, out_affine ? out_affine + bat : nullptr);
 }
 
 // ---- SRS table: table[w][i] = [2^(c*w)] P_i, affine, internal canonical packed form ---------
@@ -998,15 +1004,20 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         u32 cnt = per_group;
         xyzz29_rec* bufs[2] = {tree, contrib};  // ping-pong: contrib is free once consumed
         int which = 0;
+        bool emitted = false;
         while (cnt > 1) {
             u32 out_cnt = (cnt + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS;
             xyzz29_rec* o = out_cnt == 1 ? gsums : bufs[which];
             dim3 grid(out_cnt, (u32)total_groups);
-            k_msm_tree_sum<CV><<<grid, 256, 0, s>>>(cur, cnt, o, out_cnt);
+            const bool fin = out_cnt == 1 && g.G == 1;      // one sum per MSM left: this launch also writes the results
+            k_msm_tree_sum<CV><<<grid, 256, 0, s>>>(cur, cnt, o, out_cnt, fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
+            emitted = fin;
             cur = o; cnt = out_cnt; which ^= 1;
         }
-        if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));
-        k_msm_final<CV><<<(u32)batch, 256, 0, s>>>(g, gsums, d_out, ctx->msm_affine_out);
+        if (!emitted) {
+            if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));
+            k_msm_final<CV><<<(u32)batch, 256, 0, s>>>(g, gsums, d_out, ctx->msm_affine_out);
+        }
         HIP_TRY(ctx, hipGetLastError());
     }
     return 0;
