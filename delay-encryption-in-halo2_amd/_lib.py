@@ -184,6 +184,7 @@ class Context:
         if rc != 0:
             raise DehaloError(rc, "dehalo_ctx_create failed (no gfx950 device?); there is no CPU fallback")
         self.handle = h
+        self._tables = {}
 
     def close(self):
         if self.handle is not None:
@@ -455,9 +456,19 @@ class Context:
     def graph_release(self, graph):
         self._check(self.lib.dehalo_graph_release(self.handle, graph))
 
-    @staticmethod
-    def _ptr_table(ptrs):
-        return (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+    def _ptr_table(self, ptrs):
+        """ctypes array of a list of device pointers; the table of a list OBJECT that is passed again (a prover hands the same
+        column lists to every graph of a phase) is reused as long as the list has not changed."""
+        key = id(ptrs)
+        hit = self._tables.get(key)
+        if hit is not None and hit[0] is ptrs and hit[1] == ptrs:
+            return hit[2]
+        table = (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+        if isinstance(ptrs, list):
+            if len(self._tables) > 64:
+                self._tables.clear()
+            self._tables[key] = (ptrs, list(ptrs), table)
+        return table
 
     def graph_evaluate_device(self, graph, fixed, advice, instance, challenges, beta, gamma, theta, y, log_rows: int, rot_scale: int, d_previous: int,
                               d_out: int, stream: int = 0, form_flags: int = 0):

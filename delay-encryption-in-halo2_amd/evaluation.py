@@ -7,6 +7,7 @@ and 4 x u64 Montgomery limbs at the C ABI."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field as dc_field
+import numpy as np
 from typing import List, Optional, Sequence, Tuple
 
 from ._lib import Context
@@ -78,9 +79,12 @@ class CompiledGraph:
         """Column arguments are device pointers (extended-domain cosets, 1 << log_rows elements).  `ctx`: run on another context
         of the same device (compiled graphs may be shared between contexts, dehalo.h)."""
         e = self.field.encode
-        enc = lambda v: None if v is None else e(v)
-        ch = self.field.encode_many(list(challenges)) if challenges else None
-        (ctx or self.ctx).graph_evaluate_device(self.handle, list(fixed), list(advice), list(instance), ch, enc(beta), enc(gamma), enc(theta), enc(y), log_rows, rot_scale,
+        enc = lambda v: v if v is None or isinstance(v, np.ndarray) else e(v)           # (already encoded values pass through)
+        if isinstance(challenges, np.ndarray):
+            ch = challenges if challenges.shape[0] else None
+        else:
+            ch = self.field.encode_many(list(challenges)) if challenges else None
+        (ctx or self.ctx).graph_evaluate_device(self.handle, fixed, advice, instance, ch, enc(beta), enc(gamma), enc(theta), enc(y), log_rows, rot_scale,
                                        d_previous, d_out, stream, form_flags)
 
     def release(self):

@@ -32,15 +32,15 @@ class FieldSpec:
 
     # halo2curves in-memory form: 4 x u64 LE limbs of a * 2^256 mod p
     def encode(self, a: int) -> np.ndarray:
-        m = (a % self.p) * (1 << 256) % self.p
-        return np.array([(m >> (64 * i)) & MASK64 for i in range(4)], dtype=np.uint64)
+        return np.frombuffer(((a % self.p) * (1 << 256) % self.p).to_bytes(32, "little"), dtype=np.uint64).copy()
 
     def decode(self, limbs) -> int:
         m = sum(int(x) << (64 * i) for i, x in enumerate(limbs))
         return m * pow(1 << 256, -1, self.p) % self.p
 
     def encode_many(self, vals) -> np.ndarray:
-        return np.stack([self.encode(v) for v in vals]) if len(vals) else np.zeros((0, 4), dtype=np.uint64)
+        p = self.p
+        return np.frombuffer(b"".join(((v % p) * (1 << 256) % p).to_bytes(32, "little") for v in vals), dtype=np.uint64).reshape(-1, 4).copy()
 
     def decode_many(self, arr) -> list:
         return [self.decode(r) for r in np.asarray(arr).reshape(-1, 4)]

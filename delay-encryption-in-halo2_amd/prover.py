@@ -330,10 +330,11 @@ class Prover:
         adv_v = self._ptrs(cols, self.o_adv, A)
         inst_v = self._ptrs(instance_values, 0, self.I)
         if L:
+            theta_e, none = enc(theta), []
             for l in range(L):
                 gi, gt = pk.compress_graphs[l]
-                gi.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l].data_ptr(), 0, 0, ctx)
-                gt.evaluate_device(fixed_v, adv_v, inst_v, [], None, None, theta, None, k, 1, 0, self.compressed[2 * l + 1].data_ptr(), 0, 0, ctx)
+                gi.evaluate_device(fixed_v, adv_v, inst_v, none, None, None, theta_e, None, k, 1, 0, self.compressed[2 * l].data_ptr(), 0, 0, ctx)
+                gt.evaluate_device(fixed_v, adv_v, inst_v, none, None, None, theta_e, None, k, 1, 0, self.compressed[2 * l + 1].data_ptr(), 0, 0, ctx)
             # permuted columns are interleaved (input_l, table_l) with a stride of two columns
             base = cols[self.o_perm].data_ptr()
             self._tick("compress queued")
@@ -356,15 +357,18 @@ class Prover:
             chal.append(dj)
             dj = dj * delta % p
         perm_fixed = fixed_v + self._ptrs(pk.perm_values) + [self.omega_col.data_ptr()]
+        chal_e, beta_e, gamma_e, none = f.encode_many(chal), enc(beta), enc(gamma), []      # encoded once, not once per graph
+        den_p, num_p = self._ptrs(self.den), self._ptrs(self.num)
         for s in range(S):
             gd, gn = self.perm_graphs[s]
-            gd.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.den[s].data_ptr(), 0, 0, ctx)
-            gn.evaluate_device(perm_fixed, adv_v, inst_v, chal, beta, gamma, None, None, k, 1, 0, self.num[s].data_ptr(), 0, 0, ctx)
+            gd.evaluate_device(perm_fixed, adv_v, inst_v, chal_e, beta_e, gamma_e, None, None, k, 1, 0, den_p[s], 0, 0, ctx)
+            gn.evaluate_device(perm_fixed, adv_v, inst_v, chal_e, beta_e, gamma_e, None, None, k, 1, 0, num_p[s], 0, 0, ctx)
+        comp_p, perm_p = self._ptrs(self.compressed), self._ptrs(cols, self.o_perm, 2 * L)
         for l in range(L):
             gd, gn = self.lookup_product_graphs
-            four = [self.compressed[2 * l].data_ptr(), self.compressed[2 * l + 1].data_ptr(), cols[self.o_perm + 2 * l].data_ptr(), cols[self.o_perm + 2 * l + 1].data_ptr()]
-            gd.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.den[S + l].data_ptr(), 0, 0, ctx)
-            gn.evaluate_device([], four, [], [], beta, gamma, None, None, k, 1, 0, self.num[S + l].data_ptr(), 0, 0, ctx)
+            four = [comp_p[2 * l], comp_p[2 * l + 1], perm_p[2 * l], perm_p[2 * l + 1]]
+            gd.evaluate_device(none, four, none, none, beta_e, gamma_e, None, None, k, 1, 0, den_p[S + l], 0, 0, ctx)
+            gn.evaluate_device(none, four, none, none, beta_e, gamma_e, None, None, k, 1, 0, num_p[S + l], 0, 0, ctx)
         self._tick("product graphs queued")
         if S + L:
             ctx.grand_product_batch_device(fid, self.num.data_ptr(), self.den.data_ptr(), n, S + L, n, cols[self.o_pz].data_ptr(), 0)
