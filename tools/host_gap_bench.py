@@ -33,6 +33,9 @@ with ctx.torch_stream():
     ctx.synchronize()
     T("scale_device launch", lambda: ctx.scale_device(f.id, a[0].data_ptr(), 1 << 10, None, a[1].data_ptr(), 0))
     ctx.synchronize()
+    _p8 = [a[i % 4].data_ptr() for i in range(8)]; _c8 = f.encode_many([3] * 8)
+    T("lincomb_device(8) launch, prepared args", lambda: ctx.lincomb_device(f.id, _p8, _c8, 1 << 10, a[3].data_ptr(), None, 0))
+    ctx.synchronize()
     T("lincomb_device(8) launch", lambda: ctx.lincomb_device(f.id, [a[i % 4].data_ptr() for i in range(8)], f.encode_many([3] * 8), 1 << 10, a[3].data_ptr(), None, 0))
     ctx.synchronize()
     rng = prover.SeededRng(5)
@@ -41,5 +44,23 @@ with ctx.torch_stream():
     v = rng.scalars(5 * 21400).reshape(5, 21400, 4)
     T("to_device(5 x 21400 rows)", lambda: keygen.to_device(v), 50)
     T("torch.cuda.Event record+wait", lambda: (lambda e: (e.record(ctx.torch_stream_obj()), ctx.torch_stream_obj().wait_event(e)))(torch.cuda.Event()))
-    T("tensor slice copy_ (5 x 2^17 x 32 B) launch", lambda: a[:3].copy_(a[1:4]), 50)
-    ctx.synchronize()
+    bases = co.synth_bases(curve.id, 1 << 11)
+    h = ctx.register_bases(curve.id, bases, 0, True)
+    sc = torch.zeros(5, 1 << 11, 4, dtype=torch.int64, device="cuda"); out = torch.zeros(5, 12, dtype=torch.int64, device="cuda"); aff = torch.zeros(5, 8, dtype=torch.int64, device="cuda")
+    def msm_and_wait():
+        ctx.msm_device_affine(h, sc.data_ptr(), 1 << 11, 5, 0, aff.data_ptr(), 0)
+    import time as _t
+    ts = []
+    for _ in range(50):
+        ctx.synchronize(); t = _t.perf_counter(); msm_and_wait(); ts.append(_t.perf_counter() - t); ctx.synchronize()
+    print("%-46s %7.1f us (host time of the launches, device idle before)" % ("msm_device_affine(5 x 2^11) launch", 1e6 * sorted(ts)[len(ts) // 2]))
+    ts = []
+    for _ in range(50):
+        ctx.synchronize(); t = _t.perf_counter(); msm_and_wait(); ctx.synchronize(); ts.append(_t.perf_counter() - t)
+    print("%-46s %7.1f us (launch + device + wait)" % ("msm_device_affine(5 x 2^11) complete", 1e6 * sorted(ts)[len(ts) // 2]))
+    om = f.encode(po.BN254.scalar.omega(11)) if hasattr(po.BN254, "scalar") else None
+    if om is not None:
+        ts = []
+        for _ in range(50):
+            ctx.synchronize(); t = _t.perf_counter(); ctx.ntt_device(f.id, a[0].data_ptr(), 11, om, 5, 0); ts.append(_t.perf_counter() - t); ctx.synchronize()
+        print("%-46s %7.1f us (host time of the launches)" % ("ntt_device(5 x 2^11) launch", 1e6 * sorted(ts)[len(ts) // 2]))
