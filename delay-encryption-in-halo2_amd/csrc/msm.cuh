@@ -160,10 +160,9 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
     }
 }
 
-// column scan: for every bucket, exclusive prefix over the slices (in place) and the total count
-static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count) {
-    // (also used with nb = partitions per group for the per-partition counts; count may be null)
-    u32 gb = blockIdx.x * blockDim.x + threadIdx.x;
+// column scan: for every bucket, exclusive prefix over the slices (in place) and the total count.  One launch covers two tables:
+// blocks [0, blocks_a) the per-bucket histograms (bh, counts out), the rest the per-partition counts (pc, no totals).
+FP_DEV void colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 gb) {
     if (gb >= total_buckets) return;
     u32 grp = gb / nb, b = gb - grp * nb;
     u32* col = bh + (u64)grp * slices * nb + b;
@@ -185,6 +184,10 @@ static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32*
         run += v;
     }
     if (count) count[gb] = run;
+}
+static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 blocks_a, u32 P, u32 total_parts, u32* pc) {
+    if (blockIdx.x < blocks_a) colscan_one(nb, slices, total_buckets, bh, count, blockIdx.x * blockDim.x + threadIdx.x);
+    else colscan_one(P, slices, total_parts, pc, nullptr, (blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
 }
 
 // ---- scans (3 kernels): point offsets and record ranges -----------------------------------
@@ -238,6 +241,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_item
         if (threadIdx.x == SCAN_THREADS - 1) { carry_i += s_i[threadIdx.x]; carry_t += s_t[threadIdx.x]; }
         __syncthreads();
     }
+    if (threadIdx.x < 4) geo[(int)threadIdx.x - 4] = 0;     // the four merge-class counters sit just below geo (ws_counters): zeroed here, no fill launch
     if (threadIdx.x == 0) {
         const u64 M = carry_i;
         u64 L;
@@ -968,11 +972,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const u32 tb = (u32)total_buckets;
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
-        HIP_TRY(ctx, hipMemsetAsync(merge_counters, 0, 16, s));
         dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
         k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, bh, pc);
-        k_msm_colscan<<<(tb + 255) / 256, 256, 0, s>>>(g.nb, g.slices, tb, bh, count);
-        k_msm_colscan<<<((u32)total_groups * P + 255) / 256, 256, 0, s>>>(P, g.slices, (u32)total_groups * P, pc, nullptr);
+        const u32 cs_a = (tb + 255) / 256, cs_b = ((u32)total_groups * P + 255) / 256;
+        k_msm_colscan<<<cs_a + cs_b, 256, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc);
         TRY(run_scan(ctx, count, tb, cursor + 4, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend, s));
         k_msm_part<FS><<<grid, MSM_SORT_THREADS, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, 0, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
