@@ -65,12 +65,21 @@ struct MsmGeom {
 // ---- scalar -> signed digits -------------------------------------------------------------
 // canonical scalar s < 2^255, digits d_w in [-(2^(c-1) - 1), 2^(c-1)], sum d_w 2^(cw) = s.
 // Calls f(w, bucket, neg) for every non-zero digit with w in [w_lo, w_hi).
+FP_DEV bool fe_is_zero_words(const fe& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3] | a.v[4] | a.v[5] | a.v[6] | a.v[7]) == 0; }
+
 template <class FS, class Fn>
 FP_DEV void for_each_digit(const fe& mont_scalar, u32 c, u32 w_lo, u32 w_hi, Fn f) {
+    if (fe_is_zero_words(mont_scalar)) return;           // 0 * R = 0: a zero scalar has no digits (most rows of a permuted lookup column)
     fe s = f_from_mont<FS>(mont_scalar);
+    // windows that can hold a digit: those covering the scalar's bits, plus one for the last carry (small witness values end after a
+    // few windows; computed once per scalar, not tested per digit)
+    u32 bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (s.v[i]) bits = 32u * i + (32u - (u32)__clz((int)s.v[i]));
+    const u32 w_end = min(w_hi, (bits + c - 1) / c + 1);
     const u32 mask = (1u << c) - 1, halfv = 1u << (c - 1);
     u32 carry = 0;
-    for (u32 w = 0; w < w_hi; w++) {
+    for (u32 w = 0; w < w_end; w++) {
         u32 raw = (s.v[0] & mask) + carry;
         // s >>= c   (static indices only: keeps the limbs in registers)
 #pragma unroll
@@ -93,6 +102,7 @@ struct DigitStream {
         s = f_from_mont<FS>(mont_scalar);
         c = c_; mask = (1u << c) - 1; halfv = 1u << (c - 1); carry = 0;
     }
+    FP_DEV bool exhausted() const { return carry == 0 && fe_is_zero_words(s); }
     // next digit: bucket index (0xffffffff for a zero digit) and sign
     FP_DEV void next(u32& bucket, bool& neg) {
         u32 raw = (s.v[0] & mask) + carry;
@@ -353,15 +363,20 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
         const bool have = i < end;
         const fe s_cur = s_next;
         if (i + blockDim.x < end) s_next = f_load(&sc[i + blockDim.x]);   // the next round's scalar is in flight during this one
+        // (uniform per wave) a wave of zero scalars -- the long zero run of a sorted, permuted lookup column -- has nothing to place,
+        // and a wave of small witness values runs out of digits after the first windows
+        const bool nonzero = have && !fe_is_zero_words(s_cur);
+        if (__ballot(nonzero) == 0) continue;
         DigitStream ds;
-        if (have) ds.template init<FS>(s_cur, g.c);
+        if (nonzero) ds.template init<FS>(s_cur, g.c);
         for (u32 w0 = 0; w0 < w_hi; w0 += 8) {
+            if (__ballot(nonzero && !ds.exhausted()) == 0) break;
             u32 bk[8];
             bool ng8[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 bk[j] = 0xffffffffu; ng8[j] = false;
-                if (have && w0 + j < w_hi) {
+                if (nonzero && w0 + j < w_hi) {
                     ds.next(bk[j], ng8[j]);
                     if (w0 + j < w_lo) bk[j] = 0xffffffffu;
                 }
