@@ -14,7 +14,7 @@ _LIB = None
 SYMBOLS = [
     "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
-    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
+    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_field_op_device", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
@@ -102,6 +102,7 @@ def load_library():
     lib.dehalo_msm_batch.argtypes = [P, P, C.POINTER(C.c_void_p), sz, sz, u64p]
     lib.dehalo_msm_device.argtypes = [P, P, u64p, sz, sz, u64p, P]
     lib.dehalo_msm_device_affine.argtypes = [P, P, u64p, sz, sz, u64p, u64p, P]
+    lib.dehalo_msm_last_shape.argtypes = [P, C.POINTER(C.c_uint32)]
     lib.dehalo_best_multiexp.argtypes = [P, C.c_int, u64p, u64p, sz, u64p]
     lib.dehalo_to_affine.argtypes = [P, C.c_int, u64p, sz, u64p]
     lib.dehalo_to_affine_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
@@ -256,6 +257,11 @@ class Context:
     def msm_device_affine(self, bases: Bases, d_scalars: int, length: int, batch: int, d_out_jacobian: int, d_out_affine: int, stream: int = 0):
         """msm_device with the results (also) as affine points, normalised by the kernel that finishes the MSM (d_out_jacobian may be 0)."""
         self._check(self.lib.dehalo_msm_device_affine(self.handle, bases.handle, d_scalars, length, batch, d_out_jacobian or None, d_out_affine, stream or None))
+
+    def msm_last_shape(self) -> dict:
+        out = (C.c_uint32 * 6)()
+        self._check(self.lib.dehalo_msm_last_shape(self.handle, out))
+        return {"merge_light": out[0], "merge_32": out[1], "merge_wave": out[2], "merge_block": out[3], "points_per_lane": out[4], "pairs": out[5]}
 
     def best_multiexp(self, curve: int, scalars, affine_xy) -> np.ndarray:
         s, a = _u64(scalars, 4), _u64(affine_xy, 8)

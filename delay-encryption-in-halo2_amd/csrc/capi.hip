@@ -1073,4 +1073,15 @@ int dehalo_timing_get(dehalo_ctx* ctx, int kernel_id, double* total_ms, uint64_t
     return 0;
 }
 
+int dehalo_msm_last_shape(dehalo_ctx* ctx, uint32_t out[6]) {
+    if (!ctx || !out) return DEHALO_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    memset(out, 0, 6 * sizeof(uint32_t));
+    if (!ctx->ws_counters.p) return 0;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->ws_counters.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // extern "C"

@@ -61,6 +61,7 @@ class ProofTimings:
     total_ms: float = 0.0
     fine: bool = False                                     # also record host timestamps inside the phases (no extra syncs)
     ticks: List[Tuple[str, float]] = dc_field(default_factory=list)
+    msm_shapes: List[dict] = dc_field(default_factory=list)   # fine: Context.msm_last_shape() after each commitment phase
 
     def tick(self, label: str):
         if self.fine:
@@ -191,6 +192,8 @@ class Prover:
             before_sync()
         host = self.ctx.download(self.aff.data_ptr(), count, 8)      # waits for the commitment, then copies: one call
         tk("points on host")
+        if self._timings is not None and self._timings.fine:
+            self._timings.msm_shapes.append(dict(self.ctx.msm_last_shape(), columns=count))
         pts = decode_points(self.curve, host)
         for P in pts:
             transcript.write_point(P)

@@ -342,6 +342,10 @@ int dehalo_timing_reset(dehalo_ctx* ctx);
 /* Synchronises the context, then returns total milliseconds and number of timed regions. */
 int dehalo_timing_get(dehalo_ctx* ctx, int kernel_id, double* total_ms, uint64_t* count);
 
+/* Shape of the context's most recent MSM launch, for tuning (synchronises): out[0..3] = buckets whose partial sums were merged by one
+ * lane or quad / 32 lanes / one wave / a whole block, out[4] = points per lane of the accumulation, out[5] = (bucket, point) pairs sorted. */
+int dehalo_msm_last_shape(dehalo_ctx* ctx, uint32_t out[6]);
+
 /* Library / build info, e.g. "dehalo 0.1 gfx950". */
 const char* dehalo_version(void);
 

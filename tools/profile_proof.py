@@ -65,10 +65,15 @@ with pkg.Context(0) as ctx:
         t0 = time.perf_counter(); P2.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve), tm); ctx.synchronize(); t1 = time.perf_counter()
         if best is None or t1 - t0 < best[0]:
             best = (t1 - t0, t0, tm.ticks)
+            shapes = tm.msm_shapes
     prev = best[1]
     print("   host timeline of the best of 5 (%.2f ms): label, ms since start, ms since previous" % (1e3 * best[0]))
     for label, t in best[2]:
         print("      %-28s %8.3f %8.3f" % (label, 1e3 * (t - best[1]), 1e3 * (t - prev)))
         prev = t
+    print("   commitment MSMs (columns, sorted pairs, points per lane, buckets merged by one lane or quad / 32 lanes / one wave / a block):")
+    for sh in shapes:
+        print("      %2d columns  %9d pairs  %3d per lane   %7d %6d %5d %4d" % (sh["columns"], sh["pairs"], sh["points_per_lane"], sh["merge_light"], sh["merge_32"],
+                                                                                sh["merge_wave"], sh["merge_block"]))
     side.close()
     params.release()
