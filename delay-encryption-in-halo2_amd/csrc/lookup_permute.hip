@@ -191,11 +191,6 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe
 
     const u32 blocks_n = (u32)((n + 255) / 256), blocks_total = (u32)((total + 255) / 256), blocks_half = (u32)((half + 255) / 256);
     TRY(canon_dispatch(ctx, field, d_inputs, d_tables, stride, B, n, canon, s));
-    HIP_TRY(ctx, hipMemsetAsync(ors, 0, 4 * sizeof(unsigned long long), s));
-    k_lp_limb_or<<<blocks_total, 256, 0, s>>>(canon, total, ors);
-    unsigned long long host_ors[4];
-    HIP_TRY(ctx, hipMemcpyAsync(host_ors, ors, sizeof(host_ors), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));          // the pass plan depends on the data (the call synchronises at its end anyway)
     u32 *pin = p0, *pout = p1;
     const unsigned col_bits = 2 * B > 1 ? 32 - (unsigned)__builtin_clz(2 * B - 1) : 0;
     auto sort_pass = [&](u32 limb, unsigned begin_bit, unsigned end_bit) -> int {
@@ -205,57 +200,59 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe
         std::swap(pin, pout);
         return 0;
     };
+    u32* bad = (u32*)ors;                                      // (first word of the limb-OR area: the two uses never overlap)
+    std::vector<int> host_err(B);
     // Fast path: a theta-compressed lookup value is tag * theta + value -- pseudo-random leading bits per tag, a small integer
-    // added at the bottom -- so the low 32 bits and the leading 48 bits of the most significant non-zero limb order them: two
-    // short value passes + the stable column pass (~15 launches instead of ~40), then the whole order is verified with the full
-    // comparison.  Any violation (values that differ only in the bits in between) falls back to the full
-    // least-significant-limb-first sort.
-    int top = 3;
-    while (top > 0 && host_ors[top] == 0) top--;
-    const unsigned top_bits = host_ors[top] ? 64 - (unsigned)__builtin_clzll(host_ors[top]) : 0;
-    bool sorted_ok = false;
-    if (top_bits > 0) {
-        k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
-        const unsigned low_bits = host_ors[0] ? std::min(32u, 64 - (unsigned)__builtin_clzll(host_ors[0])) : 0;
-        if (low_bits && (top > 0 || top_bits > 48)) TRY(sort_pass(0, 0, low_bits));
-        TRY(sort_pass((u32)top, top_bits > 48 ? top_bits - 48 : 0, top_bits));
-        if (col_bits) TRY(sort_pass(4, 0, col_bits));
-        k_lp_gather<<<blocks_total, 256, 0, s>>>(canon, pin, total, S);
-        u32* bad = (u32*)ors;                                  // the limb ORs have been read: reuse the word
-        HIP_TRY(ctx, hipMemsetAsync(bad, 0, sizeof(u32), s));
-        k_lp_check_sorted<<<blocks_total, 256, 0, s>>>(S, n, total, bad);
-        u32 host_bad = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&host_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        sorted_ok = host_bad == 0;
-    }
-    if (!sorted_ok) {
+    // added at the bottom -- so the low 32 bits and the 48 bits below the modulus' top bit order them: two short value passes + the
+    // stable column pass (~15 launches instead of ~40).  The plan does not depend on the data, so nothing is read back before the
+    // end: the order is verified on the device with the full comparison (k_lp_check_sorted) while the permutation is already being
+    // built from it, and ONE read-back at the end returns the lookup errors and that verdict.  Any violation (values that differ
+    // only in the bits in between, e.g. a table of plain integers above 2^32) repeats the call with the full
+    // least-significant-limb-first sort, whose pass plan is read from the data.
+    const unsigned mod_bits = (field == DEHALO_FIELD_BN254_FR || field == DEHALO_FIELD_BN254_FQ) ? 254 : 255;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool fast = attempt == 0;
         pin = p0; pout = p1;
         k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
-        for (u32 limb = 0; limb <= 4; limb++) {
-            unsigned bits;
-            if (limb < 4) bits = host_ors[limb] ? 64 - (unsigned)__builtin_clzll(host_ors[limb]) : 0;
-            else bits = col_bits;                                 // last: the column id, stable
-            if (bits == 0) continue;
-            TRY(sort_pass(limb, 0, bits));
+        if (fast) {
+            TRY(sort_pass(0, 0, 32));
+            TRY(sort_pass(3, mod_bits - 48 - 192, mod_bits - 192));
+            if (col_bits) TRY(sort_pass(4, 0, col_bits));
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(ors, 0, 4 * sizeof(unsigned long long), s));
+            k_lp_limb_or<<<blocks_total, 256, 0, s>>>(canon, total, ors);
+            unsigned long long host_ors[4];
+            HIP_TRY(ctx, hipMemcpyAsync(host_ors, ors, sizeof(host_ors), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));          // the pass plan depends on the data
+            for (u32 limb = 0; limb <= 4; limb++) {
+                unsigned bits;
+                if (limb < 4) bits = host_ors[limb] ? 64 - (unsigned)__builtin_clzll(host_ors[limb]) : 0;
+                else bits = col_bits;                                 // last: the column id, stable
+                if (bits == 0) continue;
+                TRY(sort_pass(limb, 0, bits));
+            }
         }
         k_lp_gather<<<blocks_total, 256, 0, s>>>(canon, pin, total, S);
+        HIP_TRY(ctx, hipMemsetAsync(bad, 0, sizeof(u32), s));
+        if (fast) k_lp_check_sorted<<<blocks_total, 256, 0, s>>>(S, n, total, bad);
+        HIP_TRY(ctx, hipMemsetAsync(consumed, 0, half * 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(err, 0, B * sizeof(int), s));
+        HIP_TRY(ctx, hipMemsetAsync(lsrc, 0, half * 4, s));       // a failed lookup leaves gaps: keep every index in range
+        k_lp_flags<<<dim3(blocks_n, B), 256, 0, s>>>(S, B, n, repeated, consumed, err);
+        k_lp_not<<<blocks_half, 256, 0, s>>>(consumed, half, leftover);
+        size_t bytes = tmp_bytes;
+        HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, repeated, rrank, 0u, half, rocprim::plus<u32>(), s));
+        bytes = tmp_bytes;
+        HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, leftover, lrank, 0u, half, rocprim::plus<u32>(), s));
+        k_lp_compact<<<dim3(blocks_n, B), 256, 0, s>>>(leftover, lrank, pin, B, n, lsrc);
+        k_lp_emit<<<dim3(blocks_n, B), 256, 0, s>>>(d_inputs, d_tables, stride, pin, repeated, rrank, lsrc, B, n, d_out_inputs, d_out_tables);
+        HIP_TRY(ctx, hipGetLastError());
+        u32 host_bad = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(host_err.data(), err, B * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(&host_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));     // upstream returns Err(ConstraintSystemFailure) from this call: so must we
+        if (host_bad == 0) break;                  // (the full sort never sets it)
     }
-    HIP_TRY(ctx, hipMemsetAsync(consumed, 0, half * 4, s));
-    HIP_TRY(ctx, hipMemsetAsync(err, 0, B * sizeof(int), s));
-    HIP_TRY(ctx, hipMemsetAsync(lsrc, 0, half * 4, s));       // a failed lookup leaves gaps: keep every index in range
-    k_lp_flags<<<dim3(blocks_n, B), 256, 0, s>>>(S, B, n, repeated, consumed, err);
-    k_lp_not<<<blocks_half, 256, 0, s>>>(consumed, half, leftover);
-    size_t bytes = tmp_bytes;
-    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, repeated, rrank, 0u, half, rocprim::plus<u32>(), s));
-    bytes = tmp_bytes;
-    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, leftover, lrank, 0u, half, rocprim::plus<u32>(), s));
-    k_lp_compact<<<dim3(blocks_n, B), 256, 0, s>>>(leftover, lrank, pin, B, n, lsrc);
-    k_lp_emit<<<dim3(blocks_n, B), 256, 0, s>>>(d_inputs, d_tables, stride, pin, repeated, rrank, lsrc, B, n, d_out_inputs, d_out_tables);
-    HIP_TRY(ctx, hipGetLastError());
-    std::vector<int> host_err(B);
-    HIP_TRY(ctx, hipMemcpyAsync(host_err.data(), err, B * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));     // upstream returns Err(ConstraintSystemFailure) from this call: so must we
     for (u32 y = 0; y < B; y++)
         if (host_err[y])
             return dh_fail(ctx, DEHALO_ERR_NOT_IN_TABLE, "permute_expression_pair: lookup " + std::to_string(y) + ": an input value is not in the table (ConstraintSystemFailure)");
