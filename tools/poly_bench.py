@@ -11,11 +11,15 @@ ctx = pkg.Context(0)
 threads = min(64, os.cpu_count() or 1)
 
 def timeit(fn, reps=20):
+    """median of per-call times, each call waited for (a loop average once showed 1.9 ms for one size whose calls take 0.08 ms:
+    torch's allocator was still freeing the previous size's buffers behind the first calls -- tools/eval_outlier.py)"""
+    import torch
     for _ in range(3): fn()
-    ctx.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps): fn()
-    ctx.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e3
+    ctx.synchronize(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ctx.synchronize(); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2] * 1e3
 
 def cpu(fn, reps=3):
     fn(); t0 = time.perf_counter()

@@ -15,6 +15,7 @@ echo "[3b] create_proof k=17, unprofiled"; timeout -k 10 300 python tools/profil
 echo "[4] pmc"; bash tools/collect_pmc.sh $rev > $out/pmc.log 2>&1; cp gpurun_out/pmc/pmc_traffic.json $out/; mkdir -p $out/pmc; cp gpurun_out/pmc/main/*.csv gpurun_out/pmc/calib/*.csv $out/pmc/ 2>/dev/null || true
 for c in FETCH_SIZE WRITE_SIZE; do cp gpurun_out/pmc/main/${c}_counter_collection.csv $out/pmc/main_${c}.csv; cp gpurun_out/pmc/calib/${c}_counter_collection.csv $out/pmc/calib_${c}.csv; done
 echo "[5] host paths"; timeout -k 10 300 python tools/host_path_bench.py > $out/host_path_measurements.txt 2>/dev/null
+echo "[5b] field-vector primitives"; timeout -k 10 400 python tools/poly_bench.py > $out/field_vector_primitives.txt 2>/dev/null
 echo "[6] one-shot sweep"; timeout -k 10 300 python tools/sweep_single_row.py pallas > $out/one_shot_window_sweep.txt 2>/dev/null
 echo "[7] acc points sweep"; bash tools/sweep_acc_points.sh > $out/sweep_acc_points.txt 2>&1
 echo "[8] two ranks on one GPU (gloo)"
