@@ -368,13 +368,14 @@ __global__ __launch_bounds__(POLY_THREADS) void k_pp_apply(const fe* in, u64 in_
 // Pointers and coefficients travel as kernel arguments; the block converts the coefficients to the internal
 // form once (LDS), columns stay plain integers of their standard form: (c 2^261)(v 2^256) 2^-261 = c v 2^256.
 #define POLY_LC_MAX 40
-#define POLY_LC_EPT 4
 struct LincombArgs {
     const fe* cols[POLY_LC_MAX];
     fe coef[POLY_LC_MAX];
     u32 count;
 };
-template <class F>
+// EPT elements per thread: 4 for long vectors (independent loads and multiplications per column), 1 when that would leave the chip
+// a fraction of a wave per SIMD (2^17 coefficients at 4 per thread are 512 waves for 1024 SIMDs)
+template <class F, int POLY_LC_EPT>
 __global__ __launch_bounds__(POLY_THREADS) void k_lincomb(LincombArgs A, u64 len, fe* out, int accumulate, fe sub0, int has_sub0) {
     typedef typename f29_of<F>::type F9;
     __shared__ f29 cf[POLY_LC_MAX];
@@ -665,7 +666,8 @@ template <class F>
 int lincomb_t(dehalo_ctx* ctx, const fe* const* d_cols, const uint64_t* coefs, size_t count, uint64_t len, fe* d_out, const uint64_t* sub0, hipStream_t s) {
     if (len == 0) return 0;
     ScopedTimer timer(ctx, s, DEHALO_K_POLY);
-    const u32 grid = (u32)((len + POLY_THREADS * POLY_LC_EPT - 1) / (POLY_THREADS * POLY_LC_EPT));
+    const u32 ept = len >= (1ull << 20) ? 4 : 1;
+    const u32 grid = (u32)((len + POLY_THREADS * ept - 1) / (POLY_THREADS * ept));
     if (count == 0) HIP_TRY(ctx, hipMemsetAsync(d_out, 0, len * sizeof(fe), s));
     fe s0 = sub0 ? fe_from_u64(sub0) : fe{};
     for (size_t first = 0; first < count || (first == 0 && sub0); first += POLY_LC_MAX) {
@@ -673,7 +675,8 @@ int lincomb_t(dehalo_ctx* ctx, const fe* const* d_cols, const uint64_t* coefs, s
         A.count = (u32)std::min<size_t>(POLY_LC_MAX, count - first);
         for (u32 j = 0; j < A.count; j++) { A.cols[j] = d_cols[first + j]; A.coef[j] = fe_from_u64(coefs + 4 * (first + j)); }
         const bool last = first + POLY_LC_MAX >= count;
-        k_lincomb<F><<<grid, POLY_THREADS, 0, s>>>(A, len, d_out, first != 0 || count == 0, s0, sub0 && last ? 1 : 0);
+        if (ept == 4) k_lincomb<F, 4><<<grid, POLY_THREADS, 0, s>>>(A, len, d_out, first != 0 || count == 0, s0, sub0 && last ? 1 : 0);
+        else k_lincomb<F, 1><<<grid, POLY_THREADS, 0, s>>>(A, len, d_out, first != 0 || count == 0, s0, sub0 && last ? 1 : 0);
         if (count == 0) break;
     }
     HIP_TRY(ctx, hipGetLastError());
