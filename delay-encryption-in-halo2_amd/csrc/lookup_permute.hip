@@ -203,11 +203,11 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe
     u32* bad = (u32*)ors;                                      // (first word of the limb-OR area: the two uses never overlap)
     std::vector<int> host_err(B);
     // Fast path: a theta-compressed lookup value is tag * theta + value -- pseudo-random leading bits per tag, a small integer
-    // added at the bottom -- so the low 32 bits and the 48 bits below the modulus' top bit order them: two short value passes + the
-    // stable column pass (~15 launches instead of ~40).  The plan does not depend on the data, so nothing is read back before the
+    // added at the bottom (a range table's values are below 2^16) -- so the low 24 bits and the 40 bits below the modulus' top bit order
+    // them: two short value passes + the stable column pass (~13 launches instead of ~40).  The plan does not depend on the data, so nothing is read back before the
     // end: the order is verified on the device with the full comparison (k_lp_check_sorted) while the permutation is already being
     // built from it, and ONE read-back at the end returns the lookup errors and that verdict.  Any violation (values that differ
-    // only in the bits in between, e.g. a table of plain integers above 2^32) repeats the call with the full
+    // only in the bits in between, e.g. a table of plain integers above 2^24) repeats the call with the full
     // least-significant-limb-first sort, whose pass plan is read from the data.
     const unsigned mod_bits = (field == DEHALO_FIELD_BN254_FR || field == DEHALO_FIELD_BN254_FQ) ? 254 : 255;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -215,8 +215,8 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe
         pin = p0; pout = p1;
         k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
         if (fast) {
-            TRY(sort_pass(0, 0, 32));
-            TRY(sort_pass(3, mod_bits - 48 - 192, mod_bits - 192));
+            TRY(sort_pass(0, 0, 24));                                      // (three + five 8-bit radix passes)
+            TRY(sort_pass(3, mod_bits - 40 - 192, mod_bits - 192));
             if (col_bits) TRY(sort_pass(4, 0, col_bits));
         } else {
             HIP_TRY(ctx, hipMemsetAsync(ors, 0, 4 * sizeof(unsigned long long), s));
