@@ -123,7 +123,7 @@ class Prover:
         self.jac_side, self.aff_side = z(1, 12), z(1, 8)
         self.jac = z(max(self.NC, 8), 12)
         self.aff = z(max(self.NC, 8), 8)
-        self.evals = z(64 + 4 * (self.NC + cs.num_fixed + len(cs.permutation_columns)), 4)
+        self.evals = z(64 + 4 * (self.NC + cs.num_fixed + len(cs.permutation_columns) + 8), 4)
         # every blinding value of a proof but the random polynomial: drawn at the start (program order), uploaded once, copied into
         # the columns on the device phase by phase (a pinned torch staging buffer is not used: torch's host allocator would touch
         # the context's stream again when the buffer is freed, possibly after the context is gone)
@@ -450,26 +450,27 @@ class Prover:
         rots4 = rots[:4]
         if len(rots) > 4:
             raise ValueError("more than four distinct opening rotations")
-        plist = self._ptrs(polys, 0, self.NC) + self._ptrs(pk.fixed_polys) + self._ptrs(pk.perm_polys)
+        # (the quotient's pieces ride along: h(x) = sum_i x^(n i) h_i(x) is then four products on the host instead of two more launches
+        # in front of the read-back)
+        hp = self.h.view(m // n, n, 4)
+        plist = self._ptrs(polys, 0, self.NC) + self._ptrs(pk.fixed_polys) + self._ptrs(pk.perm_polys) + self._ptrs(hp, 0, pieces)
         ntot = len(plist)
         for j, r in enumerate(rots4):
             slots[("cols", r)], slots[("fixed", r)], slots[("sigma", r)] = off + j * ntot, off + j * ntot + self.NC, off + j * ntot + self.NC + nfix
+            slots[("hpiece", r)] = off + j * ntot + self.NC + nfix + npc
         ctx.eval_polynomial_multi_device(fid, plist, n, f.encode_many([point[r] for r in rots4]), self.evals[off].data_ptr(), 0)
         off += len(rots4) * ntot
-        # the folded quotient  h(X) = sum_i x^(n i) h_i(X)  and its value at x
-        hp = self.h.view(m // n, n, 4)
+        # the folded quotient  h(X) = sum_i x^(n i) h_i(X)  (opened below; its value at x comes from the pieces' values)
         xs, cur = [], 1
         for _ in range(pieces):
             xs.append(cur)
             cur = cur * xn % p
         ctx.lincomb_device(fid, self._ptrs(hp, 0, pieces), f.encode_many(xs), n, self.hfold.data_ptr(), None, 0)
-        slots[("hfold", 0)] = off
-        ctx.eval_polynomial_device(fid, self.hfold.data_ptr(), n, n, 1, enc(x), self.evals[off].data_ptr(), 0)
-        off += 1
         mark("evaluations_launch")
         ev_host = array_to_ints(ctx.download(self.evals.data_ptr(), off, 4))
         rinv = self._rinv
         val = lambda name, col, r: ev_host[slots[(name, r)] + col] * rinv % p
+        hfold_eval = sum(xs[i] * val("hpiece", i, 0) for i in range(pieces)) % p
 
         for col, r in cs.advice_queries:
             transcript.write_scalar(val("cols", self.o_adv + col, r))
@@ -509,7 +510,7 @@ class Prover:
             Q.append((r, pk.fixed_polys[col].data_ptr(), val("fixed", col, r)))
         for j in range(npc):                                                     # pk.permutation.open
             Q.append((0, pk.perm_polys[j].data_ptr(), val("sigma", j, 0)))
-        Q.append((0, self.hfold.data_ptr(), val("hfold", 0, 0)))                 # vanishing::Evaluated::open
+        Q.append((0, self.hfold.data_ptr(), hfold_eval))                         # vanishing::Evaluated::open
         Q.append((0, polys[self.o_rand].data_ptr(), val("cols", self.o_rand, 0)))
 
         # -- ProverGWC::create_proof: one witness polynomial per distinct point, in order of first appearance
