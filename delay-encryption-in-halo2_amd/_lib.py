@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Sequence
+from typing import Tuple, Optional, Sequence
 
 import numpy as np
 
@@ -14,7 +14,7 @@ _LIB = None
 SYMBOLS = [
     "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
-    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
+    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_lookup_h_batch_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_field_op_device", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
@@ -142,6 +142,7 @@ def load_library():
     lib.dehalo_graph_evaluate_device.argtypes = [P, P, C.POINTER(CEvalInputs), u32, u32, u64p, u64p, P]
     lib.dehalo_permutation_h_device.argtypes = [P, C.c_int, C.POINTER(CPermInputs), u32, u32, u64p, P]
     lib.dehalo_lookup_h_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u64p, P]
+    lib.dehalo_lookup_h_batch_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u32, u64p, P]
     lib.dehalo_timing_enable.argtypes = [P, C.c_int]
     lib.dehalo_timing_reset.argtypes = [P]
     lib.dehalo_timing_get.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -498,6 +499,14 @@ class Context:
         keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y)]
         inp = CLookupInputs(product, permuted_input, permuted_table, table_value, l0, l_last, l_active, *[k.ctypes.data for k in keep], form_flags)
         self._check(self.lib.dehalo_lookup_h_device(self.handle, field, C.byref(inp), log_rows, rot_scale, d_values, stream or None))
+
+    def lookup_h_batch_device(self, field: int, lookups: Sequence[Tuple[int, int, int, int]], l0: int, l_last: int, l_active: int, beta, gamma, y,
+                              log_rows: int, rot_scale: int, d_values: int, stream: int = 0, form_flags: int = 0):
+        """lookups: (product, permuted_input, permuted_table, table_value) device pointers per lookup, in upstream's order; one pass."""
+        keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma, y)]
+        arr = (CLookupInputs * len(lookups))(*[CLookupInputs(z, a, s_, tv, l0, l_last, l_active, *[k.ctypes.data for k in keep], form_flags)
+                                               for z, a, s_, tv in lookups])
+        self._check(self.lib.dehalo_lookup_h_batch_device(self.handle, field, arr, len(lookups), log_rows, rot_scale, d_values, stream or None))
 
     # ---- measurement ----
     def timing_enable(self, on: bool = True):

@@ -215,6 +215,12 @@ int do_lookup_h(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint
 #undef CALL
 }
 
+int do_lookup_h_batch(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {
+#define CALL(N) lookup_h_batch_##N(ctx, in, count, log_rows, rot_scale, v, s)
+    FIELD_SWITCH(ctx, field, CALL)
+#undef CALL
+}
+
 // Host-side compilation of upstream's GraphEvaluator into the device program: sources are
 // resolved to table indices, and every intermediate gets a slot from a liveness scan (a slot is
 // reused as soon as its value has been read for the last time; the first EVH_MAX_LDS_SLOTS slots
@@ -1031,6 +1037,26 @@ int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_input
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return do_lookup_h(ctx, field, in, log_rows, rot_scale, (fe*)d_values, pick_stream(ctx, stream));
+}
+
+int dehalo_lookup_h_batch_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale,
+                                 uint64_t* d_values, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!in || !d_values || count == 0) return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h_batch: null argument");
+    if (count > 8) return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h_batch: more than 8 lookups in one call");
+    for (uint32_t l = 0; l < count; l++) {
+        const dehalo_lookup_inputs& q = in[l];
+        if (!q.product_coset || !q.permuted_input_coset || !q.permuted_table_coset || !q.table_value || !q.l0 || !q.l_last || !q.l_active_row || !q.beta ||
+            !q.gamma || !q.y)
+            return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h_batch: null argument");
+        if (q.l0 != in[0].l0 || q.l_last != in[0].l_last || q.l_active_row != in[0].l_active_row || q.form_flags != in[0].form_flags ||
+            memcmp(q.beta, in[0].beta, 32) || memcmp(q.gamma, in[0].gamma, 32) || memcmp(q.y, in[0].y, 32))
+            return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h_batch: the lookups of one call share l0 / l_last / l_active_row, the challenges and the form flags");
+    }
+    if (log_rows > 30) return dh_fail(ctx, DEHALO_ERR_INVALID, "lookup_h: log_rows > 30");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return do_lookup_h_batch(ctx, field, in, count, log_rows, rot_scale, (fe*)d_values, pick_stream(ctx, stream));
 }
 
 // ---- measurement ------------------------------------------------------------------------------

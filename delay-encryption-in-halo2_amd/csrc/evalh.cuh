@@ -271,6 +271,49 @@ __global__ __launch_bounds__(EVH_THREADS) void k_lookup_h(LookupArgs A) {
     f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
 }
 
+// The lookups of a circuit in ONE pass over the rows: the running value and the three Lagrange columns are read once instead of
+// once per lookup (five lookups: 0.40 -> 0.26 ms over 4n rows at k = 17).  Terms and their order as in k_lookup_h, lookup after lookup.
+#define EVH_LOOKUP_BATCH 8
+struct LookupBatchArgs {
+    const fe* z[EVH_LOOKUP_BATCH]; const fe* a_perm[EVH_LOOKUP_BATCH]; const fe* s_perm[EVH_LOOKUP_BATCH]; const fe* table_value[EVH_LOOKUP_BATCH];
+    u32 count;
+    const fe* l0; const fe* l_last; const fe* l_active;
+    const fe* scalars;         // internal packed: [beta, gamma, y]
+    u32 rows_mask, rot_scale;
+    fe* values;
+    u64 rows;
+    u32 cols_internal, vals_internal;
+};
+template <class F>
+__global__ __launch_bounds__(EVH_THREADS) void k_lookup_h_batch(LookupBatchArgs A) {
+    typedef typename f29_of<F>::type F9;
+    const u64 row = (u64)blockIdx.x * EVH_THREADS + threadIdx.x;
+    if (row >= A.rows) return;
+    const f29 beta = f29_unpack(f_load(&A.scalars[0])), gamma = f29_unpack(f_load(&A.scalars[1])), y = f29_unpack(f_load(&A.scalars[2]));
+    const f29 one = f29_one<F9>();
+    const u32 r_next = ((u32)row + A.rot_scale) & A.rows_mask;
+    const u32 r_prev = ((u32)row - A.rot_scale) & A.rows_mask;
+    auto ld = [&](const fe* p, u64 i) __attribute__((always_inline)) { return A.cols_internal ? f29_unpack(f_load(&p[i])) : f29_from_std<F9>(f_load(&p[i])); };
+    auto ldv = [&](const fe* p, u64 i) __attribute__((always_inline)) { return A.vals_internal ? f29_unpack(f_load(&p[i])) : f29_from_std<F9>(f_load(&p[i])); };
+    f29 v = ldv(A.values, row);
+    const f29 l0 = ld(A.l0, row), l_last = ld(A.l_last, row), l_active = ld(A.l_active, row);
+    for (u32 l = 0; l < A.count; l++) {
+        const fe* zc = A.z[l]; const fe* ac = A.a_perm[l]; const fe* sc = A.s_perm[l];
+        const f29 z = ld(zc, row), a = ld(ac, row), s = ld(sc, row);
+        const f29 z_next = ld(zc, r_next), a_prev = ld(ac, r_prev), tv = ldv(A.table_value[l], row);
+        const f29 a_minus_s = evh_sub<F9>(a, s);
+        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(one, z), l0));
+        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(f29_sqr<F9>(z), z), l_last));
+        f29 lhs = f29_mul<F9>(f29_mul<F9>(z_next, evh_add<F9>(a, beta)), evh_add<F9>(s, gamma));
+        f29 rhs = f29_mul<F9>(z, tv);
+        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(lhs, rhs), l_active));
+        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(a_minus_s, l0));
+        f29 t = f29_mul<F9>(a_minus_s, evh_sub<F9>(a, a_prev));
+        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(t, l_active));
+    }
+    f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
+}
+
 // ==========================================================================================
 // host drivers
 // ==========================================================================================
@@ -412,6 +455,28 @@ int lookup_h_t(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_row
     return 0;
 }
 
+template <class F>
+int lookup_h_batch_t(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale, fe* d_values, hipStream_t s) {
+    const u64 rows = 1ull << log_rows;
+    ScopedTimer timer(ctx, s, DEHALO_K_EVAL_H);
+    std::vector<fe> sc = {fe_from_u64(in[0].beta), fe_from_u64(in[0].gamma), fe_from_u64(in[0].y)};
+    TRY(dh_ensure(ctx, ctx->ws_evh[0], 16 * sizeof(fe)));
+    TRY(evh_stage_scalars<F>(ctx, sc, (fe*)ctx->ws_evh[0].p, s));
+    LookupBatchArgs A{};
+    A.count = count;
+    for (uint32_t l = 0; l < count; l++) {
+        A.z[l] = (const fe*)in[l].product_coset; A.a_perm[l] = (const fe*)in[l].permuted_input_coset; A.s_perm[l] = (const fe*)in[l].permuted_table_coset;
+        A.table_value[l] = (const fe*)in[l].table_value;
+    }
+    A.l0 = (const fe*)in[0].l0; A.l_last = (const fe*)in[0].l_last; A.l_active = (const fe*)in[0].l_active_row;
+    A.scalars = (const fe*)ctx->ws_evh[0].p;
+    A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale; A.values = d_values; A.rows = rows;
+    A.cols_internal = in[0].form_flags & DEHALO_EVAL_COLUMNS_INTERNAL; A.vals_internal = in[0].form_flags & DEHALO_EVAL_VALUES_INTERNAL;
+    k_lookup_h_batch<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, 0, s>>>(A);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 #define DEFINE_EVALH_ENTRY(NAME, F)                                                                                                              \
     int convert_form_##NAME(dehalo_ctx* ctx, const fe* in, fe* out, uint64_t n, int to_internal, hipStream_t s) {                                \
         if (n) k_convert_form<F><<<(u32)((n + 255) / 256), 256, 0, s>>>(in, out, n, to_internal);                                                  \
@@ -423,4 +488,6 @@ int lookup_h_t(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_row
     int perm_h_##NAME(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {             \
         return perm_h_t<F>(ctx, in, log_rows, rot_scale, v, s); }                                                                                \
     int lookup_h_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {         \
-        return lookup_h_t<F>(ctx, in, log_rows, rot_scale, v, s); }
+        return lookup_h_t<F>(ctx, in, log_rows, rot_scale, v, s); }                                                                              \
+    int lookup_h_batch_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) { \
+        return lookup_h_batch_t<F>(ctx, in, count, log_rows, rot_scale, v, s); }

@@ -110,3 +110,11 @@ def lookup_h_device(ctx: Context, field: FieldSpec, product: int, permuted_input
     e = field.encode
     ctx.lookup_h_device(field.id, product, permuted_input, permuted_table, table_value, l0, l_last, l_active_row, e(beta), e(gamma), e(y), log_rows, rot_scale,
                         d_values, stream, form_flags)
+
+
+def lookup_h_batch_device(ctx: Context, field: FieldSpec, lookups, l0: int, l_last: int, l_active_row: int, beta: int, gamma: int, y: int, log_rows: int,
+                          rot_scale: int, d_values: int, stream: int = 0, form_flags: int = 0):
+    """Evaluator::evaluate_h's lookup loop in one pass: `lookups` = (product, permuted_input, permuted_table, table_value) device
+    pointers per lookup argument, in order; each lookup's five terms are folded into d_values as lookup_h_device folds them."""
+    e = field.encode
+    ctx.lookup_h_batch_device(field.id, list(lookups), l0, l_last, l_active_row, e(beta), e(gamma), e(y), log_rows, rot_scale, d_values, stream, form_flags)

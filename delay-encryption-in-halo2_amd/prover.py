@@ -116,7 +116,7 @@ class Prover:
         self.den = z(S + L, n, 4)
         self.ext = z(self.NC - 1 + self.I, m, 4)                # cosets of every committed column but the random one, then the instance columns
         self.h = z(m, 4)
-        self.table_value = z(m, 4)
+        self.table_value = z(max(L, 1), m, 4)                   # one column per lookup: the lookups' terms are folded in ONE pass
         self.hfold = z(n, 4)
         self.qbuf = z(4, n, 4)                                  # per opening point: the batched polynomial
         self.wbuf = z(8, n, 4)                                  # ... and its quotient (last coefficient zero)
@@ -425,10 +425,15 @@ class Prover:
             pcols = [kindmap[ck][ci] for ck, ci in cs.permutation_columns]
             ev.permutation_h_device(ctx, f, self._ptrs(self.ext, self.o_pz, S), pcols, self._ptrs(pk.perm_cosets), cs.permutation_chunk_len(), -(bf + 1), l0, l_last,
                                     l_active, beta, gamma, y, delta, d.g_coset, d.extended_omega, ek, rot_scale, self.h.data_ptr(), 0, FF)
-        for l in range(L):
-            pk.lookup_graphs[l].evaluate_device(fixed_c, adv_c, inst_c, [], beta, gamma, theta, None, ek, rot_scale, 0, self.table_value.data_ptr(), 0, FF, ctx)
-            ev.lookup_h_device(ctx, f, self.ext[self.o_lz + l].data_ptr(), self.ext[self.o_perm + 2 * l].data_ptr(), self.ext[self.o_perm + 2 * l + 1].data_ptr(),
-                               self.table_value.data_ptr(), l0, l_last, l_active, beta, gamma, y, ek, rot_scale, self.h.data_ptr(), 0, FF)
+        if L:
+            be, ge, te, none = enc(beta), enc(gamma), enc(theta), []
+            tv = self._ptrs(self.table_value)
+            for l in range(L):
+                pk.lookup_graphs[l].evaluate_device(fixed_c, adv_c, inst_c, none, be, ge, te, None, ek, rot_scale, 0, tv[l], 0, FF, ctx)
+            zc, pc = self._ptrs(self.ext, self.o_lz, L), self._ptrs(self.ext, self.o_perm, 2 * L)
+            for first in range(0, L, 8):
+                ev.lookup_h_batch_device(ctx, f, [(zc[l], pc[2 * l], pc[2 * l + 1], tv[l]) for l in range(first, min(L, first + 8))], l0, l_last, l_active,
+                                         beta, gamma, y, ek, rot_scale, self.h.data_ptr(), 0, FF)
         mark("evaluate_h")
         ctx.scale_device(fid, self.h.data_ptr(), m, self.t_inv, 0, 0)                                     # divide_by_vanishing_poly
         ctx.coset_intt_form_device(fid, self.h.data_ptr(), ek, c["ext_omega_inv"], c["ext_ifft"], c["zeta"], 1, ev.FORM_IN_INTERNAL, 0)

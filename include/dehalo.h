@@ -324,6 +324,11 @@ typedef struct {
 } dehalo_lookup_inputs;
 int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
                            void* stream);
+/* The same terms for `count` <= 8 lookups (in[0], in[1], ... in upstream's order: evaluate_h's `for lookup in lookups` loop) in ONE pass
+ * over the rows: d_values and the three Lagrange columns are read once instead of once per lookup.  The lookups of one call share
+ * l0 / l_last / l_active_row, beta / gamma / y and form_flags (checked); each brings its own cosets and table_value column. */
+int dehalo_lookup_h_batch_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale,
+                                 uint64_t* d_values, void* stream);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-kernel device time measured with HIP events on the launching stream (bench.py's

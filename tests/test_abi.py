@@ -28,6 +28,18 @@ def test_header_symbols_exported(pkg):
     assert sorted(binding.SYMBOLS) == syms
 
 
+def test_every_binding_declares_its_argument_types(pkg):
+    """A ctypes call without argtypes passes a Python int as a 32-bit C int: a device pointer would be truncated and the kernel
+    would fault.  Every bound entry point that takes arguments must declare them."""
+    import sys
+    lib = pkg.load_library()
+    binding = sys.modules["dehalo2_amd._lib"]
+    for name in binding.SYMBOLS:
+        if name == "dehalo_version":
+            continue
+        assert getattr(lib, name).argtypes, name + " has no argtypes"
+
+
 def test_version_string(pkg):
     assert pkg.load_library().dehalo_version().decode().startswith("dehalo")
 

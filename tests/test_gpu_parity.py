@@ -708,6 +708,33 @@ def test_lookup_h_vs_oracle(pkg, po, ctx, fname):
     assert _host(spec, d["values"]) == want
 
 
+@pytest.mark.parametrize("fname,count", [("bn254_fr", 5), ("pasta_fp", 8), ("bn254_fr", 1)])
+def test_lookup_h_batch_vs_oracle(pkg, po, ctx, fname, count):
+    """Several lookups folded in one pass (dehalo_lookup_h_batch_device) = the oracle's lookup_h applied lookup after lookup;
+    more than eight lookups, or lookups that do not share the Lagrange columns, are refused."""
+    f, spec = po.FIELDS[fname], pkg.fields.FIELDS[fname]
+    rng = po.Xoshiro(0x100D + count)
+    k, ext_k = 6, 8
+    rows, rot_scale = 1 << ext_k, 1 << (ext_k - k)
+    col = lambda: [rng.below(f.p) for _ in range(rows)]
+    shared = {n: col() for n in ("l0", "l_last", "l_active", "values")}
+    each = [{n: col() for n in ("product", "a", "s", "tv")} for _ in range(count)]
+    beta, gamma, y = (rng.below(f.p) for _ in range(3))
+    want = shared["values"]
+    for h in each:
+        want = po.lookup_h(f, want, h["product"], h["a"], h["s"], h["tv"], shared["l0"], shared["l_last"], shared["l_active"], beta, gamma, y, rot_scale)
+    ds = {n: _dev(spec, v) for n, v in shared.items()}
+    de = [{n: _dev(spec, v) for n, v in h.items()} for h in each]
+    tuples = [(d["product"].data_ptr(), d["a"].data_ptr(), d["s"].data_ptr(), d["tv"].data_ptr()) for d in de]
+    pkg.evaluation.lookup_h_batch_device(ctx, spec, tuples, ds["l0"].data_ptr(), ds["l_last"].data_ptr(), ds["l_active"].data_ptr(), beta, gamma, y, ext_k,
+                                         rot_scale, ds["values"].data_ptr())
+    ctx.synchronize()
+    assert _host(spec, ds["values"]) == want
+    with pytest.raises(pkg.DehaloError):
+        pkg.evaluation.lookup_h_batch_device(ctx, spec, tuples * 9, ds["l0"].data_ptr(), ds["l_last"].data_ptr(), ds["l_active"].data_ptr(), beta, gamma, y,
+                                             ext_k, rot_scale, ds["values"].data_ptr())
+
+
 @pytest.mark.parametrize("cname,k,overlapped", [("bn254", 7, False), ("pallas", 8, False), ("bn254", 8, True)])
 def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k, overlapped):
     """The same schedule with evaluate_h on the device: custom gates + 2 permutation sets + 5 lookups over the
