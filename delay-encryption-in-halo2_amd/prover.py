@@ -341,11 +341,13 @@ class Prover:
             # permuted columns are interleaved (input_l, table_l) with a stride of two columns
             base = cols[self.o_perm].data_ptr()
             self._tick("compress queued")
-            ctx.permute_expression_pair_batch_device(fid, self.compressed[0].data_ptr(), self.compressed[1].data_ptr(), u, L, 2 * n, base, base + 32 * n, 0)
-            self._tick("permute returned")
+            # the blinding rows [u, n) first: the permutation writes rows [0, u) only, and it ends with a read-back -- whatever is
+            # queued before it does not wait for the host afterwards
             rows = n - u                                         # (input_0, table_0, input_1, ...): bf + 1 rows each
             cols[self.o_perm:self.o_perm + 2 * L, u:] = self._blind_slice(2).view(L, 2 * rows + 2, 4)[:, :2 * rows].reshape(2 * L, rows, 4)
             self._tick("blinds copied")
+            ctx.permute_expression_pair_batch_device(fid, self.compressed[0].data_ptr(), self.compressed[1].data_ptr(), u, L, 2 * n, base, base + 32 * n, 0)
+            self._tick("permute returned")
             ready = columns_ready()
             self._commit(transcript, self.o_perm, 2 * L, True, before_sync=(lambda: side_ntt(self.o_perm, 2 * L, ready)) if self.side is not None else None)
         mark("lookup_permuted")
