@@ -306,7 +306,13 @@ class Prover:
             if len(vals):
                 self.instance[i, :len(vals)] = to_device(f.encode_many(list(vals)))
         instance_values = self.instance.clone() if self.I else self.instance
-        if self.I:
+        nco = self.NC - 1
+        if self.I and self.side is not None:                     # instance polynomials and their cosets depend on the inputs only: side context, now
+            ready = columns_ready()
+            self.side.torch_stream_obj().wait_event(ready)
+            self.side.intt_scaled_device(fid, self.instance.data_ptr(), k, c["omega_inv"], c["ifft"], self.I, 0)
+            self.side.coset_ntt_form_device(fid, self.instance.data_ptr(), k, self.ext[nco].data_ptr(), ek, c["ext_omega"], c["zeta"], self.I, ev.FORM_OUT_INTERNAL, 0)
+        elif self.I:
             ctx.intt_scaled_device(fid, self.instance.data_ptr(), k, c["omega_inv"], c["ifft"], self.I, 0)      # instance polys
 
         # -- advice: witness, blinding rows, commitments
@@ -413,7 +419,7 @@ class Prover:
             e = torch.cuda.Event()
             e.record(self.side.torch_stream_obj())
             ctx.torch_stream_obj().wait_event(e)
-        if self.I:
+        if self.I and self.side is None:
             ctx.coset_ntt_form_device(fid, self.instance.data_ptr(), k, self.ext[nco].data_ptr(), ek, c["ext_omega"], c["zeta"], self.I, ev.FORM_OUT_INTERNAL, 0)
         mark("ntt")
 
