@@ -324,9 +324,18 @@ class Prover:
         cols[self.o_adv:self.o_adv + A, u:] = self._blind_slice(0).view(A, n - u, 4)
         ready = columns_ready()
 
+        # one gate polynomial: Horner(0, [g], y) = g does not depend on y, so the custom-gate pass of evaluate_h needs the advice (and
+        # instance) cosets only -- queued on the side context right behind them, ~7 ms before y exists
+        gates_early = self.side is not None and len(cs.gates) == 1
+        FF = ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL
+        rot_scale_h = m // n
+
         def after_advice_queued():
             if self.side is not None:
                 side_ntt(self.o_adv, A, ready)
+            if gates_early:
+                pk.custom_gates.evaluate_device(self._ptrs(pk.fixed_cosets), self._ptrs(self.ext, self.o_adv, A), self._ptrs(self.ext, nco, self.I), [], None, None,
+                                                None, 0, ek, rot_scale_h, 0, self.h.data_ptr(), 0, FF, self.side)
             if prefetch is not None:
                 prefetch.start()
         self._commit(transcript, self.o_adv, A, True, before_sync=after_advice_queued)
@@ -427,7 +436,8 @@ class Prover:
         FF = ev.COLUMNS_INTERNAL | ev.VALUES_INTERNAL
         fixed_c, adv_c, inst_c = self._ptrs(pk.fixed_cosets), self._ptrs(self.ext, self.o_adv, A), self._ptrs(self.ext, nco, self.I)
         l0, l_last, l_active = (pk.l_ext[i].data_ptr() for i in range(3))
-        pk.custom_gates.evaluate_device(fixed_c, adv_c, inst_c, [], None, None, None, y, ek, rot_scale, 0, self.h.data_ptr(), 0, FF, ctx)
+        if not gates_early:
+            pk.custom_gates.evaluate_device(fixed_c, adv_c, inst_c, [], None, None, None, y, ek, rot_scale, 0, self.h.data_ptr(), 0, FF, ctx)
         if S:
             kindmap = {plonk.ADVICE: adv_c, plonk.FIXED: fixed_c, plonk.INSTANCE: inst_c}
             pcols = [kindmap[ck][ci] for ck, ci in cs.permutation_columns]
