@@ -398,7 +398,17 @@ class Prover:
             cols[self.o_pz:self.o_pz + S + L, n - bf:] = self._blind_slice(3).view(S + L, bf + 1, 4)[:, :bf]
         if S + L:
             ready = columns_ready()
-            self._commit(transcript, self.o_pz, S + L, True, before_sync=(lambda: side_ntt(self.o_pz, S + L, ready)) if self.side is not None else None)
+
+            def after_products_queued():
+                side_ntt(self.o_pz, S + L, ready)
+                # the lookups' (compressed input + beta)(compressed table + gamma) over the extended domain need theta, beta, gamma and
+                # the advice / fixed cosets: all there -- on the side context, beside the products' commitment, instead of after y
+                if L:
+                    be, ge, te, none = enc(beta), enc(gamma), enc(theta), []
+                    fc, ac, ic, tvp = self._ptrs(pk.fixed_cosets), self._ptrs(self.ext, self.o_adv, A), self._ptrs(self.ext, nco, self.I), self._ptrs(self.table_value)
+                    for l in range(L):
+                        pk.lookup_graphs[l].evaluate_device(fc, ac, ic, none, be, ge, te, None, ek, rot_scale_h, 0, tvp[l], 0, FF, self.side)
+            self._commit(transcript, self.o_pz, S + L, True, before_sync=after_products_queued if self.side is not None else None)
         mark("grand_products")
 
         # -- vanishing argument: a random polynomial
@@ -446,8 +456,9 @@ class Prover:
         if L:
             be, ge, te, none = enc(beta), enc(gamma), enc(theta), []
             tv = self._ptrs(self.table_value)
-            for l in range(L):
-                pk.lookup_graphs[l].evaluate_device(fixed_c, adv_c, inst_c, none, be, ge, te, None, ek, rot_scale, 0, tv[l], 0, FF, ctx)
+            if self.side is None:
+                for l in range(L):
+                    pk.lookup_graphs[l].evaluate_device(fixed_c, adv_c, inst_c, none, be, ge, te, None, ek, rot_scale, 0, tv[l], 0, FF, ctx)
             zc, pc = self._ptrs(self.ext, self.o_lz, L), self._ptrs(self.ext, self.o_perm, 2 * L)
             for first in range(0, L, 8):
                 ev.lookup_h_batch_device(ctx, f, [(zc[l], pc[2 * l], pc[2 * l + 1], tv[l]) for l in range(first, min(L, first + 8))], l0, l_last, l_active,
