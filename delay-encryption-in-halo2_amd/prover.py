@@ -307,12 +307,13 @@ class Prover:
                 self.instance[i, :len(vals)] = to_device(f.encode_many(list(vals)))
         instance_values = self.instance.clone() if self.I else self.instance
         nco = self.NC - 1
-        if self.I and self.side is not None:                     # instance polynomials and their cosets depend on the inputs only: side context, now
-            ready = columns_ready()
-            self.side.torch_stream_obj().wait_event(ready)
+        inst_ready = columns_ready() if self.I and self.side is not None else None
+
+        def side_instance():     # instance polynomials and their cosets depend on the inputs only: side context (launched behind the advice commitment's launches)
+            self.side.torch_stream_obj().wait_event(inst_ready)
             self.side.intt_scaled_device(fid, self.instance.data_ptr(), k, c["omega_inv"], c["ifft"], self.I, 0)
             self.side.coset_ntt_form_device(fid, self.instance.data_ptr(), k, self.ext[nco].data_ptr(), ek, c["ext_omega"], c["zeta"], self.I, ev.FORM_OUT_INTERNAL, 0)
-        elif self.I:
+        if self.I and self.side is None:
             ctx.intt_scaled_device(fid, self.instance.data_ptr(), k, c["omega_inv"], c["ifft"], self.I, 0)      # instance polys
 
         # -- advice: witness, blinding rows, commitments
@@ -331,6 +332,8 @@ class Prover:
         rot_scale_h = m // n
 
         def after_advice_queued():
+            if inst_ready is not None:
+                side_instance()
             if self.side is not None:
                 side_ntt(self.o_adv, A, ready)
             if gates_early:
