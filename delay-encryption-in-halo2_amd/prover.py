@@ -293,6 +293,7 @@ class Prover:
                 self.polys[first:first + count].copy_(cols[first:first + count])
             self.side.intt_scaled_device(fid, self.polys[first].data_ptr(), k, c["omega_inv"], c["ifft"], count, 0)
             self.side.coset_ntt_form_device(fid, self.polys[first].data_ptr(), k, self.ext[first].data_ptr(), ek, c["ext_omega"], c["zeta"], count, ev.FORM_OUT_INTERNAL, 0)
+        self._draw_blinds(rng)                                   # (first: the upload blocks this thread until the stream has caught up -- nothing is queued yet)
         transcript.common_scalar(pk.vk.transcript_repr)          # vk.hash_into
         # -- instance columns: values into the transcript (KZG: QUERY_INSTANCE = false), polynomials on the device
         if len(instances) != self.I:
@@ -321,7 +322,6 @@ class Prover:
         if tuple(adv.shape) != (A, n, 4):
             raise ValueError("advice must be num_advice x n x 4")
         cols[self.o_adv:self.o_adv + A].copy_(adv)
-        self._draw_blinds(rng)
         cols[self.o_adv:self.o_adv + A, u:] = self._blind_slice(0).view(A, n - u, 4)
         ready = columns_ready()
 
