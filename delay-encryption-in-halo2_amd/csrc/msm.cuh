@@ -143,9 +143,21 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
         for (int j = 0; j < 4; j++)
             if (i0 + j * blockDim.x < end) s4[j] = f_load(&sc[i0 + j * blockDim.x]);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (i0 + j * blockDim.x < end)
-                for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool) { atomicAdd(&lhist[(one ? 0u : (w - w_lo) * g.nb) + bucket], 1u); });
+        for (int j = 0; j < 4; j++) {
+            const bool valid = i0 + j * blockDim.x < end;
+            // A wave whose 64 consecutive rows hold ONE value (a grand-product column over unused rows, a permuted column's run of
+            // equal inputs) would send 64 atomics to the same LDS word for every digit; one lane adds the count instead.
+            // (k = 20 grand products, 7 columns: this kernel 5.2 ms -> see DESIGN.md)
+            const unsigned long long act = __ballot(valid);
+            bool same = true;
+#pragma unroll
+            for (int w = 0; w < 8; w++) same &= s4[j].v[w] == (u32)__builtin_amdgcn_readfirstlane((int)s4[j].v[w]);
+            const bool uniform = act != 0 && __ballot(valid && !same) == 0 && __popcll(act) > 1;
+            const u32 weight = uniform ? (u32)__popcll(act) : 1u;
+            const bool counts = uniform ? (threadIdx.x & 63) == (u32)(__ffsll((long long)act) - 1) : valid;
+            if (counts)
+                for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool) { atomicAdd(&lhist[(one ? 0u : (w - w_lo) * g.nb) + bucket], weight); });
+        }
     }
     __syncthreads();
     const u32 sub = msm_sub_bits(g.c), P = g.nb >> sub;
@@ -366,9 +378,34 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
         // (uniform per wave) a wave of zero scalars -- the long zero run of a sorted, permuted lookup column -- has nothing to place,
         // and a wave of small witness values runs out of digits after the first windows
         const bool nonzero = have && !fe_is_zero_words(s_cur);
-        if (__ballot(nonzero) == 0) continue;
+        const unsigned long long actm = __ballot(nonzero);
+        if (actm == 0) continue;
         DigitStream ds;
         if (nonzero) ds.template init<FS>(s_cur, g.c);
+        {   // the wave's rows hold ONE value (see k_msm_hist): every lane has the same digits, so a window's 64 pairs go to one
+            // partition run -- one reservation per window by the first lane, positions by lane rank, no staging
+            bool same = true;
+#pragma unroll
+            for (int w = 0; w < 8; w++) same &= s_cur.v[w] == (u32)__builtin_amdgcn_readfirstlane((int)s_cur.v[w]);
+            if (__ballot(have && !same) == 0 && actm == __ballot(have) && __popcll(actm) > 1) {
+                const u32 cnt = (u32)__popcll(actm), rank = (u32)__popcll(actm & ((1ull << lane) - 1));
+                const int first = __ffsll((long long)actm) - 1;
+                for (u32 w = 0; w < w_hi; w++) {
+                    u32 bk; bool ng1;
+                    ds.next(bk, ng1);                                     // (uniform across the wave)
+                    if (w >= w_lo && bk != 0xffffffffu) {
+                        const u32 q = (one ? 0u : (w - w_lo) * P) + (bk >> sub);
+                        u32 g0 = 0;
+                        if ((int)lane == first) g0 = atomicAdd(&pcur[q], cnt);
+                        g0 = (u32)__shfl((int)g0, first);
+                        const u32 tidx = one ? w * g.table_n + i : i;
+                        if (nonzero) pairs[g0 + rank] = ((unsigned long long)(bk & submask) << 32) | (tidx | (ng1 ? 0x80000000u : 0u));
+                    }
+                    if (ds.exhausted()) break;
+                }
+                continue;
+            }
+        }
         for (u32 w0 = 0; w0 < w_hi; w0 += 8) {
             if (__ballot(nonzero && !ds.exhausted()) == 0) break;
             u32 bk[8];
