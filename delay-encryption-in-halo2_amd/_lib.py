@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SYMBOLS = [
-    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
+    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_create_with_priority", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
     "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_lookup_h_batch_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
@@ -86,6 +86,7 @@ def load_library():
     lib.dehalo_last_error.restype = C.c_char_p
     lib.dehalo_last_error.argtypes = [P]
     lib.dehalo_ctx_create.argtypes = [C.c_int, C.POINTER(P)]
+    lib.dehalo_ctx_create_with_priority.argtypes = [C.c_int, C.c_int, C.POINTER(P)]
     lib.dehalo_ctx_destroy.argtypes = [P]
     lib.dehalo_ctx_destroy.restype = None
     lib.dehalo_ctx_synchronize.argtypes = [P]
@@ -179,10 +180,11 @@ class Bases:
 
 
 class Context:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, priority: int = 0):
+        """priority > 0: highest stream priority of the device (short kernels beside another context's long ones), < 0: lowest."""
         self.lib = load_library()
         h = C.c_void_p()
-        rc = self.lib.dehalo_ctx_create(device, C.byref(h))
+        rc = self.lib.dehalo_ctx_create_with_priority(device, priority, C.byref(h))
         if rc != 0:
             raise DehaloError(rc, "dehalo_ctx_create failed (no gfx950 device?); there is no CPU fallback")
         self.handle = h

@@ -362,7 +362,9 @@ extern "C" {
 
 const char* dehalo_version(void) { return "dehalo 0.2 gfx950"; }
 
-int dehalo_ctx_create(int device, dehalo_ctx** out) {
+int dehalo_ctx_create(int device, dehalo_ctx** out) { return dehalo_ctx_create_with_priority(device, 0, out); }
+
+int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out) {
     if (!out) return DEHALO_ERR_INVALID;
     *out = nullptr;
     int count = 0;
@@ -374,7 +376,14 @@ int dehalo_ctx_create(int device, dehalo_ctx** out) {
     dehalo_ctx* ctx = new dehalo_ctx();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
+    {   // priority > 0: the device's highest stream priority (a context of small kernels beside another context's long ones), < 0: lowest
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int prio = priority > 0 ? greatest : (priority < 0 ? least : 0);
+        const hipError_t e = priority == 0 ? hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)
+                                           : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
+        if (e != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
+    }
     if (const char* e = getenv("DEHALO_MSM_ACC_POINTS")) ctx->msm_acc_points = std::max(0, std::min(4096, atoi(e)));   // launch geometry only (dehalo_ctx_set_tuning)
     *out = ctx;
     return 0;

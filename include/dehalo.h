@@ -58,6 +58,9 @@ typedef struct dehalo_bases dehalo_bases;
 
 /* ---- context --------------------------------------------------------------------------- */
 int dehalo_ctx_create(int device, dehalo_ctx** out);
+/* The same with a stream priority: > 0 the device's highest (a context of short kernels that must not queue behind another context's
+ * long ones -- the prover's side context), < 0 its lowest, 0 the default. */
+int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out);
 void dehalo_ctx_destroy(dehalo_ctx* ctx);
 /* Human-readable text of the last error on this context (valid until the next call). */
 const char* dehalo_last_error(const dehalo_ctx* ctx);

@@ -47,7 +47,7 @@ with pkg.Context(0) as ctx:
     for _ in range(reps):
         t = time.perf_counter(); P.create_proof(adv, [[]], PlainRng(7), transcript.Blake2bWrite(curve)); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
     print("without the random-polynomial helper thread: best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
-    side = pkg.Context(0)
+    side = pkg.Context(0, priority=int(os.environ.get("SIDE_PRIO", "0")))
     P2 = prover.Prover(params, pk, ctx, side)
     want = transcript.Blake2bWrite(curve); P.create_proof(adv, [[]], prover.SeededRng(7), want)
     ts = []
