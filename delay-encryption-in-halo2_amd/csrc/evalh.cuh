@@ -401,7 +401,7 @@ int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_i
     A.cols_internal = in->form_flags & DEHALO_EVAL_COLUMNS_INTERNAL; A.vals_internal = in->form_flags & DEHALO_EVAL_VALUES_INTERNAL;
     const size_t lds = (size_t)std::max<u32>(1, g->lds_slots) * EVH_SLOT_BYTES;
     if (lds > 48 * 1024)   // per call: the attribute belongs to the device the context is bound to
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_graph_eval<F>, hipFuncAttributeMaxDynamicSharedMemorySize, EVH_LDS_BYTES));
+        HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_graph_eval<F>, EVH_LDS_BYTES));
     k_graph_eval<F><<<(u32)((rows + EVH_THREADS - 1) / EVH_THREADS), EVH_THREADS, lds, s>>>(A);
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -78,6 +79,19 @@ inline int dh_fail(dehalo_ctx* ctx, int code, const std::string& msg) {
         int rc_ = (expr);         \
         if (rc_ != 0) return rc_; \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel on the context's device: set once per (device, kernel) and only ever raised --
+// the call costs microseconds, and every MSM / NTT / graph launch used to make it
+inline hipError_t dh_func_lds(dehalo_ctx* ctx, const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> have;
+    std::lock_guard<std::mutex> lk(mu);
+    int& cur = have[std::make_pair(ctx->device, fn)];
+    if (cur >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 
 inline int dh_ensure(dehalo_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;

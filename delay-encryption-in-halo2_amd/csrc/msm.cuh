@@ -1017,10 +1017,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
 
     const size_t lds_hist = (size_t)g.nb * 4 * (g.G == 1 ? 1 : g.wb);
     if (lds_hist > 48 * 1024) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_hist<FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hist));
+        HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_hist<FS>, (int)lds_hist));
     }
     const size_t lds_part = 512 + (size_t)(MSM_SORT_THREADS / 64) * MSM_PART_WAVE_LDS;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_msm_part<FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+    HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_part<FS>, (int)lds_part));
     const u32 tb = (u32)total_buckets;
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);

@@ -376,7 +376,7 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
     }
     const size_t lds_max = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(f29);
     // per call: the attribute belongs to the device the context is bound to
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_ntt_pass<F>, (int)lds_max));
     uint32_t log_m = log_n;
     for (uint32_t p = 0; p < L; p++) {
         NttPassParams P;
