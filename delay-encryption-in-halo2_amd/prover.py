@@ -86,6 +86,7 @@ class Prover:
         self.ctx = ctx if ctx is not None else pk.ctx
         self.side = side_ctx
         self._timings = None
+        self._plan = None
         self._rinv = pow(1 << 256, -1, pk.vk.curve.scalar.p)
         with self.ctx.torch_stream():      # torch's copies and fills go on the context's stream, ordered with the kernels
             self._init(params, pk)
@@ -212,6 +213,79 @@ class Prover:
     def _blind_slice(self, which: int):
         off = sum(self.blind_counts[:which])
         return self.blind_dev[off:off + self.blind_counts[which]]
+
+    def _opening_plan(self):
+        """What depends on the circuit only: the opened polynomials' device pointers (one multi-point evaluation), where each
+        evaluation lands (evals[rotation index * polys + poly]), the order in which the transcript takes them
+        [UPSTREAM plonk/prover.rs: advice, fixed, vanishing random_eval, permutation (sigma; products), lookups] and the opening
+        queries grouped by point in order of first appearance [UPSTREAM permutation::Constructed::open, lookup::Evaluated::open,
+        pk.permutation.open, vanishing::Evaluated::open; poly/kzg/multiopen/gwc/prover.rs]."""
+        cs, pk, polys = self.cs, self.pk, self.polys
+        bf, S, L, n, m = self.bf, self.S, self.L, self.n, self.m
+        pieces = self.domain.quotient_poly_degree
+        rots = sorted({r for _, r in cs.advice_queries} | {r for _, r in cs.fixed_queries} | {0, 1, -1, -(bf + 1)})
+        if len(rots) > 4:
+            raise ValueError("more than four distinct opening rotations")
+        nfix, npc = cs.num_fixed, len(cs.permutation_columns)
+        hp_ptrs = self._ptrs(self.h.view(m // n, n, 4), 0, pieces)
+        plist = self._ptrs(polys, 0, self.NC) + self._ptrs(pk.fixed_polys) + self._ptrs(pk.perm_polys) + hp_ptrs
+        ntot = len(plist)
+        base = {"cols": 0, "fixed": self.NC, "sigma": self.NC + nfix, "hpiece": self.NC + nfix + npc}
+        idx = lambda name, col, r: rots.index(r) * ntot + base[name] + col
+        last = -(bf + 1)
+        write: List[int] = []
+        for col, r in cs.advice_queries:
+            write.append(idx("cols", self.o_adv + col, r))
+        for col, r in cs.fixed_queries:
+            write.append(idx("fixed", col, r))
+        write.append(idx("cols", self.o_rand, 0))                               # vanishing: random_eval
+        for j in range(npc):                                                     # pk.permutation.evaluate: sigma(x)
+            write.append(idx("sigma", j, 0))
+        for s in range(S):                                                       # permutation products
+            write.append(idx("cols", self.o_pz + s, 0))
+            write.append(idx("cols", self.o_pz + s, 1))
+            if s != S - 1:
+                write.append(idx("cols", self.o_pz + s, last))
+        for l in range(L):                                                       # lookups
+            zc, ai, ti = self.o_lz + l, self.o_perm + 2 * l, self.o_perm + 2 * l + 1
+            for colr in ((zc, 0), (zc, 1), (ai, 0), (ai, -1), (ti, 0)):
+                write.append(idx("cols", *colr))
+        # queries (point rotation, device polynomial, index of its evaluation; -1: the folded quotient's), in upstream's order
+        col_ptr = self._ptrs(polys, 0, self.NC)
+        fixed_ptr, sigma_ptr = self._ptrs(pk.fixed_polys), self._ptrs(pk.perm_polys)
+        Q: List[Tuple[int, int, int]] = []
+        for col, r in cs.advice_queries:
+            Q.append((r, col_ptr[self.o_adv + col], idx("cols", self.o_adv + col, r)))
+        for s in range(S):                                                       # permutation::Constructed::open
+            zc = self.o_pz + s
+            Q.append((0, col_ptr[zc], idx("cols", zc, 0)))
+            Q.append((1, col_ptr[zc], idx("cols", zc, 1)))
+        for s in range(S - 1):
+            zc = self.o_pz + s
+            Q.append((last, col_ptr[zc], idx("cols", zc, last)))
+        for l in range(L):                                                       # lookup::Evaluated::open
+            zc, ai, ti = self.o_lz + l, self.o_perm + 2 * l, self.o_perm + 2 * l + 1
+            for colr in ((zc, 0), (ai, 0), (ti, 0), (ai, -1), (zc, 1)):
+                Q.append((colr[1], col_ptr[colr[0]], idx("cols", *colr)))
+        for col, r in cs.fixed_queries:
+            Q.append((r, fixed_ptr[col], idx("fixed", col, r)))
+        for j in range(npc):                                                     # pk.permutation.open
+            Q.append((0, sigma_ptr[j], idx("sigma", j, 0)))
+        Q.append((0, self.hfold.data_ptr(), -1))                                 # vanishing::Evaluated::open
+        Q.append((0, col_ptr[self.o_rand], idx("cols", self.o_rand, 0)))
+        groups: List[Tuple[int, List[int], List[int]]] = []
+        for r, ptr, i in Q:
+            for g in groups:
+                if g[0] == r:
+                    g[1].append(ptr); g[2].append(i)
+                    break
+            else:
+                groups.append((r, [ptr], [i]))
+        if len(groups) > self.qbuf.shape[0]:
+            raise ValueError("more opening points than the prover's buffers hold")
+        need = sorted(set(write) | {i for _, _, i in Q if i >= 0} | {idx("hpiece", j, 0) for j in range(pieces)})
+        self._plan = (rots, plist, write, groups, hp_ptrs, idx("hpiece", 0, 0), len(rots) * ntot, need)
+        return self._plan
 
     def _tick(self, label: str):
         if self._timings is not None:
@@ -477,101 +551,43 @@ class Prover:
         xn = pow(x, n, p)
         self._tick("x")
 
-        # -- evaluations, in upstream's order.  Every coefficient-form column is evaluated at every rotation it is opened at
-        # with one batched launch per (buffer, point).
-        rots = sorted({r for _, r in cs.advice_queries} | {r for _, r in cs.fixed_queries} | {0, 1, -1, -(bf + 1)})
-        point = {r: rotate_omega(d, x, r) for r in rots}
-        nfix, off = cs.num_fixed, 0
-        slots: Dict[Tuple[str, int], int] = {}
-        # every opened polynomial (committed columns, fixed, sigma) at every rotation in ONE call: evals[slot[(buffer, r)] + column]
-        rots4 = rots[:4]
-        if len(rots) > 4:
-            raise ValueError("more than four distinct opening rotations")
-        # (the quotient's pieces ride along: h(x) = sum_i x^(n i) h_i(x) is then four products on the host instead of two more launches
-        # in front of the read-back)
-        hp = self.h.view(m // n, n, 4)
-        plist = self._ptrs(polys, 0, self.NC) + self._ptrs(pk.fixed_polys) + self._ptrs(pk.perm_polys) + self._ptrs(hp, 0, pieces)
-        ntot = len(plist)
-        for j, r in enumerate(rots4):
-            slots[("cols", r)], slots[("fixed", r)], slots[("sigma", r)] = off + j * ntot, off + j * ntot + self.NC, off + j * ntot + self.NC + nfix
-            slots[("hpiece", r)] = off + j * ntot + self.NC + nfix + npc
-        ctx.eval_polynomial_multi_device(fid, plist, n, f.encode_many([point[r] for r in rots4]), self.evals[off].data_ptr(), 0)
-        off += len(rots4) * ntot
-        # the folded quotient  h(X) = sum_i x^(n i) h_i(X)  (opened below; its value at x comes from the pieces' values)
+        # -- evaluations, in upstream's order.  Every opened polynomial (committed columns, fixed, sigma, the quotient's pieces) at
+        # every rotation in ONE call; which value goes where -- the transcript's order, the opening queries, their grouping by point --
+        # depends on the circuit only and is laid out once per prover (_opening_plan)
+        plan = self._plan if self._plan is not None else self._opening_plan()
+        rots4, plist, write_idx, groups, hp_ptrs, hpiece0, count, need = plan
+        point = {r: rotate_omega(d, x, r) for r in rots4}
+        ctx.eval_polynomial_multi_device(fid, plist, n, f.encode_many([point[r] for r in rots4]), self.evals.data_ptr(), 0)
+        # the folded quotient  h(X) = sum_i x^(n i) h_i(X)  (opened below; its value at x comes from the pieces' values: four products on
+        # the host instead of two more launches in front of the read-back)
         xs, cur = [], 1
         for _ in range(pieces):
             xs.append(cur)
             cur = cur * xn % p
-        ctx.lincomb_device(fid, self._ptrs(hp, 0, pieces), f.encode_many(xs), n, self.hfold.data_ptr(), None, 0)
+        ctx.lincomb_device(fid, hp_ptrs, f.encode_many(xs), n, self.hfold.data_ptr(), None, 0)
         mark("evaluations_launch")
-        ev_host = array_to_ints(ctx.download(self.evals.data_ptr(), off, 4))
         rinv = self._rinv
-        val = lambda name, col, r: ev_host[slots[(name, r)] + col] * rinv % p
-        hfold_eval = sum(xs[i] * val("hpiece", i, 0) for i in range(pieces)) % p
-
-        for col, r in cs.advice_queries:
-            transcript.write_scalar(val("cols", self.o_adv + col, r))
-        for col, r in cs.fixed_queries:
-            transcript.write_scalar(val("fixed", col, r))
-        transcript.write_scalar(val("cols", self.o_rand, 0))                    # vanishing: random_eval
-        for j in range(npc):                                                     # pk.permutation.evaluate: sigma(x)
-            transcript.write_scalar(val("sigma", j, 0))
-        last = -(bf + 1)
-        for s in range(S):                                                       # permutation products
-            transcript.write_scalar(val("cols", self.o_pz + s, 0))
-            transcript.write_scalar(val("cols", self.o_pz + s, 1))
-            if s != S - 1:
-                transcript.write_scalar(val("cols", self.o_pz + s, last))
-        for l in range(L):                                                       # lookups
-            zc, ai, ti = self.o_lz + l, self.o_perm + 2 * l, self.o_perm + 2 * l + 1
-            for colr in ((zc, 0), (zc, 1), (ai, 0), (ai, -1), (ti, 0)):
-                transcript.write_scalar(val("cols", *colr))
+        raw, E = array_to_ints(ctx.download(self.evals.data_ptr(), count, 4)), [0] * count
+        for i in need:                                           # (only what the transcript and the queries use)
+            E[i] = raw[i] * rinv % p
+        hfold_eval = sum(xs[i] * E[hpiece0 + i] for i in range(pieces)) % p
+        for i in write_idx:
+            transcript.write_scalar(E[i])
         mark("evaluations")
-
-        # -- queries (point rotation, device polynomial, evaluation), in upstream's order
-        Q: List[Tuple[int, int, int]] = []
-        for col, r in cs.advice_queries:
-            Q.append((r, polys[self.o_adv + col].data_ptr(), val("cols", self.o_adv + col, r)))
-        for s in range(S):                                                       # permutation::Constructed::open
-            zc = self.o_pz + s
-            Q.append((0, polys[zc].data_ptr(), val("cols", zc, 0)))
-            Q.append((1, polys[zc].data_ptr(), val("cols", zc, 1)))
-        for s in range(S - 1):
-            zc = self.o_pz + s
-            Q.append((last, polys[zc].data_ptr(), val("cols", zc, last)))
-        for l in range(L):                                                       # lookup::Evaluated::open
-            zc, ai, ti = self.o_lz + l, self.o_perm + 2 * l, self.o_perm + 2 * l + 1
-            for colr in ((zc, 0), (ai, 0), (ti, 0), (ai, -1), (zc, 1)):
-                Q.append((colr[1], polys[colr[0]].data_ptr(), val("cols", *colr)))
-        for col, r in cs.fixed_queries:
-            Q.append((r, pk.fixed_polys[col].data_ptr(), val("fixed", col, r)))
-        for j in range(npc):                                                     # pk.permutation.open
-            Q.append((0, pk.perm_polys[j].data_ptr(), val("sigma", j, 0)))
-        Q.append((0, self.hfold.data_ptr(), hfold_eval))                         # vanishing::Evaluated::open
-        Q.append((0, polys[self.o_rand].data_ptr(), val("cols", self.o_rand, 0)))
 
         # -- ProverGWC::create_proof: one witness polynomial per distinct point, in order of first appearance
         v = transcript.squeeze_challenge_scalar()
         self._tick("v")
-        order: List[int] = []
-        groups: Dict[int, List[Tuple[int, int]]] = {}
-        for r, ptr, e in Q:
-            if r not in groups:
-                groups[r] = []
-                order.append(r)
-            groups[r].append((ptr, e))
-        if len(order) > self.qbuf.shape[0]:
-            raise ValueError("more opening points than the prover's buffers hold")
         self.wbuf.zero_()
-        for gi, r in enumerate(order):
-            ptrs, coefs, eval_batch, pw = [], [], 0, 1
-            for ptr, e in groups[r]:
-                ptrs.append(ptr)
+        for gi, (r, ptrs, idxs) in enumerate(groups):
+            coefs, eval_batch, pw = [], 0, 1
+            for i in idxs:
                 coefs.append(pw)
-                eval_batch = (eval_batch + pw * e) % p
+                eval_batch += pw * (E[i] if i >= 0 else hfold_eval)
                 pw = pw * v % p
-            ctx.lincomb_device(fid, ptrs, f.encode_many(coefs), n, self.qbuf[gi].data_ptr(), enc(eval_batch), 0)
+            ctx.lincomb_device(fid, ptrs, f.encode_many(coefs), n, self.qbuf[gi].data_ptr(), enc(eval_batch % p), 0)
         self._tick("lincombs queued")
+        order = [r for r, _, _ in groups]
         ctx.kate_division_batch_device(fid, self._ptrs(self.qbuf, 0, len(order)), n, f.encode_many([point[r] for r in order]), self._ptrs(self.wbuf, 0, len(order)), 0)
         self._commit(transcript, 0, len(order), False, src=self.wbuf)
         mark("openings")
