@@ -23,7 +23,7 @@ SYMBOLS = [
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device",
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
     "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device", "dehalo_kate_division_batch_device",
-    "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
+    "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_graph_evaluate_batch_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
 K_MSM_ACCUMULATE, K_MSM_SORT, K_MSM_REDUCE, K_NTT_PASS, K_POLY, K_EVAL_H = 0, 1, 2, 3, 4, 5
@@ -141,6 +141,7 @@ def load_library():
     lib.dehalo_graph_create.argtypes = [P, C.c_int, u64p, u32, C.POINTER(C.c_int32), u32, C.POINTER(CCalculation), u32, C.POINTER(CSource), u32, u32, C.POINTER(P)]
     lib.dehalo_graph_release.argtypes = [P, P]
     lib.dehalo_graph_evaluate_device.argtypes = [P, P, C.POINTER(CEvalInputs), u32, u32, u64p, u64p, P]
+    lib.dehalo_graph_evaluate_batch_device.argtypes = [P, C.POINTER(C.c_void_p), u32, C.POINTER(CEvalInputs), u32, u32, C.POINTER(C.c_void_p), P]
     lib.dehalo_permutation_h_device.argtypes = [P, C.c_int, C.POINTER(CPermInputs), u32, u32, u64p, P]
     lib.dehalo_lookup_h_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u64p, P]
     lib.dehalo_lookup_h_batch_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u32, u64p, P]
@@ -488,6 +489,17 @@ class Context:
         inp = CEvalInputs(tf, len(fixed), ta, len(advice), ti, len(instance), ch.ctypes.data if ch.shape[0] else None, ch.shape[0],
                           *[k.ctypes.data if k is not None else None for k in keep], form_flags)
         self._check(self.lib.dehalo_graph_evaluate_device(self.handle, graph, C.byref(inp), log_rows, rot_scale, d_previous or None, d_out, stream or None))
+
+    def graph_evaluate_batch_device(self, graphs, fixed, advice, instance, challenges, beta, gamma, theta, y, log_rows: int, rot_scale: int, d_outs,
+                                    stream: int = 0, form_flags: int = 0):
+        """several programs over the same inputs, program i into d_outs[i] (one call)."""
+        keep = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) if v is not None else None for v in (beta, gamma, theta, y)]
+        ch = _u64(challenges, 4) if challenges is not None and len(challenges) else np.zeros((0, 4), dtype=np.uint64)
+        tf, ta, ti = self._ptr_table(fixed), self._ptr_table(advice), self._ptr_table(instance)
+        inp = CEvalInputs(tf, len(fixed), ta, len(advice), ti, len(instance), ch.ctypes.data if ch.shape[0] else None, ch.shape[0],
+                          *[k.ctypes.data if k is not None else None for k in keep], form_flags)
+        gs, outs = (C.c_void_p * len(graphs))(*graphs), (C.c_void_p * len(d_outs))(*d_outs)
+        self._check(self.lib.dehalo_graph_evaluate_batch_device(self.handle, gs, len(graphs), C.byref(inp), log_rows, rot_scale, outs, stream or None))
 
     def permutation_h_device(self, field: int, z, columns, sigma, chunk_len: int, last_rotation: int, l0: int, l_last: int, l_active: int, beta, gamma, y,
                              delta, beta_zeta, extended_omega, log_rows: int, rot_scale: int, d_values: int, stream: int = 0, form_flags: int = 0):

@@ -1023,6 +1023,16 @@ int dehalo_graph_evaluate_device(dehalo_ctx* ctx, const dehalo_graph* g, const d
     return do_graph_evaluate(ctx, g, in, log_rows, rot_scale, (const fe*)d_previous, (fe*)d_out, pick_stream(ctx, stream));
 }
 
+int dehalo_graph_evaluate_batch_device(dehalo_ctx* ctx, const dehalo_graph* const* graphs, uint32_t count, const dehalo_eval_inputs* in, uint32_t log_rows,
+                                       uint32_t rot_scale, uint64_t* const* d_outs, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((count && (!graphs || !d_outs)) || !in) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate_batch: null argument");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    for (uint32_t i = 0; i < count; i++)
+        TRY(dehalo_graph_evaluate_device(ctx, graphs[i], in, log_rows, rot_scale, nullptr, d_outs[i], stream));
+    return 0;
+}
+
 int dehalo_permutation_h_device(dehalo_ctx* ctx, int field, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,
                                 void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;

@@ -425,11 +425,9 @@ class Prover:
         adv_v = self._ptrs(cols, self.o_adv, A)
         inst_v = self._ptrs(instance_values, 0, self.I)
         if L:
-            theta_e, none = enc(theta), []
-            for l in range(L):
-                gi, gt = pk.compress_graphs[l]
-                gi.evaluate_device(fixed_v, adv_v, inst_v, none, None, None, theta_e, None, k, 1, 0, self.compressed[2 * l].data_ptr(), 0, 0, ctx)
-                gt.evaluate_device(fixed_v, adv_v, inst_v, none, None, None, theta_e, None, k, 1, 0, self.compressed[2 * l + 1].data_ptr(), 0, 0, ctx)
+            # every lookup's compressed (input, table) pair, interleaved like the output buffer: one call
+            graphs = [g.handle for pair in pk.compress_graphs for g in pair]
+            ctx.graph_evaluate_batch_device(graphs, fixed_v, adv_v, inst_v, None, None, None, enc(theta), None, k, 1, self._ptrs(self.compressed, 0, 2 * L))
             # permuted columns are interleaved (input_l, table_l) with a stride of two columns
             base = cols[self.o_perm].data_ptr()
             self._tick("compress queued")

@@ -308,6 +308,10 @@ typedef struct {
 } dehalo_eval_inputs;
 int dehalo_graph_evaluate_device(dehalo_ctx* ctx, const dehalo_graph* graph, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,
                                  const uint64_t* d_previous, uint64_t* d_out, void* stream);
+/* `count` programs over the SAME inputs (no previous value), program i into d_outs[i]: the theta-compressed input and table expressions
+ * of every lookup [UPSTREAM plonk/lookup/prover.rs commit_permuted: compress_expressions], one call from the host instead of `count`. */
+int dehalo_graph_evaluate_batch_device(dehalo_ctx* ctx, const dehalo_graph* const* graphs, uint32_t count, const dehalo_eval_inputs* in, uint32_t log_rows,
+                                       uint32_t rot_scale, uint64_t* const* d_outs, void* stream);
 typedef struct {
     const uint64_t* const* z; uint32_t num_sets;             /* permutation_product_coset per set (device pointers) */
     const uint64_t* const* columns; const uint64_t* const* sigma; uint32_t num_columns;   /* column cosets / pk.permutation.cosets */
