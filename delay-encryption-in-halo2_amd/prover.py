@@ -454,10 +454,9 @@ class Prover:
         perm_fixed = fixed_v + self._ptrs(pk.perm_values) + [self.omega_col.data_ptr()]
         chal_e, beta_e, gamma_e, none = f.encode_many(chal), enc(beta), enc(gamma), []      # encoded once, not once per graph
         den_p, num_p = self._ptrs(self.den), self._ptrs(self.num)
-        for s in range(S):
-            gd, gn = self.perm_graphs[s]
-            gd.evaluate_device(perm_fixed, adv_v, inst_v, chal_e, beta_e, gamma_e, None, None, k, 1, 0, den_p[s], 0, 0, ctx)
-            gn.evaluate_device(perm_fixed, adv_v, inst_v, chal_e, beta_e, gamma_e, None, None, k, 1, 0, num_p[s], 0, 0, ctx)
+        if S:                                                    # every set's denominator and numerator programs: same inputs, one call
+            ctx.graph_evaluate_batch_device([g.handle for pair in self.perm_graphs for g in pair], perm_fixed, adv_v, inst_v, chal_e, beta_e, gamma_e, None, None,
+                                            k, 1, [q for s in range(S) for q in (den_p[s], num_p[s])])
         comp_p, perm_p = self._ptrs(self.compressed), self._ptrs(cols, self.o_perm, 2 * L)
         for l in range(L):
             gd, gn = self.lookup_product_graphs
@@ -481,8 +480,7 @@ class Prover:
                 if L:
                     be, ge, te, none = enc(beta), enc(gamma), enc(theta), []
                     fc, ac, ic, tvp = self._ptrs(pk.fixed_cosets), self._ptrs(self.ext, self.o_adv, A), self._ptrs(self.ext, nco, self.I), self._ptrs(self.table_value)
-                    for l in range(L):
-                        pk.lookup_graphs[l].evaluate_device(fc, ac, ic, none, be, ge, te, None, ek, rot_scale_h, 0, tvp[l], 0, FF, self.side)
+                    self.side.graph_evaluate_batch_device([g.handle for g in pk.lookup_graphs], fc, ac, ic, None, be, ge, te, None, ek, rot_scale_h, tvp, 0, FF)
             self._commit(transcript, self.o_pz, S + L, True, before_sync=after_products_queued if self.side is not None else None)
         mark("grand_products")
 
