@@ -406,7 +406,16 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
     delete ctx;
 }
 
-const char* dehalo_last_error(const dehalo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* dehalo_last_error(const dehalo_ctx* ctx) {
+    if (!ctx) return "null context";
+    // a copy per calling thread, taken under the lock: another thread's error path may replace ctx->err at any time
+    static thread_local std::string copy;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<dehalo_ctx*>(ctx)->err_mu);
+        copy = ctx->err;
+    }
+    return copy.c_str();
+}
 
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return DEHALO_ERR_INVALID;

@@ -34,7 +34,8 @@ struct dehalo_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    std::string err;
+    std::string err;           // guarded by err_mu (written on error paths of any thread, with or without mu held)
+    std::mutex err_mu;
     std::recursive_mutex mu;   // recursive: host-buffer entry points hold it across their device-form calls
     // workspace (grow-only)
     DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_records, ws_merge_lists, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
@@ -61,7 +62,10 @@ struct dehalo_bases {
 };
 
 inline int dh_fail(dehalo_ctx* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->err_mu);
+        ctx->err = msg;
+    }
     return code;
 }
 

@@ -270,6 +270,21 @@ class ProvingKey:
         return cls(ctx, vk, domain, *dev)
 
 
+def vk_size(cs: plonk.ConstraintSystem, k: int, num_selectors: int) -> int:
+    """Bytes VerifyingKey.write produces (RawBytes): what the reference lists as |vk| (benches/README.md:56-60)."""
+    return 4 + 4 + 64 * cs.num_fixed + 64 * len(cs.permutation_columns) + num_selectors * (((1 << k) + 7) // 8)
+
+
+def pk_size(cs: plonk.ConstraintSystem, k: int, num_selectors: int, field: FieldSpec) -> int:
+    """Bytes ProvingKey.write produces (RawBytes): the reference's |pk|."""
+    n = 1 << k
+    m = EvaluationDomain(None, field, cs.degree(), k).extended_len()
+    poly = lambda ln: 4 + 32 * ln
+    sl = lambda cnt, ln: 4 + cnt * poly(ln)
+    nf, npc = cs.num_fixed, len(cs.permutation_columns)
+    return vk_size(cs, k, num_selectors) + 3 * poly(m) + sl(nf, n) + sl(nf, n) + sl(nf, m) + sl(npc, n) + sl(npc, n) + sl(npc, m)
+
+
 def delta_of(f: FieldSpec) -> int:
     """PrimeField::DELTA = MULTIPLICATIVE_GENERATOR^(2^S): generates the odd-order subgroup."""
     return pow(f.gen, 1 << f.two_adicity, f.p)

@@ -114,7 +114,7 @@ class ConstraintSystem:
 
     def degree(self) -> int:
         """ConstraintSystem::degree: the permutation argument needs 3, a lookup max(4, 2 + input + table), gates their own."""
-        d = 3 if self.permutation_columns else 1
+        d = 3                                                 # permutation::Argument::required_degree() == 3, unconditionally
         for inputs, tables in self.lookups:
             di = max([1] + [degree(e) for e in inputs])
             dt = max([1] + [degree(e) for e in tables])

@@ -27,11 +27,47 @@ from .keygen import ParamsKZG, ProvingKey, array_to_ints, decode_points, delta_o
 from .transcript import Blake2bWrite
 
 
+class OsRng:
+    """The default source of the prover's random scalars (blinding rows, blinds, the vanishing argument's random polynomial):
+    operating-system entropy, as the reference passes (`OsRng`, benches/delay_enc.rs:128).  Elements are uniform over the whole
+    field (256 random bits masked to the modulus' bit length, rejected when >= p); the value is handed over as a Montgomery
+    representation -- multiplication by R is a bijection of the field, so that is uniform too."""
+
+    def __init__(self, p: int):
+        self.p = p
+        self._limbs = np.array([(p >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+        self._mask = np.uint64((1 << (p.bit_length() - 192)) - 1)
+
+    def scalars(self, count: int) -> np.ndarray:
+        import os
+        out = np.empty((count, 4), dtype=np.uint64)
+        have = 0
+        while have < count:
+            m = max(16, int(1.6 * (count - have)))
+            a = np.frombuffer(os.urandom(32 * m), dtype=np.uint64).reshape(m, 4).copy()
+            a[:, 3] &= self._mask
+            lt, eq = np.zeros(m, dtype=bool), np.ones(m, dtype=bool)
+            for i in (3, 2, 1, 0):
+                lt |= eq & (a[:, i] < self._limbs[i])
+                eq &= a[:, i] == self._limbs[i]
+            good = a[lt][:count - have]
+            out[have:have + len(good)] = good
+            have += len(good)
+        return out
+
+    def fork(self, skip: int) -> "OsRng":
+        return OsRng(self.p)                                   # fresh entropy has no position
+
+    def skip(self, count: int):
+        pass
+
+
 class SeededRng:
-    """Source of the prover's random scalars (blinding rows, blinds, the vanishing argument's random polynomial).
-    Upstream draws them from the caller's RngCore (benches/delay_enc.rs:128 passes OsRng) one by one, in program
-    order; this one is deterministic so that a proof is reproducible: elements are raw 253-bit values taken as
-    Montgomery representations (every 253-bit integer is below the four moduli)."""
+    """TESTS AND BENCHMARKS ONLY -- not a CSPRNG (PCG64), and with a known seed the blinding rows and the random polynomial are
+    predictable, so a proof made with it leaks the witness.  It exists so that a proof is reproducible and can be compared byte for
+    byte with the CPU restatement's: upstream draws its scalars from the caller's RngCore one by one, in program order, and this
+    stream is consumed in that order.  Elements are raw 253-bit values taken as Montgomery representations (every 253-bit integer is
+    below the four moduli)."""
 
     def __init__(self, seed: int):
         self.gen = np.random.Generator(np.random.PCG64(seed))
@@ -260,7 +296,7 @@ class Prover:
             zc = self.o_pz + s
             Q.append((0, col_ptr[zc], idx("cols", zc, 0)))
             Q.append((1, col_ptr[zc], idx("cols", zc, 1)))
-        for s in range(S - 1):
+        for s in reversed(range(S - 1)):                                         # ... x_last: sets.iter().rev().skip(1)
             zc = self.o_pz + s
             Q.append((last, col_ptr[zc], idx("cols", zc, last)))
         for l in range(L):                                                       # lookup::Evaluated::open
@@ -300,13 +336,23 @@ class Prover:
         return [base + (first + i) * pitch for i in range(count)]
 
     # ---- the proof ----
-    def create_proof(self, advice, instances: Sequence[Sequence[int]], rng: SeededRng, transcript: Blake2bWrite,
+    def create_proof(self, advice, instances: Sequence[Sequence[int]], rng, transcript: Blake2bWrite,
                      timings: Optional[ProofTimings] = None):
+        """`rng`: None = operating-system entropy (OsRng, what the reference passes); SeededRng for reproducible test proofs."""
         self._timings = timings
-        with self.ctx.torch_stream():
-            return self._create_proof(advice, instances, rng, transcript, timings)
+        if rng is None:
+            rng = OsRng(self.f.p)
+        self._prefetch = None
+        try:
+            with self.ctx.torch_stream():
+                return self._create_proof(advice, instances, rng, transcript, timings)
+        finally:
+            # a helper thread that was started must have finished before the caller may reuse or close the contexts
+            t = self._prefetch
+            if t is not None and t.is_alive():
+                t.join()
 
-    def _create_proof(self, advice, instances: Sequence[Sequence[int]], rng: SeededRng, transcript: Blake2bWrite,
+    def _create_proof(self, advice, instances: Sequence[Sequence[int]], rng, transcript: Blake2bWrite,
                       timings: Optional[ProofTimings] = None):
         """advice: (num_advice, n, 4) u64 Montgomery (host array or device tensor); instances: one list of canonical ints per
         instance column (the reference passes &[&[&[]]]: none).  Appends the proof to `transcript`."""
@@ -337,17 +383,21 @@ class Prover:
             box = {}
 
             def _draw(r=rng.fork(draws_before)):
-                if self.side is None:
-                    with ctx.torch_stream():
-                        box["poly"] = to_device(r.scalars(n))
-                    return
-                # with a side context the random polynomial is also COMMITTED there, long before its phase
-                with self.side.torch_stream():
-                    self.polys[self.o_rand].copy_(to_device(r.scalars(n)))
-                    self.params.commit_affine_device(self.polys[self.o_rand].data_ptr(), 1, self.aff_side.data_ptr(), False, ctx=self.side)
-                    self.side.synchronize()
-                    box["point"] = decode_points(self.curve, to_host(self.aff_side[:1]))[0]
+                try:
+                    if self.side is None:
+                        with ctx.torch_stream():
+                            box["poly"] = to_device(r.scalars(n))
+                        return
+                    # with a side context the random polynomial is also COMMITTED there, long before its phase
+                    with self.side.torch_stream():
+                        self.polys[self.o_rand].copy_(to_device(r.scalars(n)))
+                        self.params.commit_affine_device(self.polys[self.o_rand].data_ptr(), 1, self.aff_side.data_ptr(), False, ctx=self.side)
+                        self.side.synchronize()
+                        box["point"] = decode_points(self.curve, to_host(self.aff_side[:1]))[0]
+                except BaseException as exc:      # noqa: BLE001 -- re-raised on the proving thread after join()
+                    box["error"] = exc
             prefetch = threading.Thread(target=_draw)      # started when the advice commitments are queued (below): the host is idle then
+            self._prefetch = prefetch
 
         def columns_ready():
             """an event after everything queued so far on the main context (a phase's columns and their blinding rows)"""
@@ -488,6 +538,8 @@ class Prover:
         polys = self.polys
         if prefetch is not None:
             prefetch.join()
+            if "error" in box:
+                raise box["error"]
             rng.skip(n)
         if self.side is not None and prefetch is not None:
             rng.scalars(1)
@@ -606,6 +658,6 @@ def proof_commitments(cs: plonk.ConstraintSystem, proof: bytes) -> bytes:
     return proof[:32 * head] + proof[32 * (head + evals):]
 
 
-def create_proof(params: ParamsKZG, pk: ProvingKey, advice, instances, rng: SeededRng, transcript: Blake2bWrite) -> Blake2bWrite:
+def create_proof(params: ParamsKZG, pk: ProvingKey, advice, instances, rng, transcript: Blake2bWrite) -> Blake2bWrite:
     """One-shot form (allocates the proof's device buffers for this call)."""
     return Prover(params, pk).create_proof(advice, instances, rng, transcript)

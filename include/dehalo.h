@@ -62,7 +62,7 @@ int dehalo_ctx_create(int device, dehalo_ctx** out);
  * long ones -- the prover's side context), < 0 its lowest, 0 the default. */
 int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out);
 void dehalo_ctx_destroy(dehalo_ctx* ctx);
-/* Human-readable text of the last error on this context (valid until the next call). */
+/* Human-readable text of the last error on this context (a per-thread copy: valid until the calling thread's next call of this function). */
 const char* dehalo_last_error(const dehalo_ctx* ctx);
 /* Launch-geometry knobs (results never depend on them).  "msm_acc_points" (default 48; also the environment variable
  * DEHALO_MSM_ACC_POINTS at context creation): the bucket-accumulation grid of an MSM is 4, 6, 8, ... layers of one wave per SIMD,
@@ -336,6 +336,129 @@ int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_input
  * l0 / l_last / l_active_row, beta / gamma / y and form_flags (checked); each brings its own cosets and table_value column. */
 int dehalo_lookup_h_batch_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale,
                                  uint64_t* d_values, void* stream);
+
+/* ==== the whole call: halo2_proofs::plonk::{keygen_vk, keygen_pk, create_proof} over KZG / GWC =====================================
+ * The reference's timed call is
+ *     create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC<_>, Challenge255<_>, _, Blake2bWrite<_, _, _>, _>(&params, &pk, &[circuit],
+ *                                                                                                          &[&[&[]]], &mut OsRng, &mut transcript)
+ * (benches/delay_enc.rs:123-131, mod_pow.rs:201-209, pose_enc.rs:127-135) over objects it builds once and caches on disk (params
+ * :41-54, vk / pk :84-115).  The entry points below are that call and those objects, one C function each: every column stays in HBM
+ * from the witness upload to the last opening; the host hashes the transcript (Blake2b-512) and orders the phases, in C++.
+ * What arrives from the caller is what halo2 holds at that point: the constraint system as data, the fixed columns and the permutation
+ * assembly keygen produced, the advice columns `synthesize` filled (witness generation stays the front-end's).
+ */
+typedef struct dehalo_params dehalo_params;         /* ParamsKZG<E>: k, g, g_lagrange (resident MSM tables), g2, s_g2 */
+typedef struct dehalo_pk dehalo_pk;                 /* ProvingKey<C> incl. its VerifyingKey and the compiled GraphEvaluator programs */
+typedef struct dehalo_prover dehalo_prover;         /* device buffers of ONE proof in flight (reused by every create_proof on it) */
+typedef struct dehalo_transcript dehalo_transcript; /* Blake2bWrite<Vec<u8>, C, Challenge255<C>> */
+
+/* ParamsKZG [UPSTREAM halo2_proofs/src/poly/kzg/commitment.rs].  g / g_lagrange: 2^k affine points each ({x, y} Montgomery, 64 B);
+ * g2 / s_g2: 128 raw bytes each (kept for write(); the prover never uses them).  read / write: SerdeFormat::RawBytes --
+ * k: u32 LE | g | g_lagrange | g2 | s_g2  (what benches/delay_enc.rs:45,54 write and read). */
+int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, const uint8_t* g2, const uint8_t* s_g2,
+                         dehalo_params** out);
+int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out);
+size_t dehalo_params_size(const dehalo_params* params);
+int dehalo_params_write(const dehalo_params* params, uint8_t* out, size_t cap);
+int dehalo_params_release(dehalo_ctx* ctx, dehalo_params* params);
+/* ParamsKZG::{commit, commit_lagrange} of `batch` device-resident columns of 2^k elements (n apart) -> affine points in HBM. */
+int dehalo_params_commit_device(dehalo_ctx* ctx, const dehalo_params* params, const uint64_t* d_polys, size_t batch, int lagrange, uint64_t* d_out_affine, void* stream);
+
+/* The circuit as data: the fields of halo2_proofs::plonk::ConstraintSystem that keygen and the prover read
+ * [UPSTREAM halo2_proofs/src/plonk/circuit.rs].  Expressions are a flat array of nodes, children before parents:
+ *   CONSTANT  a = index into `constants`;     FIXED / ADVICE / INSTANCE  a = column index, rotation;
+ *   NEGATED   a = child;  SUM / PRODUCT  a, b = children;  SCALED  a = child, b = index into `constants`.                          */
+typedef enum {
+    DEHALO_EXPR_CONSTANT = 0, DEHALO_EXPR_FIXED = 1, DEHALO_EXPR_ADVICE = 2, DEHALO_EXPR_INSTANCE = 3, DEHALO_EXPR_NEGATED = 4, DEHALO_EXPR_SUM = 5,
+    DEHALO_EXPR_PRODUCT = 6, DEHALO_EXPR_SCALED = 7
+} dehalo_expr_kind;
+typedef struct { uint32_t kind, a, b; int32_t rotation; } dehalo_expr_node;
+typedef enum { DEHALO_COLUMN_ADVICE = 0, DEHALO_COLUMN_FIXED = 1, DEHALO_COLUMN_INSTANCE = 2 } dehalo_column_kind;
+typedef struct { uint32_t kind, index; int32_t rotation; } dehalo_column_query;          /* (Column, Rotation); rotation unused for permutation columns */
+typedef struct {
+    uint32_t num_advice, num_fixed, num_instance, minimum_degree;
+    const dehalo_expr_node* nodes; uint32_t num_nodes;
+    const uint64_t* constants; uint32_t num_constants;              /* 4 x u64 Montgomery each (Expression::Constant(F)) */
+    const uint32_t* gates; uint32_t num_gates;                      /* root node of every gate polynomial, in order (gates.flat_map(polynomials)) */
+    const uint32_t* lookup_lens; uint32_t num_lookups;              /* lookup l has lookup_lens[l] (input, table) expression pairs ...          */
+    const uint32_t* lookup_inputs; const uint32_t* lookup_tables;   /* ... their root nodes, lookups concatenated                                */
+    const dehalo_column_query* permutation_columns; uint32_t num_permutation_columns;      /* cs.permutation.columns, enable_equality order */
+    const dehalo_column_query* advice_queries; uint32_t num_advice_queries;                /* first-use order: the order of the evaluations in the proof */
+    const dehalo_column_query* fixed_queries; uint32_t num_fixed_queries;
+    const dehalo_column_query* instance_queries; uint32_t num_instance_queries;
+} dehalo_constraint_system;
+
+/* keygen_vk + keygen_pk [UPSTREAM halo2_proofs/src/plonk/keygen.rs; benches/delay_enc.rs:86,103] on the device: commit_lagrange,
+ * lagrange_to_coeff and coeff_to_extended of every fixed and permutation column, l0 / l_last / l_active_row.
+ *   fixed               num_fixed x 2^k x 4 u64, host; Montgomery unless DEHALO_KEYGEN_FIXED_CANONICAL (selectors already compressed into them)
+ *   permutation_mapping num_permutation_columns x 2^k u64, host: cell (column j, row i) is mapped to cell value / 2^k, value % 2^k
+ *                       (permutation::keygen::Assembly::mapping flattened); identity = j * 2^k + i
+ *   selectors           num_selectors arrays of 2^k bytes (0 / 1): only serialised with the verifying key (vk.selectors)              */
+enum { DEHALO_KEYGEN_FIXED_CANONICAL = 1 };
+int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const dehalo_constraint_system* cs, const uint64_t* fixed, const uint64_t* permutation_mapping,
+                  const uint8_t* const* selectors, uint32_t num_selectors, uint32_t flags, dehalo_pk** out);
+/* ProvingKey::{read, write} / VerifyingKey::write with SerdeFormat::RawBytes [UPSTREAM halo2_proofs/src/plonk.rs; benches/delay_enc.rs:
+ * 88-115]: reading needs the circuit's constraint system, as upstream's read::<_, ConcreteCircuit> does. */
+int dehalo_pk_read(dehalo_ctx* ctx, int curve, const dehalo_constraint_system* cs, const uint8_t* bytes, size_t len, uint32_t num_selectors, dehalo_pk** out);
+size_t dehalo_pk_size(const dehalo_pk* pk);
+int dehalo_pk_write(dehalo_ctx* ctx, const dehalo_pk* pk, uint8_t* out, size_t cap);
+size_t dehalo_vk_size(const dehalo_pk* pk);
+int dehalo_vk_write(const dehalo_pk* pk, uint8_t* out, size_t cap);
+/* vk.transcript_repr, the first thing create_proof absorbs.  Upstream derives it from the Debug text of the pinned verifying key, which
+ * cannot be reproduced outside the crate: an integrator passes upstream's value (4 x u64 Montgomery).  Until set, the key carries a
+ * substitute: Blake2b-512("Halo2-Verify-Key") over the key's RawBytes and a binary encoding of the constraint system. */
+int dehalo_pk_set_transcript_repr(dehalo_pk* pk, const uint64_t repr[4]);
+int dehalo_pk_get_transcript_repr(const dehalo_pk* pk, uint64_t repr[4]);
+/* out[0..7] = k, extended_k, blinding_factors, degree, permutation sets, commitments before the evaluations, evaluations, opening points */
+int dehalo_pk_info(const dehalo_pk* pk, uint32_t out[8]);
+int dehalo_pk_release(dehalo_ctx* ctx, dehalo_pk* pk);
+
+/* Random scalars of one proof (see csrc/hostrng.hpp).  DEHALO_RNG_OS is what a NULL pointer selects. */
+typedef enum { DEHALO_RNG_OS = 0, DEHALO_RNG_PCG64 = 1, DEHALO_RNG_CALLBACK = 2 } dehalo_rng_kind;
+/* fills `count` scalars (4 x u64 Montgomery representations, < p); `position` = index of the first one in upstream's draw order.  May be
+ * called from a helper thread of the library, never concurrently for one proof.  Returns 0. */
+typedef int (*dehalo_rng_fill_fn)(void* user, uint64_t* out, size_t count, uint64_t position);
+typedef struct {
+    int kind;
+    uint64_t pcg_state[2], pcg_inc[2];     /* DEHALO_RNG_PCG64: numpy PCG64 state / increment, low word first; advanced past the proof's draws on return */
+    dehalo_rng_fill_fn fill; void* user;   /* DEHALO_RNG_CALLBACK */
+} dehalo_rng;
+/* `count` scalars of the field from a generator (what create_proof draws): lets a test pin the three kinds without a device. */
+int dehalo_rng_scalars(dehalo_rng* rng, int field, uint64_t skip, uint64_t* out, size_t count);
+
+/* Blake2bWrite / Challenge255 [UPSTREAM halo2_proofs/src/transcript.rs; benches/delay_enc.rs:120,134]. */
+int dehalo_transcript_create(int curve, dehalo_transcript** out);
+int dehalo_transcript_common_scalar(dehalo_transcript* t, const uint64_t scalar[4]);                 /* Montgomery */
+int dehalo_transcript_write_scalar(dehalo_transcript* t, const uint64_t scalar[4]);
+int dehalo_transcript_write_point(dehalo_transcript* t, const uint64_t affine_xy[8]);                /* Montgomery; identity rejected */
+int dehalo_transcript_squeeze_challenge(dehalo_transcript* t, uint64_t out[4]);                      /* Montgomery */
+size_t dehalo_transcript_len(const dehalo_transcript* t);
+int dehalo_transcript_finalize(const dehalo_transcript* t, uint8_t* out, size_t cap);                /* the proof bytes written so far */
+void dehalo_transcript_release(dehalo_transcript* t);
+
+/* A prover = the device buffers of one proof for a given key, on `ctx` (stream + workspace).  `side_ctx` (may be NULL): a second context of
+ * the same device; work no transcript challenge waits for (lagrange_to_coeff / coeff_to_extended of a phase's columns, the random
+ * polynomial's commitment, the gate and table-value passes of evaluate_h) is queued there and runs beside the commitment phases.
+ * Several provers over one key, each on its own context(s), may run concurrently from different threads (batch proving). */
+int dehalo_prover_create(dehalo_ctx* ctx, dehalo_ctx* side_ctx, const dehalo_params* params, const dehalo_pk* pk, dehalo_prover** out);
+int dehalo_prover_release(dehalo_prover* prover);
+/* create_proof: one circuit, its instance columns, the caller's rng and transcript.
+ *   advice     num_advice x 2^k x 4 u64 Montgomery (rows >= usable are overwritten by blinding), host memory, or device memory when
+ *              DEHALO_PROOF_ADVICE_ON_DEVICE
+ *   instances  num_instance_columns arrays of instance_lens[i] scalars (Montgomery); the reference passes none (&[&[&[]]])
+ * Errors follow upstream's: DEHALO_ERR_INVALID for instances.len() != num_instance_columns / an instance column longer than the usable
+ * rows / a commitment at infinity; DEHALO_ERR_NOT_IN_TABLE when a lookup input is missing from its table. */
+enum { DEHALO_PROOF_ADVICE_ON_DEVICE = 1 };
+int dehalo_create_proof(dehalo_prover* prover, const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns,
+                        dehalo_rng* rng, dehalo_transcript* transcript, uint32_t flags);
+/* Host wall-clock milliseconds the last create_proof on this prover spent per phase (advice, lookups, products, random, quotient, evaluations,
+ * openings, total): out[8]. */
+int dehalo_prover_last_timings(const dehalo_prover* prover, double out[8]);
+/* `count` proofs of the same circuit on `num_provers` provers, one host thread each (proof i -> prover i mod num_provers), no interpreter
+ * in the loop: advice[i] / rngs[i] / proofs_out[i] (capacity proof_cap bytes each, length into proof_lens[i]) per proof; every proof starts
+ * a fresh transcript.  Batch / throughput mode (BASELINE configs[4]). */
+int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, const uint64_t* const* advice, uint32_t count, dehalo_rng* rngs, uint32_t flags,
+                         uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-kernel device time measured with HIP events on the launching stream (bench.py's

@@ -75,7 +75,7 @@ class Shape:
         for c, _ in self.advice_queries:
             cnt[c] += 1
         self.blinding_factors = max(3, max(cnt or [1])) + 2
-        d = 3 if self.perm_columns else 1
+        d = 3                                                  # permutation::Argument::required_degree() is 3 whether or not a column is enabled
         for ins, tabs in self.lookups:
             d = max(d, max(4, 2 + max([1] + [expr_degree(e) for e in ins]) + max([1] + [expr_degree(e) for e in tabs])))
         for g in self.gates:
@@ -402,7 +402,7 @@ def create_proof(curve: po.Curve, srs, key: dict, advice_mont: np.ndarray, insta
         Q.append((rotate(r), advice_polys[c], e))
     for zp, (e0, e1, _) in zip(perm_z_polys, pz_evals):
         Q += [(x, zp, e0), (x_next, zp, e1)]
-    for zp, (_, _, el) in list(zip(perm_z_polys, pz_evals))[:-1]:
+    for zp, (_, _, el) in reversed(list(zip(perm_z_polys, pz_evals))[:-1]):      # [UPSTREAM permutation::prover::Evaluated::open: sets.iter().rev().skip(1)]
         Q.append((x_last, zp, el))
     for lk, (z0, z1, a0, am1, t0) in zip(lookups, lk_evals):
         Q += [(x, lk["z_poly"], z0), (x, lk["pi_poly"], a0), (x, lk["pt_poly"], t0), (x_inv, lk["pi_poly"], am1), (x_next, lk["z_poly"], z1)]
@@ -428,5 +428,7 @@ def create_proof(curve: po.Curve, srs, key: dict, advice_mont: np.ndarray, insta
         witness = co.kate_division(F.id, poly_batch, mm(pt))
         write_commit(srs["g"], witness)
     trace["challenges"] = dict(theta=theta, beta=beta, gamma=gamma, y=y, x=x, v=v)
+    trace["perm_last_evals"] = [el for _, _, el in pz_evals[:-1]]                        # as written to the transcript: set 0, 1, ...
+    trace["x_last_group"] = [e for _, e in groups.get(x_last, [])] if sh.num_sets > 1 else []      # as batched with 1, v, v^2, ...
     trace["h_coeffs"] = hc
     return bytes(T.proof), trace

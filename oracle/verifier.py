@@ -176,7 +176,7 @@ def verify_proof(curve: po.Curve, desc, k: int, fixed_commitments, perm_commitme
         Q.append((advice_commitments[c], rotate(r), e))
     for zc, (e0, e1, _) in zip(perm_z_commitments, perm_evals):
         Q += [(zc, x, e0), (zc, x_next, e1)]
-    for zc, (_, _, el) in list(zip(perm_z_commitments, perm_evals))[:-1]:
+    for zc, (_, _, el) in reversed(list(zip(perm_z_commitments, perm_evals))[:-1]):      # [UPSTREAM permutation::verifier::Evaluated::queries: sets.iter().rev().skip(1)]
         Q.append((zc, x_last, el))
     for (ai, ti), zc, (z0, z1, a0, am1, s0) in zip(lookups_permuted, lookup_z_commitments, lookup_evals):
         Q += [(zc, x, z0), (ai, x, a0), (ti, x, s0), (ai, x_inv, am1), (zc, x_next, z1)]

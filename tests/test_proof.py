@@ -149,6 +149,19 @@ def test_oracle_proof_is_accepted(po, chain, k, rl):
     assert not oracle_verify(po, c, proof[:-32], k) and not oracle_verify(po, c, proof + bytes(32), k)
 
 
+def test_x_last_queries_run_from_the_second_last_set_down(po, chain):
+    """[UPSTREAM plonk/permutation/prover.rs Evaluated::open, verifier.rs Evaluated::queries: `sets.iter().rev().skip(1)`] -- the
+    openings at omega^last x are queued from set S - 2 down to set 0, so z_{S-2} takes v^0 in that point's batch; the evaluations
+    themselves are WRITTEN in forward order.  pose_enc has six sets (the device prover is pinned to the same order by the
+    byte comparison with this oracle at K = 11)."""
+    c = chain(6, False)
+    proof, trace = oracle_proof(po, c)
+    last = trace["perm_last_evals"]
+    assert len(last) == 5 and len(set(last)) == 5
+    assert trace["x_last_group"] == list(reversed(last))
+    assert oracle_verify(po, c, proof, 6)
+
+
 def test_oracle_rejects_unsatisfied_witness(po, co, chain):
     """One wrong advice cell: t(X) no longer divides the numerator, h(x) (x^n - 1) differs from the folded expressions, rejected."""
     import plonk_oracle as PO
@@ -423,3 +436,58 @@ def test_two_threads_share_one_context(pkg, co, ctx):
         t.join()
     reg.release()
     assert not errors, errors
+
+
+# ---------------------------------------------------------------- sizes the reference publishes
+def _mac_ls_h(nbytes: int) -> str:
+    """`ls -lh` on the reference authors' machine (MacBook Pro, Apple M1 Pro: benches/README.md:30-33): BSD humanize_number -- powers of 1024,
+    rounded to nearest, one decimal below 10 units."""
+    if nbytes < 1000:
+        return "%dB" % nbytes
+    for unit in "KMGT":
+        nbytes /= 1024.0
+        if nbytes < 999.5:
+            return ("%.1f%s" % (nbytes, unit)) if nbytes < 9.95 else ("%d%s" % (int(nbytes + 0.5), unit))
+    raise ValueError
+
+
+def test_sizes_match_reference_readme(pkg):
+    """The reference publishes |vk|, |pk| and the size of its proof file per k (benches/README.md:56-60 delay_enc, :64-78 mod_pow,
+    :84-96 pose_enc); its bench appends one proof per criterion iteration to one transcript and writes that (benches/delay_enc.rs:
+    120-134).  This repository's RawBytes layouts and proof layout must reproduce every one of them."""
+    from dehalo2_amd import keygen, plonk, prover
+
+    f = pkg.fields.BN254_FR
+    cs = plonk.maingate_cs(True)                                     # delay_enc / mod_pow: MainGate + RangeChip, two selectors
+    for k, vk_h, pk_h in ((15, "9.3K", "138M"), (16, "17K", "276M"), (17, "33K", "552M"), (18, "65K", "1.1G"), (19, "129K", "2.2G")):
+        assert _mac_ls_h(keygen.vk_size(cs, k, 2)) == vk_h, k
+        assert _mac_ls_h(keygen.pk_size(cs, k, 2, f)) == pk_h, k
+    assert keygen.vk_size(cs, 15, 2) == 9544 and keygen.vk_size(cs, 17, 2) == 34120
+    head, evals = prover.proof_layout(cs)
+    per_proof = 32 * (head + evals + 4)                              # + one opening quotient per distinct point (x, wx, w^-1 x, w^last x)
+    assert per_proof == 2848
+    assert _mac_ls_h(101 * per_proof) == "281K" and _mac_ls_h(103 * per_proof) == "286K"      # k >= 16 / k = 15 rows of the README
+    # pose_enc: MainGate only, no selectors -- |vk| is exact to the byte in the README
+    q = plonk.maingate_cs(False)
+    assert keygen.vk_size(q, 11, 0) == 968 and _mac_ls_h(968) == "968B"
+    for k, pk_h in ((11, "4.1M"), (12, "8.3M"), (13, "17M")):
+        assert _mac_ls_h(keygen.pk_size(q, k, 0, f)) == pk_h, k
+    head, evals = prover.proof_layout(q)
+    per_proof = 32 * (head + evals + 3)                              # x, wx, w^last x (no lookups: no w^-1 x)
+    assert per_proof == 1792
+    assert _mac_ls_h(131 * per_proof) == "229K" and _mac_ls_h(115 * per_proof) == "201K"      # K = 11 / K >= 12 rows
+
+
+@pytest.mark.gpu
+def test_written_keys_have_the_published_sizes(pkg, ctx, chain, device_chain):
+    """The writers themselves (not only the size formulas): vk and pk of the delay_enc shape at k = 9 and of pose_enc at k = 11."""
+    from dehalo2_amd import keygen
+
+    for k, rl, nsel in ((9, True, 2), (11, False, 0)):
+        d, c = device_chain(k, rl), chain(k, rl)
+        buf = io.BytesIO()
+        d["pk"].vk.write(buf)
+        assert len(buf.getvalue()) == keygen.vk_size(c["circ"].cs, k, nsel)
+        buf = io.BytesIO()
+        d["pk"].write(buf)
+        assert len(buf.getvalue()) == keygen.pk_size(c["circ"].cs, k, nsel, pkg.fields.BN254_FR)

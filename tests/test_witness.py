@@ -157,3 +157,103 @@ def test_device_proof_of_the_real_delay_enc_witness(pkg, po, co, ctx):
     assert tr.finalize() == want
     assert V.verify_proof(po.BN254, c["desc"], 16, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
     params.release()
+
+
+def test_mod_pow_rows_satisfy_the_constraint_system(pkg):
+    """benches/mod_pow.rs's RSACircuit (RSA region only, :63-110) on a small exponent: rows check out and x^e mod n is right."""
+    from dehalo2_amd import witness as W
+
+    v = rsa_vectors()[0]
+    n, x = int(v["n"]), int(v["signature"])
+    p = pkg.fields.BN254_FR.p
+    circ, info = W.mod_pow_witness(p, 14, n, 0b1, x, 1)
+    assert info.rsa_result == pow(x, 1, n) and info.total_rows == info.rsa_rows == circ.used_rows
+    assert W.check_rows(circ, p) == info.total_rows
+    assert len(circ.cs.lookups) == 5 and circ.cs.degree() == 5
+
+
+@pytest.mark.gpu
+def test_device_proof_of_the_real_mod_pow_witness(pkg, po, co, ctx):
+    """BASELINE configs[2]: benches/mod_pow.rs -- RSACircuit, BITS_LEN = 2048, EXP_LIMB_BITS = 5 (:47-49), K = 17 (:258),
+    create_proof at :201-209.  Real witness -> device proof == the CPU restatement's proof, byte for byte; verifier accepts."""
+    import pairing as pr
+    import plonk_oracle as PO
+    import verifier as V
+    from dehalo2_amd import keygen, prover, transcript, witness as W
+
+    v = rsa_vectors()[1]
+    n, x = int(v["n"]), int(v["signature"])
+    assert n.bit_length() == 2048
+    e = 0b10111                                                      # a 5-bit exponent (RandomBits(EXP_LIMB_BITS), :146)
+    k = 17
+    circ, info = W.mod_pow_witness(pkg.fields.BN254_FR.p, k, n, e, x, 5)
+    assert info.rsa_result == pow(x, e, n) and info.total_rows == info.rsa_rows
+    assert 30000 < info.rsa_rows < 50000                             # reference: 41,766 rows for a 5-bit exponent (benches/README.md:71)
+    c = _oracle_chain(po, co, circ, k, 16)
+    params = keygen.ParamsKZG(ctx, pkg.fields.BN254, k, c["srs"]["g"], c["srs"]["g_lagrange"])
+    pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
+    tr = transcript.Blake2bWrite(pkg.fields.BN254)
+    prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 16)
+    proof = tr.finalize()
+    assert len(proof) == 2848 and proof == want
+    assert V.verify_proof(po.BN254, c["desc"], k, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], proof)
+    params.release()
+
+
+@pytest.mark.gpu
+def test_batch_mode_provers_make_the_proofs_a_lone_prover_makes(pkg, po, co, ctx):
+    """BASELINE configs[4] on one GPU: four provers, each on its own context and host thread, sharing the SRS tables, the proving key
+    and the compiled programs (bench.py's batch mode).  Every proof must equal, byte for byte, the proof a single prover with a side
+    context makes alone from the same seed; one of them is also compared with the CPU restatement's and verified."""
+    import threading
+
+    import pairing as pr
+    import plonk_oracle as PO
+    import verifier as V
+    from dehalo2_amd import keygen, prover, transcript, witness as W
+
+    v = rsa_vectors()[0]
+    k = 14
+    circ, info = W.delay_enc_witness(pkg.fields.BN254_FR.p, k, int(v["n"]), 0b1, int(v["signature"]), 1, [11, 22])
+    c = _oracle_chain(po, co, circ, k, 16)
+    curve = pkg.fields.BN254
+    params = keygen.ParamsKZG(ctx, curve, k, c["srs"]["g"], c["srs"]["g_lagrange"])
+    pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
+    side = pkg.Context(0)
+    lone = prover.Prover(params, pk, ctx, side)
+    seeds = list(range(100, 124))
+    alone = {}
+    for sd in seeds:
+        tr = transcript.Blake2bWrite(curve)
+        lone.create_proof(c["adv"], [[]], prover.SeededRng(sd), tr)
+        alone[sd] = tr.finalize()
+    assert len(set(alone.values())) == len(seeds)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(seeds[3]), c["rep"], 16)
+    assert alone[seeds[3]] == want
+    ctxs = [pkg.Context(0) for _ in range(4)]
+    provers = [prover.Prover(params, pk, ctx=cx) for cx in ctxs]
+    got, errors = {}, []
+
+    def work(j):
+        try:
+            for sd in seeds[j::4]:
+                tr = transcript.Blake2bWrite(curve)
+                provers[j].create_proof(c["adv"], [[]], prover.SeededRng(sd), tr)
+                got[sd] = tr.finalize()
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    th = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    bad = [sd for sd in seeds if got.get(sd) != alone[sd]]
+    assert not bad, "batch-mode proofs differ from the lone prover's for seeds %r" % bad
+    assert V.verify_proof(po.BN254, c["desc"], k, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], got[seeds[-1]])
+    for cx in ctxs:
+        cx.close()
+    side.close()
+    params.release()

@@ -29,6 +29,12 @@ __global__ void k_stream16(const uint4* table, uint64_t n16, uint32_t* out) {
     out[i] = acc;
 }
 
+// read + write of the same bytes (16 B per lane, grid-stride): the copy ceiling SURVEY.md 8(d) asks to be recorded
+__global__ void k_copy16(const uint4* src, uint4* dst, uint64_t n16) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t j = i; j < n16; j += (uint64_t)gridDim.x * blockDim.x) dst[j] = src[j];
+}
+
 int main() {
     const uint32_t n = 1u << 24;                         // 16.8 M records = 1 GiB
     rec64* table; uint32_t *idx, *out;
@@ -44,6 +50,24 @@ int main() {
         k_stream16<<<4096, 256>>>((const uint4*)table, (uint64_t)n * 4, out);
     }
     hipDeviceSynchronize();
+    {   // durations (HIP events, best of 5): read-only stream and copy of 1 GiB -> profiles/copy_ceiling.json
+        rec64* dst; hipMalloc(&dst, (size_t)n * sizeof(rec64));
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        float best_s = 1e9f, best_c = 1e9f, best_g = 1e9f, ms;
+        for (int rep = 0; rep < 5; rep++) {
+            hipEventRecord(a); k_stream16<<<4096, 256>>>((const uint4*)table, (uint64_t)n * 4, out); hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b); if (ms < best_s) best_s = ms;
+            hipEventRecord(a); k_copy16<<<8192, 256>>>((const uint4*)table, (uint4*)dst, (uint64_t)n * 4); hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b); if (ms < best_c) best_c = ms;
+            hipEventRecord(a); k_gather64<<<n / 256, 256>>>(table, idx, n, out); hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b); if (ms < best_g) best_g = ms;
+        }
+        const double gib = (double)n * 64;
+        printf("{\"copy_ceiling\": {\"k_stream16_ms\": %.4f, \"k_stream16_read_GBps\": %.1f, \"k_copy16_ms\": %.4f, \"k_copy16_GBps_read_plus_write\": %.1f, "
+               "\"k_gather64_ms\": %.4f, \"k_gather64_GBps\": %.1f, \"bytes\": %.0f, \"note\": \"1 GiB table; HIP events, best of 5\"}}\n",
+               best_s, gib / best_s / 1e6, best_c, 2 * gib / best_c / 1e6, best_g, (double)n * 68 / best_g / 1e6, gib);
+        hipFree(dst);
+    }
     printf("k_gather64: logical read bytes per launch = %llu (table) + %llu (indices); written = %llu\n", (unsigned long long)n * 64, (unsigned long long)n * 4, (unsigned long long)n * 4);
     printf("k_stream16: logical read bytes per launch = %llu\n", (unsigned long long)n * 64);
     return 0;
