@@ -23,6 +23,12 @@ SYMBOLS = [
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device",
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
     "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device", "dehalo_kate_division_batch_device",
+    "dehalo_params_create", "dehalo_params_read", "dehalo_params_size", "dehalo_params_write", "dehalo_params_release", "dehalo_params_commit_device",
+    "dehalo_keygen", "dehalo_pk_read", "dehalo_pk_size", "dehalo_pk_write", "dehalo_vk_size", "dehalo_vk_write", "dehalo_pk_set_transcript_repr",
+    "dehalo_pk_get_transcript_repr", "dehalo_pk_info", "dehalo_pk_release", "dehalo_rng_scalars", "dehalo_field_info",
+    "dehalo_transcript_create", "dehalo_transcript_common_scalar", "dehalo_transcript_write_scalar", "dehalo_transcript_write_point",
+    "dehalo_transcript_squeeze_challenge", "dehalo_transcript_len", "dehalo_transcript_finalize", "dehalo_transcript_release",
+    "dehalo_prover_create", "dehalo_prover_release", "dehalo_create_proof", "dehalo_prover_last_timings", "dehalo_create_proofs",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_graph_evaluate_batch_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
@@ -55,6 +61,32 @@ class CLookupInputs(C.Structure):
     _fields_ = [("product_coset", C.c_void_p), ("permuted_input_coset", C.c_void_p), ("permuted_table_coset", C.c_void_p), ("table_value", C.c_void_p),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p), ("beta", C.c_void_p), ("gamma", C.c_void_p), ("y", C.c_void_p),
                 ("form_flags", C.c_uint32)]
+
+
+class CExprNode(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("rotation", C.c_int32)]
+
+
+class CColumnQuery(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("rotation", C.c_int32)]
+
+
+class CConstraintSystem(C.Structure):
+    _fields_ = [("num_advice", C.c_uint32), ("num_fixed", C.c_uint32), ("num_instance", C.c_uint32), ("minimum_degree", C.c_uint32),
+                ("nodes", C.POINTER(CExprNode)), ("num_nodes", C.c_uint32), ("constants", C.c_void_p), ("num_constants", C.c_uint32),
+                ("gates", C.POINTER(C.c_uint32)), ("num_gates", C.c_uint32), ("lookup_lens", C.POINTER(C.c_uint32)), ("num_lookups", C.c_uint32),
+                ("lookup_inputs", C.POINTER(C.c_uint32)), ("lookup_tables", C.POINTER(C.c_uint32)),
+                ("permutation_columns", C.POINTER(CColumnQuery)), ("num_permutation_columns", C.c_uint32),
+                ("advice_queries", C.POINTER(CColumnQuery)), ("num_advice_queries", C.c_uint32),
+                ("fixed_queries", C.POINTER(CColumnQuery)), ("num_fixed_queries", C.c_uint32),
+                ("instance_queries", C.POINTER(CColumnQuery)), ("num_instance_queries", C.c_uint32)]
+
+
+RNG_FILL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64)
+
+
+class CRng(C.Structure):
+    _fields_ = [("kind", C.c_int), ("pcg_state", C.c_uint64 * 2), ("pcg_inc", C.c_uint64 * 2), ("fill", RNG_FILL_FN), ("user", C.c_void_p)]
 
 
 class DehaloError(RuntimeError):
@@ -145,6 +177,43 @@ def load_library():
     lib.dehalo_permutation_h_device.argtypes = [P, C.c_int, C.POINTER(CPermInputs), u32, u32, u64p, P]
     lib.dehalo_lookup_h_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u64p, P]
     lib.dehalo_lookup_h_batch_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u32, u64p, P]
+    PP = C.POINTER(P)
+    lib.dehalo_params_create.argtypes = [P, C.c_int, u32, u64p, u64p, P, P, PP]
+    lib.dehalo_params_read.argtypes = [P, C.c_int, P, sz, PP]
+    lib.dehalo_params_size.argtypes = [P]
+    lib.dehalo_params_size.restype = sz
+    lib.dehalo_params_write.argtypes = [P, P, sz]
+    lib.dehalo_params_release.argtypes = [P, P]
+    lib.dehalo_params_commit_device.argtypes = [P, P, u64p, sz, C.c_int, u64p, P]
+    lib.dehalo_keygen.argtypes = [P, P, C.POINTER(CConstraintSystem), u64p, u64p, C.POINTER(C.c_void_p), u32, u32, PP]
+    lib.dehalo_pk_read.argtypes = [P, C.c_int, C.POINTER(CConstraintSystem), P, sz, u32, PP]
+    lib.dehalo_pk_size.argtypes = [P]
+    lib.dehalo_pk_size.restype = sz
+    lib.dehalo_pk_write.argtypes = [P, P, P, sz]
+    lib.dehalo_vk_size.argtypes = [P]
+    lib.dehalo_vk_size.restype = sz
+    lib.dehalo_vk_write.argtypes = [P, P, sz]
+    lib.dehalo_pk_set_transcript_repr.argtypes = [P, u64p]
+    lib.dehalo_pk_get_transcript_repr.argtypes = [P, u64p]
+    lib.dehalo_pk_info.argtypes = [P, C.POINTER(C.c_uint32)]
+    lib.dehalo_pk_release.argtypes = [P, P]
+    lib.dehalo_field_info.argtypes = [C.c_int, u64p]
+    lib.dehalo_rng_scalars.argtypes = [C.POINTER(CRng), C.c_int, C.c_uint64, u64p, sz]
+    lib.dehalo_transcript_create.argtypes = [C.c_int, PP]
+    lib.dehalo_transcript_common_scalar.argtypes = [P, u64p]
+    lib.dehalo_transcript_write_scalar.argtypes = [P, u64p]
+    lib.dehalo_transcript_write_point.argtypes = [P, u64p]
+    lib.dehalo_transcript_squeeze_challenge.argtypes = [P, u64p]
+    lib.dehalo_transcript_len.argtypes = [P]
+    lib.dehalo_transcript_len.restype = sz
+    lib.dehalo_transcript_finalize.argtypes = [P, P, sz]
+    lib.dehalo_transcript_release.argtypes = [P]
+    lib.dehalo_transcript_release.restype = None
+    lib.dehalo_prover_create.argtypes = [P, P, P, P, PP]
+    lib.dehalo_prover_release.argtypes = [P]
+    lib.dehalo_create_proof.argtypes = [P, u64p, C.POINTER(C.c_void_p), C.POINTER(sz), u32, C.POINTER(CRng), P, u32]
+    lib.dehalo_prover_last_timings.argtypes = [P, C.POINTER(C.c_double)]
+    lib.dehalo_create_proofs.argtypes = [C.POINTER(C.c_void_p), u32, C.POINTER(C.c_void_p), u32, C.POINTER(CRng), u32, C.POINTER(C.c_void_p), sz, C.POINTER(sz)]
     lib.dehalo_timing_enable.argtypes = [P, C.c_int]
     lib.dehalo_timing_reset.argtypes = [P]
     lib.dehalo_timing_get.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

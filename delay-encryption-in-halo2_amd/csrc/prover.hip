@@ -1,0 +1,1276 @@
+// prover.hip -- the whole call behind the C ABI: ParamsKZG, keygen_vk / keygen_pk, ProvingKey / VerifyingKey RawBytes, Blake2bWrite and
+// create_proof (KZG / GWC) [UPSTREAM halo2_proofs @ v2023_04_20: poly/kzg/commitment.rs, plonk/keygen.rs, plonk.rs, transcript.rs,
+// plonk/prover.rs, plonk/{lookup,permutation,vanishing}/prover.rs, poly/kzg/multiopen/gwc/prover.rs] -- the calls the reference makes at
+// benches/delay_enc.rs:41-54 (params), :84-115 (keys), :120-134 (create_proof into a Blake2bWrite transcript).
+//
+// Host logic only: it orders the phases, hashes the transcript and does O(1) field arithmetic per challenge (hostfield.hpp); every column
+// operation is one of this library's device entry points (include/dehalo.h), called directly.  No CPU path for column work exists.
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <memory>
+#include <thread>
+
+#include "blake2b.hpp"
+#include "hostrng.hpp"
+#include "internal.hpp"
+#include "plonk_host.hpp"
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+// ---- device memory owned by an object of this file ----
+struct DevMem {
+    fe* p = nullptr;
+    size_t elems = 0;
+    DevMem() = default;
+    DevMem(const DevMem&) = delete;
+    DevMem& operator=(const DevMem&) = delete;
+    ~DevMem() { reset(); }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        elems = 0;
+    }
+    int alloc(dehalo_ctx* ctx, size_t n_elems, bool zero = true) {
+        reset();
+        if (!n_elems) return 0;
+        HIP_TRY(ctx, hipMalloc((void**)&p, n_elems * sizeof(fe)));
+        elems = n_elems;
+        if (zero) HIP_TRY(ctx, hipMemsetAsync(p, 0, n_elems * sizeof(fe), ctx->stream));
+        return 0;
+    }
+    fe* at(size_t elem) const { return p + elem; }
+    uint64_t* u64(size_t elem = 0) const { return (uint64_t*)(p + elem); }
+};
+
+__global__ void k_gather_elems(const fe* __restrict__ src, const uint64_t* __restrict__ idx, fe* __restrict__ dst, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[idx[i]];
+}
+
+void put_u32_be(std::vector<uint8_t>& o, uint32_t v) { for (int i = 3; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i))); }
+void put_u32_be(uint8_t* o, uint32_t v) { for (int i = 0; i < 4; i++) o[i] = (uint8_t)(v >> (8 * (3 - i))); }
+uint32_t get_u32_be(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+}   // namespace
+
+// ================================================================================================ ParamsKZG
+struct dehalo_params {
+    dehalo_ctx* ctx = nullptr;
+    int curve = 0;
+    uint32_t k = 0;
+    size_t n = 0;
+    std::vector<uint64_t> g, g_lagrange;      // host copies (write())
+    uint8_t g2[128] = {}, s_g2[128] = {};
+    dehalo_bases *bases_g = nullptr, *bases_gl = nullptr;
+};
+
+extern "C" int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, const uint8_t* g2, const uint8_t* s_g2,
+                                    dehalo_params** out) {
+    if (!ctx || !out || !g || !g_lagrange) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_create: null argument");
+    if (k > 28 || curve_scalar_field(curve) < 0) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_create: k or curve out of range");
+    std::unique_ptr<dehalo_params> p(new dehalo_params);
+    p->ctx = ctx; p->curve = curve; p->k = k; p->n = (size_t)1 << k;
+    p->g.assign(g, g + 8 * p->n);
+    p->g_lagrange.assign(g_lagrange, g_lagrange + 8 * p->n);
+    if (g2) memcpy(p->g2, g2, 128);
+    if (s_g2) memcpy(p->s_g2, s_g2, 128);
+    TRY(dehalo_bases_register(ctx, curve, g, p->n, 64, 0, 1, &p->bases_g));
+    const int rc = dehalo_bases_register(ctx, curve, g_lagrange, p->n, 64, 0, 1, &p->bases_gl);
+    if (rc) {
+        (void)dehalo_bases_release(ctx, p->bases_g);
+        return rc;
+    }
+    *out = p.release();
+    return 0;
+}
+
+extern "C" int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out) {
+    if (!ctx || !bytes || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: null argument");
+    if (len < 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: unexpected end of input");
+    const uint32_t k = (uint32_t)bytes[0] | ((uint32_t)bytes[1] << 8) | ((uint32_t)bytes[2] << 16) | ((uint32_t)bytes[3] << 24);      // u32 LE
+    if (k > 28) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: k out of range");
+    const size_t n = (size_t)1 << k;
+    if (len != 4 + 2 * 64 * n + 256) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: length does not match k");
+    // (the points are 8-byte aligned only if the caller's buffer is: copy through aligned vectors)
+    std::vector<uint64_t> g(8 * n), gl(8 * n);
+    memcpy(g.data(), bytes + 4, 64 * n);
+    memcpy(gl.data(), bytes + 4 + 64 * n, 64 * n);
+    return dehalo_params_create(ctx, curve, k, g.data(), gl.data(), bytes + 4 + 128 * n, bytes + 4 + 128 * n + 128, out);
+}
+
+extern "C" size_t dehalo_params_size(const dehalo_params* p) { return p ? 4 + 2 * 64 * p->n + 256 : 0; }
+
+extern "C" int dehalo_params_write(const dehalo_params* p, uint8_t* out, size_t cap) {
+    if (!p || !out) return DEHALO_ERR_INVALID;
+    if (cap < dehalo_params_size(p)) return dh_fail(p->ctx, DEHALO_ERR_INVALID, "params_write: buffer too small");
+    for (int i = 0; i < 4; i++) out[i] = (uint8_t)(p->k >> (8 * i));
+    memcpy(out + 4, p->g.data(), 64 * p->n);
+    memcpy(out + 4 + 64 * p->n, p->g_lagrange.data(), 64 * p->n);
+    memcpy(out + 4 + 128 * p->n, p->g2, 128);
+    memcpy(out + 4 + 128 * p->n + 128, p->s_g2, 128);
+    return 0;
+}
+
+extern "C" int dehalo_params_release(dehalo_ctx* ctx, dehalo_params* p) {
+    if (!p) return 0;
+    if (p->bases_g) (void)dehalo_bases_release(ctx ? ctx : p->ctx, p->bases_g);
+    if (p->bases_gl) (void)dehalo_bases_release(ctx ? ctx : p->ctx, p->bases_gl);
+    delete p;
+    return 0;
+}
+
+extern "C" int dehalo_params_commit_device(dehalo_ctx* ctx, const dehalo_params* p, const uint64_t* d_polys, size_t batch, int lagrange, uint64_t* d_out_affine,
+                                           void* stream) {
+    if (!ctx || !p) return DEHALO_ERR_INVALID;
+    return dehalo_msm_device_affine(ctx, lagrange ? p->bases_gl : p->bases_g, d_polys, p->n, batch, nullptr, d_out_affine, stream);
+}
+
+// ================================================================================================ transcript
+struct dehalo_transcript {
+    int curve = 0;
+    const HostField *fq = nullptr, *fr = nullptr;      // base field (coordinates), scalar field (challenges)
+    Blake2b state;
+    std::vector<uint8_t> proof;
+
+    void init(int c) {
+        curve = c;
+        fq = host_field(curve_base_field(c));
+        fr = host_field(curve_scalar_field(c));
+        state.init(64, "Halo2-Transcript");
+        proof.clear();
+    }
+    Fe squeeze() {      // Challenge255: Blake2b-512 over everything absorbed + the prefix byte 0 (which stays absorbed), reduced mod r
+        const uint8_t z = 0;
+        state.update(&z, 1);
+        uint8_t d[64];
+        state.digest(d);
+        return fr->from_u512(d);
+    }
+    void common_scalar(const Fe& s) {
+        uint8_t b[33];
+        b[0] = 2;
+        fr->to_bytes(s, b + 1);
+        state.update(b, 33);
+    }
+    void write_scalar(const Fe& s) {
+        uint8_t b[33];
+        b[0] = 2;
+        fr->to_bytes(s, b + 1);
+        state.update(b, 33);
+        proof.insert(proof.end(), b + 1, b + 33);
+    }
+    // affine {x, y} Montgomery; false for the identity (upstream: "cannot write points at infinity to the transcript")
+    bool write_point(const uint64_t xy[8], bool also_to_proof = true) {
+        Fe x, y;
+        memcpy(x.v, xy, 32);
+        memcpy(y.v, xy + 4, 32);
+        if (x.is_zero() && y.is_zero()) return false;
+        uint8_t b[65];
+        b[0] = 1;
+        fq->to_bytes(x, b + 1);
+        fq->to_bytes(y, b + 33);
+        state.update(b, 65);
+        if (also_to_proof) {      // GroupEncoding: x little-endian, bit 7 of the last byte = y is odd
+            uint8_t c[32];
+            memcpy(c, b + 1, 32);
+            c[31] |= (uint8_t)((b[33] & 1) << 7);
+            proof.insert(proof.end(), c, c + 32);
+        }
+        return true;
+    }
+};
+
+extern "C" int dehalo_transcript_create(int curve, dehalo_transcript** out) {
+    if (!out || curve_scalar_field(curve) < 0) return DEHALO_ERR_INVALID;
+    dehalo_transcript* t = new dehalo_transcript;
+    t->init(curve);
+    *out = t;
+    return 0;
+}
+extern "C" int dehalo_transcript_common_scalar(dehalo_transcript* t, const uint64_t s[4]) {
+    if (!t || !s) return DEHALO_ERR_INVALID;
+    Fe v;
+    memcpy(v.v, s, 32);
+    t->common_scalar(v);
+    return 0;
+}
+extern "C" int dehalo_transcript_write_scalar(dehalo_transcript* t, const uint64_t s[4]) {
+    if (!t || !s) return DEHALO_ERR_INVALID;
+    Fe v;
+    memcpy(v.v, s, 32);
+    t->write_scalar(v);
+    return 0;
+}
+extern "C" int dehalo_transcript_write_point(dehalo_transcript* t, const uint64_t xy[8]) {
+    if (!t || !xy) return DEHALO_ERR_INVALID;
+    return t->write_point(xy) ? 0 : DEHALO_ERR_INVALID;
+}
+extern "C" int dehalo_transcript_squeeze_challenge(dehalo_transcript* t, uint64_t out[4]) {
+    if (!t || !out) return DEHALO_ERR_INVALID;
+    const Fe c = t->squeeze();
+    memcpy(out, c.v, 32);
+    return 0;
+}
+extern "C" size_t dehalo_transcript_len(const dehalo_transcript* t) { return t ? t->proof.size() : 0; }
+extern "C" int dehalo_transcript_finalize(const dehalo_transcript* t, uint8_t* out, size_t cap) {
+    if (!t || (!out && !t->proof.empty())) return DEHALO_ERR_INVALID;
+    if (cap < t->proof.size()) return DEHALO_ERR_INVALID;
+    if (!t->proof.empty()) memcpy(out, t->proof.data(), t->proof.size());
+    return 0;
+}
+extern "C" void dehalo_transcript_release(dehalo_transcript* t) { delete t; }
+
+extern "C" int dehalo_field_info(int field, uint64_t out[24]) {
+    const HostField* f = host_field(field);
+    if (!f || !out) return DEHALO_ERR_INVALID;
+    memcpy(out, f->p, 32);
+    memcpy(out + 4, f->one.v, 32);
+    memcpy(out + 8, f->root_of_unity.v, 32);
+    memcpy(out + 12, f->zeta.v, 32);
+    memcpy(out + 16, f->delta.v, 32);
+    memcpy(out + 20, f->gen.v, 32);
+    return 0;
+}
+
+extern "C" int dehalo_rng_scalars(dehalo_rng* rng, int field, uint64_t skip, uint64_t* out, size_t count) {
+    const HostField* f = host_field(field);
+    if (!f || (!out && count)) return DEHALO_ERR_INVALID;
+    HostRng r;
+    TRY(r.init(rng, f));
+    r.skip(skip);
+    return r.scalars(out, count);
+}
+
+// ================================================================================================ keys
+struct dehalo_pk {
+    dehalo_ctx* ctx = nullptr;
+    int curve = 0;
+    const HostField* f = nullptr;
+    HostCS cs;
+    HostDomain dom;
+    uint32_t k = 0, num_selectors = 0;
+    std::vector<uint64_t> fixed_commitments, perm_commitments;      // Montgomery affine, 8 u64 each
+    std::vector<std::vector<uint8_t>> selectors;                    // packed 8 bools per byte, LSB first
+    Fe transcript_repr{};
+    // device: values / polys in upstream's standard form, extended-domain columns in the kernels' internal form
+    DevMem l_ext, fixed_values, fixed_polys, fixed_cosets, perm_values, perm_polys, perm_cosets;
+    dehalo_graph* custom_gates = nullptr;
+    std::vector<dehalo_graph*> lookup_graphs;
+    std::vector<std::pair<dehalo_graph*, dehalo_graph*>> compress_graphs;
+
+    ~dehalo_pk() {
+        if (custom_gates) (void)dehalo_graph_release(ctx, custom_gates);
+        for (auto* g : lookup_graphs) (void)dehalo_graph_release(ctx, g);
+        for (auto& g : compress_graphs) {
+            (void)dehalo_graph_release(ctx, g.first);
+            (void)dehalo_graph_release(ctx, g.second);
+        }
+    }
+    size_t vk_size() const { return 8 + 64 * (size_t)cs.num_fixed + 64 * cs.perm_cols.size() + (size_t)num_selectors * ((dom.n + 7) / 8); }
+    void vk_write(uint8_t* o) const {
+        put_u32_be(o, k);
+        put_u32_be(o + 4, cs.num_fixed);
+        o += 8;
+        memcpy(o, fixed_commitments.data(), 64 * (size_t)cs.num_fixed);
+        o += 64 * (size_t)cs.num_fixed;
+        memcpy(o, perm_commitments.data(), 64 * cs.perm_cols.size());
+        o += 64 * cs.perm_cols.size();
+        for (auto& s : selectors) {
+            memcpy(o, s.data(), s.size());
+            o += s.size();
+        }
+    }
+    size_t size() const {
+        const size_t n = dom.n, m = dom.m, nf = cs.num_fixed, npc = cs.perm_cols.size();
+        auto poly = [](size_t ln) { return 4 + 32 * ln; };
+        auto sl = [&](size_t cnt, size_t ln) { return 4 + cnt * poly(ln); };
+        return vk_size() + 3 * poly(m) + 2 * sl(nf, n) + sl(nf, m) + 2 * sl(npc, n) + sl(npc, m);
+    }
+    void default_transcript_repr() {
+        std::vector<uint8_t> body(vk_size());
+        vk_write(body.data());
+        cs.encode(body);
+        Blake2b h;
+        h.init(64, "Halo2-Verify-Key");
+        const uint64_t len = body.size();
+        h.update(&len, 8);
+        h.update(body.data(), body.size());
+        uint8_t d[64];
+        h.digest(d);
+        transcript_repr = f->from_u512(d);
+    }
+    int compile_graphs() {
+        TRY(custom_gates_graph(cs, f).compile(ctx, &custom_gates));
+        for (auto& lk : cs.lookups) {
+            dehalo_graph *g = nullptr, *gi = nullptr, *gt = nullptr;
+            TRY(lookup_table_value_graph(cs, lk, f).compile(ctx, &g));
+            lookup_graphs.push_back(g);
+            TRY(compress_graph(cs, lk.inputs, f).compile(ctx, &gi));
+            const int rc = compress_graph(cs, lk.tables, f).compile(ctx, &gt);
+            compress_graphs.push_back({gi, gt});
+            if (rc) return rc;
+        }
+        return 0;
+    }
+};
+
+namespace {
+
+int pk_common_init(dehalo_ctx* ctx, int curve, const dehalo_constraint_system* csd, uint32_t k, dehalo_pk* pk) {
+    pk->ctx = ctx;
+    pk->curve = curve;
+    pk->k = k;
+    pk->f = host_field(curve_scalar_field(curve));
+    if (!pk->f) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown curve");
+    const std::string err = pk->cs.load(csd);
+    if (!err.empty()) return dh_fail(ctx, DEHALO_ERR_INVALID, err);
+    if (k > 28 || !pk->dom.init(pk->f, pk->cs.degree(), k)) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "extended_k exceeds the field's two-adicity");
+    if (pk->dom.n < (size_t)pk->cs.blinding_factors() + 3) return dh_fail(ctx, DEHALO_ERR_INVALID, "not enough rows available");      // Error::NotEnoughRowsAvailable
+    return 0;
+}
+
+// values (cnt x n, standard form, device) -> polys (lagrange_to_coeff), cosets (coeff_to_extended, internal form), commitments to the host
+int lagrange_to_all(dehalo_pk* pk, const dehalo_params* params, const fe* values, size_t cnt, fe* polys, fe* cosets, uint64_t* commitments_host) {
+    dehalo_ctx* ctx = pk->ctx;
+    if (!cnt) return 0;
+    const HostDomain& d = pk->dom;
+    DevMem aff;
+    if (commitments_host) {
+        TRY(aff.alloc(ctx, 2 * cnt, false));
+        TRY(dehalo_msm_device_affine(ctx, params->bases_gl, (const uint64_t*)values, d.n, cnt, nullptr, aff.u64(), nullptr));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(polys, values, cnt * d.n * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+    TRY(dehalo_intt_scaled_device(ctx, pk->f->id, (uint64_t*)polys, d.k, d.omega_inv.v, d.ifft_divisor.v, cnt, nullptr));
+    TRY(dehalo_coset_ntt_form_device(ctx, pk->f->id, (const uint64_t*)polys, d.k, (uint64_t*)cosets, d.extended_k, d.ext_omega.v, d.g_coset.v, cnt, DEHALO_FORM_OUT_INTERNAL,
+                                     nullptr));
+    if (commitments_host) TRY(dehalo_download(ctx, aff.p, cnt * 64, commitments_host));
+    else TRY(dehalo_ctx_synchronize(ctx));
+    return 0;
+}
+
+// (n, 4) device column of omega^i: the forward NTT of the unit vector e_1
+int omega_powers(dehalo_ctx* ctx, const HostDomain& d, fe* col) {
+    HIP_TRY(ctx, hipMemsetAsync(col, 0, d.n * sizeof(fe), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(col + (d.n > 1 ? 1 : 0), d.f->one.v, 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (the source is a host object: copied before returning)
+    if (d.n > 1) TRY(dehalo_ntt_device(ctx, d.f->id, (uint64_t*)col, d.k, d.omega.v, 1, nullptr));
+    return 0;
+}
+
+}   // namespace
+
+extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const dehalo_constraint_system* csd, const uint64_t* fixed, const uint64_t* mapping,
+                             const uint8_t* const* selectors, uint32_t num_selectors, uint32_t flags, dehalo_pk** out) {
+    if (!ctx || !params || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "keygen: null argument");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    std::unique_ptr<dehalo_pk> pk(new dehalo_pk);
+    TRY(pk_common_init(ctx, params->curve, csd, params->k, pk.get()));
+    const HostCS& cs = pk->cs;
+    const HostDomain& d = pk->dom;
+    const size_t n = d.n, m = d.m, nf = cs.num_fixed, npc = cs.perm_cols.size();
+    if ((nf && !fixed) || (npc && !mapping) || (num_selectors && !selectors)) return dh_fail(ctx, DEHALO_ERR_INVALID, "keygen: null column data");
+    const int fid = pk->f->id;
+    // fixed columns
+    TRY(pk->fixed_values.alloc(ctx, nf * n, false));
+    TRY(pk->fixed_polys.alloc(ctx, nf * n, false));
+    TRY(pk->fixed_cosets.alloc(ctx, nf * m, false));
+    pk->fixed_commitments.assign(8 * nf, 0);
+    if (nf) {
+        HIP_TRY(ctx, hipMemcpyAsync(pk->fixed_values.p, fixed, nf * n * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (flags & DEHALO_KEYGEN_FIXED_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, pk->fixed_values.u64(), nullptr, pk->fixed_values.u64(), nf * n, nullptr));
+        TRY(lagrange_to_all(pk.get(), params, pk->fixed_values.p, nf, pk->fixed_polys.p, pk->fixed_cosets.p, pk->fixed_commitments.data()));
+    }
+    // permutation: sigma_j(omega^i) = delta^(column of the mapped cell) * omega^(its row)  [permutation::keygen::Assembly::build_pk]
+    TRY(pk->perm_values.alloc(ctx, npc * n, false));
+    TRY(pk->perm_polys.alloc(ctx, npc * n, false));
+    TRY(pk->perm_cosets.alloc(ctx, npc * m, false));
+    pk->perm_commitments.assign(8 * npc, 0);
+    if (npc) {
+        for (size_t i = 0; i < npc * n; i++)
+            if (mapping[i] >= npc * n) return dh_fail(ctx, DEHALO_ERR_INVALID, "keygen: permutation mapping points outside the permutation's columns");
+        DevMem ident, w;
+        uint64_t* d_map = nullptr;
+        TRY(ident.alloc(ctx, npc * n, false));
+        TRY(w.alloc(ctx, n, false));
+        TRY(omega_powers(ctx, d, w.p));
+        Fe dj = pk->f->one;
+        for (size_t j = 0; j < npc; j++) {
+            HIP_TRY(ctx, hipMemcpyAsync(ident.at(j * n), w.p, n * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+            if (j) TRY(dehalo_scale_device(ctx, fid, ident.u64(j * n), n, dj.v, 1, nullptr, nullptr));
+            dj = pk->f->mul(dj, pk->f->delta);
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&d_map, npc * n * 8));
+        hipError_t e = hipMemcpyAsync(d_map, mapping, npc * n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            k_gather_elems<<<(unsigned)((npc * n + 255) / 256), 256, 0, ctx->stream>>>(ident.p, d_map, pk->perm_values.p, npc * n);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        (void)hipFree(d_map);
+        HIP_TRY(ctx, e);
+        TRY(lagrange_to_all(pk.get(), params, pk->perm_values.p, npc, pk->perm_polys.p, pk->perm_cosets.p, pk->perm_commitments.data()));
+    }
+    // l0, l_last, l_active_row = 1 - (l_last + l_blind) over the extended domain
+    {
+        const size_t u = n - (cs.blinding_factors() + 1);
+        std::vector<Fe> lag(3 * n, Fe{{0, 0, 0, 0}});
+        lag[0] = pk->f->one;
+        lag[n + u] = pk->f->one;
+        for (size_t i = 0; i < u; i++) lag[2 * n + i] = pk->f->one;
+        DevMem vals, polys;
+        TRY(vals.alloc(ctx, 3 * n, false));
+        TRY(polys.alloc(ctx, 3 * n, false));
+        TRY(pk->l_ext.alloc(ctx, 3 * m, false));
+        HIP_TRY(ctx, hipMemcpyAsync(vals.p, lag.data(), 3 * n * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        TRY(lagrange_to_all(pk.get(), params, vals.p, 3, polys.p, pk->l_ext.p, nullptr));
+    }
+    pk->num_selectors = num_selectors;
+    for (uint32_t s = 0; s < num_selectors; s++) {
+        if (!selectors[s]) return dh_fail(ctx, DEHALO_ERR_INVALID, "keygen: null selector");
+        std::vector<uint8_t> packed((n + 7) / 8, 0);
+        for (size_t i = 0; i < n; i++)
+            if (selectors[s][i]) packed[i >> 3] |= (uint8_t)(1u << (i & 7));
+        pk->selectors.push_back(std::move(packed));
+    }
+    pk->default_transcript_repr();
+    TRY(pk->compile_graphs());
+    TRY(dehalo_ctx_synchronize(ctx));
+    *out = pk.release();
+    return 0;
+}
+
+extern "C" size_t dehalo_pk_size(const dehalo_pk* pk) { return pk ? pk->size() : 0; }
+extern "C" size_t dehalo_vk_size(const dehalo_pk* pk) { return pk ? pk->vk_size() : 0; }
+extern "C" int dehalo_vk_write(const dehalo_pk* pk, uint8_t* out, size_t cap) {
+    if (!pk || !out) return DEHALO_ERR_INVALID;
+    if (cap < pk->vk_size()) return dh_fail(pk->ctx, DEHALO_ERR_INVALID, "vk_write: buffer too small");
+    pk->vk_write(out);
+    return 0;
+}
+
+extern "C" int dehalo_pk_write(dehalo_ctx* ctx, const dehalo_pk* pk, uint8_t* out, size_t cap) {
+    if (!pk || !out) return DEHALO_ERR_INVALID;
+    if (!ctx) ctx = pk->ctx;
+    if (cap < pk->size()) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_write: buffer too small");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    const size_t n = pk->dom.n, m = pk->dom.m, nf = pk->cs.num_fixed, npc = pk->cs.perm_cols.size();
+    pk->vk_write(out);
+    uint8_t* o = out + pk->vk_size();
+    DevMem tmp;      // extended-domain columns leave in upstream's standard form
+    TRY(tmp.alloc(ctx, m, false));
+    auto poly = [&](const fe* src, size_t len, bool internal) -> int {
+        put_u32_be(o, (uint32_t)len);
+        o += 4;
+        if (internal) {
+            TRY(dehalo_convert_form_device(ctx, pk->f->id, (const uint64_t*)src, tmp.u64(), len, 0, nullptr));
+            src = tmp.p;
+        }
+        TRY(dehalo_download(ctx, src, len * 32, o));
+        o += len * 32;
+        return 0;
+    };
+    auto slice = [&](const DevMem& mem, size_t cnt, size_t len, bool internal) -> int {
+        put_u32_be(o, (uint32_t)cnt);
+        o += 4;
+        for (size_t i = 0; i < cnt; i++) TRY(poly(mem.at(i * len), len, internal));
+        return 0;
+    };
+    for (int i = 0; i < 3; i++) TRY(poly(pk->l_ext.at((size_t)i * m), m, true));
+    TRY(slice(pk->fixed_values, nf, n, false));
+    TRY(slice(pk->fixed_polys, nf, n, false));
+    TRY(slice(pk->fixed_cosets, nf, m, true));
+    TRY(slice(pk->perm_values, npc, n, false));
+    TRY(slice(pk->perm_polys, npc, n, false));
+    TRY(slice(pk->perm_cosets, npc, m, true));
+    return 0;
+}
+
+extern "C" int dehalo_pk_read(dehalo_ctx* ctx, int curve, const dehalo_constraint_system* csd, const uint8_t* bytes, size_t len, uint32_t num_selectors, dehalo_pk** out) {
+    if (!ctx || !bytes || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: null argument");
+    if (len < 8) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: unexpected end of input");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    const uint32_t k = get_u32_be(bytes), nf_file = get_u32_be(bytes + 4);
+    std::unique_ptr<dehalo_pk> pk(new dehalo_pk);
+    TRY(pk_common_init(ctx, curve, csd, k, pk.get()));
+    const size_t n = pk->dom.n, m = pk->dom.m, nf = pk->cs.num_fixed, npc = pk->cs.perm_cols.size();
+    if (nf_file != nf) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: the key's number of fixed commitments differs from the circuit's fixed columns");
+    pk->num_selectors = num_selectors;
+    if (len != pk->size()) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: length does not match the circuit (unexpected end of input or trailing bytes)");
+    const uint8_t* p = bytes + 8;
+    pk->fixed_commitments.resize(8 * nf);
+    memcpy(pk->fixed_commitments.data(), p, 64 * nf);
+    p += 64 * nf;
+    pk->perm_commitments.resize(8 * npc);
+    memcpy(pk->perm_commitments.data(), p, 64 * npc);
+    p += 64 * npc;
+    for (uint32_t s = 0; s < num_selectors; s++) {
+        pk->selectors.emplace_back(p, p + (n + 7) / 8);
+        p += (n + 7) / 8;
+    }
+    const int fid = pk->f->id;
+    auto poly = [&](fe* dst, size_t want, bool to_internal) -> int {
+        if (get_u32_be(p) != want) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: polynomial length differs from the domain's");
+        p += 4;
+        HIP_TRY(ctx, hipMemcpyAsync(dst, p, want * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        p += want * 32;
+        if (to_internal) TRY(dehalo_convert_form_device(ctx, fid, (const uint64_t*)dst, (uint64_t*)dst, want, 1, nullptr));
+        return 0;
+    };
+    auto slice = [&](DevMem& mem, size_t cnt, size_t ln, bool to_internal) -> int {
+        if (get_u32_be(p) != cnt) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: polynomial count differs from the circuit's");
+        p += 4;
+        TRY(mem.alloc(ctx, cnt * ln, false));
+        for (size_t i = 0; i < cnt; i++) TRY(poly(mem.at(i * ln), ln, to_internal));
+        return 0;
+    };
+    TRY(pk->l_ext.alloc(ctx, 3 * m, false));
+    for (int i = 0; i < 3; i++) TRY(poly(pk->l_ext.at((size_t)i * m), m, true));
+    TRY(slice(pk->fixed_values, nf, n, false));
+    TRY(slice(pk->fixed_polys, nf, n, false));
+    TRY(slice(pk->fixed_cosets, nf, m, true));
+    TRY(slice(pk->perm_values, npc, n, false));
+    TRY(slice(pk->perm_polys, npc, n, false));
+    TRY(slice(pk->perm_cosets, npc, m, true));
+    pk->default_transcript_repr();
+    TRY(pk->compile_graphs());
+    TRY(dehalo_ctx_synchronize(ctx));
+    *out = pk.release();
+    return 0;
+}
+
+extern "C" int dehalo_pk_set_transcript_repr(dehalo_pk* pk, const uint64_t repr[4]) {
+    if (!pk || !repr) return DEHALO_ERR_INVALID;
+    memcpy(pk->transcript_repr.v, repr, 32);
+    return 0;
+}
+extern "C" int dehalo_pk_get_transcript_repr(const dehalo_pk* pk, uint64_t repr[4]) {
+    if (!pk || !repr) return DEHALO_ERR_INVALID;
+    memcpy(repr, pk->transcript_repr.v, 32);
+    return 0;
+}
+extern "C" int dehalo_pk_release(dehalo_ctx* ctx, dehalo_pk* pk) {
+    if (!pk) return 0;
+    dehalo_ctx* c = ctx ? ctx : pk->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    delete pk;
+    return 0;
+}
+
+// ================================================================================================ create_proof
+struct dehalo_prover {
+    dehalo_ctx *ctx = nullptr, *side = nullptr;
+    const dehalo_params* params = nullptr;
+    const dehalo_pk* pk = nullptr;
+    const HostField* f = nullptr;
+    size_t n = 0, m = 0, u = 0;
+    uint32_t k = 0, ek = 0, bf = 0, A = 0, L = 0, S = 0, I = 0, NC = 0, pieces = 0;
+    uint32_t o_adv = 0, o_perm = 0, o_pz = 0, o_lz = 0, o_rand = 0;
+    DevMem cols, polys_own, instance, instance_values, compressed, num, den, ext, h, table_value, hfold, qbuf, wbuf, aff, aff_side, evals, blind_dev, omega_col;
+    fe* polys = nullptr;      // coefficient forms: polys_own with a side context, cols (in place) without
+    std::vector<std::pair<dehalo_graph*, dehalo_graph*>> perm_graphs;      // per set: (denominator, numerator)
+    dehalo_graph *lookup_den = nullptr, *lookup_num = nullptr;
+    hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_inst = nullptr, ev_side = nullptr;      // ev_ready: one per commitment phase
+    // opening plan (depends on the circuit only)
+    std::vector<int32_t> rots;
+    std::vector<const uint64_t*> plist;
+    std::vector<int64_t> write_idx;
+    struct Group { int32_t rot; std::vector<const uint64_t*> ptrs; std::vector<int64_t> idx; };
+    std::vector<Group> groups;
+    std::vector<const uint64_t*> hp_ptrs;
+    size_t hpiece0 = 0, eval_count = 0;
+    // host staging
+    std::vector<uint64_t> blind_host, host_aff, host_evals, rand_host;
+    double timings[8] = {};
+    std::mutex mu;      // one create_proof at a time per prover
+
+    ~dehalo_prover() {
+        for (auto& g : perm_graphs) {
+            if (g.first) (void)dehalo_graph_release(ctx, g.first);
+            if (g.second) (void)dehalo_graph_release(ctx, g.second);
+        }
+        if (lookup_den) (void)dehalo_graph_release(ctx, lookup_den);
+        if (lookup_num) (void)dehalo_graph_release(ctx, lookup_num);
+        for (hipEvent_t e : {ev_ready[0], ev_ready[1], ev_ready[2], ev_inst, ev_side})
+            if (e) (void)hipEventDestroy(e);
+    }
+
+    const uint64_t* col_ptr(const DevMem& mem, size_t col, size_t len) const { return (const uint64_t*)mem.at(col * len); }
+
+    int build_product_graphs() {
+        const HostCS& cs = pk->cs;
+        const uint32_t chunk = cs.chunk_len(), nf = cs.num_fixed, npc = (uint32_t)cs.perm_cols.size();
+        auto kind = [](uint32_t k) { return k == DEHALO_COLUMN_ADVICE ? DEHALO_SRC_ADVICE : k == DEHALO_COLUMN_FIXED ? DEHALO_SRC_FIXED : DEHALO_SRC_INSTANCE; };
+        // fixed slots: [circuit fixed..., sigma_0.., omega column]; challenges: delta^j * beta per permutation column
+        for (uint32_t s = 0; s < S; s++) {
+            GraphBuilder gd(f), gn(f);
+            GSrc dacc{}, nacc{};
+            bool first = true;
+            for (uint32_t j = s * chunk; j < std::min((s + 1) * chunk, npc); j++) {
+                const auto& pc = cs.perm_cols[j];
+                GSrc col = gd.column(kind(pc.kind), pc.index);
+                GSrc t = gd.add_calc(DEHALO_CALC_MUL, GSrc{DEHALO_SRC_BETA, 0, 0}, gd.column(DEHALO_SRC_FIXED, nf + j));
+                t = gd.add_calc(DEHALO_CALC_ADD, gd.add_calc(DEHALO_CALC_ADD, col, t), GSrc{DEHALO_SRC_GAMMA, 0, 0});
+                dacc = first ? t : gd.add_calc(DEHALO_CALC_MUL, dacc, t);
+                col = gn.column(kind(pc.kind), pc.index);
+                t = gn.add_calc(DEHALO_CALC_MUL, GSrc{DEHALO_SRC_CHALLENGE, j, 0}, gn.column(DEHALO_SRC_FIXED, nf + npc));
+                t = gn.add_calc(DEHALO_CALC_ADD, gn.add_calc(DEHALO_CALC_ADD, col, t), GSrc{DEHALO_SRC_GAMMA, 0, 0});
+                nacc = first ? t : gn.add_calc(DEHALO_CALC_MUL, nacc, t);
+                first = false;
+            }
+            gd.add_calc(DEHALO_CALC_STORE, dacc);
+            gn.add_calc(DEHALO_CALC_STORE, nacc);
+            dehalo_graph *d = nullptr, *nn = nullptr;
+            TRY(gd.compile(ctx, &d));
+            const int rc = gn.compile(ctx, &nn);
+            perm_graphs.push_back({d, nn});
+            if (rc) return rc;
+        }
+        // advice slots: [compressed_input, compressed_table, permuted_input, permuted_table]
+        GraphBuilder gd(f), gn(f);
+        gd.add_calc(DEHALO_CALC_MUL, gd.add_calc(DEHALO_CALC_ADD, gd.column(DEHALO_SRC_ADVICE, 2), GSrc{DEHALO_SRC_BETA, 0, 0}),
+                    gd.add_calc(DEHALO_CALC_ADD, gd.column(DEHALO_SRC_ADVICE, 3), GSrc{DEHALO_SRC_GAMMA, 0, 0}));
+        gn.add_calc(DEHALO_CALC_MUL, gn.add_calc(DEHALO_CALC_ADD, gn.column(DEHALO_SRC_ADVICE, 0), GSrc{DEHALO_SRC_BETA, 0, 0}),
+                    gn.add_calc(DEHALO_CALC_ADD, gn.column(DEHALO_SRC_ADVICE, 1), GSrc{DEHALO_SRC_GAMMA, 0, 0}));
+        TRY(gd.compile(ctx, &lookup_den));
+        TRY(gn.compile(ctx, &lookup_num));
+        return 0;
+    }
+
+    // Which value goes where: the transcript's order of the evaluations [UPSTREAM plonk/prover.rs: advice, fixed, vanishing random_eval,
+    // permutation (sigma; products), lookups] and the opening queries grouped by point in order of first appearance [UPSTREAM
+    // permutation::Constructed::open, lookup::Evaluated::open, pk.permutation.open, vanishing::Evaluated::open; gwc/prover.rs].
+    int opening_plan() {
+        const HostCS& cs = pk->cs;
+        std::vector<int32_t> rs = {0, 1, -1, -(int32_t)(bf + 1)};
+        for (auto& q : cs.advice_q) rs.push_back(q.rotation);
+        for (auto& q : cs.fixed_q) rs.push_back(q.rotation);
+        std::sort(rs.begin(), rs.end());
+        rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
+        if (rs.size() > 4) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "more than four distinct opening rotations");
+        rots = rs;
+        const size_t nfix = cs.num_fixed, npc = cs.perm_cols.size();
+        hp_ptrs.clear();
+        for (uint32_t i = 0; i < pieces; i++) hp_ptrs.push_back((const uint64_t*)h.at(i * n));
+        plist.clear();
+        for (uint32_t c = 0; c < NC; c++) plist.push_back((const uint64_t*)(polys + c * n));
+        for (size_t c = 0; c < nfix; c++) plist.push_back(col_ptr(pk->fixed_polys, c, n));
+        for (size_t c = 0; c < npc; c++) plist.push_back(col_ptr(pk->perm_polys, c, n));
+        for (auto* p : hp_ptrs) plist.push_back(p);
+        const size_t ntot = plist.size();
+        const size_t b_cols = 0, b_fixed = NC, b_sigma = NC + nfix, b_hp = NC + nfix + npc;
+        auto ridx = [&](int32_t r) { return (size_t)(std::find(rots.begin(), rots.end(), r) - rots.begin()); };
+        auto idx = [&](size_t base, size_t col, int32_t r) { return (int64_t)(ridx(r) * ntot + base + col); };
+        const int32_t last = -(int32_t)(bf + 1);
+        write_idx.clear();
+        for (auto& q : cs.advice_q) write_idx.push_back(idx(b_cols, o_adv + q.index, q.rotation));
+        for (auto& q : cs.fixed_q) write_idx.push_back(idx(b_fixed, q.index, q.rotation));
+        write_idx.push_back(idx(b_cols, o_rand, 0));                                   // vanishing: random_eval
+        for (size_t j = 0; j < npc; j++) write_idx.push_back(idx(b_sigma, j, 0));      // pk.permutation.evaluate
+        for (uint32_t s = 0; s < S; s++) {                                              // permutation products
+            write_idx.push_back(idx(b_cols, o_pz + s, 0));
+            write_idx.push_back(idx(b_cols, o_pz + s, 1));
+            if (s != S - 1) write_idx.push_back(idx(b_cols, o_pz + s, last));
+        }
+        for (uint32_t l = 0; l < L; l++) {                                              // lookups
+            const size_t zc = o_lz + l, ai = o_perm + 2 * l, ti = o_perm + 2 * l + 1;
+            write_idx.push_back(idx(b_cols, zc, 0));
+            write_idx.push_back(idx(b_cols, zc, 1));
+            write_idx.push_back(idx(b_cols, ai, 0));
+            write_idx.push_back(idx(b_cols, ai, -1));
+            write_idx.push_back(idx(b_cols, ti, 0));
+        }
+        struct Q { int32_t r; const uint64_t* ptr; int64_t i; };
+        std::vector<Q> qs;
+        auto cptr = [&](size_t c) { return (const uint64_t*)(polys + c * n); };
+        for (auto& q : cs.advice_q) qs.push_back({q.rotation, cptr(o_adv + q.index), idx(b_cols, o_adv + q.index, q.rotation)});
+        for (uint32_t s = 0; s < S; s++) {                                              // permutation::Constructed::open
+            qs.push_back({0, cptr(o_pz + s), idx(b_cols, o_pz + s, 0)});
+            qs.push_back({1, cptr(o_pz + s), idx(b_cols, o_pz + s, 1)});
+        }
+        for (int s = (int)S - 2; s >= 0; s--) qs.push_back({last, cptr(o_pz + s), idx(b_cols, o_pz + s, last)});      // sets.iter().rev().skip(1)
+        for (uint32_t l = 0; l < L; l++) {                                              // lookup::Evaluated::open
+            const size_t zc = o_lz + l, ai = o_perm + 2 * l, ti = o_perm + 2 * l + 1;
+            qs.push_back({0, cptr(zc), idx(b_cols, zc, 0)});
+            qs.push_back({0, cptr(ai), idx(b_cols, ai, 0)});
+            qs.push_back({0, cptr(ti), idx(b_cols, ti, 0)});
+            qs.push_back({-1, cptr(ai), idx(b_cols, ai, -1)});
+            qs.push_back({1, cptr(zc), idx(b_cols, zc, 1)});
+        }
+        for (auto& q : cs.fixed_q) qs.push_back({q.rotation, col_ptr(pk->fixed_polys, q.index, n), idx(b_fixed, q.index, q.rotation)});
+        for (size_t j = 0; j < npc; j++) qs.push_back({0, col_ptr(pk->perm_polys, j, n), idx(b_sigma, j, 0)});      // pk.permutation.open
+        qs.push_back({0, hfold.u64(), -1});                                            // vanishing::Evaluated::open: h, then the random polynomial
+        qs.push_back({0, cptr(o_rand), idx(b_cols, o_rand, 0)});
+        groups.clear();
+        for (auto& q : qs) {
+            Group* g = nullptr;
+            for (auto& gg : groups)
+                if (gg.rot == q.r) { g = &gg; break; }
+            if (!g) {
+                groups.push_back(Group{q.r, {}, {}});
+                g = &groups.back();
+            }
+            g->ptrs.push_back(q.ptr);
+            g->idx.push_back(q.i);
+        }
+        if (groups.size() > 4) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "more opening points than the prover's buffers hold");
+        hpiece0 = (size_t)idx(b_hp, 0, 0);
+        eval_count = rots.size() * ntot;
+        return 0;
+    }
+
+    int init(dehalo_ctx* c, dehalo_ctx* s, const dehalo_params* pa, const dehalo_pk* key) {
+        ctx = c; side = s; params = pa; pk = key; f = key->f;
+        const HostCS& cs = pk->cs;
+        const HostDomain& d = pk->dom;
+        n = d.n; m = d.m; k = d.k; ek = d.extended_k;
+        bf = cs.blinding_factors();
+        u = n - (bf + 1);
+        A = cs.num_advice; L = (uint32_t)cs.lookups.size(); S = cs.num_sets(); I = cs.num_instance;
+        pieces = d.quotient_poly_degree;
+        NC = A + 2 * L + S + L + 1;
+        o_adv = 0; o_perm = A; o_pz = A + 2 * L; o_lz = A + 2 * L + S; o_rand = A + 2 * L + S + L;
+        if ((size_t)pieces * n > m) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "quotient does not fit the extended domain");
+        TRY(cols.alloc(ctx, (size_t)NC * n));
+        if (side) TRY(polys_own.alloc(ctx, (size_t)NC * n));
+        polys = side ? polys_own.p : cols.p;
+        TRY(instance.alloc(ctx, (size_t)std::max<uint32_t>(I, 1) * n));
+        TRY(instance_values.alloc(ctx, (size_t)std::max<uint32_t>(I, 1) * n));
+        TRY(compressed.alloc(ctx, (size_t)std::max<uint32_t>(2 * L, 1) * n));
+        TRY(num.alloc(ctx, (size_t)std::max<uint32_t>(S + L, 1) * n));
+        TRY(den.alloc(ctx, (size_t)std::max<uint32_t>(S + L, 1) * n));
+        TRY(ext.alloc(ctx, (size_t)(NC - 1 + I) * m));
+        TRY(h.alloc(ctx, m));
+        TRY(table_value.alloc(ctx, (size_t)std::max<uint32_t>(L, 1) * m));
+        TRY(hfold.alloc(ctx, n));
+        TRY(qbuf.alloc(ctx, 4 * n));
+        TRY(wbuf.alloc(ctx, 4 * n));
+        TRY(aff.alloc(ctx, 2 * (size_t)std::max<uint32_t>(NC, 8)));
+        TRY(aff_side.alloc(ctx, 2));
+        // blinding values of a proof but the random polynomial, compacted: [advice rows | permuted rows | product rows]
+        const size_t rows = n - u;
+        TRY(blind_dev.alloc(ctx, std::max<size_t>(1, (size_t)A * rows + (size_t)2 * L * rows + (size_t)(S + L) * bf)));
+        TRY(omega_col.alloc(ctx, n, false));
+        TRY(omega_powers(ctx, d, omega_col.p));
+        TRY(build_product_graphs());
+        TRY(opening_plan());
+        TRY(evals.alloc(ctx, eval_count + 8));
+        for (hipEvent_t* e : {&ev_ready[0], &ev_ready[1], &ev_ready[2], &ev_inst, &ev_side}) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        host_aff.resize(8 * (size_t)std::max<uint32_t>(NC, 8));
+        host_evals.resize(4 * eval_count);
+        TRY(dehalo_ctx_synchronize(ctx));
+        return 0;
+    }
+
+    // commit `count` columns starting at `src`, normalise, read back, absorb (and append to the proof)
+    int commit(dehalo_transcript* tr, const fe* src, size_t count, bool lagrange, const std::function<int()>& before_sync = nullptr) {
+        TRY(dehalo_msm_device_affine(ctx, lagrange ? params->bases_gl : params->bases_g, (const uint64_t*)src, n, count, nullptr, aff.u64(), nullptr));
+        if (before_sync) TRY(before_sync());
+        TRY(dehalo_download(ctx, aff.p, count * 64, host_aff.data()));
+        for (size_t i = 0; i < count; i++)
+            if (!tr->write_point(host_aff.data() + 8 * i)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
+        return 0;
+    }
+
+    int run(const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns, dehalo_rng* rng_in,
+            dehalo_transcript* tr, uint32_t flags);
+};
+
+namespace {
+
+struct EvalIn {      // dehalo_eval_inputs with owned scalar storage
+    dehalo_eval_inputs in{};
+    void cols(const std::vector<const uint64_t*>& fixed, const std::vector<const uint64_t*>& advice, const std::vector<const uint64_t*>& instance) {
+        in.fixed = fixed.data(); in.num_fixed = (uint32_t)fixed.size();
+        in.advice = advice.data(); in.num_advice = (uint32_t)advice.size();
+        in.instance = instance.data(); in.num_instance = (uint32_t)instance.size();
+    }
+};
+
+}   // namespace
+
+int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns, dehalo_rng* rng_in,
+                       dehalo_transcript* tr, uint32_t flags) {
+    const HostCS& cs = pk->cs;
+    const HostDomain& d = pk->dom;
+    const int fid = f->id;
+    const size_t rows = n - u;
+    const uint32_t rot_scale = (uint32_t)(m / n);
+    const auto t_start = clk::now();
+    auto t_phase = t_start;
+    auto mark = [&](int slot) {
+        const auto now = clk::now();
+        timings[slot] = std::chrono::duration<double, std::milli>(now - t_phase).count();
+        t_phase = now;
+    };
+    (void)hipSetDevice(ctx->device);
+    hipStream_t ms = ctx->stream, ss = side ? side->stream : nullptr;
+
+    // ---- random scalars, in upstream's order: advice blinding rows (column after column), one blind per advice column (unused by KZG), per
+    // lookup (bf + 1 rows permuted input, bf + 1 permuted table, two unused blinds), per grand product (bf rows + one unused blind), the random
+    // polynomial (n), its blind, the h pieces' blinds
+    HostRng rng;
+    TRY(rng.init(rng_in, f));
+    const size_t c_adv = (size_t)A * rows, c_advb = A, c_lk = (size_t)L * (2 * rows + 2), c_pr = (size_t)(S + L) * (bf + 1);
+    const size_t draws_before = c_adv + c_advb + c_lk + c_pr;
+    blind_host.resize(4 * std::max<size_t>(1, draws_before));
+    // the one large draw (n scalars, drawn AFTER every blinding value) is produced, uploaded and -- with a side context -- committed by a helper
+    // thread while the earlier phases run
+    HostRng rng_poly = rng.fork(draws_before, 1);
+    TRY(rng.scalars(blind_host.data(), draws_before));
+    std::atomic<int> helper_rc{0};
+    uint64_t rand_point[8] = {};
+    std::thread helper;
+    auto helper_body = [&]() {
+        (void)hipSetDevice(ctx->device);
+        rand_host.resize(4 * n);
+        int rc = rng_poly.scalars(rand_host.data(), n);
+        if (!rc) {
+            if (side) {
+                fe* dst = polys + (size_t)o_rand * n;
+                hipError_t e = hipMemcpyAsync(dst, rand_host.data(), n * 32, hipMemcpyHostToDevice, ss);
+                if (e == hipSuccess) e = hipStreamSynchronize(ss);
+                if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial upload: ") + hipGetErrorString(e));
+                if (!rc) rc = dehalo_msm_device_affine(side, params->bases_g, (const uint64_t*)dst, n, 1, nullptr, aff_side.u64(), nullptr);
+                if (!rc) rc = dehalo_download(side, aff_side.p, 64, rand_point);
+            } else {
+                // without a side context only the draw is taken off the critical path; the upload is queued by the proving thread
+            }
+        }
+        helper_rc.store(rc);
+    };
+    struct Joiner {      // the helper must have finished before this call returns, whatever path it takes
+        std::thread& t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{helper};
+
+    // compacted blinding rows -> one upload
+    {
+        const size_t total = (size_t)A * rows + (size_t)2 * L * rows + (size_t)(S + L) * bf;
+        std::vector<uint64_t>& b = blind_host;
+        std::vector<uint64_t> packed(4 * std::max<size_t>(1, total));
+        size_t o = 0;
+        memcpy(packed.data(), b.data(), 32 * c_adv);
+        o += c_adv;
+        const uint64_t* lk = b.data() + 4 * (c_adv + c_advb);
+        for (uint32_t l = 0; l < L; l++) {      // (input rows, table rows, two unused blinds) per lookup
+            memcpy(packed.data() + 4 * o, lk + 4 * (size_t)l * (2 * rows + 2), 32 * 2 * rows);
+            o += 2 * rows;
+        }
+        const uint64_t* pr = b.data() + 4 * (c_adv + c_advb + c_lk);
+        for (uint32_t s = 0; s < S + L; s++) {      // (bf rows, one unused blind) per product
+            memcpy(packed.data() + 4 * o, pr + 4 * (size_t)s * (bf + 1), 32 * bf);
+            o += bf;
+        }
+        if (total) {
+            HIP_TRY(ctx, hipMemcpyAsync(blind_dev.p, packed.data(), total * 32, hipMemcpyHostToDevice, ms));
+            HIP_TRY(ctx, hipStreamSynchronize(ms));      // `packed` is a local
+        }
+    }
+    const fe* bl_adv = blind_dev.p;
+    const fe* bl_perm = blind_dev.p + (size_t)A * rows;
+    const fe* bl_prod = bl_perm + (size_t)2 * L * rows;
+
+    tr->common_scalar(pk->transcript_repr);      // vk.hash_into
+    // ---- instance columns: values into the transcript (KZG: QUERY_INSTANCE = false), polynomials on the device
+    if (num_instance_columns != I) return dh_fail(ctx, DEHALO_ERR_INVALID, "instances.len() != num_instance_columns");      // Error::InvalidInstances
+    if (I) HIP_TRY(ctx, hipMemsetAsync(instance.p, 0, (size_t)I * n * 32, ms));
+    for (uint32_t i = 0; i < I; i++) {
+        const size_t len = instance_lens ? instance_lens[i] : 0;
+        if (len > u) return dh_fail(ctx, DEHALO_ERR_INVALID, "instance column too long");      // Error::InstanceTooLarge
+        if (len && (!instances || !instances[i])) return dh_fail(ctx, DEHALO_ERR_INVALID, "null instance column");
+        for (size_t j = 0; j < len; j++) {
+            Fe v;
+            memcpy(v.v, instances[i] + 4 * j, 32);
+            tr->common_scalar(v);
+        }
+        if (len) {
+            HIP_TRY(ctx, hipMemcpyAsync(instance.at((size_t)i * n), instances[i], len * 32, hipMemcpyHostToDevice, ms));
+            HIP_TRY(ctx, hipStreamSynchronize(ms));
+        }
+    }
+    if (I) HIP_TRY(ctx, hipMemcpyAsync(instance_values.p, instance.p, (size_t)I * n * 32, hipMemcpyDeviceToDevice, ms));
+    const uint32_t nco = NC - 1;
+    if (I && side) HIP_TRY(ctx, hipEventRecord(ev_inst, ms));
+    if (I && !side) TRY(dehalo_intt_scaled_device(ctx, fid, instance.u64(), k, d.omega_inv.v, d.ifft_divisor.v, I, nullptr));
+
+    auto side_ntt = [&](uint32_t first, uint32_t count, hipEvent_t e) -> int {
+        // polys[first..] = lagrange_to_coeff(cols[..]), ext[..] = coeff_to_extended(..) on the side context once `e` (recorded BEFORE the phase's
+        // commitment was queued) has passed; the launches themselves are made after the commitment's, while this thread would only wait
+        HIP_TRY(side, hipStreamWaitEvent(ss, e, 0));
+        HIP_TRY(side, hipMemcpyAsync(polys + (size_t)first * n, cols.at((size_t)first * n), (size_t)count * n * 32, hipMemcpyDeviceToDevice, ss));
+        TRY(dehalo_intt_scaled_device(side, fid, (uint64_t*)(polys + (size_t)first * n), k, d.omega_inv.v, d.ifft_divisor.v, count, nullptr));
+        TRY(dehalo_coset_ntt_form_device(side, fid, (const uint64_t*)(polys + (size_t)first * n), k, ext.u64((size_t)first * m), ek, d.ext_omega.v, d.g_coset.v, count,
+                                         DEHALO_FORM_OUT_INTERNAL, nullptr));
+        return 0;
+    };
+
+    // ---- advice: witness, blinding rows, commitments
+    if (!advice) return dh_fail(ctx, DEHALO_ERR_INVALID, "null advice");
+    HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, (flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                ms));
+    if (A) HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_adv * n + u), n * 32, bl_adv, rows * 32, rows * 32, A, hipMemcpyDeviceToDevice, ms));
+    if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[0], ms));
+
+    // pointer tables of the phases
+    std::vector<const uint64_t*> fixed_v, adv_v, inst_v, fixed_c, adv_c, inst_c, none;
+    for (uint32_t i = 0; i < cs.num_fixed; i++) fixed_v.push_back(col_ptr(pk->fixed_values, i, n)), fixed_c.push_back(col_ptr(pk->fixed_cosets, i, m));
+    for (uint32_t i = 0; i < A; i++) adv_v.push_back(col_ptr(cols, o_adv + i, n)), adv_c.push_back(col_ptr(ext, o_adv + i, m));
+    for (uint32_t i = 0; i < I; i++) inst_v.push_back(col_ptr(instance_values, i, n)), inst_c.push_back(col_ptr(ext, nco + i, m));
+    const uint32_t FF = DEHALO_EVAL_COLUMNS_INTERNAL | DEHALO_EVAL_VALUES_INTERNAL;
+    // one gate polynomial: Horner(0, [g], y) = g does not depend on y, so the custom-gate pass of evaluate_h needs the advice (and instance)
+    // cosets only -- queued on the side context right behind them, long before y exists
+    const bool gates_early = side && cs.gates.size() == 1;
+    const Fe zero{{0, 0, 0, 0}};
+
+    auto after_advice_queued = [&]() -> int {
+        if (I && side) {
+            HIP_TRY(side, hipStreamWaitEvent(ss, ev_inst, 0));
+            TRY(dehalo_intt_scaled_device(side, fid, instance.u64(), k, d.omega_inv.v, d.ifft_divisor.v, I, nullptr));
+            TRY(dehalo_coset_ntt_form_device(side, fid, instance.u64(), k, ext.u64((size_t)nco * m), ek, d.ext_omega.v, d.g_coset.v, I, DEHALO_FORM_OUT_INTERNAL, nullptr));
+        }
+        if (side) TRY(side_ntt(o_adv, A, ev_ready[0]));
+        if (gates_early) {
+            EvalIn e;
+            e.cols(fixed_c, adv_c, inst_c);
+            e.in.form_flags = FF;
+            e.in.y = zero.v;
+            TRY(dehalo_graph_evaluate_device(side, pk->custom_gates, &e.in, ek, rot_scale, nullptr, h.u64(), nullptr));
+        }
+        helper = std::thread(helper_body);      // the host is idle from here to the read-back
+        return 0;
+    };
+    TRY(commit(tr, cols.at((size_t)o_adv * n), A, true, after_advice_queued));
+    mark(0);
+    const Fe theta = tr->squeeze();
+
+    // ---- lookups: compress, permute, blind, commit
+    if (L) {
+        std::vector<const dehalo_graph*> graphs;
+        std::vector<uint64_t*> outs;
+        for (uint32_t l = 0; l < L; l++) {
+            graphs.push_back(pk->compress_graphs[l].first);
+            graphs.push_back(pk->compress_graphs[l].second);
+            outs.push_back(compressed.u64((size_t)2 * l * n));
+            outs.push_back(compressed.u64((size_t)(2 * l + 1) * n));
+        }
+        EvalIn e;
+        e.cols(fixed_v, adv_v, inst_v);
+        e.in.theta = theta.v;
+        TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), 2 * L, &e.in, k, 1, outs.data(), nullptr));
+        // the blinding rows [u, n) first: the permutation writes rows [0, u) only and ends with a read-back
+        HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_perm * n + u), n * 32, bl_perm, rows * 32, rows * 32, 2 * L, hipMemcpyDeviceToDevice, ms));
+        uint64_t* base = cols.u64((size_t)o_perm * n);
+        TRY(dehalo_permute_expression_pair_batch_device(ctx, fid, compressed.u64(0), compressed.u64(n), u, L, 2 * n, base, base + 4 * n, nullptr));
+        if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[1], ms));
+        TRY(commit(tr, cols.at((size_t)o_perm * n), 2 * L, true, side ? std::function<int()>([&]() { return side_ntt(o_perm, 2 * L, ev_ready[1]); }) : nullptr));
+    }
+    mark(1);
+    const Fe beta = tr->squeeze();
+    const Fe gamma = tr->squeeze();
+
+    // ---- grand products: permutation sets, then lookups; one batched inversion
+    const uint32_t npc = (uint32_t)cs.perm_cols.size();
+    if (S + L) {
+        std::vector<Fe> chal(std::max<uint32_t>(npc, 1));
+        Fe dj = beta;
+        for (uint32_t j = 0; j < npc; j++) {
+            chal[j] = dj;
+            dj = f->mul(dj, f->delta);
+        }
+        std::vector<const uint64_t*> perm_fixed = fixed_v;
+        for (uint32_t j = 0; j < npc; j++) perm_fixed.push_back(col_ptr(pk->perm_values, j, n));
+        perm_fixed.push_back(omega_col.u64());
+        if (S) {
+            std::vector<const dehalo_graph*> graphs;
+            std::vector<uint64_t*> outs;
+            for (uint32_t s = 0; s < S; s++) {
+                graphs.push_back(perm_graphs[s].first);
+                graphs.push_back(perm_graphs[s].second);
+                outs.push_back(den.u64((size_t)s * n));
+                outs.push_back(num.u64((size_t)s * n));
+            }
+            EvalIn e;
+            e.cols(perm_fixed, adv_v, inst_v);
+            e.in.challenges = (const uint64_t*)chal.data();
+            e.in.num_challenges = npc;
+            e.in.beta = beta.v;
+            e.in.gamma = gamma.v;
+            TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), 2 * S, &e.in, k, 1, outs.data(), nullptr));
+        }
+        for (uint32_t l = 0; l < L; l++) {
+            std::vector<const uint64_t*> four = {col_ptr(compressed, 2 * l, n), col_ptr(compressed, 2 * l + 1, n), col_ptr(cols, o_perm + 2 * l, n),
+                                                 col_ptr(cols, o_perm + 2 * l + 1, n)};
+            EvalIn e;
+            e.cols(none, four, none);
+            e.in.beta = beta.v;
+            e.in.gamma = gamma.v;
+            TRY(dehalo_graph_evaluate_device(ctx, lookup_den, &e.in, k, 1, nullptr, den.u64((size_t)(S + l) * n), nullptr));
+            TRY(dehalo_graph_evaluate_device(ctx, lookup_num, &e.in, k, 1, nullptr, num.u64((size_t)(S + l) * n), nullptr));
+        }
+        TRY(dehalo_grand_product_batch_device(ctx, fid, num.u64(), den.u64(), n, S + L, n, cols.u64((size_t)o_pz * n), nullptr));
+        for (uint32_t s = 1; s < S; s++)      // z_s starts where z_{s-1} ended: z = vec![last_z]
+            TRY(dehalo_scale_device(ctx, fid, cols.u64((size_t)(o_pz + s) * n), n, nullptr, 0, cols.u64((size_t)(o_pz + s - 1) * n + u), nullptr));
+        // per column: bf blinding rows (n - bf .. n)
+        HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_pz * n + (n - bf)), n * 32, bl_prod, (size_t)bf * 32, (size_t)bf * 32, S + L, hipMemcpyDeviceToDevice, ms));
+        if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[2], ms));
+        auto after_products_queued = [&]() -> int {
+            TRY(side_ntt(o_pz, S + L, ev_ready[2]));
+            // the lookups' (compressed input + beta)(compressed table + gamma) over the extended domain need theta, beta, gamma and the advice /
+            // fixed cosets: all there -- on the side context, beside the products' commitment, instead of after y
+            if (L) {
+                std::vector<const dehalo_graph*> graphs(pk->lookup_graphs.begin(), pk->lookup_graphs.end());
+                std::vector<uint64_t*> outs;
+                for (uint32_t l = 0; l < L; l++) outs.push_back(table_value.u64((size_t)l * m));
+                EvalIn e;
+                e.cols(fixed_c, adv_c, inst_c);
+                e.in.beta = beta.v; e.in.gamma = gamma.v; e.in.theta = theta.v;
+                e.in.form_flags = FF;
+                TRY(dehalo_graph_evaluate_batch_device(side, graphs.data(), L, &e.in, ek, rot_scale, outs.data(), nullptr));
+            }
+            return 0;
+        };
+        TRY(commit(tr, cols.at((size_t)o_pz * n), S + L, true, side ? std::function<int()>(after_products_queued) : nullptr));
+    }
+    mark(2);
+
+    // ---- vanishing argument: a random polynomial
+    if (helper.joinable()) helper.join();
+    if (helper_rc.load()) return helper_rc.load();
+    rng.skip(n);
+    {
+        uint64_t blind[4];
+        TRY(rng.scalars(blind, 1));      // random_blind (unused by KZG)
+    }
+    if (side) {
+        if (!tr->write_point(rand_point)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), rand_host.data(), n * 32, hipMemcpyHostToDevice, ms));
+        TRY(commit(tr, cols.at((size_t)o_rand * n), 1, false));
+    }
+    mark(3);
+    const Fe y = tr->squeeze();
+
+    // ---- coefficient forms and cosets of everything committed so far
+    if (!side) {
+        TRY(dehalo_intt_scaled_device(ctx, fid, cols.u64(), k, d.omega_inv.v, d.ifft_divisor.v, nco, nullptr));
+        TRY(dehalo_coset_ntt_form_device(ctx, fid, cols.u64(), k, ext.u64(), ek, d.ext_omega.v, d.g_coset.v, nco, DEHALO_FORM_OUT_INTERNAL, nullptr));
+        if (I) TRY(dehalo_coset_ntt_form_device(ctx, fid, instance.u64(), k, ext.u64((size_t)nco * m), ek, d.ext_omega.v, d.g_coset.v, I, DEHALO_FORM_OUT_INTERNAL, nullptr));
+    } else {      // queued phase by phase on the side context: wait for it
+        HIP_TRY(side, hipEventRecord(ev_side, ss));
+        HIP_TRY(ctx, hipStreamWaitEvent(ms, ev_side, 0));
+    }
+
+    // ---- evaluate_h, / t(X), extended_to_coeff
+    const uint64_t *l0 = pk->l_ext.u64(0), *l_last = pk->l_ext.u64(m), *l_active = pk->l_ext.u64(2 * m);
+    if (!gates_early) {
+        EvalIn e;
+        e.cols(fixed_c, adv_c, inst_c);
+        e.in.y = y.v;
+        e.in.form_flags = FF;
+        TRY(dehalo_graph_evaluate_device(ctx, pk->custom_gates, &e.in, ek, rot_scale, nullptr, h.u64(), nullptr));
+    }
+    if (S) {
+        std::vector<const uint64_t*> z, pcols, sigma;
+        for (uint32_t s = 0; s < S; s++) z.push_back(col_ptr(ext, o_pz + s, m));
+        for (auto& pc : cs.perm_cols) pcols.push_back(pc.kind == DEHALO_COLUMN_ADVICE ? adv_c[pc.index] : pc.kind == DEHALO_COLUMN_FIXED ? fixed_c[pc.index] : inst_c[pc.index]);
+        for (uint32_t j = 0; j < npc; j++) sigma.push_back(col_ptr(pk->perm_cosets, j, m));
+        const Fe beta_zeta = f->mul(beta, d.g_coset);
+        dehalo_perm_inputs pi{};
+        pi.z = z.data(); pi.num_sets = S;
+        pi.columns = pcols.data(); pi.sigma = sigma.data(); pi.num_columns = npc;
+        pi.chunk_len = cs.chunk_len();
+        pi.last_rotation = -(int32_t)(bf + 1);
+        pi.l0 = l0; pi.l_last = l_last; pi.l_active_row = l_active;
+        pi.beta = beta.v; pi.gamma = gamma.v; pi.y = y.v; pi.delta = f->delta.v; pi.beta_zeta = beta_zeta.v; pi.extended_omega = d.ext_omega.v;
+        pi.form_flags = FF;
+        TRY(dehalo_permutation_h_device(ctx, fid, &pi, ek, rot_scale, h.u64(), nullptr));
+    }
+    if (L) {
+        if (!side) {
+            for (uint32_t l = 0; l < L; l++) {
+                EvalIn e;
+                e.cols(fixed_c, adv_c, inst_c);
+                e.in.beta = beta.v; e.in.gamma = gamma.v; e.in.theta = theta.v;
+                e.in.form_flags = FF;
+                TRY(dehalo_graph_evaluate_device(ctx, pk->lookup_graphs[l], &e.in, ek, rot_scale, nullptr, table_value.u64((size_t)l * m), nullptr));
+            }
+        }
+        for (uint32_t first = 0; first < L; first += 8) {
+            std::vector<dehalo_lookup_inputs> li;
+            for (uint32_t l = first; l < std::min(L, first + 8); l++) {
+                dehalo_lookup_inputs x{};
+                x.product_coset = col_ptr(ext, o_lz + l, m);
+                x.permuted_input_coset = col_ptr(ext, o_perm + 2 * l, m);
+                x.permuted_table_coset = col_ptr(ext, o_perm + 2 * l + 1, m);
+                x.table_value = table_value.u64((size_t)l * m);
+                x.l0 = l0; x.l_last = l_last; x.l_active_row = l_active;
+                x.beta = beta.v; x.gamma = gamma.v; x.y = y.v;
+                x.form_flags = FF;
+                li.push_back(x);
+            }
+            TRY(dehalo_lookup_h_batch_device(ctx, fid, li.data(), (uint32_t)li.size(), ek, rot_scale, h.u64(), nullptr));
+        }
+    }
+    TRY(dehalo_scale_device(ctx, fid, h.u64(), m, (const uint64_t*)d.t_inv.data(), (uint32_t)d.t_inv.size(), nullptr, nullptr));      // divide_by_vanishing_poly
+    TRY(dehalo_coset_intt_form_device(ctx, fid, h.u64(), ek, d.ext_omega_inv.v, d.ext_ifft_divisor.v, d.g_coset.v, 1, DEHALO_FORM_IN_INTERNAL, nullptr));
+    {
+        std::vector<uint64_t> hb(4 * (size_t)pieces);
+        TRY(rng.scalars(hb.data(), pieces));      // h_blinds (unused by KZG)
+    }
+    TRY(commit(tr, h.p, pieces, false));
+    mark(4);
+    const Fe x = tr->squeeze();
+    const Fe xn = f->pow_u64(x, (uint64_t)n);
+
+    // ---- evaluations, in upstream's order: every opened polynomial at every rotation in ONE call
+    std::vector<Fe> point(rots.size());
+    for (size_t i = 0; i < rots.size(); i++) point[i] = d.rotate_omega(x, rots[i]);
+    TRY(dehalo_eval_polynomial_multi_device(ctx, fid, plist.data(), plist.size(), n, (const uint64_t*)point.data(), (uint32_t)rots.size(), evals.u64(), nullptr));
+    // the folded quotient h(X) = sum_i x^(n i) h_i(X) (opened below; its value at x comes from the pieces' values)
+    std::vector<Fe> xs(pieces);
+    {
+        Fe cur = f->one;
+        for (uint32_t i = 0; i < pieces; i++) {
+            xs[i] = cur;
+            cur = f->mul(cur, xn);
+        }
+    }
+    TRY(dehalo_lincomb_device(ctx, fid, hp_ptrs.data(), (const uint64_t*)xs.data(), pieces, n, hfold.u64(), nullptr, nullptr));
+    TRY(dehalo_download(ctx, evals.p, eval_count * 32, host_evals.data()));
+    const Fe* E = (const Fe*)host_evals.data();
+    Fe hfold_eval = zero;
+    for (uint32_t i = 0; i < pieces; i++) hfold_eval = f->add(hfold_eval, f->mul(xs[i], E[hpiece0 + i]));
+    for (int64_t i : write_idx) tr->write_scalar(E[i]);
+    mark(5);
+
+    // ---- ProverGWC::create_proof: one witness polynomial per distinct point, in order of first appearance
+    const Fe v = tr->squeeze();
+    HIP_TRY(ctx, hipMemsetAsync(wbuf.p, 0, 4 * n * 32, ms));
+    std::vector<const uint64_t*> qptrs;
+    std::vector<uint64_t*> wptrs;
+    std::vector<Fe> qpoints;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        const Group& g = groups[gi];
+        std::vector<Fe> coefs(g.idx.size());
+        Fe eval_batch = zero, pw = f->one;
+        for (size_t i = 0; i < g.idx.size(); i++) {
+            coefs[i] = pw;
+            eval_batch = f->add(eval_batch, f->mul(pw, g.idx[i] >= 0 ? E[g.idx[i]] : hfold_eval));
+            pw = f->mul(pw, v);
+        }
+        TRY(dehalo_lincomb_device(ctx, fid, g.ptrs.data(), (const uint64_t*)coefs.data(), g.ptrs.size(), n, qbuf.u64(gi * n), eval_batch.v, nullptr));
+        qptrs.push_back(qbuf.u64(gi * n));
+        wptrs.push_back(wbuf.u64(gi * n));
+        qpoints.push_back(point[(size_t)(std::find(rots.begin(), rots.end(), g.rot) - rots.begin())]);
+    }
+    TRY(dehalo_kate_division_batch_device(ctx, fid, qptrs.data(), n, (const uint64_t*)qpoints.data(), wptrs.data(), groups.size(), nullptr));
+    TRY(commit(tr, wbuf.p, groups.size(), false));
+    mark(6);
+    timings[7] = ms_since(t_start);
+    // a PCG64 caller's generator moves past this proof's draws (upstream's `&mut rng`)
+    if (rng_in && rng_in->kind == DEHALO_RNG_PCG64) {
+        rng_in->pcg_state[0] = (uint64_t)rng.pcg.state;
+        rng_in->pcg_state[1] = (uint64_t)(rng.pcg.state >> 64);
+    }
+    return 0;
+}
+
+extern "C" int dehalo_prover_create(dehalo_ctx* ctx, dehalo_ctx* side_ctx, const dehalo_params* params, const dehalo_pk* pk, dehalo_prover** out) {
+    if (!ctx || !params || !pk || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "prover_create: null argument");
+    if (params->k != pk->k || params->curve != pk->curve) return dh_fail(ctx, DEHALO_ERR_INVALID, "prover_create: params and proving key disagree on k / curve");
+    if (side_ctx && (side_ctx == ctx || side_ctx->device != ctx->device)) return dh_fail(ctx, DEHALO_ERR_INVALID, "prover_create: the side context must be another context of the same device");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    std::unique_ptr<dehalo_prover> p(new dehalo_prover);
+    TRY(p->init(ctx, side_ctx, params, pk));
+    *out = p.release();
+    return 0;
+}
+
+extern "C" int dehalo_prover_release(dehalo_prover* p) {
+    if (!p) return 0;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->side) (void)hipStreamSynchronize(p->side->stream);
+    delete p;
+    return 0;
+}
+
+extern "C" int dehalo_create_proof(dehalo_prover* p, const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns,
+                                   dehalo_rng* rng, dehalo_transcript* transcript, uint32_t flags) {
+    if (!p || !transcript) return DEHALO_ERR_INVALID;
+    if (transcript->curve != p->pk->curve) return dh_fail(p->ctx, DEHALO_ERR_INVALID, "create_proof: the transcript's curve differs from the key's");
+    std::lock_guard<std::mutex> lk(p->mu);
+    const int rc = p->run(advice, instances, instance_lens, num_instance_columns, rng, transcript, flags);
+    if (rc) {      // leave nothing of this proof in flight on either context
+        (void)hipStreamSynchronize(p->ctx->stream);
+        if (p->side) (void)hipStreamSynchronize(p->side->stream);
+    }
+    return rc;
+}
+
+extern "C" int dehalo_prover_last_timings(const dehalo_prover* p, double out[8]) {
+    if (!p || !out) return DEHALO_ERR_INVALID;
+    memcpy(out, p->timings, sizeof p->timings);
+    return 0;
+}
+
+extern "C" int dehalo_pk_info(const dehalo_pk* pk, uint32_t out[8]) {
+    if (!pk || !out) return DEHALO_ERR_INVALID;
+    const HostCS& cs = pk->cs;
+    const uint32_t L = (uint32_t)cs.lookups.size(), S = cs.num_sets();
+    out[0] = pk->k;
+    out[1] = pk->dom.extended_k;
+    out[2] = cs.blinding_factors();
+    out[3] = cs.degree();
+    out[4] = S;
+    out[5] = cs.num_advice + 2 * L + S + L + 1 + (cs.degree() - 1);
+    out[6] = (uint32_t)(cs.advice_q.size() + cs.fixed_q.size() + 1 + cs.perm_cols.size() + (S ? 3 * S - 1 : 0) + 5 * L);
+    std::vector<int32_t> rs = {0, 1, -(int32_t)(cs.blinding_factors() + 1)};
+    if (L) rs.push_back(-1);
+    for (auto& q : cs.advice_q) rs.push_back(q.rotation);
+    for (auto& q : cs.fixed_q) rs.push_back(q.rotation);
+    std::sort(rs.begin(), rs.end());
+    out[7] = (uint32_t)(std::unique(rs.begin(), rs.end()) - rs.begin());
+    return 0;
+}
+
+extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, const uint64_t* const* advice, uint32_t count, dehalo_rng* rngs, uint32_t flags,
+                                    uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens) {
+    if (!provers || !num_provers || (count && (!advice || !proofs_out || !proof_lens))) return DEHALO_ERR_INVALID;
+    for (uint32_t i = 0; i < num_provers; i++)
+        if (!provers[i]) return DEHALO_ERR_INVALID;
+    std::vector<int> rcs(num_provers, 0);
+    auto work = [&](uint32_t t) {
+        dehalo_prover* p = provers[t];
+        for (uint32_t i = t; i < count && !rcs[t]; i += num_provers) {
+            dehalo_transcript tr;
+            tr.init(p->pk->curve);
+            int rc = dehalo_create_proof(p, advice[i], nullptr, nullptr, p->I ? p->I : 0, rngs ? &rngs[i] : nullptr, &tr, flags);
+            if (!rc && tr.proof.size() > proof_cap) rc = dh_fail(p->ctx, DEHALO_ERR_INVALID, "create_proofs: proof buffer too small");
+            if (!rc) {
+                memcpy(proofs_out[i], tr.proof.data(), tr.proof.size());
+                proof_lens[i] = tr.proof.size();
+            }
+            rcs[t] = rc;
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < num_provers; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    for (int rc : rcs)
+        if (rc) return rc;
+    return 0;
+}

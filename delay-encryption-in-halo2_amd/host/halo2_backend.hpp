@@ -169,4 +169,156 @@ class ParamsIPA {
     dehalo_bases* gl_ = nullptr;
 };
 
+// ---- the whole call: plonk::{ConstraintSystem, keygen_vk, keygen_pk, create_proof}, ParamsKZG, Blake2bWrite ---------------------------
+// (include/dehalo.h "the whole call"; reference call sites benches/delay_enc.rs:41-54, 84-115, 120-134)
+
+// plonk::ConstraintSystem as the prover reads it, built the way a circuit's configure() builds it; expressions are handles.
+class ConstraintSystem {
+  public:
+    using Expr = uint32_t;
+    ConstraintSystem(uint32_t num_advice, uint32_t num_fixed, uint32_t num_instance) { d_.num_advice = num_advice; d_.num_fixed = num_fixed; d_.num_instance = num_instance; }
+    Expr constant(const Fe& c) { return node(DEHALO_EXPR_CONSTANT, add_constant(c), 0, 0); }
+    Expr query_advice(uint32_t col, int32_t rot = 0) { query(aq_, DEHALO_COLUMN_ADVICE, col, rot); return node(DEHALO_EXPR_ADVICE, col, 0, rot); }
+    Expr query_fixed(uint32_t col, int32_t rot = 0) { query(fq_, DEHALO_COLUMN_FIXED, col, rot); return node(DEHALO_EXPR_FIXED, col, 0, rot); }
+    Expr query_instance(uint32_t col, int32_t rot = 0) { query(iq_, DEHALO_COLUMN_INSTANCE, col, rot); return node(DEHALO_EXPR_INSTANCE, col, 0, rot); }
+    Expr neg(Expr a) { return node(DEHALO_EXPR_NEGATED, a, 0, 0); }
+    Expr sum(Expr a, Expr b) { return node(DEHALO_EXPR_SUM, a, b, 0); }
+    Expr product(Expr a, Expr b) { return node(DEHALO_EXPR_PRODUCT, a, b, 0); }
+    Expr scaled(Expr a, const Fe& c) { return node(DEHALO_EXPR_SCALED, a, add_constant(c), 0); }
+    void enable_equality(dehalo_column_kind kind, uint32_t col) {
+        std::vector<dehalo_column_query>& q = kind == DEHALO_COLUMN_ADVICE ? aq_ : kind == DEHALO_COLUMN_FIXED ? fq_ : iq_;
+        query(q, kind, col, 0);
+        for (auto& c : perm_) if (c.kind == (uint32_t)kind && c.index == col) return;
+        perm_.push_back(dehalo_column_query{(uint32_t)kind, col, 0});
+    }
+    void create_gate(const std::vector<Expr>& polys) { gates_.insert(gates_.end(), polys.begin(), polys.end()); }
+    void lookup(const std::vector<std::pair<Expr, Expr>>& pairs) {
+        lens_.push_back((uint32_t)pairs.size());
+        for (auto& pr : pairs) { lin_.push_back(pr.first); ltab_.push_back(pr.second); }
+    }
+    void set_minimum_degree(uint32_t d) { d_.minimum_degree = d; }
+    const dehalo_constraint_system* descriptor() {
+        d_.nodes = nodes_.data(); d_.num_nodes = (uint32_t)nodes_.size();
+        d_.constants = consts_.empty() ? nullptr : consts_[0].data(); d_.num_constants = (uint32_t)consts_.size();
+        d_.gates = gates_.data(); d_.num_gates = (uint32_t)gates_.size();
+        d_.lookup_lens = lens_.data(); d_.num_lookups = (uint32_t)lens_.size(); d_.lookup_inputs = lin_.data(); d_.lookup_tables = ltab_.data();
+        d_.permutation_columns = perm_.data(); d_.num_permutation_columns = (uint32_t)perm_.size();
+        d_.advice_queries = aq_.data(); d_.num_advice_queries = (uint32_t)aq_.size();
+        d_.fixed_queries = fq_.data(); d_.num_fixed_queries = (uint32_t)fq_.size();
+        d_.instance_queries = iq_.data(); d_.num_instance_queries = (uint32_t)iq_.size();
+        return &d_;
+    }
+
+  private:
+    Expr node(uint32_t kind, uint32_t a, uint32_t b, int32_t rot) { nodes_.push_back(dehalo_expr_node{kind, a, b, rot}); return (Expr)nodes_.size() - 1; }
+    uint32_t add_constant(const Fe& c) {
+        for (size_t i = 0; i < consts_.size(); i++) if (consts_[i] == c) return (uint32_t)i;
+        consts_.push_back(c);
+        return (uint32_t)consts_.size() - 1;
+    }
+    static void query(std::vector<dehalo_column_query>& q, uint32_t kind, uint32_t col, int32_t rot) {
+        for (auto& e : q) if (e.index == col && e.rotation == rot) return;
+        q.push_back(dehalo_column_query{kind, col, rot});
+    }
+    dehalo_constraint_system d_{};
+    std::vector<dehalo_expr_node> nodes_;
+    std::vector<Fe> consts_;
+    std::vector<uint32_t> gates_, lens_, lin_, ltab_;
+    std::vector<dehalo_column_query> perm_, aq_, fq_, iq_;
+};
+
+// ParamsKZG<Bn256>
+class ParamsKZG {
+  public:
+    ParamsKZG(const Backend& be, dehalo_curve curve, const std::vector<uint8_t>& raw_bytes) : be_(be) {      // ParamsKZG::read (RawBytes)
+        be_.check(dehalo_params_read(be_.raw(), curve, raw_bytes.data(), raw_bytes.size(), &p_));
+    }
+    ~ParamsKZG() { dehalo_params_release(be_.raw(), p_); }
+    ParamsKZG(const ParamsKZG&) = delete;
+    std::vector<uint8_t> write() const {
+        std::vector<uint8_t> out(dehalo_params_size(p_));
+        be_.check(dehalo_params_write(p_, out.data(), out.size()));
+        return out;
+    }
+    dehalo_params* raw() const { return p_; }
+
+  private:
+    const Backend& be_;
+    dehalo_params* p_ = nullptr;
+};
+
+// ProvingKey<G1Affine> (with its VerifyingKey)
+class ProvingKey {
+  public:
+    // keygen_vk + keygen_pk: fixed = num_fixed x 2^k elements (Montgomery), mapping = permutation assembly (cell -> cell)
+    ProvingKey(const Backend& be, const ParamsKZG& params, ConstraintSystem& cs, const std::vector<Fe>& fixed, const std::vector<uint64_t>& mapping,
+               const std::vector<std::vector<uint8_t>>& selectors = {}, uint32_t flags = 0) : be_(be) {
+        std::vector<const uint8_t*> sp;
+        for (auto& s : selectors) sp.push_back(s.data());
+        be_.check(dehalo_keygen(be_.raw(), params.raw(), cs.descriptor(), fixed.empty() ? nullptr : fixed[0].data(), mapping.data(), sp.data(), (uint32_t)sp.size(), flags, &pk_));
+    }
+    // ProvingKey::read::<_, Circuit>(.., SerdeFormat::RawBytes)
+    ProvingKey(const Backend& be, dehalo_curve curve, ConstraintSystem& cs, const std::vector<uint8_t>& raw_bytes, uint32_t num_selectors) : be_(be) {
+        be_.check(dehalo_pk_read(be_.raw(), curve, cs.descriptor(), raw_bytes.data(), raw_bytes.size(), num_selectors, &pk_));
+    }
+    ~ProvingKey() { dehalo_pk_release(be_.raw(), pk_); }
+    ProvingKey(const ProvingKey&) = delete;
+    std::vector<uint8_t> write() const {
+        std::vector<uint8_t> out(dehalo_pk_size(pk_));
+        be_.check(dehalo_pk_write(be_.raw(), pk_, out.data(), out.size()));
+        return out;
+    }
+    std::vector<uint8_t> vk_write() const {
+        std::vector<uint8_t> out(dehalo_vk_size(pk_));
+        be_.check(dehalo_vk_write(pk_, out.data(), out.size()));
+        return out;
+    }
+    void set_transcript_repr(const Fe& r) { be_.check(dehalo_pk_set_transcript_repr(pk_, r.data())); }
+    dehalo_pk* raw() const { return pk_; }
+
+  private:
+    const Backend& be_;
+    dehalo_pk* pk_ = nullptr;
+};
+
+// Blake2bWrite<Vec<u8>, G1Affine, Challenge255<_>>
+class Blake2bWrite {
+  public:
+    explicit Blake2bWrite(dehalo_curve curve) {
+        if (dehalo_transcript_create(curve, &t_) != 0) throw std::runtime_error("dehalo_transcript_create failed");
+    }
+    ~Blake2bWrite() { dehalo_transcript_release(t_); }
+    Blake2bWrite(const Blake2bWrite&) = delete;
+    std::vector<uint8_t> finalize() const {
+        std::vector<uint8_t> out(dehalo_transcript_len(t_));
+        if (dehalo_transcript_finalize(t_, out.data(), out.size()) != 0) throw std::runtime_error("dehalo_transcript_finalize failed");
+        return out;
+    }
+    dehalo_transcript* raw() const { return t_; }
+
+  private:
+    dehalo_transcript* t_ = nullptr;
+};
+
+// create_proof(&params, &pk, &[circuit], &[instances], rng, &mut transcript): `advice` is what circuit.synthesize assigned
+class Prover {
+  public:
+    Prover(const Backend& be, const ParamsKZG& params, const ProvingKey& pk, const Backend* side = nullptr) : be_(be) {
+        be_.check(dehalo_prover_create(be_.raw(), side ? side->raw() : nullptr, params.raw(), pk.raw(), &p_));
+    }
+    ~Prover() { dehalo_prover_release(p_); }
+    Prover(const Prover&) = delete;
+    // rng == nullptr: operating-system entropy (the reference's OsRng)
+    void create_proof(const std::vector<Fe>& advice, const std::vector<std::vector<Fe>>& instances, dehalo_rng* rng, Blake2bWrite& transcript) const {
+        std::vector<const uint64_t*> ip;
+        std::vector<size_t> il;
+        for (auto& col : instances) { ip.push_back(col.empty() ? nullptr : col[0].data()); il.push_back(col.size()); }
+        be_.check(dehalo_create_proof(p_, advice[0].data(), ip.data(), il.data(), (uint32_t)ip.size(), rng, transcript.raw(), 0));
+    }
+
+  private:
+    const Backend& be_;
+    dehalo_prover* p_ = nullptr;
+};
+
 }  // namespace halo2_amd

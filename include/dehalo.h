@@ -481,6 +481,10 @@ int dehalo_timing_get(dehalo_ctx* ctx, int kernel_id, double* total_ms, uint64_t
  * lane or quad / 32 lanes / one wave / a whole block, out[4] = points per lane of the accumulation, out[5] = (bucket, point) pairs sorted. */
 int dehalo_msm_last_shape(dehalo_ctx* ctx, uint32_t out[6]);
 
+/* The host-side constants of a field as the library computed them (4 x u64 Montgomery each): out[0] = modulus (plain integer), out[1] = R mod p (one),
+ * out[2] = ROOT_OF_UNITY, out[3] = ZETA, out[4] = DELTA, out[5] = MULTIPLICATIVE_GENERATOR [UPSTREAM halo2curves / pasta_curves PrimeField, WithSmallOrderMulGroup]. */
+int dehalo_field_info(int field, uint64_t out[24]);
+
 /* Library / build info, e.g. "dehalo 0.1 gfx950". */
 const char* dehalo_version(void);
 
