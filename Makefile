@@ -6,7 +6,7 @@ CSRC := $(PKG)/csrc
 OBJDIR := $(CSRC)/obj
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off
 LIB := $(PKG)/libdehalo.so
-UNITS := capi prover lookup_permute msm_bn254 msm_pallas msm_vesta ntt_bn254_fr ntt_bn254_fq ntt_pasta_fp ntt_pasta_fq
+UNITS := capi prover witness lookup_permute msm_bn254 msm_pallas msm_vesta ntt_bn254_fr ntt_bn254_fq ntt_pasta_fp ntt_pasta_fq
 OBJS := $(UNITS:%=$(OBJDIR)/%.o)
 HDRS := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/dehalo.h
 

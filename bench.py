@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --force-device rehearse N > 1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1)
     ap.add_argument("--proof-k", type=int, default=17, help="k of the delay_enc-shaped create_proof (0 = skip every proof section)")
-    ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 4 per GPU; 0 = skip)")
+    ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 32 per GPU; 0 = skip)")
     ap.add_argument("--proofs-inflight", type=int, default=4, help="batch mode: proofs in flight per GPU (one context + host thread each)")
     ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
     ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves with the whole-rounds rule (0 = library default: msm_acc_points)")
@@ -168,15 +168,17 @@ def ctx_device(ctx):
 
 
 class ProofSetup:
-    """Circuit, SRS, proving key and a Prover for one (k, shape): the one-time work the reference caches on disk
-    (benches/delay_enc.rs:41-54, 84-115).  The SRS travels through ParamsKZG's RawBytes format, as the reference's does."""
+    """Circuit, SRS, proving key and a prover for one (k, circuit): the one-time work the reference caches on disk
+    (benches/delay_enc.rs:41-54, 84-115).  Everything goes through the whole-call C ABI (dehalo_params_read, dehalo_keygen,
+    dehalo_prover_create, dehalo_create_proof): Python only passes pointers.  The SRS travels through ParamsKZG's RawBytes format, as
+    the reference's does."""
 
     def __init__(self, pkg, ctx, k, circuit, threads):
         import io
         import plonk_oracle as PO          # synthetic-input generation (the SRS) + the cpu_baseline / checker leg
         import pairing as pr
         import numpy as np
-        from dehalo2_amd import circuits, keygen, prover
+        from dehalo2_amd import circuits, keygen, native
 
         po = sys.modules["pyoracle"]
         self.curve, self.ocurve, self.k, self.circuit = pkg.fields.BN254, po.BN254, k, circuit
@@ -186,17 +188,19 @@ class ProofSetup:
         tw = time.time()
         self.srs = PO.setup_srs(self.ocurve, k, self.s, threads)
         t1 = time.time()
-        buf = io.BytesIO()
-        buf.write(k.to_bytes(4, "little") + np.ascontiguousarray(self.srs["g"]).tobytes() + np.ascontiguousarray(self.srs["g_lagrange"]).tobytes() +
-                  pr.g2_to_raw(pr.G2) + pr.g2_to_raw(pr.g2_mul(self.s, pr.G2)))
-        buf.seek(0)
-        self.params = keygen.ParamsKZG.read(ctx, self.curve, buf)
+        raw = (k.to_bytes(4, "little") + np.ascontiguousarray(self.srs["g"]).tobytes() + np.ascontiguousarray(self.srs["g_lagrange"]).tobytes() +
+               pr.g2_to_raw(pr.G2) + pr.g2_to_raw(pr.g2_mul(self.s, pr.G2)))
+        self.params = native.ParamsKZG.read(ctx, self.curve, raw)
         t2 = time.time()
-        self.pk = keygen.keygen(ctx, self.params, self.circ.cs, self.circ.fixed, self.circ.assembly, self.circ.selectors)
+        self.pk = native.ProvingKey.keygen(ctx, self.params, self.circ.cs, self.circ.fixed, self.circ.assembly, self.circ.selectors)
         ctx.synchronize()
         t3 = time.time()
+        # the verifying key as the (Python) verifier reads it, and the transcript_repr convention shared with the CPU restatement
+        self.vk = keygen.VerifyingKey.read(self.curve, self.circ.cs, io.BytesIO(self.pk.vk_bytes()), len(self.circ.selectors))
+        self.pk.transcript_repr = self.vk.transcript_repr
+        self.ctx = ctx
         self.side = pkg.Context(ctx_device(ctx))                      # NTTs and the random commitment run beside the commitment phases
-        self.prover = prover.Prover(self.params, self.pk, ctx, self.side)
+        self.prover = native.Prover(self.params, self.pk, ctx, self.side)
         with ctx.torch_stream():
             self.advice = keygen.to_device(self.circ.advice)          # the witness, resident in HBM (Montgomery form)
             ctx.field_op_device(self.curve.scalar.id, "to_mont", self.advice.data_ptr(), 0, self.advice.data_ptr(), self.advice.numel() // 4, 0)
@@ -204,13 +208,13 @@ class ProofSetup:
         self.setup_s = {"witness_python": round(tw - t0, 2), "srs_cpu": round(t1 - tw, 2), "params_read_and_tables": round(t2 - t1, 2), "keygen_gpu": round(t3 - t2, 3)}
         self.witness_ms = round(1e3 * (tw - t0), 1)
 
-    def prove(self, seed, timings=None, which=None):
-        from dehalo2_amd import prover, transcript
-        tr = transcript.Blake2bWrite(self.curve)
-        (which or self.prover).create_proof(self.advice, [[]], prover.SeededRng(seed), tr, timings)
-        return tr.finalize()
+    def prove(self, seed, which=None):
+        from dehalo2_amd import prover
+        return (which or self.prover).create_proof(self.advice, [[]], prover.SeededRng(seed)).finalize()
 
     def release(self):
+        self.prover.release()
+        self.pk.release()
         self.params.release()
         self.side.close()
 
@@ -225,7 +229,7 @@ def verify_with_device_vk(st, proof):
     import pairing as pr
     import verifier as V
     from dehalo2_amd import keygen
-    vk = st.pk.vk
+    vk = st.vk
     return V.verify_proof(st.ocurve, st.circ.cs.description(), st.k, keygen.decode_points(st.curve, vk.fixed_commitments),
                           keygen.decode_points(st.curve, vk.permutation_commitments), vk.transcript_repr, (1, 2), pr.G2, pr.g2_mul(st.s, pr.G2), [[]], proof)
 
@@ -247,14 +251,14 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
         again = st.prove(7)
         ts.append(1e3 * (time.perf_counter() - t))
         assert again == proof, "the same witness, SRS and blinding gave different proof bytes"
-    tm = prover.ProofTimings()
-    st.prove(7, tm)
+    phases = st.prover.last_timings()
     cs = st.circ.cs
     n_evals = len(cs.advice_queries) + len(cs.fixed_queries) + 1 + len(cs.permutation_columns) + max(0, 3 * cs.num_permutation_sets() - 1) + 5 * len(cs.lookups)
     out = {"circuit": CIRCUIT_TEXT[circuit],
            "k": k, "curve": "bn254 (KZG, GWC)", "rows_used": st.circ.used_rows, "commitments": len(proof) // 32 - n_evals,
            "proof_bytes": len(proof), "gpu_ms": round(min(ts), 3), "gpu_ms_median": round(sorted(ts)[len(ts) // 2], 3),
-           "gpu_phase_ms_with_syncs": {a: round(b, 3) for a, b in tm.phases_ms.items()},
+           "gpu_phase_ms": {a: round(b, 3) for a, b in phases.items()},
+           "driver": "dehalo_create_proof: phases, transcript and every launch in C++ behind the C ABI; Python passes pointers",
            "witness": st.witness + "; resident in HBM when the timed call starts; blinding scalars generated on the host inside the timed call",
            "witness_ms": st.witness_ms,
            "witness_note": "witness generation (the reference's Circuit::synthesize, which ITS timed create_proof includes) is single-threaded Python here and is NOT part of gpu_ms",
@@ -275,7 +279,7 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
             cpu_runs[th] = time.time() - t2
         best_th = min(cpu_runs, key=cpu_runs.get)
         t2, t3 = 0.0, cpu_runs[best_th]
-        assert rep == st.pk.vk.transcript_repr, "verifying key differs from the CPU restatement's"
+        assert rep == st.vk.transcript_repr and st.pk.vk_bytes() == PO.vk_bytes(st.ocurve, key, st.circ.selectors), "verifying key differs from the CPU restatement's"
         assert proof == want, "device proof differs from the CPU restatement's proof"
         out.update({"identical_to_cpu_proof": True, "cpu_ms": round(1e3 * (t3 - t2), 1), "cpu_keygen_ms": round(1e3 * (t1 - t0), 1), "cpu_cores": best_th, "host_cores": host_cores(),
                     "cpu_ms_by_threads": {str(a): round(1e3 * b, 1) for a, b in cpu_runs.items()},
@@ -290,45 +294,24 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
 
 
 def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, check=True):
-    """configs[4]: a batch of delay_enc-shaped proofs dealt round-robin to the ranks (proof p -> rank p mod N, SRS and proving
-    key replicated), then ONE all-gather of every proof's commitments (31 x 64 B affine each).  After the timed region every
-    rank re-makes each of ITS proofs alone (one prover, nothing else in flight) from the same seed and requires the gathered blob to
-    hold exactly that proof's commitments; rank 0 also puts one batch-made proof through the pairing check.  -> dict on every rank."""
+    """configs[4]: a batch of delay_enc proofs dealt round-robin to the ranks (proof p -> rank p mod N, SRS and proving key
+    replicated), `inflight` provers per GPU (one context + one library thread each: dehalo_create_proofs, no interpreter in the loop),
+    then ONE all-gather of every proof's commitments (31 x 32 B compressed each).  After the timed region every rank re-makes each of
+    ITS proofs alone (one prover with a side context, nothing else in flight) from the same seed and requires the batch-made proof and
+    the gathered blob to hold exactly that proof; rank 0 also puts one batch-made proof through the pairing check."""
     import torch
-    from dehalo2_amd import sharding, transcript, keygen
+    from dehalo2_amd import native, prover, sharding
     st = ProofSetup(pkg, ctx, k, "delay_enc", min(host_cores(), 256))
     mine = sharding.units_for_rank(total, rank, world)
     st.prove(1000)                                            # warm-up
-    from dehalo2_amd import prover
-    import threading
     cs = st.circ.cs
-    # `inflight` proofs at a time on this GPU, each prover on its own context (stream + workspace) and host thread: one proof's
-    # transcript hashing, host gaps and latency-bound kernel tails are covered by the other's kernels
-    extra = [pkg.Context(device) for _ in range(max(1, inflight) - 1)]
-    provers = [st.prover] + [prover.Prover(st.params, st.pk, c) for c in extra]
-    for pv in provers:
-        st.prove(999, which=pv)                               # warm-up of every prover's buffers
-    blobs = [None] * len(mine)
-    full = [None] * len(mine)
-    errors = []
-
-    def work(t):
-        try:
-            for j in range(t, len(mine), len(provers)):
-                full[j] = st.prove(1000 + mine[j], which=provers[t])                                   # every proof its own blinding
-                blobs[j] = prover.proof_commitments(cs, full[j])
-        except Exception as e:      # noqa: BLE001
-            errors.append(e)
-
+    ctxs = [pkg.Context(device) for _ in range(max(1, inflight))]
+    provers = [native.Prover(st.params, st.pk, c) for c in ctxs]
+    native.create_proofs(provers, st.advice, [prover.SeededRng(999 - i) for i in range(2 * len(provers))])      # warm-up of every prover's buffers
     fence_all(world)
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=work, args=(t,)) for t in range(len(provers))]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    if errors:
-        raise errors[0]
+    full = native.create_proofs(provers, st.advice, [prover.SeededRng(1000 + unit) for unit in mine])          # every proof its own blinding
+    blobs = [prover.proof_commitments(cs, pf) for pf in full]
     allc = sharding.gather_proof_commitments(blobs, total, rank, world, "cuda" if backend == "nccl" else "cpu")
     per = len(allc[0]) // 32
     fence_all(world)
@@ -344,10 +327,13 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
         if rank == 0 and mine:
             assert verify_with_device_vk(st, full[-1]), "the verifier rejected a batch-made proof"
             checked += "; verifier accepts a batch-made proof"
-    st.release()
-    for c in extra:
+    for p in provers:
+        p.release()
+    for c in ctxs:
         c.close()
+    st.release()
     return {"k": k, "proofs": total, "n_gpus": world, "proofs_in_flight_per_gpu": len(provers), "proofs_per_s": round(total / elapsed, 2), "ms_per_proof_per_gpu": round(1e3 * elapsed / max(1, len(mine)), 3),
+            "driver": "dehalo_create_proofs: one library thread per prover, no interpreter in the loop",
             "gathered": "%d proofs x %d compressed commitments (32 B each) on every rank, one all_gather" % (total, per),
             "checked_after_timed_region": checked,
             "parallelism": "proof p -> rank p mod N; SRS / proving key replicated; no data-path collective"}
@@ -511,7 +497,7 @@ def main():
     ctx.timing_enable(False)
     single = collect([ctx]) if rank == 0 else None
 
-    n_proofs = args.proofs if args.proofs >= 0 else 8 * world
+    n_proofs = args.proofs if args.proofs >= 0 else 32 * world
     batch = None
     if args.proof_k > 0 and n_proofs > 0:
         batch = batch_proofs(pkg, ctx, args.proof_k, n_proofs, rank, world, args.dist_backend, local_rank, args.proofs_inflight)

@@ -7,6 +7,8 @@
 // operation is one of this library's device entry points (include/dehalo.h), called directly.  No CPU path for column work exists.
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -592,6 +594,12 @@ struct dehalo_prover {
     // host staging
     std::vector<uint64_t> blind_host, host_aff, host_evals, rand_host;
     double timings[8] = {};
+    bool trace = false;      // DEHALO_PROVER_TRACE=1: host timestamps inside the phases go to stderr after each proof
+    std::vector<std::pair<const char*, double>> ticks;
+    clk::time_point t0;
+    void tk(const char* label) {
+        if (trace) ticks.push_back({label, ms_since(t0)});
+    }
     std::mutex mu;      // one create_proof at a time per prover
 
     ~dehalo_prover() {
@@ -775,8 +783,11 @@ struct dehalo_prover {
     // commit `count` columns starting at `src`, normalise, read back, absorb (and append to the proof)
     int commit(dehalo_transcript* tr, const fe* src, size_t count, bool lagrange, const std::function<int()>& before_sync = nullptr) {
         TRY(dehalo_msm_device_affine(ctx, lagrange ? params->bases_gl : params->bases_g, (const uint64_t*)src, n, count, nullptr, aff.u64(), nullptr));
+        tk("commit queued");
         if (before_sync) TRY(before_sync());
+        tk("side work queued");
         TRY(dehalo_download(ctx, aff.p, count * 64, host_aff.data()));
+        tk("points on host");
         for (size_t i = 0; i < count; i++)
             if (!tr->write_point(host_aff.data() + 8 * i)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
         return 0;
@@ -808,6 +819,9 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     const uint32_t rot_scale = (uint32_t)(m / n);
     const auto t_start = clk::now();
     auto t_phase = t_start;
+    ticks.clear();
+    t0 = t_start;
+    trace = getenv("DEHALO_PROVER_TRACE") != nullptr;
     auto mark = [&](int slot) {
         const auto now = clk::now();
         timings[slot] = std::chrono::duration<double, std::milli>(now - t_phase).count();
@@ -831,10 +845,13 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     std::atomic<int> helper_rc{0};
     uint64_t rand_point[8] = {};
     std::thread helper;
+    double helper_ms[3] = {};
     auto helper_body = [&]() {
         (void)hipSetDevice(ctx->device);
+        const auto th0 = clk::now();
         rand_host.resize(4 * n);
         int rc = rng_poly.scalars(rand_host.data(), n);
+        helper_ms[0] = ms_since(th0);
         if (!rc) {
             if (side) {
                 fe* dst = polys + (size_t)o_rand * n;
@@ -842,7 +859,9 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
                 if (e == hipSuccess) e = hipStreamSynchronize(ss);
                 if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial upload: ") + hipGetErrorString(e));
                 if (!rc) rc = dehalo_msm_device_affine(side, params->bases_g, (const uint64_t*)dst, n, 1, nullptr, aff_side.u64(), nullptr);
+                helper_ms[1] = ms_since(th0);
                 if (!rc) rc = dehalo_download(side, aff_side.p, 64, rand_point);
+                helper_ms[2] = ms_since(th0);
             } else {
                 // without a side context only the draw is taken off the critical path; the upload is queued by the proving thread
             }
@@ -877,6 +896,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             HIP_TRY(ctx, hipStreamSynchronize(ms));      // `packed` is a local
         }
     }
+    tk("blinds drawn and uploaded");
     const fe* bl_adv = blind_dev.p;
     const fe* bl_perm = blind_dev.p + (size_t)A * rows;
     const fe* bl_prod = bl_perm + (size_t)2 * L * rows;
@@ -919,6 +939,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     if (!advice) return dh_fail(ctx, DEHALO_ERR_INVALID, "null advice");
     HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, (flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                 ms));
+    if (flags & DEHALO_PROOF_ADVICE_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, cols.u64((size_t)o_adv * n), nullptr, cols.u64((size_t)o_adv * n), (size_t)A * n, nullptr));
     if (A) HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_adv * n + u), n * 32, bl_adv, rows * 32, rows * 32, A, hipMemcpyDeviceToDevice, ms));
     if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[0], ms));
 
@@ -953,6 +974,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     TRY(commit(tr, cols.at((size_t)o_adv * n), A, true, after_advice_queued));
     mark(0);
     const Fe theta = tr->squeeze();
+    tk("theta");
 
     // ---- lookups: compress, permute, blind, commit
     if (L) {
@@ -968,16 +990,19 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         e.cols(fixed_v, adv_v, inst_v);
         e.in.theta = theta.v;
         TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), 2 * L, &e.in, k, 1, outs.data(), nullptr));
+        tk("compress queued");
         // the blinding rows [u, n) first: the permutation writes rows [0, u) only and ends with a read-back
         HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_perm * n + u), n * 32, bl_perm, rows * 32, rows * 32, 2 * L, hipMemcpyDeviceToDevice, ms));
         uint64_t* base = cols.u64((size_t)o_perm * n);
         TRY(dehalo_permute_expression_pair_batch_device(ctx, fid, compressed.u64(0), compressed.u64(n), u, L, 2 * n, base, base + 4 * n, nullptr));
+        tk("permute returned");
         if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[1], ms));
         TRY(commit(tr, cols.at((size_t)o_perm * n), 2 * L, true, side ? std::function<int()>([&]() { return side_ntt(o_perm, 2 * L, ev_ready[1]); }) : nullptr));
     }
     mark(1);
     const Fe beta = tr->squeeze();
     const Fe gamma = tr->squeeze();
+    tk("beta gamma");
 
     // ---- grand products: permutation sets, then lookups; one batched inversion
     const uint32_t npc = (uint32_t)cs.perm_cols.size();
@@ -1018,6 +1043,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             TRY(dehalo_graph_evaluate_device(ctx, lookup_den, &e.in, k, 1, nullptr, den.u64((size_t)(S + l) * n), nullptr));
             TRY(dehalo_graph_evaluate_device(ctx, lookup_num, &e.in, k, 1, nullptr, num.u64((size_t)(S + l) * n), nullptr));
         }
+        tk("product graphs queued");
         TRY(dehalo_grand_product_batch_device(ctx, fid, num.u64(), den.u64(), n, S + L, n, cols.u64((size_t)o_pz * n), nullptr));
         for (uint32_t s = 1; s < S; s++)      // z_s starts where z_{s-1} ended: z = vec![last_z]
             TRY(dehalo_scale_device(ctx, fid, cols.u64((size_t)(o_pz + s) * n), n, nullptr, 0, cols.u64((size_t)(o_pz + s - 1) * n + u), nullptr));
@@ -1045,7 +1071,10 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     mark(2);
 
     // ---- vanishing argument: a random polynomial
+    tk("products done");
     if (helper.joinable()) helper.join();
+    tk("helper joined");
+    if (trace) fprintf(stderr, "  helper: draw %.3f, upload + commit queued %.3f, point on host %.3f ms after its start\n", helper_ms[0], helper_ms[1], helper_ms[2]);
     if (helper_rc.load()) return helper_rc.load();
     rng.skip(n);
     {
@@ -1060,6 +1089,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     }
     mark(3);
     const Fe y = tr->squeeze();
+    tk("y");
 
     // ---- coefficient forms and cosets of everything committed so far
     if (!side) {
@@ -1128,6 +1158,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         std::vector<uint64_t> hb(4 * (size_t)pieces);
         TRY(rng.scalars(hb.data(), pieces));      // h_blinds (unused by KZG)
     }
+    tk("quotient queued");
     TRY(commit(tr, h.p, pieces, false));
     mark(4);
     const Fe x = tr->squeeze();
@@ -1147,7 +1178,9 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         }
     }
     TRY(dehalo_lincomb_device(ctx, fid, hp_ptrs.data(), (const uint64_t*)xs.data(), pieces, n, hfold.u64(), nullptr, nullptr));
+    tk("evaluations queued");
     TRY(dehalo_download(ctx, evals.p, eval_count * 32, host_evals.data()));
+    tk("evaluations on host");
     const Fe* E = (const Fe*)host_evals.data();
     Fe hfold_eval = zero;
     for (uint32_t i = 0; i < pieces; i++) hfold_eval = f->add(hfold_eval, f->mul(xs[i], E[hpiece0 + i]));
@@ -1156,6 +1189,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
 
     // ---- ProverGWC::create_proof: one witness polynomial per distinct point, in order of first appearance
     const Fe v = tr->squeeze();
+    tk("v");
     HIP_TRY(ctx, hipMemsetAsync(wbuf.p, 0, 4 * n * 32, ms));
     std::vector<const uint64_t*> qptrs;
     std::vector<uint64_t*> wptrs;
@@ -1178,6 +1212,14 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     TRY(commit(tr, wbuf.p, groups.size(), false));
     mark(6);
     timings[7] = ms_since(t_start);
+    if (trace) {
+        double prev = 0;
+        for (auto& t : ticks) {
+            fprintf(stderr, "  %8.3f (+%6.3f) %s\n", t.second, t.second - prev, t.first);
+            prev = t.second;
+        }
+        fprintf(stderr, "  %8.3f total\n", timings[7]);
+    }
     // a PCG64 caller's generator moves past this proof's draws (upstream's `&mut rng`)
     if (rng_in && rng_in->kind == DEHALO_RNG_PCG64) {
         rng_in->pcg_state[0] = (uint64_t)rng.pcg.state;

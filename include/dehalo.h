@@ -448,7 +448,7 @@ int dehalo_prover_release(dehalo_prover* prover);
  *   instances  num_instance_columns arrays of instance_lens[i] scalars (Montgomery); the reference passes none (&[&[&[]]])
  * Errors follow upstream's: DEHALO_ERR_INVALID for instances.len() != num_instance_columns / an instance column longer than the usable
  * rows / a commitment at infinity; DEHALO_ERR_NOT_IN_TABLE when a lookup input is missing from its table. */
-enum { DEHALO_PROOF_ADVICE_ON_DEVICE = 1 };
+enum { DEHALO_PROOF_ADVICE_ON_DEVICE = 1, DEHALO_PROOF_ADVICE_CANONICAL = 2 /* plain integers < p: converted on the device */ };
 int dehalo_create_proof(dehalo_prover* prover, const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns,
                         dehalo_rng* rng, dehalo_transcript* transcript, uint32_t flags);
 /* Host wall-clock milliseconds the last create_proof on this prover spent per phase (advice, lookups, products, random, quotient, evaluations,
@@ -459,6 +459,35 @@ int dehalo_prover_last_timings(const dehalo_prover* prover, double out[8]);
  * a fresh transcript.  Batch / throughput mode (BASELINE configs[4]). */
 int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, const uint64_t* const* advice, uint32_t count, dehalo_rng* rngs, uint32_t flags,
                          uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens);
+
+/* ---- Circuit::synthesize of the reference's circuits, as values (csrc/witness.hip) --------------------------------------------------
+ * What the reference's timed create_proof does BEFORE its first commitment: DelayEncryptCircuit::synthesize (src/lib.rs:164-318: RSA
+ * time-lock x^e mod n over BigIntChip rows, Poseidon sponge of the packed result, Poseidon cipher of the message under the hash's two
+ * outputs), benches/mod_pow.rs:63-110's RSACircuit (the RSA region alone) and PoseidonEncCircuit (src/encryption/chip.rs:114-204, the
+ * cipher region alone) -- laid out over MainGate + RangeChip by this library's own layouter (halo2wrong's region code is upstream and
+ * not in the reference tree), so the columns belong to THIS library's keygen of the same constraint system.
+ *   advice     out, 5 x 2^k x 4 u64, CANONICAL values (pass DEHALO_PROOF_ADVICE_CANONICAL to dehalo_create_proof), rows beyond the
+ *              circuit zero; NULL = not wanted
+ *   fixed      out, (15 | 9 for pose_enc) x 2^k x 4 u64 canonical (DEHALO_KEYGEN_FIXED_CANONICAL), range table included; NULL = not wanted
+ *   mapping    out, 6 x 2^k u64: the permutation assembly for dehalo_keygen; NULL = not wanted
+ *   selectors  out, two arrays of 2^k bytes (s_composition, s_overflow; none for pose_enc); NULL = not wanted
+ * Per proof only `advice` is needed; the other three are keygen's.  DEHALO_ERR_INVALID when the circuit does not fit 2^k rows. */
+typedef enum { DEHALO_CIRCUIT_DELAY_ENC = 0, DEHALO_CIRCUIT_MOD_POW = 1, DEHALO_CIRCUIT_POSE_ENC = 2 } dehalo_circuit_kind;
+typedef struct {
+    uint32_t circuit, k;
+    uint32_t bits_len, exp_bits;        /* RSA: modulus bits (BITS_LEN = 2048, limbs of 64 bits), exponent bits (<= 64) */
+    const uint64_t *n, *x;              /* modulus and base, bits_len / 64 limbs, little-endian */
+    uint64_t e;                         /* exponent */
+    const uint64_t* message; uint32_t message_len;   /* <= 2 canonical field elements (4 u64 each) */
+    const uint64_t* key;                /* pose_enc: 2 canonical field elements */
+    uint32_t t, rate, r_f, r_p;         /* Poseidon; 0 = the reference's (5, 4, 8, 57) */
+} dehalo_circuit_inputs;
+typedef struct {
+    uint64_t rsa_rows, total_rows;
+    uint64_t rsa_result[128];           /* x^e mod n, little-endian limbs */
+    uint64_t cipher[12]; uint32_t cipher_len;   /* the ciphertext (canonical), message_len + 1 elements */
+} dehalo_synthesis_info;
+int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advice, uint64_t* fixed, uint64_t* mapping, uint8_t* const* selectors, dehalo_synthesis_info* info);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-kernel device time measured with HIP events on the launching stream (bench.py's

@@ -311,49 +311,6 @@ def test_msm_full_size_2_20(pkg, co, ctx, cname):
     assert np.array_equal(ctx.to_affine(spec.id, jab)[0], s)
 
 
-# ---------------------------------------------------------------- prover-shaped schedule (device-resident, batched)
-@pytest.mark.parametrize("cname,k", [("bn254", 8), ("pallas", 9)])
-def test_prover_shape_vs_oracle(pkg, po, co, ctx, cname, k):
-    """The 31 MSMs + 48 NTTs of one delay_enc-shaped create_proof through the batched device entry
-    points, every output checked against the oracle."""
-    import torch
-    from dehalo2_amd import prover_shape as ps
-    curve = pkg.fields.CURVES[cname]
-    f = curve.scalar
-    n = 1 << k
-    g = co.synth_bases(curve.id, n)
-    gl = g[::-1].copy()
-    cols = ps.synthetic_columns(lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed), f.id, k, 3)
-    bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, gl, 0, False)
-    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
-    polys_before = cols["polys"].copy()
-    res = shape.run()
-    assert res.commitments.shape == (31, 12)
-    got = ctx.to_affine(curve.id, res.commitments)
-    # the affine points the schedule hands to the transcript after every phase (device-side conversion) are the same ones
-    tp = np.concatenate([shape.transcript_points[name].numpy().view(np.uint64) for name, _, _ in ps.MSM_PHASES])
-    assert np.array_equal(tp, got)
-    row = 0
-    for name, cnt, _ in ps.MSM_PHASES:
-        basis = gl if name in ("advice", "lookup_permuted", "grand_products") else g
-        for i in range(cnt):
-            want = co.to_affine(curve.id, co.best_multiexp(curve.id, cols[name][i], basis, 2))
-            assert np.array_equal(got[row], want), (name, i)
-            row += 1
-    d, e = shape.domain, f.encode
-    coeffs_dev = shape.polys.cpu().numpy().view(np.uint64)
-    ext_dev = shape.ext.cpu().numpy().view(np.uint64)
-    for i in range(ps.N_INTT):
-        want = co.lagrange_to_coeff(f.id, polys_before[i], k, e(d.omega_inv), e(d.ifft_divisor), 2)
-        assert np.array_equal(coeffs_dev[i], want), i
-    for i in range(ps.N_COSET):
-        want = co.coeff_to_extended(f.id, coeffs_dev[i], k, d.extended_k, e(d.extended_omega), e(d.g_coset), 2)
-        if i == 0:  # the schedule takes extended vector 0 back through extended_to_coeff
-            want = co.extended_to_coeff(f.id, want, d.extended_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), 2)
-        assert np.array_equal(ext_dev[i], want), i
-    bg.release(); bgl.release()
-
-
 def test_two_contexts_concurrently(pkg, co, ctx):
     """bench.py keeps several steps in flight, one context (stream + workspace) each, sharing one SRS."""
     import torch
@@ -733,60 +690,6 @@ def test_lookup_h_batch_vs_oracle(pkg, po, ctx, fname, count):
     with pytest.raises(pkg.DehaloError):
         pkg.evaluation.lookup_h_batch_device(ctx, spec, tuples * 9, ds["l0"].data_ptr(), ds["l_last"].data_ptr(), ds["l_active"].data_ptr(), beta, gamma, y,
                                              ext_k, rot_scale, ds["values"].data_ptr())
-
-
-@pytest.mark.parametrize("cname,k,overlapped", [("bn254", 7, False), ("pallas", 8, False), ("bn254", 8, True)])
-def test_prover_shape_with_quotient_vs_oracle(pkg, po, co, ctx, cname, k, overlapped):
-    """The same schedule with evaluate_h on the device: custom gates + 2 permutation sets + 5 lookups over the
-    extended domain, then extended_to_coeff, against the C oracle run on the same cosets."""
-    from dehalo2_amd import prover_shape as ps
-    curve = pkg.fields.CURVES[cname]
-    f = curve.scalar
-    n = 1 << k
-    g = co.synth_bases(curve.id, n)
-    fill = lambda fid, dist, m, seed: co.fill_scalars(fid, dist, m, seed)
-    cols = ps.synthetic_columns(fill, f.id, k, 3)
-    bg, bgl = ctx.register_bases(curve.id, g, 0, True), ctx.register_bases(curve.id, g[::-1].copy(), 0, True)
-    shape0 = ps.ProverShape(ctx, curve, k, bgl, bg, cols)
-    cols.update(ps.synthetic_proving_key(fill, f, k, shape0.domain.extended_k, 55))
-    shape = ps.ProverShape(ctx, curve, k, bgl, bg, cols, with_quotient=True)
-    if overlapped:   # NTTs on a second context, overlapping the MSM phases: same results
-        ctx2 = pkg.Context(0)
-        assert shape.run_overlapped(ctx2) > 0
-        ctx2.close()
-    else:
-        res = shape.run()
-        assert res.ms_eval_h > 0
-    d, e = shape.domain, f.encode
-    # the schedule keeps the cosets in the kernels' internal form: bring a copy back to the standard form, and check it
-    # against the oracle's coeff_to_extended while at it
-    std = shape.ext.clone()
-    ctx.convert_form_device(f.id, std.data_ptr(), std.data_ptr(), std.shape[0] * std.shape[1], False, 0)
-    ctx.synchronize()
-    ext = std.cpu().numpy().view(np.uint64)
-    coeffs_dev = shape.polys.cpu().numpy().view(np.uint64)
-    for i in (0, 7, 22):
-        assert np.array_equal(ext[i], co.coeff_to_extended(f.id, coeffs_dev[i], k, d.extended_k, e(d.extended_omega), e(d.g_coset), 2)), i
-    pk = {name: cols["pk_" + name] for name in ("fixed", "sigma", "l")}
-    ch = cols["challenges"]
-    ext_k, rot_scale = d.extended_k, (1 << d.extended_k) // n
-    zero_col = np.zeros((1 << ext_k, 4), dtype=np.uint64)
-    mg = ps.maingate_graph()
-    fixed, advice = [pk["fixed"][i] for i in range(ps.N_FIXED)], [ext[i] for i in range(5)]
-    h = co.graph_evaluate(f.id, f.encode_many(mg.constants), mg.rotations, mg.calculations, mg.num_intermediates, fixed, advice, [zero_col], None, None, None, None,
-                          e(ch["y"]), ext_k, rot_scale, None, 4)
-    h = co.permutation_h(f.id, h, [ext[15], ext[16]], advice + [fixed[14]], [pk["sigma"][i] for i in range(ps.N_SIGMA)], ps.PERM_CHUNK, ps.LAST_ROTATION,
-                         pk["l"][0], pk["l"][1], pk["l"][2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]), e(ch["delta"]), e(ch["beta"] * d.g_coset % f.p),
-                         e(d.extended_omega), ext_k, rot_scale, 4)
-    for i in range(ps.N_LOOKUPS):
-        lg = ps.lookup_graph(i)
-        tv = co.graph_evaluate(f.id, f.encode_many(lg.constants), lg.rotations, lg.calculations, lg.num_intermediates, fixed, advice, [], None, e(ch["beta"]),
-                               e(ch["gamma"]), e(ch["theta"]), None, ext_k, rot_scale, None, 4)
-        h = co.lookup_h(f.id, h, ext[17 + i], ext[5 + 2 * i], ext[6 + 2 * i], tv, pk["l"][0], pk["l"][1], pk["l"][2], e(ch["beta"]), e(ch["gamma"]), e(ch["y"]),
-                        ext_k, rot_scale, 4)
-    want = co.extended_to_coeff(f.id, h, ext_k, e(d.extended_omega_inv), e(d.extended_ifft_divisor), e(d.g_coset), 2)
-    assert np.array_equal(shape.h.cpu().numpy().view(np.uint64), want)
-    bg.release(); bgl.release()
 
 
 # ---------------------------------------------------------------- lookup permutation (SURVEY.md 8(f) row 2)

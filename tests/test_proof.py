@@ -491,3 +491,44 @@ def test_written_keys_have_the_published_sizes(pkg, ctx, chain, device_chain):
         buf = io.BytesIO()
         d["pk"].write(buf)
         assert len(buf.getvalue()) == keygen.pk_size(c["circ"].cs, k, nsel, pkg.fields.BN254_FR)
+
+
+@pytest.mark.gpu
+def test_prover_intermediate_buffers_vs_oracle(pkg, po, co, ctx, chain, device_chain):
+    """What a proof leaves in the prover's device buffers, phase by phase, against the C oracle (the assertions of round 1's schedule
+    replay, now on the real prover): every committed column's MSM, its lagrange_to_coeff and coeff_to_extended, and the quotient's
+    coefficients [UPSTREAM ParamsKZG::commit_lagrange, EvaluationDomain::{lagrange_to_coeff, coeff_to_extended, extended_to_coeff}]."""
+    from dehalo2_amd import keygen, prover, transcript
+
+    k, rl = 9, True
+    c, d = chain(k, rl), device_chain(k, rl)
+    f = pkg.fields.BN254_FR
+    side = pkg.Context(0)
+    P = prover.Prover(d["params"], d["pk"], ctx, side)
+    tr = transcript.Blake2bWrite(pkg.fields.BN254)
+    P.create_proof(c["adv"], [[]], prover.SeededRng(7), tr)
+    ctx.synchronize(); side.synchronize()
+    want, trace = oracle_proof(po, c)
+    assert tr.finalize() == want
+    dom, e = d["pk"].domain, f.encode
+    cols = keygen.to_host(P.cols)                      # Lagrange values with their blinding rows (the random polynomial lives in polys only)
+    polys = keygen.to_host(P.polys)
+    std = P.ext.clone()
+    ctx.convert_form_device(f.id, std.data_ptr(), std.data_ptr(), std.numel() // 4, False, 0)
+    ctx.synchronize()
+    ext = keygen.to_host(std)
+    nco = P.NC - 1
+    commitments = trace["commitments"]
+    assert len(commitments) == P.NC + dom.quotient_poly_degree + 4
+    for col in range(nco):                             # advice | permuted (input, table)... | permutation z | lookup z: transcript order
+        pt = co.to_affine(0, co.best_multiexp(0, cols[col], c["srs"]["g_lagrange"], 4))
+        assert keygen.decode_points(pkg.fields.BN254, pt.reshape(1, 8))[0] == commitments[col], col
+        coeff = co.lagrange_to_coeff(f.id, cols[col], k, e(dom.omega_inv), e(dom.ifft_divisor), 2)
+        assert np.array_equal(polys[col], coeff), col
+        if col % 4 == 0:
+            assert np.array_equal(ext[col], co.coeff_to_extended(f.id, coeff, k, dom.extended_k, e(dom.extended_omega), e(dom.g_coset), 2)), col
+    pt = co.to_affine(0, co.best_multiexp(0, polys[nco], c["srs"]["g"], 4))                     # the random polynomial: commit, not commit_lagrange
+    assert keygen.decode_points(pkg.fields.BN254, pt.reshape(1, 8))[0] == commitments[nco]
+    h = keygen.to_host(P.h)[: dom.n * dom.quotient_poly_degree]
+    assert np.array_equal(h, np.asarray(trace["h_coeffs"])[: len(h)])
+    side.close()
