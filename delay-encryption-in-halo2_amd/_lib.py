@@ -25,7 +25,7 @@ SYMBOLS = [
     "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device", "dehalo_kate_division_batch_device",
     "dehalo_params_create", "dehalo_params_read", "dehalo_params_size", "dehalo_params_write", "dehalo_params_release", "dehalo_params_commit_device",
     "dehalo_keygen", "dehalo_pk_read", "dehalo_pk_size", "dehalo_pk_write", "dehalo_vk_size", "dehalo_vk_write", "dehalo_pk_set_transcript_repr",
-    "dehalo_pk_get_transcript_repr", "dehalo_pk_info", "dehalo_pk_release", "dehalo_rng_scalars", "dehalo_field_info",
+    "dehalo_pk_get_transcript_repr", "dehalo_pk_info", "dehalo_pk_release", "dehalo_rng_scalars", "dehalo_field_info", "dehalo_synthesize",
     "dehalo_transcript_create", "dehalo_transcript_common_scalar", "dehalo_transcript_write_scalar", "dehalo_transcript_write_point",
     "dehalo_transcript_squeeze_challenge", "dehalo_transcript_len", "dehalo_transcript_finalize", "dehalo_transcript_release",
     "dehalo_prover_create", "dehalo_prover_release", "dehalo_create_proof", "dehalo_prover_last_timings", "dehalo_create_proofs",
@@ -80,6 +80,15 @@ class CConstraintSystem(C.Structure):
                 ("advice_queries", C.POINTER(CColumnQuery)), ("num_advice_queries", C.c_uint32),
                 ("fixed_queries", C.POINTER(CColumnQuery)), ("num_fixed_queries", C.c_uint32),
                 ("instance_queries", C.POINTER(CColumnQuery)), ("num_instance_queries", C.c_uint32)]
+
+
+class CCircuitInputs(C.Structure):
+    _fields_ = [("circuit", C.c_uint32), ("k", C.c_uint32), ("bits_len", C.c_uint32), ("exp_bits", C.c_uint32), ("n", C.c_void_p), ("x", C.c_void_p), ("e", C.c_uint64),
+                ("message", C.c_void_p), ("message_len", C.c_uint32), ("key", C.c_void_p), ("t", C.c_uint32), ("rate", C.c_uint32), ("r_f", C.c_uint32), ("r_p", C.c_uint32)]
+
+
+class CSynthesisInfo(C.Structure):
+    _fields_ = [("rsa_rows", C.c_uint64), ("total_rows", C.c_uint64), ("rsa_result", C.c_uint64 * 128), ("cipher", C.c_uint64 * 12), ("cipher_len", C.c_uint32)]
 
 
 RNG_FILL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64)
@@ -197,6 +206,7 @@ def load_library():
     lib.dehalo_pk_get_transcript_repr.argtypes = [P, u64p]
     lib.dehalo_pk_info.argtypes = [P, C.POINTER(C.c_uint32)]
     lib.dehalo_pk_release.argtypes = [P, P]
+    lib.dehalo_synthesize.argtypes = [C.POINTER(CCircuitInputs), u64p, u64p, u64p, C.POINTER(C.c_void_p), C.POINTER(CSynthesisInfo)]
     lib.dehalo_field_info.argtypes = [C.c_int, u64p]
     lib.dehalo_rng_scalars.argtypes = [C.POINTER(CRng), C.c_int, C.c_uint64, u64p, sz]
     lib.dehalo_transcript_create.argtypes = [C.c_int, PP]

@@ -11,14 +11,15 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import plonk
-from ._lib import (CColumnQuery, CConstraintSystem, CExprNode, CRng, Context, DehaloError, RNG_FILL_FN, load_library)
+from ._lib import (CCircuitInputs, CColumnQuery, CConstraintSystem, CExprNode, CRng, CSynthesisInfo, Context, DehaloError, RNG_FILL_FN, load_library)
 from .fields import CurveSpec, FieldSpec
 
 EXPR_KIND = {"const": 0, plonk.FIXED: 1, plonk.ADVICE: 2, plonk.INSTANCE: 3, "neg": 4, "sum": 5, "product": 6, "scaled": 7}
 COLUMN_KIND = {plonk.ADVICE: 0, plonk.FIXED: 1, plonk.INSTANCE: 2}
 RNG_OS, RNG_PCG64, RNG_CALLBACK = 0, 1, 2
 KEYGEN_FIXED_CANONICAL = 1
-PROOF_ADVICE_ON_DEVICE = 1
+PROOF_ADVICE_ON_DEVICE, PROOF_ADVICE_CANONICAL = 1, 2
+CIRCUIT_DELAY_ENC, CIRCUIT_MOD_POW, CIRCUIT_POSE_ENC = 0, 1, 2
 PHASES = ("advice", "lookups", "products", "random", "quotient", "evaluations", "openings", "total")
 
 
@@ -284,15 +285,16 @@ class Prover:
         self.handle = C.c_void_p()
         _check(self.ctx, load_library().dehalo_prover_create(self.ctx.handle, side_ctx.handle if side_ctx is not None else None, params.handle, pk.handle, C.byref(self.handle)))
 
-    def create_proof(self, advice, instances: Sequence[Sequence[int]] = ((),), rng=None, transcript: Optional[Blake2bWrite] = None) -> Blake2bWrite:
-        """advice: (num_advice, n, 4) u64 Montgomery -- a host array or a device tensor (anything with .data_ptr()).  instances: one
-        list of canonical ints per instance column.  rng: None = OS entropy; prover.SeededRng for reproducible test proofs."""
+    def create_proof(self, advice, instances: Sequence[Sequence[int]] = ((),), rng=None, transcript: Optional[Blake2bWrite] = None, canonical: bool = False) -> Blake2bWrite:
+        """advice: (num_advice, n, 4) u64 Montgomery (or plain integers < p with canonical=True: what native.synthesize returns) -- a host
+        array or a device tensor (anything with .data_ptr()).  instances: one list of canonical ints per instance column.  rng: None = OS
+        entropy; prover.SeededRng for reproducible test proofs."""
         lib = load_library()
         tr = transcript if transcript is not None else Blake2bWrite(self.pk.curve)
         f = self.pk.curve.scalar
-        flags = 0
+        flags = PROOF_ADVICE_CANONICAL if canonical else 0
         if hasattr(advice, "data_ptr"):
-            adv_ptr, flags = advice.data_ptr(), PROOF_ADVICE_ON_DEVICE
+            adv_ptr, flags = advice.data_ptr(), flags | PROOF_ADVICE_ON_DEVICE
             if hasattr(advice, "is_cuda") and advice.is_cuda:
                 import torch
                 torch.cuda.current_stream().synchronize()      # the library reads the tensor on its own stream
@@ -356,3 +358,37 @@ def create_proofs(provers: Sequence[Prover], advice, rngs: Sequence, count: Opti
     if rc != 0:
         raise DehaloError(rc, "; ".join(lib.dehalo_last_error(p.ctx.handle).decode() for p in provers))
     return [bufs[i][:lens[i]].tobytes() for i in range(count)]
+
+
+def _limbs(x: int, count: int) -> np.ndarray:
+    return np.frombuffer(int(x).to_bytes(8 * count, "little"), dtype=np.uint64).copy()
+
+
+def synthesize(circuit: int, k: int, *, n_big: int = 0, e: int = 0, x: int = 0, exp_bits: int = 0, message: Sequence[int] = (), key: Sequence[int] = (), bits_len: int = 2048,
+               keygen: bool = False) -> dict:
+    """dehalo_synthesize: Circuit::synthesize of the reference's circuits as values, in C++ (csrc/witness.hip; src/lib.rs:164-318,
+    benches/mod_pow.rs:63-110, src/encryption/chip.rs:114-204).  -> {"advice": (5, n, 4) u64 CANONICAL, "rows", "rsa_rows", "rsa_result",
+    "cipher"} and, with keygen=True, "fixed" (canonical), "mapping", "selectors"."""
+    lib = load_library()
+    nl = bits_len // 64
+    inp = CCircuitInputs()
+    inp.circuit, inp.k, inp.bits_len, inp.exp_bits, inp.e = circuit, k, bits_len, exp_bits, e
+    keep = [_limbs(n_big, nl), _limbs(x, nl), np.ascontiguousarray(np.frombuffer(b"".join(int(m).to_bytes(32, "little") for m in message) or bytes(32), dtype=np.uint64)),
+            np.ascontiguousarray(np.frombuffer(b"".join(int(m).to_bytes(32, "little") for m in key) or bytes(64), dtype=np.uint64))]
+    inp.n, inp.x, inp.message, inp.message_len, inp.key = keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, len(message), keep[3].ctypes.data
+    n = 1 << k
+    nfix = 9 if circuit == CIRCUIT_POSE_ENC else 15
+    advice = np.empty((5, n, 4), dtype=np.uint64)
+    fixed = np.empty((nfix, n, 4), dtype=np.uint64) if keygen else None
+    mapping = np.empty(6 * n, dtype=np.uint64) if keygen else None
+    sels = [np.zeros(n, dtype=np.uint8) for _ in range(2)] if keygen and circuit != CIRCUIT_POSE_ENC else []
+    sel_ptrs = (C.c_void_p * 2)(*[s.ctypes.data for s in sels]) if sels else None
+    info = CSynthesisInfo()
+    rc = lib.dehalo_synthesize(C.byref(inp), advice.ctypes.data, fixed.ctypes.data if keygen else None, mapping.ctypes.data if keygen else None, sel_ptrs, C.byref(info))
+    if rc != 0:
+        raise ValueError("dehalo_synthesize failed (%d): bad inputs or not enough rows available" % rc)
+    out = {"advice": advice, "rows": int(info.total_rows), "rsa_rows": int(info.rsa_rows), "rsa_result": sum(int(v) << (64 * i) for i, v in enumerate(info.rsa_result)),
+           "cipher": [sum(int(info.cipher[4 * i + j]) << (64 * j) for j in range(4)) for i in range(info.cipher_len)]}
+    if keygen:
+        out.update(fixed=fixed, mapping=mapping, selectors=[s.astype(bool) for s in sels])
+    return out

@@ -380,3 +380,43 @@ def test_cpp_host_example_proves_without_an_interpreter(pkg, po, ctx, chain, tmp
     assert proof == want and oracle_verify(po, c, proof, k)
     assert (tmp_path / "vk.bin").read_bytes() == PO.vk_bytes(po.BN254, c["key"], c["circ"].selectors)
     assert len((tmp_path / "pk.bin").read_bytes()) == keygen.pk_size(c["circ"].cs, k, 0, f)
+
+
+@pytest.mark.gpu
+def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
+    """dehalo_synthesize -> dehalo_keygen -> dehalo_create_proof(DEHALO_PROOF_ADVICE_CANONICAL): the reference's whole timed call
+    (synthesize + prove, benches/delay_enc.rs:123-131 over src/lib.rs:164-318) without Python integers anywhere; the proof equals the
+    CPU restatement's proof of witness.py's (identical) columns and is accepted by the verifier."""
+    import json
+    import os
+
+    import pairing as pr
+    import plonk_oracle as PO
+    import verifier as V
+    from conftest import ROOT
+    from dehalo2_amd import native, plonk, prover
+
+    v = json.load(open(os.path.join(ROOT, "tests", "golden", "rsa_vectors.json")))[1]
+    n, x, k = int(v["n"]), int(v["signature"]), 16
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, k, n_big=n, e=0b10011, x=x, exp_bits=5, message=[123456789, 987654321], keygen=True)
+    assert nat["rsa_result"] == pow(x, 0b10011, n)
+    cs = plonk.maingate_cs(True)
+    asm = plonk.Assembly(6, 1 << k)
+    asm.mapping = nat["mapping"].astype(np.int64)
+    s = 0x5EED5EED5EED5EED
+    srs = PO.setup_srs(po.BN254, k, s, 16)
+    key = PO.keygen(po.BN254, srs, cs.description(), k, nat["fixed"], asm.mapping, 16)
+    rep = PO.transcript_repr(po.BN254, key, nat["selectors"])
+    params = native.ParamsKZG.create(ctx, pkg.fields.BN254, k, srs["g"], srs["g_lagrange"])
+    pk = native.ProvingKey.keygen(ctx, params, cs, nat["fixed"], asm, nat["selectors"])
+    assert pk.vk_bytes() == PO.vk_bytes(po.BN254, key, nat["selectors"])
+    pk.transcript_repr = rep
+    side = pkg.Context(0)
+    P = native.Prover(params, pk, ctx, side)
+    proof = P.create_proof(nat["advice"], [[]], prover.SeededRng(5), canonical=True).finalize()
+    adv_m = np.stack([co.field_op(0, "to_mont", nat["advice"][i]) for i in range(5)])
+    want, _ = PO.create_proof(po.BN254, srs, key, adv_m, [[]], prover.SeededRng(5), rep, 16)
+    assert proof == want
+    assert V.verify_proof(po.BN254, cs.description(), k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(s, pr.G2), [[]], proof)
+    assert P.create_proof(adv_m, [[]], prover.SeededRng(5)).finalize() == want              # Montgomery input, same proof
+    P.release(); pk.release(); params.release(); side.close()

@@ -257,3 +257,67 @@ def test_batch_mode_provers_make_the_proofs_a_lone_prover_makes(pkg, po, co, ctx
         cx.close()
     side.close()
     params.release()
+
+
+# ---------------------------------------------------------------- native witness generation (dehalo_synthesize, csrc/witness.hip)
+def _same_circuit(nat, circ, info):
+    assert nat["rows"] == info.total_rows == circ.used_rows and nat["rsa_rows"] == info.rsa_rows
+    assert nat["rsa_result"] == info.rsa_result and nat["cipher"] == info.cipher
+    assert np.array_equal(nat["advice"], circ.advice)
+    assert np.array_equal(nat["fixed"], circ.fixed)
+    assert np.array_equal(nat["mapping"].astype(np.int64), circ.assembly.mapping)
+    assert len(nat["selectors"]) == len(circ.selectors) and all(np.array_equal(a, b) for a, b in zip(nat["selectors"], circ.selectors))
+
+
+def test_native_synthesize_equals_witness_py_bit_for_bit(pkg):
+    """The C++ restatement of the three circuits' synthesize lays out the same rows as witness.py: advice, fixed columns (range table
+    included), the permutation assembly and the selectors are identical arrays; x^e mod n and the ciphertext are the same values."""
+    import time
+    from dehalo2_amd import native, witness as W
+
+    p = pkg.fields.BN254_FR.p
+    v = rsa_vectors()
+    n, x = int(v[0]["n"]), int(v[0]["signature"])
+    # delay_enc, 1-bit exponent, k = 14
+    circ, info = W.delay_enc_witness(p, 14, n, 0b1, x, 1, [11, 22])
+    _same_circuit(native.synthesize(native.CIRCUIT_DELAY_ENC, 14, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22], keygen=True), circ, info)
+    # the reference's checked-in parameters: 5-bit exponent, k = 16 (src/lib.rs:122-124); other modulus, other message
+    n2, x2 = int(v[1]["n"]), int(v[1]["signature"])
+    circ, info = W.delay_enc_witness(p, 16, n2, 0b10011, x2, 5, [123456789, p - 5])
+    t = time.perf_counter()
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 16, n_big=n2, e=0b10011, x=x2, exp_bits=5, message=[123456789, p - 5], keygen=True)
+    assert time.perf_counter() - t < 2.0
+    _same_circuit(nat, circ, info)
+    assert nat["rsa_result"] == pow(x2, 0b10011, n2)
+    # mod_pow (RSA region only) and an 8-bit exponent (range-assigned exponent cell)
+    circ, info = W.mod_pow_witness(p, 15, n, 0b101, x, 3)
+    _same_circuit(native.synthesize(native.CIRCUIT_MOD_POW, 15, n_big=n, e=0b101, x=x, exp_bits=3, keygen=True), circ, info)
+    circ, info = W.mod_pow_witness(p, 17, n2, 0xA7, x2, 8)
+    _same_circuit(native.synthesize(native.CIRCUIT_MOD_POW, 17, n_big=n2, e=0xA7, x=x2, exp_bits=8, keygen=True), circ, info)
+    # pose_enc, K = 11 (MainGate only: 9 fixed columns, no selectors)
+    circ, info = W.pose_enc_witness(p, 11, [0xABCDEF, p - 1], [42, 43])
+    _same_circuit(native.synthesize(native.CIRCUIT_POSE_ENC, 11, key=[0xABCDEF, p - 1], message=[42, 43], keygen=True), circ, info)
+    # advice alone (what a proof needs) is the same array; a circuit that does not fit is refused
+    adv_only = native.synthesize(native.CIRCUIT_DELAY_ENC, 14, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22])
+    assert np.array_equal(adv_only["advice"], W.delay_enc_witness(p, 14, n, 0b1, x, 1, [11, 22])[0].advice)
+    with pytest.raises(ValueError):
+        native.synthesize(native.CIRCUIT_DELAY_ENC, 13, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22])
+
+
+def test_native_synthesize_is_fast_at_the_north_star_size(pkg):
+    """k = 17, 2048-bit modulus, 15-bit exponent (benches/README.md:59-60): the advice columns of one proof."""
+    import random
+    import time
+    from dehalo2_amd import native
+
+    rnd = random.Random(5)
+    n_big, x, e = rnd.getrandbits(2048) | (1 << 2047) | 1, rnd.getrandbits(2040), rnd.getrandbits(15) | (1 << 14)
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 17, n_big=n_big, e=e, x=x, exp_bits=15, message=[7, 8])
+        el = time.perf_counter() - t
+        best = el if best is None or el < best else best
+    assert nat["rsa_result"] == pow(x, e, n_big) and 100000 < nat["rows"] < 131000
+    print("native synthesize, k = 17, 15-bit exponent: %.1f ms for %d rows" % (1e3 * best, nat["rows"]))
+    assert best < 0.5
