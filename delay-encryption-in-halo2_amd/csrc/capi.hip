@@ -945,6 +945,24 @@ int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, cons
                                (fe*)d_permuted_tables, pick_stream(ctx, stream));
 }
 
+int dehalo_permute_expression_pair_ptrs_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
+                                               uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!d_inputs || !d_tables || !d_permuted_inputs || !d_permuted_tables) && batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
+    if (batch >= 4096) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: batch too large");
+    if (field < 0 || field > 3) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
+    for (size_t y = 0; y < batch && usable_rows; y++) {
+        if (!d_inputs[y] || !d_tables[y] || !d_permuted_inputs[y] || !d_permuted_tables[y]) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null column");
+        for (size_t z = 0; z < batch; z++)
+            if (d_permuted_inputs[y] == d_inputs[z] || d_permuted_inputs[y] == d_tables[z] || d_permuted_tables[y] == d_inputs[z] || d_permuted_tables[y] == d_tables[z])
+                return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: outputs may not alias inputs");
+    }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return lookup_permute_ptrs(ctx, field, (const fe* const*)d_inputs, (const fe* const*)d_tables, usable_rows, batch, (fe* const*)d_permuted_inputs, (fe* const*)d_permuted_tables,
+                               pick_stream(ctx, stream));
+}
+
 int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,
                                           uint64_t* d_permuted_input, uint64_t* d_permuted_table, void* stream) {
     return dehalo_permute_expression_pair_batch_device(ctx, field, d_input, d_table, usable_rows, 1, usable_rows, d_permuted_input, d_permuted_table, stream);

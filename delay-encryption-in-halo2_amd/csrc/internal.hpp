@@ -198,6 +198,9 @@ DECL_POLY(pasta_fq)
 int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe* d_tables, uint64_t n, size_t batch, uint64_t stride, fe* d_out_inputs,
                         fe* d_out_tables, hipStream_t s);
 
+int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, const fe* const* d_tables, uint64_t n, size_t batch, fe* const* d_out_inputs,
+                        fe* const* d_out_tables, hipStream_t s);
+
 // quotient-numerator kernels (evalh.cuh)
 struct dehalo_graph;
 #define DECL_EVALH(NAME)                                                                                                                    \

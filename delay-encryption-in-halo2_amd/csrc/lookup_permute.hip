@@ -11,17 +11,15 @@
 //             repeated row.
 // The blinding rows upstream appends are the caller's (they are random).
 //
-// Upstream: Vec::sort + BTreeMap on one thread.  Here: canonical keys -> one pass of rocPRIM's 64-bit radix sort on the leading
-// bits + a verification of the full order (fallback: four stable LSD passes), carrying a permutation (rocPRIM is header-only, compiled in; the
-// sort is not the prover's hot loop and a hand-written 256-bit radix sort would be the same
-// algorithm), then flag / binary-search / scan / scatter kernels.  Outputs are gathered from the
-// ORIGINAL Montgomery elements, so no value is ever re-encoded.
+// Upstream: Vec::sort + BTreeMap on one thread.  Here only the TABLE is sorted -- once per distinct table column of a call (the five
+// range lookups of the delay-encryption circuit share one) -- by a merge sort on the full 256-bit keys (LDS bitonic tiles, then
+// merge-path passes: no digit plan, no fallback, nothing read back).  The inputs are never sorted: every input value finds its table
+// position by binary search (a miss is the error), positions are counted, and A' / S' are WRITTEN from the counts -- A' is the sorted
+// table with every entry repeated as often as it was looked up, S' the first occurrences plus the unused entries from the end.
+// Everything is hand-written here (round 3 replaced the rocPRIM radix sort and scans this file used to call).
 #include <cstring>
 #include <string>
 #include <vector>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "fp.cuh"
 #include "field_constants.h"
@@ -29,50 +27,19 @@
 
 namespace {
 
-// Batched layout: 2B key columns of n rows each, inputs first then tables, at canon[y * n + i].
-template <class F>
-__global__ void k_lp_canon(const fe* inputs, const fe* tables, u64 stride, u32 B, u64 n, fe* canon) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 y = blockIdx.y;
-    if (i >= n) return;
-    const fe* src = y < B ? inputs + (u64)y * stride : tables + (u64)(y - B) * stride;
-    f_store(&canon[(u64)y * n + i], f_from_mont<F>(f_load(&src[i])));
-}
-__global__ void k_lp_iota(u32* p, u64 n) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (u32)i;
-}
-// keys[i] = 64-bit limb `limb` of canon[perm[i]]   (limb == 4: the column id perm[i] / n)
-__global__ void k_lp_limb(const fe* canon, const u32* perm, u32 limb, u64 n_col, u64 total, unsigned long long* keys) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const u32 src = perm[i];
-    if (limb == 4) { keys[i] = src / n_col; return; }
-    const u32* w = canon[src].v;
-    keys[i] = (unsigned long long)w[2 * limb] | ((unsigned long long)w[2 * limb + 1] << 32);
-}
-// ors[l] |= every key's 64-bit limb l: limbs that are zero everywhere need no sort pass, and the
-// highest set bit bounds the digits of the others (range tables hold small values)
-__global__ void k_lp_limb_or(const fe* canon, u64 total, unsigned long long* ors) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v[4] = {0, 0, 0, 0};
-    if (i < total) {
-        const u32* w = canon[i].v;
-#pragma unroll
-        for (int l = 0; l < 4; l++) v[l] = (unsigned long long)w[2 * l] | ((unsigned long long)w[2 * l + 1] << 32);
-    }
-#pragma unroll
-    for (int l = 0; l < 4; l++) {
-        unsigned long long x = v[l];
-        for (int d = 32; d >= 1; d >>= 1) x |= __shfl_xor(x, d);
-        // only a wave that would ADD bits touches the shared word (4 hot addresses otherwise serialise ~10^5 atomics)
-        if ((threadIdx.x & 63) == 0 && (x & ~__atomic_load_n(&ors[l], __ATOMIC_RELAXED)) != 0) atomicOr(&ors[l], x);
-    }
-}
-__global__ void k_lp_gather(const fe* canon, const u32* perm, u64 total, fe* sorted) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) f_store(&sorted[i], f_load(&canon[perm[i]]));
-}
+constexpr u32 LP_TILE = 2048, LP_THREADS = 256, LP_PER = LP_TILE / LP_THREADS;      // 8 keys per thread (scan / emit kernels)
+constexpr u32 LP_SORT_THREADS = 1024;                                               // tile sort, rank: one compare-exchange per thread per stage
+constexpr u32 LP_MERGE_OUT = 512, LP_MERGE_THREADS = 128, LP_MERGE_PER = LP_MERGE_OUT / LP_MERGE_THREADS;      // a merge block's outputs
+constexpr u32 LP_MAX_BATCH = 16;
+
+struct LpCols {      // per lookup: its input column, its outputs, which sorted table it uses; per distinct table: the column
+    const fe* in[LP_MAX_BATCH];
+    fe* out_in[LP_MAX_BATCH];
+    fe* out_tab[LP_MAX_BATCH];
+    const fe* tab[LP_MAX_BATCH];      // distinct tables
+    u32 table_of[LP_MAX_BATCH];
+};
+
 FP_DEV int lp_cmp(const fe& a, const fe& b) {          // canonical integers, most significant word first
 #pragma unroll
     for (int i = 7; i >= 0; i--) {
@@ -80,181 +47,443 @@ FP_DEV int lp_cmp(const fe& a, const fe& b) {          // canonical integers, mo
     }
     return 0;
 }
-// lookup y: A = S[y], T = S[B + y] (both sorted).  repeated[i] = A[i] == A[i-1]; every first
-// occurrence looks its value up in T and marks the FIRST copy there as consumed; a miss raises err[y].
-__global__ void k_lp_flags(const fe* S, u32 B, u64 n, u32* repeated, u32* consumed, int* err) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 y = blockIdx.y;
-    if (i >= n) return;
-    const fe* A = S + (u64)y * n;
-    const fe* T = S + (u64)(B + y) * n;
-    const fe a = f_load(&A[i]);
-    bool first = i == 0 || lp_cmp(a, f_load(&A[i - 1])) != 0;
-    repeated[(u64)y * n + i] = first ? 0u : 1u;
-    if (!first) return;
-    u64 lo = 0, hi = n;                                   // lower bound of a in T
-    while (lo < hi) {
-        u64 mid = (lo + hi) >> 1;
-        if (lp_cmp(f_load(&T[mid]), a) < 0) lo = mid + 1; else hi = mid;
+// keys in LDS as eight planes of LP_TILE words (word w of key i at lds[w * LP_TILE + i]): conflict-free for consecutive i
+FP_DEV fe lds_key(const u32* lds, u32 i) {
+    fe r;
+#pragma unroll
+    for (int w = 0; w < 8; w++) r.v[w] = lds[w * LP_TILE + i];
+    return r;
+}
+FP_DEV void lds_put(u32* lds, u32 i, const fe& k) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) lds[w * LP_TILE + i] = k.v[w];
+}
+FP_DEV bool lds_less(const u32* lds, u32 i, u32 j) {      // key[i] < key[j]
+    for (int w = 7; w >= 0; w--) {
+        const u32 a = lds[w * LP_TILE + i], b = lds[w * LP_TILE + j];
+        if (a != b) return a < b;
     }
-    if (lo < n && lp_cmp(f_load(&T[lo]), a) == 0) consumed[(u64)y * n + lo] = 1u;
-    else atomicExch(&err[y], 1);
+    return false;
 }
-// bad += 1 for every adjacent pair of one key column that is out of order under the FULL 256-bit comparison (the fast path sorted
-// on the leading bits only)
-__global__ void k_lp_check_sorted(const fe* S, u64 n, u64 total, u32* bad) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total || i % n == 0) return;
-    if (lp_cmp(f_load(&S[i - 1]), f_load(&S[i])) > 0) atomicAdd(bad, 1u);
+
+// canonical keys of the distinct tables, padded to whole tiles with +infinity (all ones: above every canonical value)
+template <class F>
+__global__ void k_lp_canon_tables(LpCols c, u64 n, u64 npad, fe* keys) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = blockIdx.y;
+    if (i >= npad) return;
+    fe k;
+    if (i < n) k = f_from_mont<F>(f_load(&c.tab[t][i]));
+    else {
+#pragma unroll
+        for (int w = 0; w < 8; w++) k.v[w] = 0xFFFFFFFFu;
+    }
+    f_store(&keys[(u64)t * npad + i], k);
 }
-__global__ void k_lp_not(const u32* consumed, u64 total, u32* leftover) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) leftover[i] = consumed[i] ? 0u : 1u;
+
+// one tile of LP_TILE keys sorted in LDS (bitonic network on the full keys)
+__global__ void __launch_bounds__(LP_SORT_THREADS) k_lp_tile_sort(const fe* in, fe* out, u64 npad) {
+    extern __shared__ u32 lds[];
+    const u64 base = (u64)blockIdx.y * npad + (u64)blockIdx.x * LP_TILE;
+    for (u32 i = threadIdx.x; i < LP_TILE; i += LP_SORT_THREADS) lds_put(lds, i, f_load(&in[base + i]));
+    __syncthreads();
+    const u32 t = threadIdx.x;
+    for (u32 k = 2; k <= LP_TILE; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            // both operands are loaded in full before they are compared (an early-exit compare on LDS words is a chain of eight dependent
+            // round trips when the keys are equal, and table columns are mostly equal keys)
+            const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // 2 j (t / j) + t % j, j a power of two
+            const fe a = lds_key(lds, i), b = lds_key(lds, i + j);
+            const int cmp = lp_cmp(a, b);
+            if (((i & k) == 0) ? cmp > 0 : cmp < 0) {
+                lds_put(lds, i, b);
+                lds_put(lds, i + j, a);
+            }
+            __syncthreads();
+        }
+    }
+    for (u32 i = threadIdx.x; i < LP_TILE; i += LP_SORT_THREADS) f_store(&out[base + i], lds_key(lds, i));
 }
-// lsrc[y][q] = original table row of lookup y's q-th leftover (ascending); ranks are global scans,
-// made column-local by subtracting the rank at the column's first row
-__global__ void k_lp_compact(const u32* leftover, const u32* lrank, const u32* perm, u32 B, u64 n, u32* lsrc) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+
+// merge path: the number of elements taken from A among the first d of merge(A, B) (A first on ties).  One wave searches 64 candidates
+// per round (three rounds cover 2^18 positions) instead of a lane walking a 17-step dependent chain of global loads.
+__device__ u64 lp_merge_path_wave(const fe* A, u64 la, const fe* B, u64 lb, u64 d) {
+    u64 lo = d > lb ? d - lb : 0, hi = d < la ? d : la;      // the answer lies in [lo, hi]
+    const u32 lane = threadIdx.x & 63;
+    while (lo < hi) {
+        const u64 span = hi - lo;                            // candidates mid in [lo, hi): "take A[mid]" iff A[mid] <= B[d - 1 - mid]
+        const u64 step = (span + 63) / 64;
+        const u64 mid = lo + (u64)lane * step;
+        bool take = false;
+        if (mid < hi) take = lp_cmp(f_load(&A[mid]), f_load(&B[d - 1 - mid])) <= 0;
+        const u64 mask = __ballot(take);                     // monotone: true ... true false ... false
+        const u32 cnt = (u32)__popcll(mask);
+        // the answer is > the last true candidate and <= the first false one
+        const u64 new_lo = cnt ? lo + (u64)(cnt - 1) * step + 1 : lo;
+        const u64 first_false = lo + (u64)cnt * step;
+        const u64 new_hi = first_false < hi ? first_false : hi;
+        lo = new_lo;
+        hi = new_hi;
+    }
+    return lo;
+}
+
+// runs of `run` keys (sorted) -> runs of 2 * run: every block writes LP_MERGE_OUT consecutive outputs of one pair of runs (small blocks:
+// a column of 2^17 keys is 256 of them, one per compute unit)
+__global__ void __launch_bounds__(LP_MERGE_THREADS) k_lp_merge(const fe* in, fe* out, u64 npad, u64 run) {
+    __shared__ u32 lds[8 * LP_MERGE_OUT];                    // LP_MERGE_OUT keys, eight planes
+    __shared__ u64 part[2];
+    constexpr u32 PITCH = LP_MERGE_OUT;
+    const u64 col = (u64)blockIdx.y * npad;
+    const u64 o = (u64)blockIdx.x * LP_MERGE_OUT;            // first output of this block, within the column
+    const u64 pair = o / (2 * run), within = o % (2 * run);
+    const u64 a0 = pair * 2 * run;
+    const u64 la = run < npad - a0 ? run : npad - a0;
+    const u64 b0 = a0 + la;
+    const u64 lb = b0 < npad ? (run < npad - b0 ? run : npad - b0) : 0;
+    const fe* A = in + col + a0;
+    const fe* B = in + col + b0;
+    const u64 d0 = within, d1 = (within + LP_MERGE_OUT < la + lb) ? within + LP_MERGE_OUT : la + lb;
+    const u32 wave = threadIdx.x >> 6;
+    {
+        const u64 r = lp_merge_path_wave(A, la, B, lb, wave == 0 ? d0 : d1);
+        if ((threadIdx.x & 63) == 0) part[wave] = r;
+    }
+    __syncthreads();
+    const u64 ai0 = part[0], ai1 = part[1], bi0 = d0 - ai0, bi1 = d1 - ai1;
+    const u32 na = (u32)(ai1 - ai0), nb = (u32)(bi1 - bi0);   // na + nb <= LP_MERGE_OUT
+    for (u32 i = threadIdx.x; i < na + nb; i += LP_MERGE_THREADS) {
+        const fe k = i < na ? f_load(&A[ai0 + i]) : f_load(&B[bi0 + (i - na)]);
+#pragma unroll
+        for (int w = 0; w < 8; w++) lds[w * PITCH + i] = k.v[w];
+    }
+    __syncthreads();
+    auto key = [&](u32 i) {
+        fe r;
+#pragma unroll
+        for (int w = 0; w < 8; w++) r.v[w] = lds[w * PITCH + i];
+        return r;
+    };
+    // every thread merges LP_MERGE_PER outputs starting at its own diagonal
+    const u32 total = na + nb;
+    const u32 d = threadIdx.x * LP_MERGE_PER < total ? threadIdx.x * LP_MERGE_PER : total;
+    u32 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (lp_cmp(key(mid), key(na + (d - 1 - mid))) <= 0) lo = mid + 1;      // A[mid] <= B[d - 1 - mid]
+        else hi = mid;
+    }
+    u32 ai = lo, bi = d - lo;
+    fe ka, kb;
+    bool ha = ai < na, hb = bi < nb;
+    if (ha) ka = key(ai);
+    if (hb) kb = key(na + bi);
+    for (u32 k = 0; k < LP_MERGE_PER && d + k < total; k++) {
+        const bool from_a = ha && (!hb || lp_cmp(ka, kb) <= 0);
+        f_store(&out[col + o + d + k], from_a ? ka : kb);
+        if (from_a) {
+            ai++;
+            ha = ai < na;
+            if (ha) ka = key(ai);
+        } else {
+            bi++;
+            hb = bi < nb;
+            if (hb) kb = key(na + bi);
+        }
+    }
+}
+
+// Every input value's position in its sorted table (first copy): counted.  A tile's positions are sorted in LDS and run-length encoded,
+// so that a value looked up thousands of times (zero, in the unused rows) costs one atomic per tile instead of one per row.
+template <class F>
+__global__ void __launch_bounds__(LP_SORT_THREADS) k_lp_rank(LpCols c, const fe* sorted, u64 n, u64 npad, u32* cnt, int* err) {
+    __shared__ u32 pos[LP_TILE];
+    constexpr u32 RP = LP_TILE / LP_SORT_THREADS;      // 2 inputs per thread
     const u32 y = blockIdx.y;
-    if (j >= n) return;
-    const u64 base = (u64)y * n;
-    if (leftover[base + j]) lsrc[base + (lrank[base + j] - lrank[base])] = perm[(u64)(B + y) * n + j] - (u32)((u64)(B + y) * n);
+    const fe* T = sorted + (u64)c.table_of[y] * npad;
+    const u64 base = (u64)blockIdx.x * LP_TILE;
+    bool miss = false;
+    {
+        // the thread's lower-bound searches advance together: each step issues all its 32-byte loads before comparing
+        fe a[RP];
+        u64 lo[RP];
+#pragma unroll
+        for (u32 k = 0; k < RP; k++) {
+            const u64 i = base + threadIdx.x + k * LP_SORT_THREADS;
+            a[k] = f_from_mont<F>(f_load(&c.in[y][i < n ? i : n - 1]));
+            lo[k] = 0;
+        }
+        for (u64 len = n; len > 1;) {                              // invariant: the lower bound lies in [lo, lo + len]
+            const u64 half = len >> 1;
+            fe t[RP];
+#pragma unroll
+            for (u32 k = 0; k < RP; k++) t[k] = f_load(&T[lo[k] + half - 1]);
+#pragma unroll
+            for (u32 k = 0; k < RP; k++)
+                if (lp_cmp(t[k], a[k]) < 0) lo[k] += half;
+            len -= half;
+        }
+#pragma unroll
+        for (u32 k = 0; k < RP; k++) {
+            const u32 li = threadIdx.x + k * LP_SORT_THREADS;
+            const u64 i = base + li;
+            u32 p = 0xFFFFFFFFu;
+            if (i < n) {
+                u64 l = lo[k];
+                if (lp_cmp(f_load(&T[l]), a[k]) < 0) l++;          // the one remaining candidate
+                if (l < n && lp_cmp(f_load(&T[l]), a[k]) == 0) p = (u32)l;
+                else miss = true;
+            }
+            pos[li] = p;
+        }
+    }
+    if (miss) atomicExch(&err[y], 1);
+    __syncthreads();
+    for (u32 k = 2; k <= LP_TILE; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            const u32 t = threadIdx.x;
+            const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i + j;
+            const u32 a = pos[i], b = pos[x];
+            if (((i & k) == 0) ? (b < a) : (a < b)) {
+                pos[i] = b;
+                pos[x] = a;
+            }
+            __syncthreads();
+        }
+    }
+    for (u32 k = 0; k < RP; k++) {
+        const u32 li = threadIdx.x * RP + k;
+        const u32 v = pos[li];
+        if (v == 0xFFFFFFFFu || (li > 0 && pos[li - 1] == v)) continue;      // padding / misses sort to the end; only run heads count
+        u32 lo = li + 1, hi = LP_TILE;                                       // end of the run: first position with a larger value
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (pos[mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        atomicAdd(&cnt[(u64)y * n + v], lo - li);
+    }
 }
-__global__ void k_lp_emit(const fe* inputs, const fe* tables, u64 stride, const u32* perm, const u32* repeated, const u32* rrank, const u32* lsrc, u32 B, u64 n,
-                          fe* out_inputs, fe* out_tables) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+
+// exclusive scans over the n table positions of every lookup, of cnt (-> the first output row of each table entry) and of "never looked
+// up" flags (-> the entry's rank among the leftovers), written COMPACTED: used entries (first row, position) and leftover positions;
+// three launches: tile sums, their scan, apply
+__global__ void __launch_bounds__(LP_THREADS) k_lp_scan_tiles(const u32* cnt, u64 n, u32 tiles, u32* tile_sums) {
+    __shared__ u32 red[2][LP_THREADS / 64];
+    const u32 y = blockIdx.y;
+    const u64 base = (u64)blockIdx.x * LP_TILE;
+    u32 s0 = 0, s1 = 0;
+    for (u32 k = 0; k < LP_PER; k++) {
+        const u64 i = base + threadIdx.x + k * LP_THREADS;
+        if (i < n) {
+            const u32 v = cnt[(u64)y * n + i];
+            s0 += v;
+            s1 += v == 0;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d);
+        s1 += __shfl_xor(s1, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s0;
+        red[1][threadIdx.x >> 6] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 a = 0, b = 0;
+        for (u32 w = 0; w < LP_THREADS / 64; w++) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        tile_sums[((u64)y * tiles + blockIdx.x) * 2] = a;
+        tile_sums[((u64)y * tiles + blockIdx.x) * 2 + 1] = b;
+    }
+}
+// one block per lookup: exclusive scan of its tile sums in place; totals[y] = (rows counted, leftovers)
+__global__ void __launch_bounds__(1024) k_lp_scan_top(u32* tile_sums, u32 tiles, u32* totals) {
+    __shared__ u32 sh[2][1024];
+    const u32 y = blockIdx.x;
+    u32* ts = tile_sums + (u64)y * tiles * 2;
+    u32 carry0 = 0, carry1 = 0;
+    for (u32 base = 0; base < tiles; base += 1024) {
+        const u32 i = base + threadIdx.x;
+        const u32 v0 = i < tiles ? ts[2 * i] : 0, v1 = i < tiles ? ts[2 * i + 1] : 0;
+        sh[0][threadIdx.x] = v0;
+        sh[1][threadIdx.x] = v1;
+        __syncthreads();
+        for (u32 d = 1; d < 1024; d <<= 1) {
+            const u32 a = threadIdx.x >= d ? sh[0][threadIdx.x - d] : 0, b = threadIdx.x >= d ? sh[1][threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[0][threadIdx.x] += a;
+            sh[1][threadIdx.x] += b;
+            __syncthreads();
+        }
+        if (i < tiles) {
+            ts[2 * i] = carry0 + sh[0][threadIdx.x] - v0;
+            ts[2 * i + 1] = carry1 + sh[1][threadIdx.x] - v1;
+        }
+        carry0 += sh[0][1023];
+        carry1 += sh[1][1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[2 * y] = carry0;
+        totals[2 * y + 1] = carry1;
+    }
+}
+__global__ void __launch_bounds__(LP_THREADS) k_lp_scan_apply(const u32* cnt, u64 n, u32 tiles, const u32* tile_sums, u32* used_start, u32* used_idx, u32* lsrc) {
+    __shared__ u32 sh[2][LP_THREADS];
+    const u32 y = blockIdx.y;
+    const u64 base = (u64)blockIdx.x * LP_TILE + (u64)threadIdx.x * LP_PER;      // a thread owns LP_PER consecutive positions
+    u32 v[LP_PER], s0 = 0, s1 = 0;
+    for (u32 k = 0; k < LP_PER; k++) {
+        v[k] = base + k < n ? cnt[(u64)y * n + base + k] : 0;
+        s0 += v[k];
+        s1 += (base + k < n) && v[k] == 0;
+    }
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (u32 d = 1; d < LP_THREADS; d <<= 1) {
+        const u32 a = threadIdx.x >= d ? sh[0][threadIdx.x - d] : 0, b = threadIdx.x >= d ? sh[1][threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[0][threadIdx.x] += a;
+        sh[1][threadIdx.x] += b;
+        __syncthreads();
+    }
+    u32 r0 = tile_sums[((u64)y * tiles + blockIdx.x) * 2] + sh[0][threadIdx.x] - s0;      // rows before this entry
+    u32 r1 = tile_sums[((u64)y * tiles + blockIdx.x) * 2 + 1] + sh[1][threadIdx.x] - s1;  // leftovers before this entry
+    for (u32 k = 0; k < LP_PER; k++) {
+        const u64 j = base + k;
+        if (j >= n) break;
+        if (v[k]) {      // the (j - r1)-th USED entry: its rows start at r0
+            used_start[(u64)y * n + (j - r1)] = r0;
+            used_idx[(u64)y * n + (j - r1)] = (u32)j;
+        } else {
+            lsrc[(u64)y * n + r1] = (u32)j;      // the r1-th leftover (ascending)
+        }
+        r0 += v[k];
+        r1 += v[k] == 0;
+    }
+}
+
+FP_DEV u64 lp_last_le(const u32* a, u64 n, u32 x) {      // the last index with a[index] <= x (a non-decreasing, a[0] <= x)
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+// output row i of lookup y.  The row belongs to the k-th USED table entry (the last one whose rows start at or before i); on the first
+// row of the entry S' = A'; otherwise the row is the r-th repeated one and takes the (m - 1 - r)-th leftover (ascending), m = leftovers =
+// repeated rows.  The search runs over the used entries only (a few hundred for a range table, all of them cache-resident).
+template <class F>
+__global__ void k_lp_emit(LpCols c, const fe* sorted, u64 n, u64 npad, const u32* used_start, const u32* used_idx, const u32* lsrc, const u32* totals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 y = blockIdx.y;
     if (i >= n) return;
-    const u64 base = (u64)y * n;
-    const fe* input = inputs + (u64)y * stride;
-    const fe* table = tables + (u64)y * stride;
-    const fe a = f_load(&input[perm[base + i] - (u32)base]);
-    f_store(&out_inputs[(u64)y * stride + i], a);
-    if (!repeated[base + i]) { f_store(&out_tables[(u64)y * stride + i], a); return; }
-    const u32 m = rrank[base + n - 1] + repeated[base + n - 1] - rrank[base];   // repeated rows of this lookup = its leftovers
-    const u32 r = rrank[base + i] - rrank[base];
-    f_store(&out_tables[(u64)y * stride + i], f_load(&table[lsrc[base + (m - 1 - r)]]));
+    if (totals[2 * y] != (u32)n) return;                  // a missing input value: the call fails, nothing meaningful to write
+    const fe* T = sorted + (u64)c.table_of[y] * npad;
+    const u32 m = totals[2 * y + 1];
+    const u64 k = lp_last_le(used_start + (u64)y * n, n - m, (u32)i);
+    const fe a = f_to_mont<F>(f_load(&T[used_idx[(u64)y * n + k]]));
+    f_store(&c.out_in[y][i], a);
+    if (used_start[(u64)y * n + k] == (u32)i) {
+        f_store(&c.out_tab[y][i], a);
+        return;
+    }
+    const u32 r = (u32)i - (u32)(k + 1);
+    f_store(&c.out_tab[y][i], f_to_mont<F>(f_load(&T[lsrc[(u64)y * n + (m - 1 - r)]])));
 }
 
 template <class F>
-void launch_canon(const fe* in, const fe* tab, u64 stride, u32 B, u64 n, fe* out, hipStream_t s) {
-    k_lp_canon<F><<<dim3((u32)((n + 255) / 256), 2 * B), 256, 0, s>>>(in, tab, stride, B, n, out);
-}
-int canon_dispatch(dehalo_ctx* ctx, int field, const fe* in, const fe* tab, u64 stride, u32 B, u64 n, fe* out, hipStream_t s) {
-    switch (field) {
-        case DEHALO_FIELD_BN254_FR: launch_canon<Bn254Fr>(in, tab, stride, B, n, out, s); break;
-        case DEHALO_FIELD_BN254_FQ: launch_canon<Bn254Fq>(in, tab, stride, B, n, out, s); break;
-        case DEHALO_FIELD_PASTA_FP: launch_canon<PastaFp>(in, tab, stride, B, n, out, s); break;
-        case DEHALO_FIELD_PASTA_FQ: launch_canon<PastaFq>(in, tab, stride, B, n, out, s); break;
-        default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
+int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s) {
+    const u64 tiles = (n + LP_TILE - 1) / LP_TILE, npad = tiles * LP_TILE;
+    const size_t pad = 256;
+    const size_t bytes = 2 * ((size_t)U * npad * sizeof(fe) + pad) + 4 * ((size_t)B * n * 4 + pad) + ((size_t)B * tiles * 8 + pad) + 2 * ((size_t)B * 8 + pad) + 4096;
+    TRY(dh_ensure(ctx, ctx->ws_lookup, bytes));
+    char* p = (char*)ctx->ws_lookup.p;
+    auto take = [&](size_t b) { char* r = p; p += (b + 255) & ~(size_t)255; return r; };
+    fe* k0 = (fe*)take((size_t)U * npad * sizeof(fe));
+    fe* k1 = (fe*)take((size_t)U * npad * sizeof(fe));
+    u32* cnt = (u32*)take((size_t)B * n * 4);
+    u32* used_start = (u32*)take((size_t)B * n * 4);
+    u32* used_idx = (u32*)take((size_t)B * n * 4);
+    u32* lsrc = (u32*)take((size_t)B * n * 4);
+    u32* tile_sums = (u32*)take((size_t)B * tiles * 8);
+    u32* totals = (u32*)take((size_t)B * 8);
+    int* err = (int*)take((size_t)B * 4);
+    const int lds_keys = LP_TILE * 32;
+    HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_lp_tile_sort, lds_keys));
+    k_lp_canon_tables<F><<<dim3((u32)((npad + 255) / 256), U), 256, 0, s>>>(c, n, npad, k0);
+    k_lp_tile_sort<<<dim3((u32)tiles, U), LP_SORT_THREADS, lds_keys, s>>>(k0, k1, npad);
+    fe *src = k1, *dst = k0;
+    for (u64 run = LP_TILE; run < npad; run <<= 1) {
+        k_lp_merge<<<dim3((u32)(npad / LP_MERGE_OUT), U), LP_MERGE_THREADS, 0, s>>>(src, dst, npad, run);
+        std::swap(src, dst);
     }
+    HIP_TRY(ctx, hipMemsetAsync(cnt, 0, (size_t)B * n * 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(err, 0, (size_t)B * 4, s));
+    k_lp_rank<F><<<dim3((u32)tiles, B), LP_SORT_THREADS, 0, s>>>(c, src, n, npad, cnt, err);
+    k_lp_scan_tiles<<<dim3((u32)tiles, B), LP_THREADS, 0, s>>>(cnt, n, (u32)tiles, tile_sums);
+    k_lp_scan_top<<<B, 1024, 0, s>>>(tile_sums, (u32)tiles, totals);
+    k_lp_scan_apply<<<dim3((u32)tiles, B), LP_THREADS, 0, s>>>(cnt, n, (u32)tiles, tile_sums, used_start, used_idx, lsrc);
+    k_lp_emit<F><<<dim3((u32)((n + 255) / 256), B), 256, 0, s>>>(c, src, n, npad, used_start, used_idx, lsrc, totals);
+    HIP_TRY(ctx, hipGetLastError());
+    int host_err[LP_MAX_BATCH];
+    HIP_TRY(ctx, hipMemcpyAsync(host_err, err, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));     // upstream returns Err(ConstraintSystemFailure) from this call: so must we
+    for (u32 y = 0; y < B; y++)
+        if (host_err[y])
+            return dh_fail(ctx, DEHALO_ERR_NOT_IN_TABLE, "permute_expression_pair: an input value of lookup " + std::to_string(y) + " of the call is not in the table (ConstraintSystemFailure)");
     return 0;
 }
-
-struct Carve {
-    char* p;
-    template <class T> T* take(size_t count) {
-        T* r = (T*)p;
-        p += (count * sizeof(T) + 255) & ~(size_t)255;
-        return r;
-    }
-};
 
 }  // namespace
 
-// `batch` lookups at once: column y of inputs / tables / outputs starts y * stride elements in.
-// All 2 * batch key columns go through the SAME global sort passes (value limbs, then a last
-// stable pass on the column id), so the number of launches does not grow with the batch.
+// `batch` lookups at once, given as pointer lists: lookups whose table pointers are equal share one sort.
+int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, const fe* const* d_tables, uint64_t n, size_t batch, fe* const* d_out_inputs,
+                        fe* const* d_out_tables, hipStream_t s) {
+    if (n == 0 || batch == 0) return 0;
+    if (n >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: too many rows");
+    ScopedTimer timer(ctx, s, DEHALO_K_POLY);
+    for (size_t first = 0; first < batch; first += LP_MAX_BATCH) {
+        const u32 B = (u32)std::min<size_t>(LP_MAX_BATCH, batch - first);
+        LpCols c{};
+        u32 U = 0;
+        for (u32 y = 0; y < B; y++) {
+            c.in[y] = d_inputs[first + y];
+            c.out_in[y] = d_out_inputs[first + y];
+            c.out_tab[y] = d_out_tables[first + y];
+            u32 t = 0;
+            while (t < U && c.tab[t] != d_tables[first + y]) t++;
+            if (t == U) c.tab[U++] = d_tables[first + y];
+            c.table_of[y] = t;
+        }
+        int rc;
+        switch (field) {
+            case DEHALO_FIELD_BN254_FR: rc = lp_run<Bn254Fr>(ctx, c, B, U, n, s); break;
+            case DEHALO_FIELD_BN254_FQ: rc = lp_run<Bn254Fq>(ctx, c, B, U, n, s); break;
+            case DEHALO_FIELD_PASTA_FP: rc = lp_run<PastaFp>(ctx, c, B, U, n, s); break;
+            case DEHALO_FIELD_PASTA_FQ: rc = lp_run<PastaFq>(ctx, c, B, U, n, s); break;
+            default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// column y of inputs / tables / outputs starts y * stride elements in
 int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe* d_tables, uint64_t n, size_t batch, uint64_t stride, fe* d_out_inputs,
                         fe* d_out_tables, hipStream_t s) {
-    if (n == 0 || batch == 0) return 0;
-    const u32 B = (u32)batch;
-    const u64 total = 2ull * B * n, half = (u64)B * n;
-    if (total >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: too many rows");
-    ScopedTimer timer(ctx, s, DEHALO_K_POLY);
-    size_t sort_tmp = 0, scan_tmp = 0;
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0, 64, s));
-    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scan_tmp, (u32*)nullptr, (u32*)nullptr, 0u, half, rocprim::plus<u32>(), s));
-    const size_t tmp_bytes = std::max(sort_tmp, scan_tmp);
-    const size_t pad = 256;
-    size_t bytes_total = 2 * (total * sizeof(fe) + pad) + 2 * (total * 8 + pad) + 2 * (total * 4 + pad) + 6 * (half * 4 + pad) + (B * 4 + pad) + 1024 + tmp_bytes + pad;
-    TRY(dh_ensure(ctx, ctx->ws_lookup, bytes_total));
-    Carve c{(char*)ctx->ws_lookup.p};
-    fe* canon = c.take<fe>(total); fe* S = c.take<fe>(total);
-    unsigned long long* keys_a = c.take<unsigned long long>(total); unsigned long long* keys_b = c.take<unsigned long long>(total);
-    u32* p0 = c.take<u32>(total); u32* p1 = c.take<u32>(total);
-    u32* repeated = c.take<u32>(half); u32* consumed = c.take<u32>(half); u32* leftover = c.take<u32>(half); u32* rrank = c.take<u32>(half);
-    u32* lrank = c.take<u32>(half); u32* lsrc = c.take<u32>(half);
-    int* err = c.take<int>(B);
-    unsigned long long* ors = c.take<unsigned long long>(4);
-    void* tmp = c.take<char>(tmp_bytes);
-
-    const u32 blocks_n = (u32)((n + 255) / 256), blocks_total = (u32)((total + 255) / 256), blocks_half = (u32)((half + 255) / 256);
-    TRY(canon_dispatch(ctx, field, d_inputs, d_tables, stride, B, n, canon, s));
-    u32 *pin = p0, *pout = p1;
-    const unsigned col_bits = 2 * B > 1 ? 32 - (unsigned)__builtin_clz(2 * B - 1) : 0;
-    auto sort_pass = [&](u32 limb, unsigned begin_bit, unsigned end_bit) -> int {
-        k_lp_limb<<<blocks_total, 256, 0, s>>>(canon, pin, limb, n, total, keys_a);
-        size_t bytes = tmp_bytes;
-        HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp, bytes, keys_a, keys_b, pin, pout, total, begin_bit, end_bit, s));
-        std::swap(pin, pout);
-        return 0;
-    };
-    u32* bad = (u32*)ors;                                      // (first word of the limb-OR area: the two uses never overlap)
-    std::vector<int> host_err(B);
-    // Fast path: a theta-compressed lookup value is tag * theta + value -- pseudo-random leading bits per tag, a small integer
-    // added at the bottom (a range table's values are below 2^16) -- so the low 24 bits and the 40 bits below the modulus' top bit order
-    // them: two short value passes + the stable column pass (~13 launches instead of ~40).  The plan does not depend on the data, so nothing is read back before the
-    // end: the order is verified on the device with the full comparison (k_lp_check_sorted) while the permutation is already being
-    // built from it, and ONE read-back at the end returns the lookup errors and that verdict.  Any violation (values that differ
-    // only in the bits in between, e.g. a table of plain integers above 2^24) repeats the call with the full
-    // least-significant-limb-first sort, whose pass plan is read from the data.
-    const unsigned mod_bits = (field == DEHALO_FIELD_BN254_FR || field == DEHALO_FIELD_BN254_FQ) ? 254 : 255;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        const bool fast = attempt == 0;
-        pin = p0; pout = p1;
-        k_lp_iota<<<blocks_total, 256, 0, s>>>(p0, total);
-        if (fast) {
-            TRY(sort_pass(0, 0, 24));                                      // (three + five 8-bit radix passes)
-            TRY(sort_pass(3, mod_bits - 40 - 192, mod_bits - 192));
-            if (col_bits) TRY(sort_pass(4, 0, col_bits));
-        } else {
-            HIP_TRY(ctx, hipMemsetAsync(ors, 0, 4 * sizeof(unsigned long long), s));
-            k_lp_limb_or<<<blocks_total, 256, 0, s>>>(canon, total, ors);
-            unsigned long long host_ors[4];
-            HIP_TRY(ctx, hipMemcpyAsync(host_ors, ors, sizeof(host_ors), hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));          // the pass plan depends on the data
-            for (u32 limb = 0; limb <= 4; limb++) {
-                unsigned bits;
-                if (limb < 4) bits = host_ors[limb] ? 64 - (unsigned)__builtin_clzll(host_ors[limb]) : 0;
-                else bits = col_bits;                                 // last: the column id, stable
-                if (bits == 0) continue;
-                TRY(sort_pass(limb, 0, bits));
-            }
-        }
-        k_lp_gather<<<blocks_total, 256, 0, s>>>(canon, pin, total, S);
-        HIP_TRY(ctx, hipMemsetAsync(bad, 0, sizeof(u32), s));
-        if (fast) k_lp_check_sorted<<<blocks_total, 256, 0, s>>>(S, n, total, bad);
-        HIP_TRY(ctx, hipMemsetAsync(consumed, 0, half * 4, s));
-        HIP_TRY(ctx, hipMemsetAsync(err, 0, B * sizeof(int), s));
-        HIP_TRY(ctx, hipMemsetAsync(lsrc, 0, half * 4, s));       // a failed lookup leaves gaps: keep every index in range
-        k_lp_flags<<<dim3(blocks_n, B), 256, 0, s>>>(S, B, n, repeated, consumed, err);
-        k_lp_not<<<blocks_half, 256, 0, s>>>(consumed, half, leftover);
-        size_t bytes = tmp_bytes;
-        HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, repeated, rrank, 0u, half, rocprim::plus<u32>(), s));
-        bytes = tmp_bytes;
-        HIP_TRY(ctx, rocprim::exclusive_scan(tmp, bytes, leftover, lrank, 0u, half, rocprim::plus<u32>(), s));
-        k_lp_compact<<<dim3(blocks_n, B), 256, 0, s>>>(leftover, lrank, pin, B, n, lsrc);
-        k_lp_emit<<<dim3(blocks_n, B), 256, 0, s>>>(d_inputs, d_tables, stride, pin, repeated, rrank, lsrc, B, n, d_out_inputs, d_out_tables);
-        HIP_TRY(ctx, hipGetLastError());
-        u32 host_bad = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(host_err.data(), err, B * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipMemcpyAsync(&host_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));     // upstream returns Err(ConstraintSystemFailure) from this call: so must we
-        if (host_bad == 0) break;                  // (the full sort never sets it)
+    std::vector<const fe*> in(batch), tab(batch);
+    std::vector<fe*> oi(batch), ot(batch);
+    for (size_t y = 0; y < batch; y++) {
+        in[y] = d_inputs + y * stride;
+        tab[y] = d_tables + y * stride;
+        oi[y] = d_out_inputs + y * stride;
+        ot[y] = d_out_tables + y * stride;
     }
-    for (u32 y = 0; y < B; y++)
-        if (host_err[y])
-            return dh_fail(ctx, DEHALO_ERR_NOT_IN_TABLE, "permute_expression_pair: lookup " + std::to_string(y) + ": an input value is not in the table (ConstraintSystemFailure)");
-    return 0;
+    return lookup_permute_ptrs(ctx, field, in.data(), tab.data(), n, batch, oi.data(), ot.data(), s);
 }

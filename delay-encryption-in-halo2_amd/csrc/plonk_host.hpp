@@ -82,6 +82,29 @@ struct HostCS {
             default: return expr_degree(e.a) + expr_degree(e.b);
         }
     }
+    bool expr_equal(uint32_t a, uint32_t b) const {      // structural equality of two expressions
+        if (a == b) return true;
+        const dehalo_expr_node &x = nodes[a], &y = nodes[b];
+        if (x.kind != y.kind) return false;
+        switch (x.kind) {
+            case DEHALO_EXPR_CONSTANT: return constants[x.a] == constants[y.a];
+            case DEHALO_EXPR_FIXED: case DEHALO_EXPR_ADVICE: case DEHALO_EXPR_INSTANCE: return x.a == y.a && x.rotation == y.rotation;
+            case DEHALO_EXPR_NEGATED: return expr_equal(x.a, y.a);
+            case DEHALO_EXPR_SCALED: return constants[x.b] == constants[y.b] && expr_equal(x.a, y.a);
+            default: return expr_equal(x.a, y.a) && expr_equal(x.b, y.b);
+        }
+    }
+    // the first lookup whose table expressions equal lookup l's (l itself if none before it): their theta-compressed table columns are
+    // the same column, computed and sorted once
+    uint32_t table_representative(uint32_t l) const {
+        for (uint32_t m = 0; m < l; m++) {
+            if (lookups[m].tables.size() != lookups[l].tables.size()) continue;
+            bool same = true;
+            for (size_t i = 0; i < lookups[l].tables.size() && same; i++) same = expr_equal(lookups[m].tables[i], lookups[l].tables[i]);
+            if (same) return m;
+        }
+        return l;
+    }
     uint32_t blinding_factors() const {           // max(3, most queries to one advice column) + 2
         std::vector<uint32_t> cnt(num_advice, 0);
         for (auto& q : advice_q) cnt[q.index]++;

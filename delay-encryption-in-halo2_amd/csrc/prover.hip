@@ -581,6 +581,7 @@ struct dehalo_prover {
     DevMem cols, polys_own, instance, instance_values, compressed, num, den, ext, h, table_value, hfold, qbuf, wbuf, aff, aff_side, evals, blind_dev, omega_col;
     fe* polys = nullptr;      // coefficient forms: polys_own with a side context, cols (in place) without
     std::vector<std::pair<dehalo_graph*, dehalo_graph*>> perm_graphs;      // per set: (denominator, numerator)
+    std::vector<uint32_t> table_rep;      // per lookup: the first lookup with the same table expressions (shares its compressed table)
     dehalo_graph *lookup_den = nullptr, *lookup_num = nullptr;
     hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_inst = nullptr, ev_side = nullptr;      // ev_ready: one per commitment phase
     // opening plan (depends on the circuit only)
@@ -770,6 +771,8 @@ struct dehalo_prover {
         TRY(blind_dev.alloc(ctx, std::max<size_t>(1, (size_t)A * rows + (size_t)2 * L * rows + (size_t)(S + L) * bf)));
         TRY(omega_col.alloc(ctx, n, false));
         TRY(omega_powers(ctx, d, omega_col.p));
+        table_rep.clear();
+        for (uint32_t l = 0; l < L; l++) table_rep.push_back(cs.table_representative(l));
         TRY(build_product_graphs());
         TRY(opening_plan());
         TRY(evals.alloc(ctx, eval_count + 8));
@@ -980,21 +983,30 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     if (L) {
         std::vector<const dehalo_graph*> graphs;
         std::vector<uint64_t*> outs;
-        for (uint32_t l = 0; l < L; l++) {
+        for (uint32_t l = 0; l < L; l++) {      // lookups with the same table expressions share ONE compressed table column (their representative's)
             graphs.push_back(pk->compress_graphs[l].first);
-            graphs.push_back(pk->compress_graphs[l].second);
             outs.push_back(compressed.u64((size_t)2 * l * n));
-            outs.push_back(compressed.u64((size_t)(2 * l + 1) * n));
+            if (table_rep[l] == l) {
+                graphs.push_back(pk->compress_graphs[l].second);
+                outs.push_back(compressed.u64((size_t)(2 * l + 1) * n));
+            }
         }
         EvalIn e;
         e.cols(fixed_v, adv_v, inst_v);
         e.in.theta = theta.v;
-        TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), 2 * L, &e.in, k, 1, outs.data(), nullptr));
+        TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), (uint32_t)graphs.size(), &e.in, k, 1, outs.data(), nullptr));
         tk("compress queued");
         // the blinding rows [u, n) first: the permutation writes rows [0, u) only and ends with a read-back
         HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_perm * n + u), n * 32, bl_perm, rows * 32, rows * 32, 2 * L, hipMemcpyDeviceToDevice, ms));
-        uint64_t* base = cols.u64((size_t)o_perm * n);
-        TRY(dehalo_permute_expression_pair_batch_device(ctx, fid, compressed.u64(0), compressed.u64(n), u, L, 2 * n, base, base + 4 * n, nullptr));
+        std::vector<const uint64_t*> pin, ptab;
+        std::vector<uint64_t*> pout_in, pout_tab;
+        for (uint32_t l = 0; l < L; l++) {
+            pin.push_back(compressed.u64((size_t)2 * l * n));
+            ptab.push_back(compressed.u64((size_t)(2 * table_rep[l] + 1) * n));
+            pout_in.push_back(cols.u64((size_t)(o_perm + 2 * l) * n));
+            pout_tab.push_back(cols.u64((size_t)(o_perm + 2 * l + 1) * n));
+        }
+        TRY(dehalo_permute_expression_pair_ptrs_device(ctx, fid, pin.data(), ptab.data(), u, L, pout_in.data(), pout_tab.data(), nullptr));
         tk("permute returned");
         if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[1], ms));
         TRY(commit(tr, cols.at((size_t)o_perm * n), 2 * L, true, side ? std::function<int()>([&]() { return side_ntt(o_perm, 2 * L, ev_ready[1]); }) : nullptr));
@@ -1034,7 +1046,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), 2 * S, &e.in, k, 1, outs.data(), nullptr));
         }
         for (uint32_t l = 0; l < L; l++) {
-            std::vector<const uint64_t*> four = {col_ptr(compressed, 2 * l, n), col_ptr(compressed, 2 * l + 1, n), col_ptr(cols, o_perm + 2 * l, n),
+            std::vector<const uint64_t*> four = {col_ptr(compressed, 2 * l, n), col_ptr(compressed, 2 * table_rep[l] + 1, n), col_ptr(cols, o_perm + 2 * l, n),
                                                  col_ptr(cols, o_perm + 2 * l + 1, n)};
             EvalIn e;
             e.cols(none, four, none);

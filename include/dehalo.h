@@ -187,6 +187,8 @@ int dehalo_field_op_device(dehalo_ctx* ctx, int field, int op, const uint64_t* d
  *   plonk/lookup/prover.rs permute_expression_pair: permuted_input = the `usable_rows` input values
  *   sorted ascending by canonical value; permuted_table[row] = permuted_input[row] at every first
  *   occurrence, the table's remaining values (ascending) in the repeated rows taken from the end.
+ *   Only the table is sorted (merge sort on the 256-bit keys); every input value finds its table position by binary search and the
+ *   outputs are written from the position counts (csrc/lookup_permute.hip).
  *   DEHALO_ERR_NOT_IN_TABLE when an input value does not occur in the table.  The caller appends
  *   upstream's random blinding rows.  The device form synchronises its stream (it has to return
  *   that error).                                                                                 */
@@ -198,6 +200,10 @@ int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint
  * All key columns share the sort passes, so the cost barely grows with the batch.                                                */
 int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, const uint64_t* d_inputs, const uint64_t* d_tables, size_t usable_rows, size_t batch,
                                                 size_t stride_elems, uint64_t* d_permuted_inputs, uint64_t* d_permuted_tables, void* stream);
+/* The same with the columns given as HOST arrays of DEVICE pointers.  Lookups whose table pointers are EQUAL share one table sort (the five
+ * range lookups of the reference's circuit compress the same (tag, value) table expressions: one sort per proof instead of five). */
+int dehalo_permute_expression_pair_ptrs_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
+                                               uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, void* stream);
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]);
 int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
                                   const uint64_t point[4], uint64_t* d_out, void* stream);

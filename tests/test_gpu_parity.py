@@ -736,6 +736,51 @@ def test_grand_product_batch_shares_one_inversion(pkg, co, ctx):
         assert not z[b, n:].any()                                    # the padding between columns is untouched
 
 
+def test_permute_expression_pair_shared_tables_and_odd_sizes(pkg, co, ctx):
+    """dehalo_permute_expression_pair_ptrs_device: lookups given as pointer lists; those whose TABLE pointer is the same column share one
+    table sort (the reference's five range lookups).  Sizes around the merge sort's 2048-key tiles, tables of all-distinct full-width
+    values, more lookups than one launch group holds (16), and an error in ONE lookup of the batch."""
+    import torch
+    fid = 0
+    rng = np.random.default_rng(7)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    for n in (1, 2, 2047, 2048, 2049, 4097, 6000, 100003):
+        t_shared = co.fill_scalars(fid, "uniform", n, 500 + n % 89)                       # n distinct full-width values
+        t_other = t_shared.copy()
+        t_other[n // 2:] = t_other[0]                                                     # half of it one repeated value
+        B = 18 if n == 4097 else 5
+        ins = [(t_shared if y % 3 != 2 else t_other)[rng.integers(0, max(1, (n // (y + 1))), size=n)] for y in range(B)]
+        d_shared, d_other = dev(t_shared), dev(t_other)
+        d_ins = [dev(a) for a in ins]
+        outs_i = [torch.zeros((n, 4), dtype=torch.int64, device="cuda") for _ in range(B)]
+        outs_t = [torch.zeros((n, 4), dtype=torch.int64, device="cuda") for _ in range(B)]
+        torch.cuda.synchronize()
+        tabs = [d_shared if y % 3 != 2 else d_other for y in range(B)]
+        ctx.permute_expression_pair_ptrs_device(fid, [a.data_ptr() for a in d_ins], [t.data_ptr() for t in tabs], n, [o.data_ptr() for o in outs_i],
+                                                [o.data_ptr() for o in outs_t], 0)
+        ctx.synchronize()
+        for y in range(B):
+            want = co.permute_expression_pair(fid, ins[y], t_shared if y % 3 != 2 else t_other, n)
+            assert want is not None
+            assert np.array_equal(outs_i[y].cpu().numpy().view(np.uint64), want[0]), (n, y)
+            assert np.array_equal(outs_t[y].cpu().numpy().view(np.uint64), want[1]), (n, y)
+    # one lookup of the batch has an input that is not in its table
+    n = 3000
+    table = co.fill_scalars(fid, "uniform", n, 5)
+    good = table[rng.integers(0, n, size=n)]
+    bad = good.copy()
+    bad[n - 1] = co.fill_scalars(fid, "uniform", 1, 6)[0]
+    d_t, d_g, d_b = dev(table), dev(good), dev(bad)
+    o = [torch.zeros((n, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.DehaloError) as e:
+        ctx.permute_expression_pair_ptrs_device(fid, [d_g.data_ptr(), d_b.data_ptr()], [d_t.data_ptr(), d_t.data_ptr()], n, [o[0].data_ptr(), o[1].data_ptr()],
+                                                [o[2].data_ptr(), o[3].data_ptr()], 0)
+    assert e.value.code == -6
+    with pytest.raises(pkg.DehaloError):      # an output aliasing an input is refused
+        ctx.permute_expression_pair_ptrs_device(fid, [d_g.data_ptr()], [d_t.data_ptr()], n, [d_g.data_ptr()], [o[2].data_ptr()], 0)
+
+
 def test_permute_expression_pair_small_values(pkg, co, ctx):
     """Range-table shaped columns (values < 2^16): the sort skips the limbs that are zero everywhere."""
     fid, n = 0, 40000
