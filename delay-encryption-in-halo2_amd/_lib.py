@@ -14,7 +14,7 @@ _LIB = None
 SYMBOLS = [
     "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_create_with_priority", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
-    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_lookup_h_batch_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
+    "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_lookup_h_batch_device", "dehalo_product_terms_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_field_op_device", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
@@ -96,6 +96,12 @@ RNG_FILL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t
 
 class CRng(C.Structure):
     _fields_ = [("kind", C.c_int), ("pcg_state", C.c_uint64 * 2), ("pcg_inc", C.c_uint64 * 2), ("fill", RNG_FILL_FN), ("user", C.c_void_p)]
+
+
+class CProductInputs(C.Structure):
+    _fields_ = [("columns", C.POINTER(C.c_void_p)), ("sigma", C.POINTER(C.c_void_p)), ("num_columns", C.c_uint32), ("chunk_len", C.c_uint32), ("omega_powers", C.c_void_p),
+                ("beta", C.c_void_p), ("gamma", C.c_void_p), ("delta", C.c_void_p), ("set_factors", C.c_void_p), ("compressed_input", C.POINTER(C.c_void_p)),
+                ("compressed_table", C.POINTER(C.c_void_p)), ("permuted_input", C.POINTER(C.c_void_p)), ("permuted_table", C.POINTER(C.c_void_p)), ("num_lookups", C.c_uint32)]
 
 
 class DehaloError(RuntimeError):
@@ -188,6 +194,7 @@ def load_library():
     lib.dehalo_graph_evaluate_batch_device.argtypes = [P, C.POINTER(C.c_void_p), u32, C.POINTER(CEvalInputs), u32, u32, C.POINTER(C.c_void_p), P]
     lib.dehalo_permutation_h_device.argtypes = [P, C.c_int, C.POINTER(CPermInputs), u32, u32, u64p, P]
     lib.dehalo_lookup_h_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u64p, P]
+    lib.dehalo_product_terms_device.argtypes = [P, C.c_int, C.POINTER(CProductInputs), sz, u64p, u64p, sz, P]
     lib.dehalo_lookup_h_batch_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u32, u64p, P]
     PP = C.POINTER(P)
     lib.dehalo_params_create.argtypes = [P, C.c_int, u32, u64p, u64p, P, P, PP]
@@ -612,6 +619,19 @@ class Context:
         self._check(self.lib.dehalo_lookup_h_batch_device(self.handle, field, arr, len(lookups), log_rows, rot_scale, d_values, stream or None))
 
     # ---- measurement ----
+    def product_terms_device(self, field: int, columns: Sequence[int], sigma: Sequence[int], chunk_len: int, omega_powers: int, beta, gamma, delta, set_factors,
+                             lookups: Sequence[Tuple[int, int, int, int]], n: int, d_num: int, d_den: int, stride: int, stream: int = 0):
+        """every grand product's per-row numerator / denominator in one launch; lookups = (A, S, a', s') device pointers per lookup;
+        beta / gamma / delta: 4 x u64 Montgomery; set_factors: (sets, 4) = beta * delta^(chunk_len * set)"""
+        arr = lambda xs: (C.c_void_p * max(1, len(xs)))(*xs)
+        keep = [np.ascontiguousarray(a, dtype=np.uint64) for a in (beta, gamma, delta, set_factors)]
+        inp = CProductInputs()
+        inp.columns, inp.sigma, inp.num_columns, inp.chunk_len, inp.omega_powers = arr(columns), arr(sigma), len(columns), chunk_len, omega_powers
+        inp.beta, inp.gamma, inp.delta, inp.set_factors = (k.ctypes.data for k in keep)
+        inp.compressed_input, inp.compressed_table = arr([l[0] for l in lookups]), arr([l[1] for l in lookups])
+        inp.permuted_input, inp.permuted_table, inp.num_lookups = arr([l[2] for l in lookups]), arr([l[3] for l in lookups]), len(lookups)
+        self._check(self.lib.dehalo_product_terms_device(self.handle, field, C.byref(inp), n, d_num, d_den, stride, stream or None))
+
     def timing_enable(self, on: bool = True):
         self._check(self.lib.dehalo_timing_enable(self.handle, int(on)))
 

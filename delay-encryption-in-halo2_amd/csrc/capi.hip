@@ -1085,6 +1085,27 @@ int dehalo_lookup_h_device(dehalo_ctx* ctx, int field, const dehalo_lookup_input
     return do_lookup_h(ctx, field, in, log_rows, rot_scale, (fe*)d_values, pick_stream(ctx, stream));
 }
 
+int dehalo_product_terms_device(dehalo_ctx* ctx, int field, const dehalo_product_inputs* in, size_t n, uint64_t* d_num, uint64_t* d_den, size_t stride_elems, void* stream) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (!in || !d_num || !d_den || !in->beta || !in->gamma) return dh_fail(ctx, DEHALO_ERR_INVALID, "product_terms: null argument");
+    if (in->num_columns && (!in->columns || !in->sigma || !in->omega_powers || !in->delta || !in->set_factors || in->chunk_len == 0))
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "product_terms: incomplete permutation inputs");
+    if (in->num_lookups && (!in->compressed_input || !in->compressed_table || !in->permuted_input || !in->permuted_table))
+        return dh_fail(ctx, DEHALO_ERR_INVALID, "product_terms: incomplete lookup inputs");
+    if (in->num_columns > 256 || in->num_lookups > 256) return dh_fail(ctx, DEHALO_ERR_INVALID, "product_terms: too many columns");
+    if (stride_elems < n) return dh_fail(ctx, DEHALO_ERR_INVALID, "product_terms: stride shorter than the columns");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = pick_stream(ctx, stream);
+    switch (field) {
+        case DEHALO_FIELD_BN254_FR: return product_terms_bn254_fr(ctx, in, n, (fe*)d_num, (fe*)d_den, stride_elems, s);
+        case DEHALO_FIELD_BN254_FQ: return product_terms_bn254_fq(ctx, in, n, (fe*)d_num, (fe*)d_den, stride_elems, s);
+        case DEHALO_FIELD_PASTA_FP: return product_terms_pasta_fp(ctx, in, n, (fe*)d_num, (fe*)d_den, stride_elems, s);
+        case DEHALO_FIELD_PASTA_FQ: return product_terms_pasta_fq(ctx, in, n, (fe*)d_num, (fe*)d_den, stride_elems, s);
+        default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
+    }
+}
+
 int dehalo_lookup_h_batch_device(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale,
                                  uint64_t* d_values, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;

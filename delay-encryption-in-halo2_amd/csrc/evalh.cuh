@@ -315,6 +315,52 @@ __global__ __launch_bounds__(EVH_THREADS) void k_lookup_h_batch(LookupBatchArgs 
     f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
 }
 
+
+// ---- the grand products' per-row factors (permutation::Argument::commit, lookup::Permuted::commit_product) --------------------
+// [UPSTREAM halo2_proofs/src/plonk/permutation/prover.rs: "modified_values" -- per set of columns the denominator prod_j (value_j + beta
+// sigma_j + gamma) and the numerator prod_j (value_j + delta^j beta omega^i + gamma); plonk/lookup/prover.rs commit_product: denominator
+// (a' + beta)(s' + gamma), numerator (A + beta)(S + gamma)] over the n rows of the ORIGINAL domain, every product of a proof in ONE
+// launch (grid.y = product: permutation sets, then lookups).  Standard-form columns in, standard-form num / den out (the inputs of
+// dehalo_grand_product_batch_device).  ptrs: [cols (ncols) | sigma (ncols) | per lookup: A, S, a', s'].
+struct ProductArgs {
+    const fe* const* ptrs;
+    const fe* omega;           // omega^i, standard form
+    const fe* scalars;         // internal packed: [beta, gamma, delta, beta delta^(chunk_len s) for s < nsets]
+    u32 nsets, ncols, chunk_len, nlookups;
+    fe* num; fe* den;
+    u64 stride, n;
+};
+template <class F>
+__global__ __launch_bounds__(EVH_THREADS) void k_product_terms(ProductArgs A) {
+    typedef typename f29_of<F>::type F9;
+    const u64 row = (u64)blockIdx.x * EVH_THREADS + threadIdx.x;
+    const u32 p = blockIdx.y;
+    if (row >= A.n) return;
+    const f29 beta = f29_unpack(f_load(&A.scalars[0])), gamma = f29_unpack(f_load(&A.scalars[1]));
+    auto ld = [&](const fe* c) __attribute__((always_inline)) { return f29_from_std<F9>(f_load(&c[row])); };
+    f29 num, den;
+    if (p < A.nsets) {
+        const f29 delta = f29_unpack(f_load(&A.scalars[2]));
+        f29 cur = f29_mul<F9>(f29_unpack(f_load(&A.scalars[3 + p])), ld(A.omega));      // beta delta^(first column of the set) omega^row
+        const u32 c0 = p * A.chunk_len, c1 = min(c0 + A.chunk_len, A.ncols);
+        for (u32 j = c0; j < c1; j++) {
+            const f29 col = ld(A.ptrs[j]);
+            const f29 t = evh_add<F9>(evh_add<F9>(col, f29_mul<F9>(beta, ld(A.ptrs[A.ncols + j]))), gamma);
+            const f29 u = evh_add<F9>(evh_add<F9>(col, cur), gamma);
+            den = j == c0 ? t : f29_mul<F9>(den, t);
+            num = j == c0 ? u : f29_mul<F9>(num, u);
+            cur = f29_mul<F9>(cur, delta);
+        }
+        if (c0 >= c1) num = den = f29_one<F9>();
+    } else {
+        const fe* const* q = A.ptrs + 2 * A.ncols + 4 * (p - A.nsets);
+        num = f29_mul<F9>(evh_add<F9>(ld(q[0]), beta), evh_add<F9>(ld(q[1]), gamma));
+        den = f29_mul<F9>(evh_add<F9>(ld(q[2]), beta), evh_add<F9>(ld(q[3]), gamma));
+    }
+    f_store(&A.num[(u64)p * A.stride + row], f29_to_std<F9>(num));
+    f_store(&A.den[(u64)p * A.stride + row], f29_to_std<F9>(den));
+}
+
 // ==========================================================================================
 // host drivers
 // ==========================================================================================
@@ -478,6 +524,38 @@ int lookup_h_batch_t(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t c
     return 0;
 }
 
+
+template <class F>
+int product_terms_t(dehalo_ctx* ctx, const dehalo_product_inputs* in, uint64_t n, fe* d_num, fe* d_den, uint64_t stride, hipStream_t s) {
+    ScopedTimer timer(ctx, s, DEHALO_K_EVAL_H);
+    const u32 nsets = in->num_columns ? (in->num_columns + in->chunk_len - 1) / in->chunk_len : 0;
+    std::vector<fe> sc = {fe_from_u64(in->beta), fe_from_u64(in->gamma), in->delta ? fe_from_u64(in->delta) : fe{}};
+    for (u32 i = 0; i < nsets; i++) sc.push_back(fe_from_u64(in->set_factors + 4 * (size_t)i));
+    TRY(dh_ensure(ctx, ctx->ws_evh[0], (sc.size() + 8) * sizeof(fe)));
+    TRY(evh_stage_scalars<F>(ctx, sc, (fe*)ctx->ws_evh[0].p, s));
+    std::vector<const fe*> ptrs;
+    for (u32 i = 0; i < in->num_columns; i++) ptrs.push_back((const fe*)in->columns[i]);
+    for (u32 i = 0; i < in->num_columns; i++) ptrs.push_back((const fe*)in->sigma[i]);
+    for (u32 l = 0; l < in->num_lookups; l++) {
+        ptrs.push_back((const fe*)in->compressed_input[l]);
+        ptrs.push_back((const fe*)in->compressed_table[l]);
+        ptrs.push_back((const fe*)in->permuted_input[l]);
+        ptrs.push_back((const fe*)in->permuted_table[l]);
+    }
+    TRY(dh_ensure(ctx, ctx->ws_evh[2], (ptrs.size() + 1) * sizeof(void*)));
+    TRY(evh_stage_ptrs(ctx, ptrs, (const void**)ctx->ws_evh[2].p, s));
+    ProductArgs A{};
+    A.ptrs = (const fe* const*)ctx->ws_evh[2].p;
+    A.omega = (const fe*)in->omega_powers;
+    A.scalars = (const fe*)ctx->ws_evh[0].p;
+    A.nsets = nsets; A.ncols = in->num_columns; A.chunk_len = in->chunk_len; A.nlookups = in->num_lookups;
+    A.num = d_num; A.den = d_den; A.stride = stride; A.n = n;
+    if (nsets + in->num_lookups)
+        k_product_terms<F><<<dim3((u32)((n + EVH_THREADS - 1) / EVH_THREADS), nsets + in->num_lookups), EVH_THREADS, 0, s>>>(A);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 #define DEFINE_EVALH_ENTRY(NAME, F)                                                                                                              \
     int convert_form_##NAME(dehalo_ctx* ctx, const fe* in, fe* out, uint64_t n, int to_internal, hipStream_t s) {                                \
         if (n) k_convert_form<F><<<(u32)((n + 255) / 256), 256, 0, s>>>(in, out, n, to_internal);                                                  \
@@ -491,4 +569,6 @@ int lookup_h_batch_t(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t c
     int lookup_h_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {         \
         return lookup_h_t<F>(ctx, in, log_rows, rot_scale, v, s); }                                                                              \
     int lookup_h_batch_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) { \
-        return lookup_h_batch_t<F>(ctx, in, count, log_rows, rot_scale, v, s); }
+        return lookup_h_batch_t<F>(ctx, in, count, log_rows, rot_scale, v, s); }                                                                 \
+    int product_terms_##NAME(dehalo_ctx* ctx, const dehalo_product_inputs* in, uint64_t n, fe* num, fe* den, uint64_t stride, hipStream_t s) {    \
+        return product_terms_t<F>(ctx, in, n, num, den, stride, s); }

@@ -210,7 +210,8 @@ struct dehalo_graph;
                               const fe* prev, fe* out, hipStream_t s);                                                                     \
     int perm_h_##NAME(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s);         \
     int lookup_h_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s);    \
-    int lookup_h_batch_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s);
+    int lookup_h_batch_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s); \
+    int product_terms_##NAME(dehalo_ctx* ctx, const dehalo_product_inputs* in, uint64_t n, fe* num, fe* den, uint64_t stride, hipStream_t s);
 DECL_EVALH(bn254_fr)
 DECL_EVALH(bn254_fq)
 DECL_EVALH(pasta_fp)

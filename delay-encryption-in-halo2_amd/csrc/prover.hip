@@ -1025,36 +1025,26 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             chal[j] = dj;
             dj = f->mul(dj, f->delta);
         }
-        std::vector<const uint64_t*> perm_fixed = fixed_v;
-        for (uint32_t j = 0; j < npc; j++) perm_fixed.push_back(col_ptr(pk->perm_values, j, n));
-        perm_fixed.push_back(omega_col.u64());
-        if (S) {
-            std::vector<const dehalo_graph*> graphs;
-            std::vector<uint64_t*> outs;
-            for (uint32_t s = 0; s < S; s++) {
-                graphs.push_back(perm_graphs[s].first);
-                graphs.push_back(perm_graphs[s].second);
-                outs.push_back(den.u64((size_t)s * n));
-                outs.push_back(num.u64((size_t)s * n));
-            }
-            EvalIn e;
-            e.cols(perm_fixed, adv_v, inst_v);
-            e.in.challenges = (const uint64_t*)chal.data();
-            e.in.num_challenges = npc;
-            e.in.beta = beta.v;
-            e.in.gamma = gamma.v;
-            TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), 2 * S, &e.in, k, 1, outs.data(), nullptr));
-        }
+        // every product's numerator and denominator columns in ONE launch (k_product_terms) instead of a GraphEvaluator program per column
+        std::vector<const uint64_t*> pcolv, psig, pA, pS, pa, ps;
+        for (auto& pc : cs.perm_cols) pcolv.push_back(pc.kind == DEHALO_COLUMN_ADVICE ? adv_v[pc.index] : pc.kind == DEHALO_COLUMN_FIXED ? fixed_v[pc.index] : inst_v[pc.index]);
+        for (uint32_t j = 0; j < npc; j++) psig.push_back(col_ptr(pk->perm_values, j, n));
         for (uint32_t l = 0; l < L; l++) {
-            std::vector<const uint64_t*> four = {col_ptr(compressed, 2 * l, n), col_ptr(compressed, 2 * table_rep[l] + 1, n), col_ptr(cols, o_perm + 2 * l, n),
-                                                 col_ptr(cols, o_perm + 2 * l + 1, n)};
-            EvalIn e;
-            e.cols(none, four, none);
-            e.in.beta = beta.v;
-            e.in.gamma = gamma.v;
-            TRY(dehalo_graph_evaluate_device(ctx, lookup_den, &e.in, k, 1, nullptr, den.u64((size_t)(S + l) * n), nullptr));
-            TRY(dehalo_graph_evaluate_device(ctx, lookup_num, &e.in, k, 1, nullptr, num.u64((size_t)(S + l) * n), nullptr));
+            pA.push_back(col_ptr(compressed, 2 * l, n));
+            pS.push_back(col_ptr(compressed, 2 * table_rep[l] + 1, n));
+            pa.push_back(col_ptr(cols, o_perm + 2 * l, n));
+            ps.push_back(col_ptr(cols, o_perm + 2 * l + 1, n));
         }
+        std::vector<Fe> set_factors(std::max<uint32_t>(S, 1));
+        for (uint32_t s2 = 0; s2 < S; s2++) set_factors[s2] = chal[std::min<uint32_t>(s2 * cs.chunk_len(), npc ? npc - 1 : 0)];      // beta delta^(first column of the set)
+        dehalo_product_inputs pin{};
+        pin.columns = pcolv.data(); pin.sigma = psig.data(); pin.num_columns = npc; pin.chunk_len = cs.chunk_len();
+        pin.omega_powers = omega_col.u64();
+        pin.beta = beta.v; pin.gamma = gamma.v; pin.delta = f->delta.v;
+        pin.set_factors = (const uint64_t*)set_factors.data();
+        pin.compressed_input = pA.data(); pin.compressed_table = pS.data(); pin.permuted_input = pa.data(); pin.permuted_table = ps.data();
+        pin.num_lookups = L;
+        TRY(dehalo_product_terms_device(ctx, fid, &pin, n, num.u64(), den.u64(), n, nullptr));
         tk("product graphs queued");
         TRY(dehalo_grand_product_batch_device(ctx, fid, num.u64(), den.u64(), n, S + L, n, cols.u64((size_t)o_pz * n), nullptr));
         for (uint32_t s = 1; s < S; s++)      // z_s starts where z_{s-1} ended: z = vec![last_z]

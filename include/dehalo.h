@@ -495,6 +495,22 @@ typedef struct {
 } dehalo_synthesis_info;
 int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advice, uint64_t* fixed, uint64_t* mapping, uint8_t* const* selectors, dehalo_synthesis_info* info);
 
+/* The grand products' per-row factors, every product of a proof in one launch [UPSTREAM plonk/permutation/prover.rs Argument::commit:
+ * per set of columns  den = prod_j (value_j + beta sigma_j + gamma),  num = prod_j (value_j + delta^j beta omega^i + gamma);
+ * plonk/lookup/prover.rs Permuted::commit_product:  den = (a' + beta)(s' + gamma),  num = (A + beta)(S + gamma)] over the `n` rows of the
+ * ORIGINAL domain.  Product p (permutation sets first, then lookups) is written to d_num / d_den + p * stride_elems; all columns and
+ * results in upstream's standard form: the inputs of dehalo_grand_product_batch_device. */
+typedef struct {
+    const uint64_t* const* columns; const uint64_t* const* sigma; uint32_t num_columns, chunk_len;   /* the permutation's columns (values) and sigma_j values */
+    const uint64_t* omega_powers;                    /* device column: omega^i */
+    const uint64_t *beta, *gamma, *delta;            /* host, 4 u64 each */
+    const uint64_t* set_factors;                     /* host, one per set: beta * delta^(chunk_len * set) */
+    const uint64_t* const* compressed_input; const uint64_t* const* compressed_table;     /* per lookup: A, S (theta-compressed) ... */
+    const uint64_t* const* permuted_input; const uint64_t* const* permuted_table;         /* ... a', s' */
+    uint32_t num_lookups;
+} dehalo_product_inputs;
+int dehalo_product_terms_device(dehalo_ctx* ctx, int field, const dehalo_product_inputs* in, size_t n, uint64_t* d_num, uint64_t* d_den, size_t stride_elems, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-kernel device time measured with HIP events on the launching stream (bench.py's
  * roofline leg).  kernel ids: see dehalo_kernel_id.                                          */

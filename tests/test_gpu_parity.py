@@ -1061,3 +1061,49 @@ def test_permute_expression_pair_leading_bit_ties_fall_back(pkg, po, co, ctx):
     got = ctx.permute_expression_pair(f.id, ti, tt, n)
     want = co.permute_expression_pair(f.id, ti, tt, n)
     assert want is not None and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", ["bn254_fr", "pasta_fq"])
+def test_product_terms_vs_python_integers(pkg, co, ctx, fname):
+    """dehalo_product_terms_device: the grand products' per-row numerators / denominators [UPSTREAM plonk/permutation/prover.rs commit,
+    plonk/lookup/prover.rs commit_product] against a direct evaluation on Python integers: 7 columns in chunks of 3 (three sets, the last
+    with one column), two lookups, a row count that is not a multiple of the block size."""
+    import torch
+    from dehalo2_amd.keygen import delta_of
+
+    f = pkg.fields.FIELDS[fname]
+    n, stride, ncols, chunk, nl = 333, 340, 7, 3, 2
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    cols = [co.fill_scalars(f.id, "uniform", n, 40 + j) for j in range(ncols)]
+    sig = [co.fill_scalars(f.id, "uniform", n, 60 + j) for j in range(ncols)]
+    lk = [[co.fill_scalars(f.id, "witness" if t % 2 else "uniform", n, 80 + 4 * l + t) for t in range(4)] for l in range(nl)]
+    omega = pow(f.root_of_unity, 1 << (f.two_adicity - 9), f.p)
+    om = f.encode_many([pow(omega, i, f.p) for i in range(n)])
+    beta, gamma, delta = 0x1234567 * 0x9E3779B97F4A7C15 % f.p, 0xABCDEF123 * 0xC2B2AE3D27D4EB4F % f.p, delta_of(f)
+    sets = (ncols + chunk - 1) // chunk
+    d_cols, d_sig, d_om = [dev(c) for c in cols], [dev(c) for c in sig], dev(om)
+    d_lk = [[dev(c) for c in four] for four in lk]
+    num = torch.zeros((sets + nl, stride, 4), dtype=torch.int64, device="cuda")
+    den = torch.zeros_like(num)
+    torch.cuda.synchronize()
+    ctx.product_terms_device(f.id, [c.data_ptr() for c in d_cols], [c.data_ptr() for c in d_sig], chunk, d_om.data_ptr(), f.encode(beta), f.encode(gamma), f.encode(delta),
+                             f.encode_many([beta * pow(delta, chunk * s, f.p) % f.p for s in range(sets)]), [tuple(c.data_ptr() for c in four) for four in d_lk], n,
+                             num.data_ptr(), den.data_ptr(), stride)
+    ctx.synchronize()
+    got_n, got_d = num.cpu().numpy().view(np.uint64), den.cpu().numpy().view(np.uint64)
+    C, S, LK = [f.decode_many(c) for c in cols], [f.decode_many(c) for c in sig], [[f.decode_many(c) for c in four] for four in lk]
+    for s in range(sets):
+        wn, wd = [], []
+        for i in range(n):
+            a = b = 1
+            for j in range(s * chunk, min(ncols, (s + 1) * chunk)):
+                b = b * (C[j][i] + beta * S[j][i] + gamma) % f.p
+                a = a * (C[j][i] + pow(delta, j, f.p) * beta % f.p * pow(omega, i, f.p) + gamma) % f.p
+            wn.append(a); wd.append(b)
+        assert f.decode_many(got_n[s, :n]) == wn and f.decode_many(got_d[s, :n]) == wd, s
+    for l in range(nl):
+        A, Sx, a_, s_ = LK[l]
+        assert f.decode_many(got_n[sets + l, :n]) == [(A[i] + beta) * (Sx[i] + gamma) % f.p for i in range(n)]
+        assert f.decode_many(got_d[sets + l, :n]) == [(a_[i] + beta) * (s_[i] + gamma) % f.p for i in range(n)]
+    assert not got_n[:, n:].any() and not got_d[:, n:].any()      # the padding between columns is untouched
