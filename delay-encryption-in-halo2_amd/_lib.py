@@ -194,7 +194,8 @@ def load_library():
     lib.dehalo_graph_evaluate_batch_device.argtypes = [P, C.POINTER(C.c_void_p), u32, C.POINTER(CEvalInputs), u32, u32, C.POINTER(C.c_void_p), P]
     lib.dehalo_permutation_h_device.argtypes = [P, C.c_int, C.POINTER(CPermInputs), u32, u32, u64p, P]
     lib.dehalo_lookup_h_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u64p, P]
-    lib.dehalo_product_terms_device.argtypes = [P, C.c_int, C.POINTER(CProductInputs), sz, u64p, u64p, sz, P]
+    if hasattr(lib, "dehalo_product_terms_device"):
+        lib.dehalo_product_terms_device.argtypes = [P, C.c_int, C.POINTER(CProductInputs), sz, u64p, u64p, sz, P]
     lib.dehalo_lookup_h_batch_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u32, u64p, P]
     PP = C.POINTER(P)
     lib.dehalo_params_create.argtypes = [P, C.c_int, u32, u64p, u64p, P, P, PP]

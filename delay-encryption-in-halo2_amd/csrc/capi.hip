@@ -226,8 +226,44 @@ int do_lookup_h_batch(dehalo_ctx* ctx, int field, const dehalo_lookup_inputs* in
 // reused as soon as its value has been read for the last time; the first EVH_MAX_LDS_SLOTS slots
 // live in LDS, the rest in an HBM scratch column).
 int compile_graph(dehalo_ctx* ctx, dehalo_graph* g, const int32_t* rotations, uint32_t num_rotations, const dehalo_calculation* calcs, uint32_t num_calcs,
-                  const dehalo_source* parts, uint32_t num_parts, uint32_t num_intermediates, std::vector<DevCalc>& out_calcs, std::vector<DevSrc>& out_parts) {
+                  const dehalo_source* parts, uint32_t num_parts, uint32_t num_intermediates, std::vector<DevCalc>& out_calcs, std::vector<DevSrc>& out_parts,
+                  bool propagate = true) {
     const uint32_t NEVER = 0xffffffffu;
+    if (propagate) {
+        // Copy propagation.  Upstream's GraphEvaluator::add_expression wraps EVERY column query in Calculation::Store(source) so that its
+        // CPU loop loads a cell once; on the device a Store is a calculation of its own (fetch, slot write) and every later use a slot
+        // read, while reading the column directly costs the same fetch.  A Store of a non-intermediate source whose target is written
+        // exactly once is therefore dropped and its uses read the source (MainGate's gate: 34 calculations / 7 slots -> 20 / 3; fewer
+        // slots is more resident waves: the kernel's occupancy is bounded by its LDS slots).  The original program is validated first.
+        {
+            std::vector<DevCalc> tc;
+            std::vector<DevSrc> tp;
+            dehalo_graph probe = *g;
+            TRY(compile_graph(ctx, &probe, rotations, num_rotations, calcs, num_calcs, parts, num_parts, num_intermediates, tc, tp, false));
+        }
+        std::vector<uint32_t> defs(num_intermediates, 0);
+        for (uint32_t i = 0; i < num_calcs; i++) defs[calcs[i].target]++;
+        std::vector<int> aliased(num_intermediates, 0);
+        std::vector<dehalo_source> alias(num_intermediates);
+        std::vector<dehalo_calculation> cc;
+        std::vector<dehalo_source> pp(parts, parts + num_parts);
+        auto sub = [&](dehalo_source s) { return (s.kind == DEHALO_SRC_INTERMEDIATE && aliased[s.index]) ? alias[s.index] : s; };
+        for (uint32_t i = 0; i < num_calcs; i++) {
+            dehalo_calculation c = calcs[i];
+            c.a = sub(c.a);
+            c.b = sub(c.b);
+            if (c.op == DEHALO_CALC_HORNER)
+                for (uint32_t k = 0; k < c.parts_len; k++) pp[c.parts_begin + k] = sub(pp[c.parts_begin + k]);
+            if (c.op == DEHALO_CALC_STORE && c.a.kind != DEHALO_SRC_INTERMEDIATE && i + 1 != num_calcs && defs[c.target] == 1) {
+                aliased[c.target] = 1;
+                alias[c.target] = c.a;
+                continue;
+            }
+            cc.push_back(c);
+        }
+        g->num_calcs = (uint32_t)cc.size();
+        return compile_graph(ctx, g, rotations, num_rotations, cc.data(), (uint32_t)cc.size(), pp.data(), num_parts, num_intermediates, out_calcs, out_parts, false);
+    }
     std::vector<uint32_t> last_use(num_intermediates, NEVER), first_def(num_intermediates, NEVER);
     auto check_src = [&](const dehalo_source& src, uint32_t at) -> int {
         switch (src.kind) {
