@@ -334,7 +334,8 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     mine = sharding.units_for_rank(total, rank, world)
     st.prove(1000)                                            # warm-up
     cs = st.circ.cs
-    ctxs = [pkg.Context(device) for _ in range(max(1, inflight))]
+    prios = (1, 0, -1) if os.environ.get("DEHALO_BENCH_FLAT_PRIORITIES") is None else (0,)      # (see main(): hardware queues are pooled per priority)
+    ctxs = [pkg.Context(device, priority=prios[i % len(prios)]) for i in range(max(1, inflight))]
     provers = [native.Prover(st.params, st.pk, c) for c in ctxs]
     native.create_proofs(provers, st.advice, [prover.SeededRng(999 - i) for i in range(2 * len(provers))])      # warm-up of every prover's buffers
     fence_all(world)
@@ -443,7 +444,10 @@ def main():
     # independent units (different columns / proofs), so step i+1's sort and bucket accumulation
     # overlap step i's latency-bound bucket reduction.  The SRS tables are shared.
     inflight = max(1, args.inflight)
-    ctxs = [pkg.Context(local_rank) for _ in range(inflight)]
+    # stream priorities alternate (highest / default / lowest): the runtime keeps a pool of hardware queues PER priority and maps streams of one
+    # priority onto few of them -- four default-priority streams were measured running two at a time (tools/stream_concurrency.hip)
+    prios = (1, 0, -1) if os.environ.get("DEHALO_BENCH_FLAT_PRIORITIES") is None else (0,)
+    ctxs = [pkg.Context(local_rank, priority=prios[i % len(prios)]) for i in range(inflight)]
     ctx = ctxs[0]
     if args.acc_waves:
         for c in ctxs:

@@ -365,6 +365,10 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     if (!affine_xy || !out || n == 0 || stride_bytes < 64 || n >= (1ull << 30)) return dh_fail(ctx, DEHALO_ERR_INVALID, "bases_register: bad argument");
     if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return dh_fail(ctx, DEHALO_ERR_INVALID, "window_bits must be 0 or in [4, 16]");
     uint32_t c = window_bits ? (uint32_t)window_bits : (precompute ? choose_window(n) : choose_window_single(n));
+    if (!window_bits && precompute) {      // DEHALO_WINDOW_BITS: tuning experiments (results never depend on the window)
+        const char* e = getenv("DEHALO_WINDOW_BITS");
+        if (e && atoi(e) >= 4 && atoi(e) <= 16) c = (uint32_t)atoi(e);
+    }
     if (c < 4) c = 4;
     uint32_t W = signed_windows(scalar_modulus_words(curve), c);
     if (precompute && (uint64_t)n * W >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "precomputed table too large");

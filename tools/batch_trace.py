@@ -12,6 +12,7 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 nprov = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 with_side = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
+prio_mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # 1: contexts alternate between the highest / default / lowest stream priority
 curve = pkg.fields.BN254
 circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc")
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
@@ -22,7 +23,7 @@ with ctx.torch_stream():
 ctx.synchronize()
 nparams = native.ParamsKZG.create(ctx, curve, k, srs["g"], srs["g_lagrange"])
 npk = native.ProvingKey.keygen(ctx, nparams, circ.cs, circ.fixed, circ.assembly, circ.selectors)
-ctxs = [pkg.Context(0) for _ in range(nprov)]
+ctxs = [pkg.Context(0, priority=((1, 0, -1)[i % 3] if prio_mode else 0)) for i in range(nprov)]
 sides = [pkg.Context(0) for _ in range(nprov)] if with_side else [None] * nprov
 provers = [native.Prover(nparams, npk, c, s) for c, s in zip(ctxs, sides)]
 native.create_proofs(provers, adv, [prover.SeededRng(1000 + i) for i in range(2 * nprov)])
@@ -36,4 +37,4 @@ el = time.perf_counter() - t
 torch.cuda.synchronize()
 marker2 = torch.zeros(12345, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
-print("batch of %d on %d provers%s: %.1f proofs/s (%.3f ms per proof)" % (batch, nprov, " + side contexts" if with_side else "", batch / el, 1e3 * el / batch))
+print("batch of %d on %d provers%s%s [GPU_MAX_HW_QUEUES=%s]: %.1f proofs/s (%.3f ms per proof)" % (batch, nprov, " + side contexts" if with_side else "", " mixed priorities" if prio_mode else "", os.environ.get("GPU_MAX_HW_QUEUES", "default"), batch / el, 1e3 * el / batch))

@@ -32,3 +32,24 @@ for r in win:
     c = agg.setdefault(nm, [0, 0]); c[0] += 1; c[1] += d
 for nm, (cnt, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
     print("  %-50s %6.1f launches / proof  %7.3f ms / proof  avg %8.1f us" % (nm, cnt / proofs, d / 1e6 / proofs, d / 1e3 / cnt))
+# time during which exactly ONE kernel was running, by kernel (who runs alone?), and total time by concurrency level
+ev = []
+for r in win:
+    nm = r['Kernel_Name'].split('(')[0].replace('void ', '')[:40]
+    ev.append((int(r['Start_Timestamp']), 1, nm)); ev.append((int(r['End_Timestamp']), -1, nm))
+ev.sort()
+active, alone, level = {}, {}, {}
+prev = None
+for t, d, nm in ev:
+    if prev is not None and t > prev:
+        n_act = sum(active.values())
+        level[n_act] = level.get(n_act, 0) + (t - prev)
+        if n_act == 1:
+            k = next(k for k, v in active.items() if v)
+            alone[k] = alone.get(k, 0) + (t - prev)
+    active[nm] = active.get(nm, 0) + d
+    prev = t
+print("time by number of kernels running: " + ", ".join("%d: %.1f%%" % (k, 100.0 * v / W) for k, v in sorted(level.items())))
+print("running ALONE (ms per proof):")
+for nm, v in sorted(alone.items(), key=lambda kv: -kv[1])[:12]:
+    print("  %-42s %7.3f" % (nm, v / 1e6 / proofs))
