@@ -160,6 +160,8 @@ static __global__ void k_evh_ptrs(PtrBatch b, const void** out, u32 n) {
     if (i < n) out[i] = b.p[i];
 }
 
+// (every  v = v y + term * l  below is ONE reduction of two products, f29_mul2: the reduction is the larger half of a bn256::Fr multiplication --
+// tools/ubench_mfma_price.hip: product 81 multiply-adds 2.4 ms, reduction 2.9 ms of the same run)
 // ---- permutation argument terms (Evaluator::evaluate_h, "Permutation constraints") ------------
 // sets: the grand-product cosets z_0 .. z_{S-1}; cols: the permuted columns' cosets in order,
 // chunk_len per set; sigma: pk.permutation.cosets in the same order.  Per row (X = zeta w^row):
@@ -198,12 +200,12 @@ __global__ __launch_bounds__(EVH_THREADS) void k_perm_h(PermArgs A) {
     const f29 l0 = ld(A.l0, row), l_last = ld(A.l_last, row), l_active = ld(A.l_active, row);
     if (A.nsets) {
         f29 z0 = ld(A.z[0], row);
-        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(one, z0), l0));
+        v = f29_mul2<F9>(v, y, evh_sub<F9>(one, z0), l0);
         f29 zl = ld(A.z[A.nsets - 1], row);
-        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(f29_sqr<F9>(zl), zl), l_last));
+        v = f29_mul2<F9>(v, y, evh_sub<F9>(f29_sqr<F9>(zl), zl), l_last);
         for (u32 s = 1; s < A.nsets; s++) {
             f29 t = evh_sub<F9>(ld(A.z[s], row), ld(A.z[s - 1], r_last));
-            v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(t, l0));
+            v = f29_mul2<F9>(v, y, t, l0);
         }
         // beta * zeta * omega_ext^row, omega_ext^row from the NTT twiddle table (omega^(rows/2) = -1)
         const u64 half = A.rows >> 1;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(EVH_THREADS) void k_perm_h(PermArgs A) {
                 right = f29_mul<F9>(right, u);
                 current_delta = f29_mul<F9>(current_delta, delta);
             }
-            v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(left, right), l_active));
+            v = f29_mul2<F9>(v, y, evh_sub<F9>(left, right), l_active);
         }
     }
     f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
@@ -260,14 +262,14 @@ __global__ __launch_bounds__(EVH_THREADS) void k_lookup_h(LookupArgs A) {
     const f29 l0 = ld(A.l0, row), l_last = ld(A.l_last, row), l_active = ld(A.l_active, row);
     const f29 z = ld(A.z, row), a = ld(A.a_perm, row), s = ld(A.s_perm, row);
     const f29 a_minus_s = evh_sub<F9>(a, s);
-    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(one, z), l0));
-    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(f29_sqr<F9>(z), z), l_last));
+    v = f29_mul2<F9>(v, y, evh_sub<F9>(one, z), l0);
+    v = f29_mul2<F9>(v, y, evh_sub<F9>(f29_sqr<F9>(z), z), l_last);
     f29 lhs = f29_mul<F9>(f29_mul<F9>(ld(A.z, r_next), evh_add<F9>(a, beta)), evh_add<F9>(s, gamma));
     f29 rhs = f29_mul<F9>(z, ldv(A.table_value, row));
-    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(lhs, rhs), l_active));
-    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(a_minus_s, l0));
+    v = f29_mul2<F9>(v, y, evh_sub<F9>(lhs, rhs), l_active);
+    v = f29_mul2<F9>(v, y, a_minus_s, l0);
     f29 t = f29_mul<F9>(a_minus_s, evh_sub<F9>(a, ld(A.a_perm, r_prev)));
-    v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(t, l_active));
+    v = f29_mul2<F9>(v, y, t, l_active);
     f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
 }
 
@@ -303,14 +305,14 @@ __global__ __launch_bounds__(EVH_THREADS) void k_lookup_h_batch(LookupBatchArgs 
         const f29 z = ld(zc, row), a = ld(ac, row), s = ld(sc, row);
         const f29 z_next = ld(zc, r_next), a_prev = ld(ac, r_prev), tv = ldv(A.table_value[l], row);
         const f29 a_minus_s = evh_sub<F9>(a, s);
-        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(one, z), l0));
-        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(f29_sqr<F9>(z), z), l_last));
+        v = f29_mul2<F9>(v, y, evh_sub<F9>(one, z), l0);
+        v = f29_mul2<F9>(v, y, evh_sub<F9>(f29_sqr<F9>(z), z), l_last);
         f29 lhs = f29_mul<F9>(f29_mul<F9>(z_next, evh_add<F9>(a, beta)), evh_add<F9>(s, gamma));
         f29 rhs = f29_mul<F9>(z, tv);
-        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(evh_sub<F9>(lhs, rhs), l_active));
-        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(a_minus_s, l0));
+        v = f29_mul2<F9>(v, y, evh_sub<F9>(lhs, rhs), l_active);
+        v = f29_mul2<F9>(v, y, a_minus_s, l0);
         f29 t = f29_mul<F9>(a_minus_s, evh_sub<F9>(a, a_prev));
-        v = evh_add<F9>(f29_mul<F9>(v, y), f29_mul<F9>(t, l_active));
+        v = f29_mul2<F9>(v, y, t, l_active);
     }
     f_store(&A.values[row], A.vals_internal ? f29_to_packed_canon<F9>(v) : f29_to_std<F9>(v));
 }

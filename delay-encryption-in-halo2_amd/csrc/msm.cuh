@@ -1036,7 +1036,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_ACCUMULATE);
         u32 blocks = (u32)((lanes_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
-        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, 0, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + 4);
+        // DEHALO_MSM_ACC_LDS (bytes of dynamic LDS per block, unused by the kernel): caps the accumulation's resident blocks per CU so that
+        // wave slots and registers stay free for the kernels of other contexts (tuning experiments; results never depend on it)
+        static const unsigned acc_lds = [] { const char* e = getenv("DEHALO_MSM_ACC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, acc_lds, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + 4);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
