@@ -1,7 +1,8 @@
 // hostrng.hpp -- sources of the prover's random scalars (blinding rows, blinds, the vanishing argument's random polynomial), the
 // `rng: R` argument of create_proof [UPSTREAM halo2_proofs/src/plonk/prover.rs; the reference passes OsRng, benches/delay_enc.rs:128].
 //   DEHALO_RNG_OS        the default: 32 bytes of operating-system entropy (getrandom) key a ChaCha20 stream per call; every scalar is
-//                        256 stream bits masked to the modulus' bit length and rejected when >= p -- uniform over the field;
+//                        256 stream bits masked to the modulus' bit length and rejected when >= p -- uniform over the field (the blinding
+//                        rows on the host; the random polynomial's n scalars by a ChaCha20 KERNEL under the same key, prover.hip);
 //   DEHALO_RNG_PCG64     TESTS / BENCHMARKS ONLY (not a CSPRNG): numpy's PCG64 stream from a given state, four 64-bit outputs per scalar,
 //                        top word masked to 61 bits -- the stream dehalo2_amd.prover.SeededRng and the CPU restatement consume, so that
 //                        proofs can be compared byte for byte;

@@ -53,6 +53,43 @@ __global__ void k_gather_elems(const fe* __restrict__ src, const uint64_t* __res
     if (i < count) dst[i] = src[idx[i]];
 }
 
+// DEHALO_RNG_OS, the vanishing argument's random polynomial (n scalars: 4 MiB at k = 17): generated ON THE DEVICE from the proof's ChaCha20 key (32 bytes of
+// operating-system entropy) instead of being drawn on a host thread and uploaded.  Scalar i = the first of ChaCha20 blocks (counter low = i, counter high =
+// attempt 0, 1, ...), nonce = the helper's stream, whose first 256 bits masked to the modulus' length are < p: uniform over the field.
+struct ChaKey { u32 k[8]; };
+__device__ __forceinline__ u32 cha_rotl(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+__global__ void k_chacha_scalars(ChaKey key, u64 stream, fe p, u32 top_mask, fe* out, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (u32 attempt = 0;; attempt++) {
+        u32 st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3], key.k[4], key.k[5], key.k[6], key.k[7],
+                      (u32)i, ((u32)(i >> 32) & 0xffffu) | (attempt << 16), (u32)stream, (u32)(stream >> 32)};
+        u32 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = st[j];
+#define CHA_QR(a, b, c, d)                                                                                         \
+    x[a] += x[b]; x[d] = cha_rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = cha_rotl(x[b] ^ x[c], 12);                \
+    x[a] += x[b]; x[d] = cha_rotl(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = cha_rotl(x[b] ^ x[c], 7);
+        for (int r = 0; r < 10; r++) {
+            CHA_QR(0, 4, 8, 12) CHA_QR(1, 5, 9, 13) CHA_QR(2, 6, 10, 14) CHA_QR(3, 7, 11, 15)
+            CHA_QR(0, 5, 10, 15) CHA_QR(1, 6, 11, 12) CHA_QR(2, 7, 8, 13) CHA_QR(3, 4, 9, 14)
+        }
+#undef CHA_QR
+        fe v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v.v[j] = x[j] + st[j];
+        v.v[7] &= top_mask;
+        bool below = false, decided = false;
+#pragma unroll
+        for (int j = 7; j >= 0; j--)
+            if (!decided && v.v[j] != p.v[j]) { below = v.v[j] < p.v[j]; decided = true; }
+        if (below) {
+            out[i] = v;
+            return;
+        }
+    }
+}
+
 void put_u32_be(std::vector<uint8_t>& o, uint32_t v) { for (int i = 3; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i))); }
 void put_u32_be(uint8_t* o, uint32_t v) { for (int i = 0; i < 4; i++) o[i] = (uint8_t)(v >> (8 * (3 - i))); }
 uint32_t get_u32_be(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
@@ -849,17 +886,35 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     uint64_t rand_point[8] = {};
     std::thread helper;
     double helper_ms[3] = {};
+    const bool device_rng = rng.kind == DEHALO_RNG_OS;      // the large draw comes from a ChaCha20 kernel keyed with this proof's entropy
+    auto device_draw = [&](fe* dst, hipStream_t st) -> int {
+        ChaKey ck;
+        memcpy(ck.k, rng.key, 32);
+        fe pw;
+        for (int i = 0; i < 4; i++) { pw.v[2 * i] = (u32)f->p[i]; pw.v[2 * i + 1] = (u32)(f->p[i] >> 32); }
+        const u32 top_mask = f->bits >= 256 ? 0xffffffffu : ((1u << (f->bits - 224)) - 1);
+        k_chacha_scalars<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ck, /* stream of the fork */ 1, pw, top_mask, dst, n);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
     auto helper_body = [&]() {
         (void)hipSetDevice(ctx->device);
         const auto th0 = clk::now();
-        rand_host.resize(4 * n);
-        int rc = rng_poly.scalars(rand_host.data(), n);
+        int rc = 0;
+        if (!device_rng) {
+            rand_host.resize(4 * n);
+            rc = rng_poly.scalars(rand_host.data(), n);
+        }
         helper_ms[0] = ms_since(th0);
         if (!rc) {
             if (side) {
                 fe* dst = polys + (size_t)o_rand * n;
-                hipError_t e = hipMemcpyAsync(dst, rand_host.data(), n * 32, hipMemcpyHostToDevice, ss);
-                if (e == hipSuccess) e = hipStreamSynchronize(ss);
+                hipError_t e = hipSuccess;
+                if (device_rng) rc = device_draw(dst, ss);
+                else {
+                    e = hipMemcpyAsync(dst, rand_host.data(), n * 32, hipMemcpyHostToDevice, ss);
+                    if (e == hipSuccess) e = hipStreamSynchronize(ss);
+                }
                 if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial upload: ") + hipGetErrorString(e));
                 if (!rc) rc = dehalo_msm_device_affine(side, params->bases_g, (const uint64_t*)dst, n, 1, nullptr, aff_side.u64(), nullptr);
                 helper_ms[1] = ms_since(th0);
@@ -1086,7 +1141,8 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     if (side) {
         if (!tr->write_point(rand_point)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
     } else {
-        HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), rand_host.data(), n * 32, hipMemcpyHostToDevice, ms));
+        if (device_rng) TRY(device_draw(cols.at((size_t)o_rand * n), ms));
+        else HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), rand_host.data(), n * 32, hipMemcpyHostToDevice, ms));
         TRY(commit(tr, cols.at((size_t)o_rand * n), 1, false));
     }
     mark(3);

@@ -198,8 +198,10 @@ def test_native_proof_matches_oracle_and_verifies(pkg, po, ctx, chain, native_ch
     # OS entropy (rng = None): a different, valid proof every time
     p1, p2 = P2.create_proof(c["adv"], [[]]).finalize(), P2.create_proof(c["adv"], [[]]).finalize()
     assert p1 != p2 != want and len(p1) == len(want)
+    p3 = P.create_proof(c["adv"], [[]]).finalize()                     # no side context: the random polynomial's kernel runs on the main stream
+    assert p3 != p1 and len(p3) == len(want)
     if k <= 11:
-        assert oracle_verify(po, c, p1, k) and oracle_verify(po, c, p2, k)
+        assert oracle_verify(po, c, p1, k) and oracle_verify(po, c, p2, k) and oracle_verify(po, c, p3, k)
     P.release(); P2.release(); side.close()
 
 
