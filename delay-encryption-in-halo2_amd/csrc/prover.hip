@@ -615,7 +615,7 @@ struct dehalo_prover {
     size_t n = 0, m = 0, u = 0;
     uint32_t k = 0, ek = 0, bf = 0, A = 0, L = 0, S = 0, I = 0, NC = 0, pieces = 0;
     uint32_t o_adv = 0, o_perm = 0, o_pz = 0, o_lz = 0, o_rand = 0;
-    DevMem cols, polys_own, instance, instance_values, compressed, num, den, ext, h, table_value, hfold, qbuf, wbuf, aff, aff_side, evals, blind_dev, omega_col;
+    DevMem cols, polys_own, instance, instance_values, compressed, num, den, ext, h, table_value, hfold, qbuf, wbuf, jac, jac_side, evals, blind_dev, omega_col;
     fe* polys = nullptr;      // coefficient forms: polys_own with a side context, cols (in place) without
     std::vector<std::pair<dehalo_graph*, dehalo_graph*>> perm_graphs;      // per set: (denominator, numerator)
     std::vector<uint32_t> table_rep;      // per lookup: the first lookup with the same table expressions (shares its compressed table)
@@ -630,7 +630,7 @@ struct dehalo_prover {
     std::vector<const uint64_t*> hp_ptrs;
     size_t hpiece0 = 0, eval_count = 0;
     // host staging
-    std::vector<uint64_t> blind_host, host_aff, host_evals, rand_host;
+    std::vector<uint64_t> blind_host, host_aff, host_jac, host_evals, rand_host;
     double timings[8] = {};
     bool trace = false;      // DEHALO_PROVER_TRACE=1: host timestamps inside the phases go to stderr after each proof
     std::vector<std::pair<const char*, double>> ticks;
@@ -801,8 +801,8 @@ struct dehalo_prover {
         TRY(hfold.alloc(ctx, n));
         TRY(qbuf.alloc(ctx, 4 * n));
         TRY(wbuf.alloc(ctx, 4 * n));
-        TRY(aff.alloc(ctx, 2 * (size_t)std::max<uint32_t>(NC, 8)));
-        TRY(aff_side.alloc(ctx, 2));
+        TRY(jac.alloc(ctx, 3 * (size_t)std::max<uint32_t>(NC, 8)));
+        TRY(jac_side.alloc(ctx, 3));
         // blinding values of a proof but the random polynomial, compacted: [advice rows | permuted rows | product rows]
         const size_t rows = n - u;
         TRY(blind_dev.alloc(ctx, std::max<size_t>(1, (size_t)A * rows + (size_t)2 * L * rows + (size_t)(S + L) * bf)));
@@ -815,19 +815,50 @@ struct dehalo_prover {
         TRY(evals.alloc(ctx, eval_count + 8));
         for (hipEvent_t* e : {&ev_ready[0], &ev_ready[1], &ev_ready[2], &ev_inst, &ev_side}) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
         host_aff.resize(8 * (size_t)std::max<uint32_t>(NC, 8));
+        host_jac.resize(12 * (size_t)std::max<uint32_t>(NC, 8));
         host_evals.resize(4 * eval_count);
         TRY(dehalo_ctx_synchronize(ctx));
         return 0;
     }
 
-    // commit `count` columns starting at `src`, normalise, read back, absorb (and append to the proof)
+    // Jacobian {x, y, z} (Montgomery, base field) -> affine on the HOST: one inversion per phase by Montgomery's trick (a dozen field
+    // multiplications per point, one exponentiation per call: ~15 us) instead of a 12 k-instruction safegcd chain on ONE lane of the MSM's last
+    // kernel in front of every read-back (~50 us of device latency per commitment phase, six phases per proof).  false: a point at infinity.
+    bool normalize_host(const uint64_t* jac, size_t count, uint64_t* affine_out) const {
+        const HostField* fq = host_field(curve_base_field(pk->curve));
+        std::vector<Fe> z(count), pre(count);
+        Fe acc = fq->one;
+        for (size_t i = 0; i < count; i++) {
+            memcpy(z[i].v, jac + 12 * i + 8, 32);
+            if (z[i].is_zero()) return false;
+            pre[i] = acc;
+            acc = fq->mul(acc, z[i]);
+        }
+        Fe inv = fq->invert(acc);
+        for (size_t i = count; i-- > 0;) {
+            const Fe zi = fq->mul(inv, pre[i]);
+            inv = fq->mul(inv, z[i]);
+            const Fe zi2 = fq->sqr(zi), zi3 = fq->mul(zi2, zi);
+            Fe x, y;
+            memcpy(x.v, jac + 12 * i, 32);
+            memcpy(y.v, jac + 12 * i + 4, 32);
+            x = fq->mul(x, zi2);
+            y = fq->mul(y, zi3);
+            memcpy(affine_out + 8 * i, x.v, 32);
+            memcpy(affine_out + 8 * i + 4, y.v, 32);
+        }
+        return true;
+    }
+
+    // commit `count` columns starting at `src`, read back, normalise, absorb (and append to the proof)
     int commit(dehalo_transcript* tr, const fe* src, size_t count, bool lagrange, const std::function<int()>& before_sync = nullptr) {
-        TRY(dehalo_msm_device_affine(ctx, lagrange ? params->bases_gl : params->bases_g, (const uint64_t*)src, n, count, nullptr, aff.u64(), nullptr));
+        TRY(dehalo_msm_device(ctx, lagrange ? params->bases_gl : params->bases_g, (const uint64_t*)src, n, count, jac.u64(), nullptr));
         tk("commit queued");
         if (before_sync) TRY(before_sync());
         tk("side work queued");
-        TRY(dehalo_download(ctx, aff.p, count * 64, host_aff.data()));
+        TRY(dehalo_download(ctx, jac.p, count * 96, host_jac.data()));
         tk("points on host");
+        if (!normalize_host(host_jac.data(), count, host_aff.data())) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
         for (size_t i = 0; i < count; i++)
             if (!tr->write_point(host_aff.data() + 8 * i)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
         return 0;
@@ -916,9 +947,11 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
                     if (e == hipSuccess) e = hipStreamSynchronize(ss);
                 }
                 if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial upload: ") + hipGetErrorString(e));
-                if (!rc) rc = dehalo_msm_device_affine(side, params->bases_g, (const uint64_t*)dst, n, 1, nullptr, aff_side.u64(), nullptr);
+                uint64_t rj[12];
+                if (!rc) rc = dehalo_msm_device(side, params->bases_g, (const uint64_t*)dst, n, 1, jac_side.u64(), nullptr);
                 helper_ms[1] = ms_since(th0);
-                if (!rc) rc = dehalo_download(side, aff_side.p, 64, rand_point);
+                if (!rc) rc = dehalo_download(side, jac_side.p, 96, rj);
+                if (!rc && !normalize_host(rj, 1, rand_point)) memset(rand_point, 0, sizeof rand_point);      // (the identity: refused by write_point below)
                 helper_ms[2] = ms_since(th0);
             } else {
                 // without a side context only the draw is taken off the critical path; the upload is queued by the proving thread
