@@ -292,3 +292,16 @@ FP_DEV xyzz29 x29_double_quad(const xyzz29& a) {
     r.y = f29_norm(f29_sub(mt, wy, F::KM));
     return r;
 }
+
+// sum over groups of W consecutive lanes (W a power of two, 8 <= W <= 64) whose QUADS hold replicated values: log2(W / 4) levels of
+// quad-cooperative additions (4 multiplication rounds each) instead of log2(W) full additions on single lanes; quad 0 of each group gets it.
+template <class F, int W>
+FP_DEV xyzz29 x29_group_reduce_quad(xyzz29 v) {
+    const int gl = threadIdx.x & (W - 1);
+    for (int d = W >> 1; d >= 4; d >>= 1) {
+        xyzz29 o = x29_shfl_down<W>(v, d);
+        if (gl + d >= W) o = x29_identity();   // quads past the fold add nothing (and never see P + P)
+        v = x29_add_quad<F>(v, o);
+    }
+    return v;
+}

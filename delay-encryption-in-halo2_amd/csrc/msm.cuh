@@ -684,46 +684,49 @@ FP_DEV void merge_light_section(u32 blk, u32 nblk, const u32* rbeg, const u32* r
     }
 }
 
-// groups of G lanes (32 or 64) walk a class list: strided lane sums, then a shuffle reduction
+// groups of G lanes (32 or 64) = G / 4 quads walk a class list: strided QUAD sums (quad-cooperative additions: four lanes share one addition, four
+// multiplication rounds instead of fourteen), then a shuffle reduction over the quads.  (Round 3; one lane per chain and a full-addition shuffle tree
+// before: a heavy bucket's 9-15 tree levels at 10-20 us each were the floor of the skewed commitment phases.)
 template <class F, int G>
 FP_DEV void merge_group_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list) {
     const u32 groups_per_block = MSM_MERGE_THREADS / G;
-    const u32 gl = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    const u32 gl = threadIdx.x & (G - 1), grp = threadIdx.x / G, q = gl >> 2, Q = G / 4;
     for (u32 i = blk * groups_per_block + grp; i < count; i += nblk * groups_per_block) {
         u32 b = list[i];
         u32 beg = rbeg[b], end = rend[b];
         xyzz29 acc = x29_identity();
-        u32 p = beg + gl;
+        u32 p = beg + q;
         if (p < end) {
             acc = x29_load(&partial[p]);
-            for (p += G; p < end; p += G) acc = x29_add<F>(acc, x29_load(&partial[p]));
+            for (p += Q; p < end; p += Q) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
         }
-        acc = x29_group_reduce<F, G>(acc);
+        acc = x29_group_reduce_quad<F, G>(acc);
         if (gl == 0) x29_store(&buckets[b], acc);
     }
 }
 
-// whole blocks walk the heaviest class: strided lane sums, shuffle reduction per wave, the wave
-// results through LDS, shuffle reduction again.  Chain: ceil(S / 512) + 9 adds.
+// whole blocks walk the heaviest class: strided quad sums, shuffle reduction over the quads of a wave, the wave results through LDS, quad reduction
+// again.  Chain: ceil(S / 128) + 4 + 3 quad-cooperative additions.
 template <class F>
 FP_DEV void merge_heavy_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list,
                                 xyzz29_rec* sh) {
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = threadIdx.x >> 2, Q = MSM_MERGE_THREADS / 4;
     for (u32 i = blk; i < count; i += nblk) {
         u32 b = list[i];
         u32 beg = rbeg[b], end = rend[b];
         xyzz29 acc = x29_identity();
-        u32 p = beg + threadIdx.x;
+        u32 p = beg + q;
         if (p < end) {
             acc = x29_load(&partial[p]);
-            for (p += MSM_MERGE_THREADS; p < end; p += MSM_MERGE_THREADS) acc = x29_add<F>(acc, x29_load(&partial[p]));
+            for (p += Q; p < end; p += Q) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
         }
-        acc = x29_group_reduce<F, 64>(acc);
+        acc = x29_group_reduce_quad<F, 64>(acc);
         if (lane == 0) x29_store(&sh[wave], acc);
         __syncthreads();
         if (wave == 0) {
-            xyzz29 v = lane < MSM_MERGE_THREADS / 64 ? x29_load(&sh[lane]) : x29_identity();
-            v = x29_group_reduce<F, MSM_MERGE_THREADS / 64>(v);
+            constexpr u32 NW = MSM_MERGE_THREADS / 64;                              // 8 wave results, one per quad of the first 32 lanes
+            xyzz29 v = (lane >> 2) < NW ? x29_load(&sh[lane >> 2]) : x29_identity();
+            v = x29_group_reduce_quad<F, 4 * NW>(v);
             if (lane == 0) x29_store(&buckets[b], v);
         }
         __syncthreads();
