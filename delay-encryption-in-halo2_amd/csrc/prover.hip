@@ -3,6 +3,7 @@
 // plonk/prover.rs, plonk/{lookup,permutation,vanishing}/prover.rs, poly/kzg/multiopen/gwc/prover.rs] -- the calls the reference makes at
 // benches/delay_enc.rs:41-54 (params), :84-115 (keys), :120-134 (create_proof into a Blake2bWrite transcript).
 //
+// Every C entry point is a function-try-block: an allocation failure on the host (std::bad_alloc) leaves as DEHALO_ERR_OOM, never as an exception.
 // Host logic only: it orders the phases, hashes the transcript and does O(1) field arithmetic per challenge (hostfield.hpp); every column
 // operation is one of this library's device entry points (include/dehalo.h), called directly.  No CPU path for column work exists.
 #include <atomic>
@@ -108,7 +109,7 @@ struct dehalo_params {
 };
 
 extern "C" int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, const uint8_t* g2, const uint8_t* s_g2,
-                                    dehalo_params** out) {
+                                    dehalo_params** out) try {
     if (!ctx || !out || !g || !g_lagrange) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_create: null argument");
     if (k > 28 || curve_scalar_field(curve) < 0) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_create: k or curve out of range");
     std::unique_ptr<dehalo_params> p(new dehalo_params);
@@ -125,9 +126,9 @@ extern "C" int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, cons
     }
     *out = p.release();
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out) {
+extern "C" int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out) try {
     if (!ctx || !bytes || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: null argument");
     if (len < 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: unexpected end of input");
     const uint32_t k = (uint32_t)bytes[0] | ((uint32_t)bytes[1] << 8) | ((uint32_t)bytes[2] << 16) | ((uint32_t)bytes[3] << 24);      // u32 LE
@@ -139,11 +140,11 @@ extern "C" int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* byt
     memcpy(g.data(), bytes + 4, 64 * n);
     memcpy(gl.data(), bytes + 4 + 64 * n, 64 * n);
     return dehalo_params_create(ctx, curve, k, g.data(), gl.data(), bytes + 4 + 128 * n, bytes + 4 + 128 * n + 128, out);
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 extern "C" size_t dehalo_params_size(const dehalo_params* p) { return p ? 4 + 2 * 64 * p->n + 256 : 0; }
 
-extern "C" int dehalo_params_write(const dehalo_params* p, uint8_t* out, size_t cap) {
+extern "C" int dehalo_params_write(const dehalo_params* p, uint8_t* out, size_t cap) try {
     if (!p || !out) return DEHALO_ERR_INVALID;
     if (cap < dehalo_params_size(p)) return dh_fail(p->ctx, DEHALO_ERR_INVALID, "params_write: buffer too small");
     for (int i = 0; i < 4; i++) out[i] = (uint8_t)(p->k >> (8 * i));
@@ -152,21 +153,21 @@ extern "C" int dehalo_params_write(const dehalo_params* p, uint8_t* out, size_t 
     memcpy(out + 4 + 128 * p->n, p->g2, 128);
     memcpy(out + 4 + 128 * p->n + 128, p->s_g2, 128);
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_params_release(dehalo_ctx* ctx, dehalo_params* p) {
+extern "C" int dehalo_params_release(dehalo_ctx* ctx, dehalo_params* p) try {
     if (!p) return 0;
     if (p->bases_g) (void)dehalo_bases_release(ctx ? ctx : p->ctx, p->bases_g);
     if (p->bases_gl) (void)dehalo_bases_release(ctx ? ctx : p->ctx, p->bases_gl);
     delete p;
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 extern "C" int dehalo_params_commit_device(dehalo_ctx* ctx, const dehalo_params* p, const uint64_t* d_polys, size_t batch, int lagrange, uint64_t* d_out_affine,
-                                           void* stream) {
+                                           void* stream) try {
     if (!ctx || !p) return DEHALO_ERR_INVALID;
     return dehalo_msm_device_affine(ctx, lagrange ? p->bases_gl : p->bases_g, d_polys, p->n, batch, nullptr, d_out_affine, stream);
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 // ================================================================================================ transcript
 struct dehalo_transcript {
@@ -223,47 +224,47 @@ struct dehalo_transcript {
     }
 };
 
-extern "C" int dehalo_transcript_create(int curve, dehalo_transcript** out) {
+extern "C" int dehalo_transcript_create(int curve, dehalo_transcript** out) try {
     if (!out || curve_scalar_field(curve) < 0) return DEHALO_ERR_INVALID;
     dehalo_transcript* t = new dehalo_transcript;
     t->init(curve);
     *out = t;
     return 0;
-}
-extern "C" int dehalo_transcript_common_scalar(dehalo_transcript* t, const uint64_t s[4]) {
+} catch (...) { return DEHALO_ERR_OOM; }
+extern "C" int dehalo_transcript_common_scalar(dehalo_transcript* t, const uint64_t s[4]) try {
     if (!t || !s) return DEHALO_ERR_INVALID;
     Fe v;
     memcpy(v.v, s, 32);
     t->common_scalar(v);
     return 0;
-}
-extern "C" int dehalo_transcript_write_scalar(dehalo_transcript* t, const uint64_t s[4]) {
+} catch (...) { return DEHALO_ERR_OOM; }
+extern "C" int dehalo_transcript_write_scalar(dehalo_transcript* t, const uint64_t s[4]) try {
     if (!t || !s) return DEHALO_ERR_INVALID;
     Fe v;
     memcpy(v.v, s, 32);
     t->write_scalar(v);
     return 0;
-}
-extern "C" int dehalo_transcript_write_point(dehalo_transcript* t, const uint64_t xy[8]) {
+} catch (...) { return DEHALO_ERR_OOM; }
+extern "C" int dehalo_transcript_write_point(dehalo_transcript* t, const uint64_t xy[8]) try {
     if (!t || !xy) return DEHALO_ERR_INVALID;
     return t->write_point(xy) ? 0 : DEHALO_ERR_INVALID;
-}
-extern "C" int dehalo_transcript_squeeze_challenge(dehalo_transcript* t, uint64_t out[4]) {
+} catch (...) { return DEHALO_ERR_OOM; }
+extern "C" int dehalo_transcript_squeeze_challenge(dehalo_transcript* t, uint64_t out[4]) try {
     if (!t || !out) return DEHALO_ERR_INVALID;
     const Fe c = t->squeeze();
     memcpy(out, c.v, 32);
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 extern "C" size_t dehalo_transcript_len(const dehalo_transcript* t) { return t ? t->proof.size() : 0; }
-extern "C" int dehalo_transcript_finalize(const dehalo_transcript* t, uint8_t* out, size_t cap) {
+extern "C" int dehalo_transcript_finalize(const dehalo_transcript* t, uint8_t* out, size_t cap) try {
     if (!t || (!out && !t->proof.empty())) return DEHALO_ERR_INVALID;
     if (cap < t->proof.size()) return DEHALO_ERR_INVALID;
     if (!t->proof.empty()) memcpy(out, t->proof.data(), t->proof.size());
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 extern "C" void dehalo_transcript_release(dehalo_transcript* t) { delete t; }
 
-extern "C" int dehalo_field_info(int field, uint64_t out[24]) {
+extern "C" int dehalo_field_info(int field, uint64_t out[24]) try {
     const HostField* f = host_field(field);
     if (!f || !out) return DEHALO_ERR_INVALID;
     memcpy(out, f->p, 32);
@@ -273,16 +274,16 @@ extern "C" int dehalo_field_info(int field, uint64_t out[24]) {
     memcpy(out + 16, f->delta.v, 32);
     memcpy(out + 20, f->gen.v, 32);
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_rng_scalars(dehalo_rng* rng, int field, uint64_t skip, uint64_t* out, size_t count) {
+extern "C" int dehalo_rng_scalars(dehalo_rng* rng, int field, uint64_t skip, uint64_t* out, size_t count) try {
     const HostField* f = host_field(field);
     if (!f || (!out && count)) return DEHALO_ERR_INVALID;
     HostRng r;
     TRY(r.init(rng, f));
     r.skip(skip);
     return r.scalars(out, count);
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 // ================================================================================================ keys
 struct dehalo_pk {
@@ -403,7 +404,7 @@ int omega_powers(dehalo_ctx* ctx, const HostDomain& d, fe* col) {
 }   // namespace
 
 extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const dehalo_constraint_system* csd, const uint64_t* fixed, const uint64_t* mapping,
-                             const uint8_t* const* selectors, uint32_t num_selectors, uint32_t flags, dehalo_pk** out) {
+                             const uint8_t* const* selectors, uint32_t num_selectors, uint32_t flags, dehalo_pk** out) try {
     if (!ctx || !params || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "keygen: null argument");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
@@ -482,18 +483,18 @@ extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const
     TRY(dehalo_ctx_synchronize(ctx));
     *out = pk.release();
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 extern "C" size_t dehalo_pk_size(const dehalo_pk* pk) { return pk ? pk->size() : 0; }
 extern "C" size_t dehalo_vk_size(const dehalo_pk* pk) { return pk ? pk->vk_size() : 0; }
-extern "C" int dehalo_vk_write(const dehalo_pk* pk, uint8_t* out, size_t cap) {
+extern "C" int dehalo_vk_write(const dehalo_pk* pk, uint8_t* out, size_t cap) try {
     if (!pk || !out) return DEHALO_ERR_INVALID;
     if (cap < pk->vk_size()) return dh_fail(pk->ctx, DEHALO_ERR_INVALID, "vk_write: buffer too small");
     pk->vk_write(out);
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_pk_write(dehalo_ctx* ctx, const dehalo_pk* pk, uint8_t* out, size_t cap) {
+extern "C" int dehalo_pk_write(dehalo_ctx* ctx, const dehalo_pk* pk, uint8_t* out, size_t cap) try {
     if (!pk || !out) return DEHALO_ERR_INVALID;
     if (!ctx) ctx = pk->ctx;
     if (cap < pk->size()) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_write: buffer too small");
@@ -529,9 +530,9 @@ extern "C" int dehalo_pk_write(dehalo_ctx* ctx, const dehalo_pk* pk, uint8_t* ou
     TRY(slice(pk->perm_polys, npc, n, false));
     TRY(slice(pk->perm_cosets, npc, m, true));
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_pk_read(dehalo_ctx* ctx, int curve, const dehalo_constraint_system* csd, const uint8_t* bytes, size_t len, uint32_t num_selectors, dehalo_pk** out) {
+extern "C" int dehalo_pk_read(dehalo_ctx* ctx, int curve, const dehalo_constraint_system* csd, const uint8_t* bytes, size_t len, uint32_t num_selectors, dehalo_pk** out) try {
     if (!ctx || !bytes || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: null argument");
     if (len < 8) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: unexpected end of input");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -584,19 +585,19 @@ extern "C" int dehalo_pk_read(dehalo_ctx* ctx, int curve, const dehalo_constrain
     TRY(dehalo_ctx_synchronize(ctx));
     *out = pk.release();
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_pk_set_transcript_repr(dehalo_pk* pk, const uint64_t repr[4]) {
+extern "C" int dehalo_pk_set_transcript_repr(dehalo_pk* pk, const uint64_t repr[4]) try {
     if (!pk || !repr) return DEHALO_ERR_INVALID;
     memcpy(pk->transcript_repr.v, repr, 32);
     return 0;
-}
-extern "C" int dehalo_pk_get_transcript_repr(const dehalo_pk* pk, uint64_t repr[4]) {
+} catch (...) { return DEHALO_ERR_OOM; }
+extern "C" int dehalo_pk_get_transcript_repr(const dehalo_pk* pk, uint64_t repr[4]) try {
     if (!pk || !repr) return DEHALO_ERR_INVALID;
     memcpy(repr, pk->transcript_repr.v, 32);
     return 0;
-}
-extern "C" int dehalo_pk_release(dehalo_ctx* ctx, dehalo_pk* pk) {
+} catch (...) { return DEHALO_ERR_OOM; }
+extern "C" int dehalo_pk_release(dehalo_ctx* ctx, dehalo_pk* pk) try {
     if (!pk) return 0;
     dehalo_ctx* c = ctx ? ctx : pk->ctx;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -604,7 +605,7 @@ extern "C" int dehalo_pk_release(dehalo_ctx* ctx, dehalo_pk* pk) {
     (void)hipStreamSynchronize(c->stream);
     delete pk;
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 // ================================================================================================ create_proof
 struct dehalo_prover {
@@ -1319,7 +1320,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     return 0;
 }
 
-extern "C" int dehalo_prover_create(dehalo_ctx* ctx, dehalo_ctx* side_ctx, const dehalo_params* params, const dehalo_pk* pk, dehalo_prover** out) {
+extern "C" int dehalo_prover_create(dehalo_ctx* ctx, dehalo_ctx* side_ctx, const dehalo_params* params, const dehalo_pk* pk, dehalo_prover** out) try {
     if (!ctx || !params || !pk || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "prover_create: null argument");
     if (params->k != pk->k || params->curve != pk->curve) return dh_fail(ctx, DEHALO_ERR_INVALID, "prover_create: params and proving key disagree on k / curve");
     if (side_ctx && (side_ctx == ctx || side_ctx->device != ctx->device)) return dh_fail(ctx, DEHALO_ERR_INVALID, "prover_create: the side context must be another context of the same device");
@@ -1329,19 +1330,19 @@ extern "C" int dehalo_prover_create(dehalo_ctx* ctx, dehalo_ctx* side_ctx, const
     TRY(p->init(ctx, side_ctx, params, pk));
     *out = p.release();
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_prover_release(dehalo_prover* p) {
+extern "C" int dehalo_prover_release(dehalo_prover* p) try {
     if (!p) return 0;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->side) (void)hipStreamSynchronize(p->side->stream);
     delete p;
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 extern "C" int dehalo_create_proof(dehalo_prover* p, const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns,
-                                   dehalo_rng* rng, dehalo_transcript* transcript, uint32_t flags) {
+                                   dehalo_rng* rng, dehalo_transcript* transcript, uint32_t flags) try {
     if (!p || !transcript) return DEHALO_ERR_INVALID;
     if (transcript->curve != p->pk->curve) return dh_fail(p->ctx, DEHALO_ERR_INVALID, "create_proof: the transcript's curve differs from the key's");
     std::lock_guard<std::mutex> lk(p->mu);
@@ -1351,15 +1352,15 @@ extern "C" int dehalo_create_proof(dehalo_prover* p, const uint64_t* advice, con
         if (p->side) (void)hipStreamSynchronize(p->side->stream);
     }
     return rc;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_prover_last_timings(const dehalo_prover* p, double out[8]) {
+extern "C" int dehalo_prover_last_timings(const dehalo_prover* p, double out[8]) try {
     if (!p || !out) return DEHALO_ERR_INVALID;
     memcpy(out, p->timings, sizeof p->timings);
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_pk_info(const dehalo_pk* pk, uint32_t out[8]) {
+extern "C" int dehalo_pk_info(const dehalo_pk* pk, uint32_t out[8]) try {
     if (!pk || !out) return DEHALO_ERR_INVALID;
     const HostCS& cs = pk->cs;
     const uint32_t L = (uint32_t)cs.lookups.size(), S = cs.num_sets();
@@ -1377,10 +1378,10 @@ extern "C" int dehalo_pk_info(const dehalo_pk* pk, uint32_t out[8]) {
     std::sort(rs.begin(), rs.end());
     out[7] = (uint32_t)(std::unique(rs.begin(), rs.end()) - rs.begin());
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }
 
 extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, const uint64_t* const* advice, uint32_t count, dehalo_rng* rngs, uint32_t flags,
-                                    uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens) {
+                                    uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens) try {
     if (!provers || !num_provers || (count && (!advice || !proofs_out || !proof_lens))) return DEHALO_ERR_INVALID;
     for (uint32_t i = 0; i < num_provers; i++)
         if (!provers[i]) return DEHALO_ERR_INVALID;
@@ -1406,4 +1407,4 @@ extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_
     for (int rc : rcs)
         if (rc) return rc;
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }

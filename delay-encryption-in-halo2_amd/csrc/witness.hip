@@ -652,7 +652,7 @@ Fe fe_from(const uint64_t* p) {
 }   // namespace
 
 extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advice, uint64_t* fixed, uint64_t* mapping, uint8_t* const* selectors,
-                                 dehalo_synthesis_info* info) {
+                                 dehalo_synthesis_info* info) try {
     if (!in || (!advice && !fixed && !mapping && !info)) return DEHALO_ERR_INVALID;
     const HostField* f = host_field(DEHALO_FIELD_BN254_FR);
     const bool keygen_outputs = fixed || mapping || selectors;
@@ -766,4 +766,4 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         }
     }
     return 0;
-}
+} catch (...) { return DEHALO_ERR_OOM; }

@@ -69,6 +69,11 @@ const char* dehalo_last_error(const dehalo_ctx* ctx);
  * the fewest that leave a lane at most this many points; 0 selects the older rule, whole rounds of "msm_acc_waves" in [1, 4]
  * waves per SIMD (below 4 the kernel leaves wave slots and registers free for the latency-bound kernels of other contexts). */
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
+/* Environment variables read by the library (measurement and tuning only; results never depend on them):
+ *   DEHALO_MSM_ACC_POINTS   default of "msm_acc_points" at context creation
+ *   DEHALO_WINDOW_BITS      Pippenger window of tables registered with window_bits = 0 (4 .. 16)
+ *   DEHALO_MSM_ACC_LDS      bytes of (unused) dynamic LDS per block of the bucket accumulation: caps its resident blocks per CU
+ *   DEHALO_PROVER_TRACE     dehalo_create_proof writes the host's timeline inside the phases to stderr                                        */
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
  * kernels by enqueueing it on the same stream. */
 void* dehalo_ctx_stream(dehalo_ctx* ctx);
