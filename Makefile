@@ -25,6 +25,10 @@ oracle:
 host_example: $(LIB) $(PKG)/host/halo2_backend.hpp $(PKG)/host/example.cpp
 	g++ -std=c++17 -O1 -Wall -o $(PKG)/host/example $(PKG)/host/example.cpp -L$(PKG) -ldehalo -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
+# the host-only code (witness generation, field arithmetic, Blake2b, random scalars) under AddressSanitizer + UndefinedBehaviorSanitizer (g++, no device needed)
+host_sanitize: tests/native_host/host_sanitize.cpp $(CSRC)/witness.hip $(HDRS)
+	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -x c++ -o tests/native_host/host_sanitize tests/native_host/host_sanitize.cpp -x c++ $(CSRC)/witness.hip
+
 clean:
 	rm -rf $(LIB) $(OBJDIR) $(PKG)/host/example; $(MAKE) -C oracle clean
-.PHONY: all oracle clean host_example
+.PHONY: all oracle clean host_example host_sanitize

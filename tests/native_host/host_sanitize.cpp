@@ -1,0 +1,66 @@
+// host_sanitize.cpp -- the HOST-only parts of the library (witness generation: big-integer division, the layouter, Grain / Poseidon; field arithmetic;
+// Blake2b; ChaCha20 / PCG64) built with AddressSanitizer + UndefinedBehaviorSanitizer by g++ and exercised on the reference's circuit sizes.  GPU
+// sanitizers are not available on the pool; this covers the code that needs no device.  Prints a digest of everything it computed: the test compares it
+// with the digest of the regular build's dehalo_synthesize output.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/dehalo.h"
+#include "../../delay-encryption-in-halo2_amd/csrc/blake2b.hpp"
+#include "../../delay-encryption-in-halo2_amd/csrc/hostrng.hpp"
+
+int main(int argc, char** argv) {
+    const uint32_t k = argc > 1 ? (uint32_t)atoi(argv[1]) : 15;
+    const uint32_t exp_bits = argc > 2 ? (uint32_t)atoi(argv[2]) : 3;
+    std::vector<uint64_t> n(32), x(32);
+    uint64_t s = 0x9E3779B97F4A7C15ULL;
+    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (auto& v : n) v = next();
+    for (auto& v : x) v = next();
+    n[31] |= 1ULL << 63; n[0] |= 1; x[31] >>= 8;
+    const uint64_t message[8] = {11, 0, 0, 0, 22, 0, 0, 0};
+    dehalo_circuit_inputs in{};
+    in.circuit = DEHALO_CIRCUIT_DELAY_ENC; in.k = k; in.bits_len = 2048; in.exp_bits = exp_bits; in.n = n.data(); in.x = x.data();
+    in.e = (1ULL << (exp_bits - 1)) | 1; in.message = message; in.message_len = 2;
+    const size_t rows = (size_t)1 << k;
+    std::vector<uint64_t> advice(5 * rows * 4), fixed(15 * rows * 4), mapping(6 * rows);
+    std::vector<uint8_t> s0(rows), s1(rows);
+    uint8_t* sels[2] = {s0.data(), s1.data()};
+    dehalo_synthesis_info info{};
+    int rc = dehalo_synthesize(&in, advice.data(), fixed.data(), mapping.data(), sels, &info);
+    if (rc != 0) { printf("synthesize failed: %d\n", rc); return 1; }
+    Blake2b h;
+    h.init(32, "host-sanitize-ru");      // (16-byte personalisation)
+    h.update(advice.data(), advice.size() * 8);
+    h.update(fixed.data(), fixed.size() * 8);
+    h.update(mapping.data(), mapping.size() * 8);
+    h.update(s0.data(), rows); h.update(s1.data(), rows);
+    // the too-small circuit and bad arguments are refused, not overrun
+    in.k = 10;
+    if (dehalo_synthesize(&in, advice.data(), nullptr, nullptr, nullptr, nullptr) == 0) { printf("k = 10 accepted\n"); return 1; }
+    in.k = k; in.exp_bits = 65;
+    if (dehalo_synthesize(&in, advice.data(), nullptr, nullptr, nullptr, nullptr) == 0) { printf("exp_bits = 65 accepted\n"); return 1; }
+    // random scalars: OS entropy below p, PCG64 with a seek
+    const HostField* f = host_field(0);
+    HostRng r;
+    if (r.init(nullptr, f) != 0) return 1;
+    std::vector<uint64_t> sc(4 * 1000);
+    if (r.scalars(sc.data(), 1000) != 0) return 1;
+    for (int i = 0; i < 1000; i++) if (HostField::geq(sc.data() + 4 * i, f->p)) { printf("scalar >= p\n"); return 1; }
+    dehalo_rng pr{};
+    pr.kind = DEHALO_RNG_PCG64; pr.pcg_state[0] = 123; pr.pcg_inc[0] = 457;
+    if (r.init(&pr, f) != 0) return 1;
+    HostRng fk = r.fork(5000, 1);
+    r.skip(5000);
+    uint64_t a4[4], b4[4];
+    r.scalars(a4, 1); fk.scalars(b4, 1);
+    if (memcmp(a4, b4, 32)) { printf("fork != skip\n"); return 1; }
+    h.update(a4, 32);
+    uint8_t d[32];
+    h.digest(d);
+    for (int i = 0; i < 32; i++) printf("%02x", d[i]);
+    printf(" rows %llu\n", (unsigned long long)info.total_rows);
+    return 0;
+}

@@ -321,3 +321,41 @@ def test_native_synthesize_is_fast_at_the_north_star_size(pkg):
     assert nat["rsa_result"] == pow(x, e, n_big) and 100000 < nat["rows"] < 131000
     print("native synthesize, k = 17, 15-bit exponent: %.1f ms for %d rows" % (1e3 * best, nat["rows"]))
     assert best < 0.5
+
+
+def test_host_code_under_address_and_ub_sanitizers(pkg):
+    """The library's host-only code -- dehalo_synthesize (big-integer division, layouter, Grain / Poseidon), hostfield, Blake2b, the random-scalar
+    sources -- rebuilt by g++ with -fsanitize=address,undefined (GPU sanitizers are not available on the pool) and run on a k = 15 delay_enc circuit:
+    no report, and the digest of everything it computed equals the digest of the regular build's output for the same inputs."""
+    import ctypes as C
+    import hashlib
+    import subprocess
+    from conftest import ROOT
+    from dehalo2_amd import native
+    from dehalo2_amd._lib import CRng, load_library
+
+    out = subprocess.run(["make", "-C", ROOT, "host_sanitize"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    run = subprocess.run([os.path.join(ROOT, "tests", "native_host", "host_sanitize"), "15", "3"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stdout + run.stderr
+    digest, _, rows = run.stdout.split()
+    # the same inputs through the regular library
+    s, M = 0x9E3779B97F4A7C15, (1 << 64) - 1
+    def nxt():
+        nonlocal s
+        s ^= (s << 13) & M; s ^= s >> 7; s ^= (s << 17) & M
+        return s
+    nl = [nxt() for _ in range(32)]
+    xl = [nxt() for _ in range(32)]
+    nl[31] |= 1 << 63; nl[0] |= 1; xl[31] >>= 8
+    n_big, x_big = sum(v << (64 * i) for i, v in enumerate(nl)), sum(v << (64 * i) for i, v in enumerate(xl))
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 15, n_big=n_big, e=(1 << 2) | 1, x=x_big, exp_bits=3, message=[11, 22], keygen=True)
+    assert nat["rows"] == int(rows) and nat["rsa_result"] == pow(x_big, 5, n_big)
+    r = CRng()
+    r.kind, r.pcg_state[0], r.pcg_inc[0] = 1, 123, 457
+    a4 = np.zeros(4, dtype=np.uint64)
+    assert load_library().dehalo_rng_scalars(C.byref(r), 0, 5000, a4.ctypes.data, 1) == 0
+    h = hashlib.blake2b(digest_size=32, person=b"host-sanitize-ru")
+    for part in (nat["advice"], nat["fixed"], nat["mapping"], nat["selectors"][0].astype(np.uint8), nat["selectors"][1].astype(np.uint8), a4):
+        h.update(np.ascontiguousarray(part).tobytes())
+    assert h.hexdigest() == digest
