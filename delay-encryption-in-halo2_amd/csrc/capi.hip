@@ -470,6 +470,11 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value) {
         ctx->msm_acc_waves = value;
         return 0;
     }
+    if (!strcmp(key, "ntt_full_table_log")) {
+        if (value < 0 || value > 30) return dh_fail(ctx, DEHALO_ERR_INVALID, "ntt_full_table_log must be in [0, 30]");
+        ctx->ntt_full_table_log = value;
+        return 0;
+    }
     return dh_fail(ctx, DEHALO_ERR_INVALID, std::string("unknown tuning key: ") + key);
 }
 

@@ -22,6 +22,7 @@ struct TwiddleEntry {
     uint32_t log_n;
     int form;  // 0: standard Montgomery (R = 2^256)
     uint64_t omega[4];
+    uint64_t len;   // powers held: N (full table) or N / 2
     fe* tw;
 };
 
@@ -47,6 +48,9 @@ struct dehalo_ctx {
                              // on three quarters of the wave slots -- k = 17 proof 12.6 -> 12.05 ms); 0: rounds of msm_acc_waves waves per SIMD
     int msm_acc_waves = 3;   // sizes the accumulation's points per lane (dehalo_ctx_set_tuning): 3 -> 43 points per lane at 2^20 x 16, ~1.5
                              // rounds of the 4 waves per SIMD that are resident; measured best (one round of 86 points at 3 resident waves: 1.30 ms)
+    int ntt_full_table_log = 0;    // transforms up to this size keep all N twiddles (32 B x N; one load per inter-pass twiddle), larger ones N / 2 and a
+                                   // negation.  Measured equal at 23 x 2^19 with warm clocks (1.19 ms either way: the negation hides behind the load), so
+                                   // the default keeps the smaller table
     bool timing = false;
     std::vector<TimedRegion> regions;
     double timing_ms[DEHALO_K_COUNT] = {};

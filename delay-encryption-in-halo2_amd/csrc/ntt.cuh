@@ -41,12 +41,14 @@
 struct NttPassParams {
     const fe* src;
     fe* dst;
-    const fe* tw;        // omega^j * 2^261 (canonical, packed), j < N/2
+    const fe* tw;        // omega^j * 2^261 (canonical, packed), j < N (tw_full) or j < N/2
     u32 log_n;           // N
     u32 log_m;           // sub-problem size at this pass
     u32 r;               // log2 of this pass's radix
     u32 log_c;           // log2 of columns per tile
     u32 is_final;
+    u32 skip2;           // first pass of a transform whose input is zero beyond N / 4: the first two stages are copies (see the load)
+    u32 tw_full;         // the table holds all N powers (log_n <= ntt_full_table_log): the inter-pass twiddle is one load, no negation
     u32 r1;              // log2 of the first pass's radix (final pass store)
     u32 nrev;            // number of middle digits to reverse in the final pass
     u32 rev_r[NTT_MAX_PASSES];  // their log2 radices, most significant first
@@ -62,9 +64,10 @@ struct NttPassParams {
 
 FP_DEV u32 bitrev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// omega^e for e < N from the half table (omega^(N/2) = -1)
+// omega^e for e < N: straight from a full table, or from the half table (omega^(N/2) = -1)
 template <class F>
-FP_DEV fe tw_lookup(const fe* tw, u64 e, u32 log_n) {
+FP_DEV fe tw_lookup(const fe* tw, u64 e, u32 log_n, bool full) {
+    if (full) return f_load(&tw[e]);
     u64 half = 1ull << (log_n - 1);
     bool neg = e >= half;
     fe w = f_load(&tw[neg ? e - half : e]);
@@ -155,6 +158,27 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     }
 
     // ---- load: global (standard form, canonical) -> limbs, into row bitrev(j) (DIT input order) ----
+    if (P.skip2) {
+        // zero-padded input, at most N / 4 coefficients (coeff_to_extended): only rows j < R / 4 hold anything, they land on rows
+        // 4 i of the bit-reversed order, and the first two stages -- (x, 0) -> (x, x), then (x, 0), (x, 0) -> (x, x), (x, x) -- only
+        // copy: row 4 i is written to rows 4 i .. 4 i + 3 and the stages start at s = 2 (no loads of zero rows, one LDS round trip,
+        // one barrier and a quarter multiplication per element less)
+        for (u32 idx = tid; idx < (tile >> 2); idx += NTT_THREADS) {
+            const u32 j = idx >> log_c, c = idx & (Cc - 1);
+            const u64 g = (q << P.log_m) + ((u64)j << log_cols) + np0 + c;
+            f29 v = f29_zero();
+            if (g < P.src_len) {
+                v = f29_unpack(f_load(&src[g]));
+                if (P.pre_mode) {
+                    u32 m3 = (u32)(g % 3);
+                    if (m3 == 1) v = f29_mul<F9>(v, pre1);
+                    else if (m3 == 2) v = f29_mul<F9>(v, pre2);
+                }
+            }
+            const u32 a0 = (bitrev32(j, r) << log_c) + c;
+            lds29_store(L, a0, v); lds29_store(L, a0 + Cc, v); lds29_store(L, a0 + 2 * Cc, v); lds29_store(L, a0 + 3 * Cc, v);
+        }
+    } else
     for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
         u32 j, c;
         u64 g;
@@ -181,7 +205,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     __syncthreads();
 
     // ---- DIT stages, two per round ----
-    u32 s = 0;
+    u32 s = P.skip2 ? 2 : 0;
     for (; s + 1 < r; s += 2) {
         const u32 h = 1u << s;
         const u32 ngroups = tile >> 2;   // radix-4 groups in the tile
@@ -256,7 +280,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         if (!P.is_final) {
             u64 np = np0 + c;
             u64 e = (np * k) << (P.log_n - P.log_m);
-            w = f29_unpack(tw_lookup<F>(P.tw, e, P.log_n));
+            w = f29_unpack(tw_lookup<F>(P.tw, e, P.log_n, P.tw_full != 0));
             o = (q << P.log_m) + ((u64)k << log_cols) + np;
         } else {
             o = (((u64)k1blk << log_c) + c) + (revrest << P.r1) + ((u64)k << (P.log_n - r));
@@ -271,7 +295,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     }
 }
 
-// tw[j] = omega^j * 2^261 mod p (canonical, packed), j < half.  Thread t fills a run of 64
+// tw[j] = omega^j * 2^261 mod p (canonical, packed), j < half (`half` = the table's length: N for a full table).  Thread t fills a run of 64
 // starting from omega^(64 t); the running power is kept in standard form.
 template <class F>
 __global__ void k_twiddle_gen(fe* tw, fe omega, u64 half) {
@@ -320,14 +344,18 @@ __global__ void k_field_op(int op, const fe* a, const fe* b, fe* out, u64 n) {
 // ==========================================================================================
 // host driver (instantiated once per field in ntt_<field>.hip)
 // ==========================================================================================
+// `full` (optional out): whether the table returned holds all N powers.  A caller that only reads j < N / 2 (evalh.cuh) takes either.
 template <class F>
-int get_twiddles(dehalo_ctx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t s, const fe** out) {
+int get_twiddles(dehalo_ctx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t s, const fe** out, bool* full = nullptr) {
+    // up to 2^ntt_full_table_log the table holds all N powers (32 B x N: 16 MiB at 2^19), beyond that the first half
+    const bool want_full = log_n >= 1 && log_n <= (uint32_t)ctx->ntt_full_table_log;
+    uint64_t half = log_n == 0 ? 1 : want_full ? (1ull << log_n) : (1ull << (log_n - 1));
+    if (full) *full = want_full;
     for (auto& t : ctx->twiddles)
-        if (t.field == F::ID && t.log_n == log_n && t.form == 0 && !memcmp(t.omega, omega, 32)) {
+        if (t.field == F::ID && t.log_n == log_n && t.form == 0 && t.len == half && !memcmp(t.omega, omega, 32)) {
             *out = t.tw;
             return 0;
         }
-    uint64_t half = log_n ? (1ull << (log_n - 1)) : 1;
     fe* tw = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&tw, half * sizeof(fe)));
     uint64_t threads = (half + 63) / 64;
@@ -340,7 +368,7 @@ int get_twiddles(dehalo_ctx* ctx, uint32_t log_n, const uint64_t omega[4], hipSt
         ctx->twiddles.erase(ctx->twiddles.begin());
     }
     TwiddleEntry e;
-    e.field = F::ID; e.log_n = log_n; e.form = 0; memcpy(e.omega, omega, 32); e.tw = tw;
+    e.field = F::ID; e.log_n = log_n; e.form = 0; memcpy(e.omega, omega, 32); e.len = half; e.tw = tw;
     ctx->twiddles.push_back(e);
     *out = tw;
     return 0;
@@ -356,7 +384,8 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
     if (batch > 65535) return dh_fail(ctx, DEHALO_ERR_INVALID, "ntt: batch > 65535 (grid.y)");
     if (batch == 0) return 0;
     const fe* tw = nullptr;
-    TRY(get_twiddles<F>(ctx, log_n, omega, s, &tw));
+    bool tw_full = false;
+    TRY(get_twiddles<F>(ctx, log_n, omega, s, &tw, &tw_full));
     ScopedTimer timer(ctx, s, DEHALO_K_NTT_PASS);
 
     // plan: radices
@@ -385,6 +414,10 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         P.tw = tw;
         P.log_n = log_n; P.log_m = log_m; P.r = rad[p];
         P.is_final = last ? 1 : 0;
+        P.tw_full = tw_full ? 1 : 0;
+        // (DEHALO_NTT_SKIP=0: the general first pass, for A/B measurements)
+        static const bool skip_ok = [] { const char* e = getenv("DEHALO_NTT_SKIP"); return !(e && e[0] == '0'); }();
+        P.skip2 = skip_ok && first && !last && rad[p] >= 2 && src_len * 4 <= N ? 1 : 0;
         P.r1 = L > 1 ? rad[0] : 0;
         if (first) { P.src = src; P.src_len = src_len; P.src_stride = src_stride; }
         else { P.src = scratch; P.src_len = N; P.src_stride = N; }

@@ -67,12 +67,15 @@ const char* dehalo_last_error(const dehalo_ctx* ctx);
 /* Launch-geometry knobs (results never depend on them).  "msm_acc_points" (default 48; also the environment variable
  * DEHALO_MSM_ACC_POINTS at context creation): the bucket-accumulation grid of an MSM is 4, 6, 8, ... layers of one wave per SIMD,
  * the fewest that leave a lane at most this many points; 0 selects the older rule, whole rounds of "msm_acc_waves" in [1, 4]
- * waves per SIMD (below 4 the kernel leaves wave slots and registers free for the latency-bound kernels of other contexts). */
+ * waves per SIMD (below 4 the kernel leaves wave slots and registers free for the latency-bound kernels of other contexts).
+ * "ntt_full_table_log" (default 0, in [0, 30]): transforms of up to 2^value points keep all N powers of omega on the device
+ * (32 B x N) so that an inter-pass twiddle is one load; larger ones keep N / 2 and negate (measured equal on MI355X). */
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
 /* Environment variables read by the library (measurement and tuning only; results never depend on them):
  *   DEHALO_MSM_ACC_POINTS   default of "msm_acc_points" at context creation
  *   DEHALO_WINDOW_BITS      Pippenger window of tables registered with window_bits = 0 (4 .. 16)
  *   DEHALO_MSM_ACC_LDS      bytes of (unused) dynamic LDS per block of the bucket accumulation: caps its resident blocks per CU
+ *   DEHALO_NTT_SKIP         0: the first pass of a zero-padded transform (input <= N / 4) runs its two copy stages like any other
  *   DEHALO_PROVER_TRACE     dehalo_create_proof writes the host's timeline inside the phases to stderr                                        */
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
  * kernels by enqueueing it on the same stream. */

@@ -105,6 +105,26 @@ def test_ntt_vs_c_oracle(pkg, po, co, ctx, fname, log_n):
         assert np.array_equal(got, want)
 
 
+def test_ntt_full_twiddle_table(pkg, po, co, fname="bn254_fr"):
+    """Transforms up to the context's "ntt_full_table_log" keep all N powers of omega (no negation of the upper half): switched on here
+    at sizes the C restatement checks, forward and inverse roots, plus a padded coeff_to_extended."""
+    spec = pkg.fields.FIELDS[fname]
+    f = po.FIELDS[fname]
+    ctx = pkg.Context(0)
+    ctx.set_tuning("ntt_full_table_log", 24)
+    for log_n in (12, 17):
+        a = co.fill_scalars(spec.id, "uniform", 1 << log_n, 900 + log_n)
+        for w in (f.omega(log_n), f.inv(f.omega(log_n))):
+            omega = spec.encode(w)
+            assert np.array_equal(pkg.best_fft(ctx, spec, a, omega, log_n), co.best_fft(spec.id, a, omega, log_n, 8))
+    d = pkg.EvaluationDomain(ctx, spec, 5, 12)
+    coeffs = co.fill_scalars(spec.id, "uniform", d.n, 77)
+    e = spec.encode
+    assert np.array_equal(d.coeff_to_extended(coeffs), co.coeff_to_extended(spec.id, coeffs, 12, d.extended_k, e(d.extended_omega), e(d.g_coset), 8))
+    with pytest.raises(pkg.DehaloError):
+        ctx.set_tuning("ntt_full_table_log", 31)
+
+
 @pytest.mark.parametrize("fname,log_n", [("pasta_fp", 20), ("bn254_fr", 20), ("pasta_fq", 19), ("pasta_fp", 22), ("bn254_fr", 24)])
 def test_ntt_full_size(pkg, po, co, ctx, fname, log_n):
     """BASELINE sizes: direct comparison with the C restatement (2^20 takes it ~1 s) and
