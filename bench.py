@@ -59,8 +59,30 @@ def parse():
     ap.add_argument("--proofs-inflight", type=int, default=4, help="batch mode: proofs in flight per GPU (one context + host thread each)")
     ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
     ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves with the whole-rounds rule (0 = library default: msm_acc_points)")
+    ap.add_argument("--preheat-s", type=float, default=1.0, help="untimed device work of the measured kind right before every warm-up + timed region (steps one at a time / "
+                    "proofs), so that the region runs at the clocks of a busy prover instead of ramping up from idle after the host-side setup (0 = off)")
     ap.add_argument("--inflight", type=int, default=4, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
+
+
+PREHEAT_S = 1.0     # --preheat-s
+
+
+def preheat(fn, sync=None):
+    """Calls fn until PREHEAT_S seconds have passed (at least once).  The device clocks ramp up over ~0.2 s of load: 20 timed steps after
+    5 / 60 / 200 warm-up steps measured 737-743 / 758 / 777 Mpoints/s on one box (gpurun_out/warmup_sweep.txt -> DESIGN.md 6)."""
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn()
+        n += 1
+        if sync is not None and n % 8 == 0:
+            sync()
+        if time.perf_counter() - t0 >= PREHEAT_S:
+            break
+    if sync is not None:
+        sync()
+    return n
 
 
 def host_cores():
@@ -271,8 +293,8 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
     from dehalo2_amd import prover
     threads = min(host_cores(), 256)
     st = ProofSetup(pkg, ctx, k, circuit, threads)
-    for _ in range(2):
-        proof = st.prove(7)
+    proof = st.prove(7)
+    preheat(lambda: st.prove(7))
     ts = []
     for _ in range(reps):
         t = time.perf_counter()
@@ -337,7 +359,7 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     prios = (1, 0, -1) if os.environ.get("DEHALO_BENCH_FLAT_PRIORITIES") is None else (0,)      # (see main(): hardware queues are pooled per priority)
     ctxs = [pkg.Context(device, priority=prios[i % len(prios)]) for i in range(max(1, inflight))]
     provers = [native.Prover(st.params, st.pk, c) for c in ctxs]
-    native.create_proofs(provers, st.advice, [prover.SeededRng(999 - i) for i in range(2 * len(provers))])      # warm-up of every prover's buffers
+    preheat(lambda: native.create_proofs(provers, st.advice, [prover.SeededRng(999 - i) for i in range(2 * len(provers))]))      # warm-up of every prover's buffers, clocks up
     fence_all(world)
     t0 = time.perf_counter()
     full = native.create_proofs(provers, st.advice, [prover.SeededRng(1000 + unit) for unit in mine])          # every proof its own blinding
@@ -411,6 +433,8 @@ def fence_all(world):
 
 def main():
     args = parse()
+    global PREHEAT_S
+    PREHEAT_S = max(0.0, args.preheat_s)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -493,6 +517,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def step_alone():
+        ctx.msm_device(bases, d_scalars.data_ptr(), n, 1, d_out_all[0].data_ptr(), 0)
+        ctx.ntt_device(field.id, d_polys[0].data_ptr(), log_n, omega, 1, 0)
+    preheat_steps = preheat(step_alone, ctx.synchronize) if PREHEAT_S > 0 else 0
     for _ in range(args.warmup):
         step()
     gather_commitments(0, max(args.warmup, 1))
@@ -572,6 +600,10 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preheat": {"seconds": PREHEAT_S, "steps_one_at_a_time": preheat_steps,
+                        "what": "untimed, before the W warm-up steps: the same step one at a time for --preheat-s seconds, so that the timed region runs at a busy "
+                                "prover's clocks rather than ramping up from idle after the host-side setup (the proofs' and batch mode's regions are preceded "
+                                "by the same amount of untimed proofs); --preheat-s 0 switches it off"},
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
             "scaling": "weak",

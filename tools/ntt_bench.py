@@ -7,9 +7,8 @@ import numpy as np, torch
 import __graft_entry__ as entry
 pkg = entry.load_package(); po, co = entry.load_oracle()
 ctx = pkg.Context(0)
-half = ctx
-ctx = pkg.Context(0)
-ctx.set_tuning("ntt_full_table_log", 24)
+full = pkg.Context(0)
+full.set_tuning("ntt_full_table_log", 24)
 
 def best(fn, c, reps=30):
     for _ in range(10): fn()
@@ -33,7 +32,7 @@ for fname, log_n, batch in (("pasta_fp", 20, 1), ("bn254_fr", 19, 23), ("bn254_f
     om = f.encode(po.FIELDS[fname].omega(log_n))
     torch.cuda.synchronize()
     row = []
-    for name, c in (("full table", ctx), ("half table", half), ("full again", ctx), ("half again", half)):
+    for name, c in (("half table", ctx), ("full table", full), ("half again", ctx), ("full again", full)):
         row.append("%s %.4f ms" % (name, best(lambda: c.ntt_device(f.id, d.data_ptr(), log_n, om, batch, 0), c)))
     print("%s 2^%d x %d: %s" % (fname, log_n, batch, " | ".join(row)))
 
