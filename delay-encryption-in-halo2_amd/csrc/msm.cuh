@@ -737,26 +737,27 @@ FP_DEV void merge_heavy_section(u32 blk, u32 nblk, const u32* rbeg, const u32* r
 // shorter than its position leaves at once, so the sections run side by side on short lists
 template <class CV>
 __global__ __launch_bounds__(MSM_MERGE_THREADS) void k_msm_merge_all(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters,
-                                                                    const u32* lists, u32 cap) {
+                                                                    const u32* lists, u32 cap, int only) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     __shared__ xyzz29_rec sh[MSM_MERGE_THREADS / 64];
     u32 blk = blockIdx.x;
+    // `only` >= 0 (DEHALO_MSM_MERGE_SPLIT, measurements): this launch runs one section, the others leave at once
     if (blk < MSM_MERGE_BLOCKS_HEAVY) {
-        merge_heavy_section<F>(blk, MSM_MERGE_BLOCKS_HEAVY, rbeg, rend, partial, buckets, counters[3], lists + 3 * (size_t)cap, sh);
+        if (only < 0 || only == 3) merge_heavy_section<F>(blk, MSM_MERGE_BLOCKS_HEAVY, rbeg, rend, partial, buckets, counters[3], lists + 3 * (size_t)cap, sh);
         return;
     }
     blk -= MSM_MERGE_BLOCKS_HEAVY;
     if (blk < MSM_MERGE_BLOCKS_G64) {
-        merge_group_section<F, 64>(blk, MSM_MERGE_BLOCKS_G64, rbeg, rend, partial, buckets, counters[2], lists + 2 * (size_t)cap);
+        if (only < 0 || only == 2) merge_group_section<F, 64>(blk, MSM_MERGE_BLOCKS_G64, rbeg, rend, partial, buckets, counters[2], lists + 2 * (size_t)cap);
         return;
     }
     blk -= MSM_MERGE_BLOCKS_G64;
     if (blk < MSM_MERGE_BLOCKS_G32) {
-        merge_group_section<F, 32>(blk, MSM_MERGE_BLOCKS_G32, rbeg, rend, partial, buckets, counters[1], lists + 1 * (size_t)cap);
+        if (only < 0 || only == 1) merge_group_section<F, 32>(blk, MSM_MERGE_BLOCKS_G32, rbeg, rend, partial, buckets, counters[1], lists + 1 * (size_t)cap);
         return;
     }
     blk -= MSM_MERGE_BLOCKS_G32;
-    merge_light_section<F>(blk, MSM_MERGE_BLOCKS_LIGHT, rbeg, rend, partial, buckets, counters[0], lists);
+    if (only < 0 || only == 0) merge_light_section<F>(blk, MSM_MERGE_BLOCKS_LIGHT, rbeg, rend, partial, buckets, counters[0], lists);
 }
 
 // ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
@@ -1052,8 +1053,13 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // list runs one LANE per bucket and is kept to 11 full-width additions)
         const u32 c0max = tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
         k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
-        k_msm_merge_all<CV><<<MSM_MERGE_BLOCKS_HEAVY + MSM_MERGE_BLOCKS_G64 + MSM_MERGE_BLOCKS_G32 + MSM_MERGE_BLOCKS_LIGHT, MSM_MERGE_THREADS, 0, s>>>(
-            rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        // DEHALO_MSM_MERGE_SPLIT=1 (measurements, tools/merge_split.sh): one launch per class -- block, wave, 32 lanes, light -- so that a kernel trace shows each one's time
+        static const bool merge_split = [] { const char* e = getenv("DEHALO_MSM_MERGE_SPLIT"); return e && e[0] == '1'; }();
+        for (int only = merge_split ? 3 : -1; only >= -1; only--) {
+            k_msm_merge_all<CV><<<MSM_MERGE_BLOCKS_HEAVY + MSM_MERGE_BLOCKS_G64 + MSM_MERGE_BLOCKS_G32 + MSM_MERGE_BLOCKS_LIGHT, MSM_MERGE_THREADS, 0, s>>>(
+                rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, only);
+            if (only <= 0) break;
+        }
         // bucket reduction
         uint64_t nblocks4 = (uint64_t)per_group * total_groups;       // 4-bucket blocks
         if (nblocks4 * 4 <= 192 * 1024) {   // <= ~3 waves per SIMD at 4 lanes per block (two rounds of resident quads still beat one lane per block: 0.58 -> 0.28 ms for a batch of ten 2^17 MSMs)
