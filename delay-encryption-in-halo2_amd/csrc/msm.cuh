@@ -48,6 +48,9 @@
 #define MSM_HIST_ATTR
 #endif
 #define MSM_RED_M 4        // buckets per lane in the bucket reduction
+#ifndef MSM_RED_THREADS
+#define MSM_RED_THREADS 256   // one wave per SIMD per block: with 128-thread blocks the second block on a CU shared SIMDs with the first (3-4 columns at c = 15: 134 -> 86 us)
+#endif
 
 struct MsmGeom {
     u32 n;          // scalars per MSM
@@ -619,10 +622,14 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accu
 // commitments; one launch: the longest of the four).
 #define MSM_C1_MAX 128
 #define MSM_C2_MAX 512
-#define MSM_MERGE_THREADS 512    // 2 waves per SIMD: room for the ~170 VGPRs of a group addition (1024 threads would spill)
-#define MSM_MERGE_BLOCKS_LIGHT 512
-#define MSM_MERGE_BLOCKS_G32 512
-#define MSM_MERGE_BLOCKS_G64 512
+#ifndef MSM_MERGE_THREADS
+#define MSM_MERGE_THREADS 256    // one wave per SIMD per block.  A lone wave of group additions already fills its SIMD's issue slots (tools/ubench_chain.hip: 3.1 us per
+                                 // quad-cooperative addition at one wave per SIMD, 5.2-6.2 at two), and the two waves per SIMD of a 512-thread block cost 15-25 % of this
+                                 // kernel whenever its lists were short enough to leave other CUs idle (profiles/r03_tail_block_shapes.txt)
+#endif
+#define MSM_MERGE_BLOCKS_LIGHT (512 * 512 / MSM_MERGE_THREADS)
+#define MSM_MERGE_BLOCKS_G32 (512 * 512 / MSM_MERGE_THREADS)
+#define MSM_MERGE_BLOCKS_G64 (512 * 512 / MSM_MERGE_THREADS)
 #define MSM_MERGE_BLOCKS_HEAVY 256
 #ifndef MSM_LIGHT_QUAD_MAX
 #define MSM_LIGHT_QUAD_MAX 65536   // listed buckets up to which the light class runs one quad per bucket (2 waves per SIMD of quads)
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(MSM_MERGE_THREADS) void k_msm_merge_all(const u32* 
 // quad-cooperative (ec29.cuh).  With many groups (large batches) the lanes are better spent one
 // per block (QUAD = false): quads trade 1.6x the work for 2.4x less latency.
 template <class CV, bool QUAD>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
+__global__ __launch_bounds__(MSM_RED_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
     const u32 per_group = (nb + MSM_RED_M - 1) / MSM_RED_M;
     u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void k_msm_reduce_local(u32 nb, u3
     // k0 * run, MSB-first double-and-add (k0 < 2^15); nothing to weight when the block is empty.
     // acc is parked in LDS for the duration (LDS operations of one wave complete in order, so no
     // barrier is needed): three live points plus an addition's temporaries spill to scratch.
-    __shared__ xyzz29_rec park[MSM_ACC_THREADS];
+    __shared__ xyzz29_rec park[MSM_RED_THREADS];
     if (k0 && !f29_all_zero(run.zz)) {
         x29_store(&park[threadIdx.x], acc);
         int top = 31 - __clz(k0);
@@ -1063,9 +1070,9 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // bucket reduction
         uint64_t nblocks4 = (uint64_t)per_group * total_groups;       // 4-bucket blocks
         if (nblocks4 * 4 <= 192 * 1024) {   // <= ~3 waves per SIMD at 4 lanes per block (two rounds of resident quads still beat one lane per block: 0.58 -> 0.28 ms for a batch of ten 2^17 MSMs)
-            k_msm_reduce_local<CV, true><<<(u32)((nblocks4 * 4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+            k_msm_reduce_local<CV, true><<<(u32)((nblocks4 * 4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS), MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
         } else {
-            k_msm_reduce_local<CV, false><<<(u32)((nblocks4 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+            k_msm_reduce_local<CV, false><<<(u32)((nblocks4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS), MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
         }
         const xyzz29_rec* cur = contrib;
         u32 cnt = per_group;

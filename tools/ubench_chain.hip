@@ -55,6 +55,36 @@ static void run_walk(const char* name, int K, int blocks) {
     hipFree(in); hipFree(out);
 }
 
+// the same chain in blocks of T threads: where does the dispatcher put the waves of B blocks?
+template <class CV, class F, int T>
+__global__ __launch_bounds__(T) void k_shape(int K, xyzz29_rec* out) {
+    typedef typename f29_of<typename CV::Base>::type F0;
+    fe gx, gy;
+    for (int i = 0; i < 8; i++) { gx.v[i] = CV::GX_M[i]; gy.v[i] = CV::GY_M[i]; }
+    xyzz29 g; g.x = f29_from_std<F0>(gx); g.y = f29_from_std<F0>(gy); g.zz = f29_one<F0>(); g.zzz = f29_one<F0>();
+    xyzz29 a = x29_add<F0>(x29_double<F0>(g), g), b = x29_double<F0>(a);
+    for (int i = 0; i < K; i++) a = x29_add_quad<F>(a, b);
+    x29_store(&out[blockIdx.x * T + threadIdx.x], a);
+}
+template <class CV, class F, int T>
+static void run_shape(int blocks, int K) {
+    xyzz29_rec* out;
+    hipMalloc(&out, sizeof(xyzz29_rec) * (size_t)T * blocks);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k_shape<CV, F, T><<<blocks, T>>>(K, out);
+    hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; rep++) {
+        hipEventRecord(e0);
+        k_shape<CV, F, T><<<blocks, T>>>(K, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    printf("  %5d blocks x %3d threads = %5d waves: %8.3f us per quad-cooperative addition\n", blocks, T, blocks * T / 64, 1e3 * best / K);
+    hipFree(out);
+}
+
 template <class CV, class F, int OP>
 __global__ __launch_bounds__(64) void k_chain(int K, xyzz29_rec* out, unsigned long long* cyc) {
     typedef typename f29_of<typename CV::Base>::type F0;
@@ -122,5 +152,10 @@ int main() {
     run_walk<CurveBn254, FL, 0>("load, then add; 64 waves on the chip", 200, 64);
     run_walk<CurveBn254, FL, 1>("next record loaded before the addition; 64 waves", 200, 64);
     run_walk<CurveBn254, FL, 0>("load, then add; 2 waves per SIMD", 200, 2048);
+    printf("placement: the same chain of quad-cooperative additions (latency schedule) by block shape\n");
+    run_shape<CurveBn254, FL, 64>(256, 200); run_shape<CurveBn254, FL, 64>(512, 200); run_shape<CurveBn254, FL, 64>(1024, 200); run_shape<CurveBn254, FL, 64>(2048, 200);
+    run_shape<CurveBn254, FL, 128>(128, 200); run_shape<CurveBn254, FL, 128>(256, 200); run_shape<CurveBn254, FL, 128>(512, 200); run_shape<CurveBn254, FL, 128>(1024, 200);
+    run_shape<CurveBn254, FL, 256>(64, 200); run_shape<CurveBn254, FL, 256>(128, 200); run_shape<CurveBn254, FL, 256>(256, 200); run_shape<CurveBn254, FL, 256>(512, 200);
+    run_shape<CurveBn254, FL, 512>(64, 200); run_shape<CurveBn254, FL, 512>(128, 200); run_shape<CurveBn254, FL, 512>(256, 200);
     return 0;
 }
