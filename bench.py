@@ -517,10 +517,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step_alone():
-        ctx.msm_device(bases, d_scalars.data_ptr(), n, 1, d_out_all[0].data_ptr(), 0)
-        ctx.ntt_device(field.id, d_polys[0].data_ptr(), log_n, omega, 1, 0)
-    preheat_steps = preheat(step_alone, ctx.synchronize) if PREHEAT_S > 0 else 0
+    pre = [0]
+
+    def step_preheat():          # the timed region's own pattern (steps dealt round-robin to the contexts in flight), results to a spare row
+        c = ctxs[pre[0] % inflight]
+        c.msm_device(bases, d_scalars.data_ptr(), n, 1, d_out_all[args.warmup + args.steps].data_ptr(), 0)
+        c.ntt_device(field.id, d_polys[pre[0] % inflight].data_ptr(), log_n, omega, 1, 0)
+        pre[0] += 1
+    preheat_steps = preheat(step_preheat, lambda: [c.synchronize() for c in ctxs]) if PREHEAT_S > 0 else 0
     for _ in range(args.warmup):
         step()
     gather_commitments(0, max(args.warmup, 1))
@@ -600,8 +604,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "preheat": {"seconds": PREHEAT_S, "steps_one_at_a_time": preheat_steps,
-                        "what": "untimed, before the W warm-up steps: the same step one at a time for --preheat-s seconds, so that the timed region runs at a busy "
+            "preheat": {"seconds": PREHEAT_S, "steps": preheat_steps,
+                        "what": "untimed, before the W warm-up steps: the same steps, dealt to the same contexts, for --preheat-s seconds, so that the timed region runs at a busy "
                                 "prover's clocks rather than ramping up from idle after the host-side setup (the proofs' and batch mode's regions are preceded "
                                 "by the same amount of untimed proofs); --preheat-s 0 switches it off"},
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),

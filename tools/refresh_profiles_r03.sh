@@ -20,6 +20,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/bt -o bt 
 python3 tools/busy_fraction.py $out/bt/bt_kernel_trace.csv 32 > $out/batch_busy_fraction.txt
 echo "[5] python-driven vs native prover"; timeout -k 10 400 python tools/native_bench.py 17 delay_enc 32 > $out/native_vs_python_k17.txt 2>/dev/null
 echo "[6] microbenchmarks"; timeout -k 5 100 ./tools/stream_concurrency > $out/stream_concurrency.txt 2>&1; timeout -k 5 100 ./tools/ubench_mfma_price > $out/ubench_mfma_price.txt 2>&1; timeout -k 5 100 ./tools/pmc_calib > $out/pmc_calib.txt 2>&1
+timeout -k 5 100 ./tools/ubench_chain > $out/ubench_chain.txt 2>&1; timeout -k 10 200 python tools/ntt_bench.py > $out/ntt_bench.txt 2>/dev/null
+echo "[6b] clock ramp: the step bench by untimed work before the timed region"
+for p in 0 0.3 1.0 3.0; do timeout -k 10 200 python bench.py --no-cpu-baseline --proof-k 0 --proofs 0 --preheat-s $p 2>/dev/null | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('preheat %.1f s (%d steps): %.1f Mpoints/s, %.4f ms per step; k_msm_accum0 alone %.4f ms' % (d['preheat']['seconds'], d['preheat']['steps'], d['value'], d['ms_per_step'], d['roofline']['avg_kernel_ms']))
+"; done > $out/clock_ramp.txt
 echo "[7] two ranks on one GPU (gloo)"
 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --dist-backend gloo --force-device 0 --proofs 16 --no-cpu-baseline > $out/bench_2rank_one_gpu_gloo.log 2>&1 || echo "2-rank run failed"
 rm -f $out/kp/kp_kernel_trace.csv $out/kt/kt_kernel_trace.csv $out/k1/k1_kernel_trace.csv $out/bt/bt_kernel_trace.csv; rm -rf $out/*/*agent_info*
