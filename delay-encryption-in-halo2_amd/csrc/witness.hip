@@ -2,7 +2,7 @@
 // the fixed columns and the permutation) before create_proof commits them -- the part of the reference's timed call that precedes the
 // first commitment [src/lib.rs:164-318 DelayEncryptCircuit::synthesize; benches/mod_pow.rs:63-110 RSACircuit; src/encryption/chip.rs:
 // 114-204 PoseidonEncCircuit].  Restated from:
-//   big_pow_mod                                   src/big_integer/utils.rs:2-17
+//   big_pow_mod (its value: read off the pow_mod rows)   src/big_integer/utils.rs:2-17
 //   BigIntChip::{mul, mul_mod, pow_mod, is_equal_muled}   src/big_integer/chip.rs:389-422, 545-632, 667-699, 825-898
 //   Grain LFSR, Cauchy MDS, the permutation       src/poseidon/grain.rs:12-157, spec.rs:170-180, permutation.rs:60-80
 //   sponge (RATE 4) and cipher                    src/hash/chip.rs:63-85, src/encryption/poseidon_enc.rs:66-133, src/lib.rs:222-316
@@ -116,18 +116,6 @@ void big_divmod(const Big& u_in, const Big& v_in, Big& q, Big& r) {
     big_trim(q);
     big_trim(r);
 }
-Big big_mulmod(const Big& a, const Big& b, const Big& n) {
-    Big q, r;
-    big_divmod(big_mul(a, b), n, q, r);
-    return r;
-}
-// src/big_integer/utils.rs:2-17 (square-and-multiply; b = 0 -> 1): same value as the recursion there
-Big big_pow_mod(const Big& a, uint64_t e, const Big& n) {
-    if (e == 0) return Big{1};
-    Big x = big_pow_mod(a, (e - (e & 1)) / 2, n);
-    Big x2 = big_mulmod(x, x, n);
-    return (e & 1) ? big_mulmod(a, x2, n) : x2;
-}
 Big big_limbs(const Big& a, size_t n) {
     Big r(n, 0);
     for (size_t i = 0; i < std::min(n, a.size()); i++) r[i] = a[i];
@@ -142,7 +130,17 @@ struct Fld {
     Fe add(const Fe& a, const Fe& b) const { return f->add(a, b); }
     Fe sub(const Fe& a, const Fe& b) const { return f->sub(a, b); }
     Fe neg(const Fe& a) const { return f->neg(a); }
-    Fe mul(const Fe& a, const Fe& b) const { return f->mul(f->mul(a, b), f->r2); }      // (a b / R) R^2 / R = a b
+    Fe mul(const Fe& a, const Fe& b) const {
+        // most products of these circuits are limb x limb or limb x word (64 x 64, 128 x 64 bits): below 2^192 < p, the integer product IS the field product
+        const int la = a.v[3] ? 4 : a.v[2] ? 3 : a.v[1] ? 2 : 1, lb = b.v[3] ? 4 : b.v[2] ? 3 : b.v[1] ? 2 : 1;
+        if (la + lb <= 3) {
+            const Fe& x = la >= lb ? a : b;      // x: up to two limbs, y: one
+            const uint64_t y = la >= lb ? b.v[0] : a.v[0];
+            const u128 p0 = (u128)x.v[0] * y, p1 = (u128)x.v[1] * y + (uint64_t)(p0 >> 64);
+            return Fe{{(uint64_t)p0, (uint64_t)p1, (uint64_t)(p1 >> 64), 0}};
+        }
+        return f->mul(f->mul(a, b), f->r2);      // (a b / R) R^2 / R = a b
+    }
     Fe inv(const Fe& a) const {      // canonical inverse: to Montgomery, invert, back
         if (a.is_zero()) return a;
         return f->to_canonical(f->invert(f->from_canonical(a)));
@@ -205,7 +203,8 @@ struct Grain {
 struct PoseidonSpec {
     Fld F;
     uint32_t t, r_f, r_p;
-    std::vector<std::vector<Fe>> constants, mds;
+    std::vector<std::vector<Fe>> constants, mds, mds_m;      // mds_m: the same matrix times R (Montgomery form): ONE Montgomery product gives m * x for a canonical x
+    Fe mds_mul(uint32_t i, uint32_t j, const Fe& x) const { return F.f->mul(mds_m[i][j], x); }
     PoseidonSpec(const HostField* f, uint32_t t_, uint32_t rf, uint32_t rp) : F{f}, t(t_), r_f(rf), r_p(rp) {
         Grain g(f, t, r_f, r_p);
         constants.assign(r_f + r_p, std::vector<Fe>(t));
@@ -215,6 +214,8 @@ struct PoseidonSpec {
         for (auto& y : ys) y = g.field_element_mod();
         mds.assign(t, std::vector<Fe>(t));
         for (uint32_t i = 0; i < t; i++) for (uint32_t j = 0; j < t; j++) mds[i][j] = F.inv(F.add(xs[i], ys[j]));
+        mds_m = mds;
+        for (auto& row : mds_m) for (auto& m : row) m = f->from_canonical(m);
     }
     Fe pow5(const Fe& x) const {
         const Fe x2 = F.mul(x, x);
@@ -227,7 +228,7 @@ struct PoseidonSpec {
             if (r < half || r >= half + r_p) for (auto& e : st) e = pow5(e);
             else st[0] = pow5(st[0]);
             std::vector<Fe> nx(t, F.zero());
-            for (uint32_t i = 0; i < t; i++) for (uint32_t j = 0; j < t; j++) nx[i] = F.add(nx[i], F.mul(mds[i][j], st[j]));
+            for (uint32_t i = 0; i < t; i++) for (uint32_t j = 0; j < t; j++) nx[i] = F.add(nx[i], mds_mul(i, j, st[j]));
             st = nx;
         }
         return st;
@@ -254,21 +255,31 @@ struct Copy { uint32_t c0, r0, c1, r1; };
 struct Layouter {
     Fld F;
     bool want_fixed;                 // fixed columns and copies are only needed at keygen
-    std::vector<Fe> adv[5];
+    // the advice columns are written where they are wanted: straight into the caller's 2^k-row columns (or into `own` when the caller only asks for
+    // the summary); rows past the capacity are counted, not stored -- the caller's "not enough rows" check then refuses the circuit
+    Fe* adv[5];
+    size_t cap;
+    uint32_t nrows = 0;
+    std::vector<Fe> own;
     std::vector<Fe> fix[NUM_FIX];
     std::vector<Copy> copies;
-    explicit Layouter(const HostField* f, bool fixed_too) : F{f}, want_fixed(fixed_too) {}
-    uint32_t rows() const { return (uint32_t)adv[0].size(); }
+    Layouter(const HostField* f, bool fixed_too, uint64_t* advice, size_t n) : F{f}, want_fixed(fixed_too), cap(n) {
+        if (!advice) own.resize(5 * n);
+        Fe* base = advice ? reinterpret_cast<Fe*>(advice) : own.data();
+        for (int i = 0; i < 5; i++) adv[i] = base + (size_t)i * n;
+    }
+    uint32_t rows() const { return nrows; }
 
     void row(const Arg* cells, int ncells, const Sel* sel, int nsel, Cell out[5]) {
-        const uint32_t r = rows();
+        const uint32_t r = nrows++;
+        const bool store = r < cap;
         for (int i = 0; i < 5; i++) {
             Fe v{{0, 0, 0, 0}};
             if (i < ncells) {
                 v = cells[i].c.val;
                 if (cells[i].c.is_cell() && want_fixed) copies.push_back(Copy{(uint32_t)cells[i].c.col, cells[i].c.row, (uint32_t)i, r});
             }
-            adv[i].push_back(v);
+            if (store) adv[i][r] = v;
             out[i].col = i; out[i].row = r; out[i].val = v;
         }
         if (want_fixed) {
@@ -342,11 +353,14 @@ struct Layouter {
     // s = q 2^width + r over the integers (the value is far below p)
     void div_mod(const Cell& s, unsigned width, Cell& q, Cell& r) {
         Fe qv{{0, 0, 0, 0}}, rv{{0, 0, 0, 0}};
-        for (unsigned i = 0; i < 256; i++) {
-            const uint64_t b = (s.val.v[i >> 6] >> (i & 63)) & 1;
-            if (!b) continue;
-            if (i < width) rv.v[i >> 6] |= (uint64_t)1 << (i & 63);
-            else qv.v[(i - width) >> 6] |= (uint64_t)1 << ((i - width) & 63);
+        const unsigned wl = width >> 6, wb = width & 63;      // (width < 256)
+        for (unsigned i = 0; i < 4; i++) {
+            if (i < wl) rv.v[i] = s.val.v[i];
+            else if (i == wl && wb) rv.v[i] = s.val.v[i] & (((uint64_t)1 << wb) - 1);
+            if (i + wl < 4) {
+                qv.v[i] = s.val.v[i + wl] >> wb;
+                if (wb && i + wl + 1 < 4) qv.v[i] |= s.val.v[i + wl + 1] << (64 - wb);
+            }
         }
         Cell o[5];
         Arg a[3] = {Arg(qv), Arg(rv), Arg(s)};
@@ -441,6 +455,35 @@ struct BigIntChip {
     std::vector<Cell> mul(const std::vector<Cell>& a, const std::vector<Cell>& b) {
         const size_t d0 = a.size(), d1 = b.size();
         std::vector<Cell> out;
+        // Proving (no fixed columns, no copies wanted) with one-word limbs -- every call of these circuits: the same rows written directly.  A product
+        // limb is a sum of <= min(d0, d1) products of two 64-bit words: three words hold it, no field arithmetic is needed (half of all rows of the
+        // delay-encryption circuit are these: 1087 per multiplication, 60 multiplications at a 15-bit exponent).
+        bool words = !lay.want_fixed && std::min(d0, d1) <= ((size_t)1 << 60);
+        for (size_t i = 0; words && i < d0; i++) words = !(a[i].val.v[1] | a[i].val.v[2] | a[i].val.v[3]);
+        for (size_t i = 0; words && i < d1; i++) words = !(b[i].val.v[1] | b[i].val.v[2] | b[i].val.v[3]);
+        if (words) {
+            out.reserve(d0 + d1 - 1);
+            const Fe zero{{0, 0, 0, 0}};
+            for (size_t i = 0; i + 1 < d0 + d1; i++) {
+                Cell acc = lay.assign_constant(zero);
+                uint64_t w0 = 0, w1 = 0, w2 = 0;
+                for (size_t j = d1 >= i + 1 ? 0 : i + 1 - d1; j < d0 && j <= i; j++) {
+                    const uint64_t x = a[j].val.v[0], y = b[i - j].val.v[0];
+                    const u128 p = (u128)x * y;
+                    const u128 s0 = (u128)w0 + (uint64_t)p;
+                    const u128 s1 = (u128)w1 + (uint64_t)(p >> 64) + (uint64_t)(s0 >> 64);
+                    const Fe prev{{w0, w1, w2, 0}};
+                    w0 = (uint64_t)s0; w1 = (uint64_t)s1; w2 += (uint64_t)(s1 >> 64);
+                    const uint32_t r = lay.nrows++;
+                    acc.col = 3; acc.row = r; acc.val = Fe{{w0, w1, w2, 0}};
+                    if (r < lay.cap) {
+                        lay.adv[0][r] = Fe{{x, 0, 0, 0}}; lay.adv[1][r] = Fe{{y, 0, 0, 0}}; lay.adv[2][r] = prev; lay.adv[3][r] = acc.val; lay.adv[4][r] = zero;
+                    }
+                }
+                out.push_back(acc);
+            }
+            return out;
+        }
         for (size_t i = 0; i + 1 < d0 + d1; i++) {
             Cell acc = lay.assign_constant(lay.F.zero());
             for (size_t j = d1 >= i + 1 ? 0 : i + 1 - d1; j < d0 && j <= i; j++) acc = lay.mul_add(Arg(a[j]), Arg(b[i - j]), Arg(acc));
@@ -531,16 +574,17 @@ struct PoseidonRows {
         const Cell x4 = lay.mul(Arg(x2), Arg(x2));
         return lay.mul(Arg(x4), Arg(x));
     }
-    Cell linear(const std::vector<Cell>& st, const std::vector<Fe>& coeffs, const Fe& constant) {
+    Cell linear(const std::vector<Cell>& st, uint32_t mds_row, const Fe& constant) {
         Fld& F = lay.F;
+        const std::vector<Fe>& coeffs = sp.mds[mds_row];
         Fe part = F.zero();
-        for (int i = 0; i < 4; i++) part = F.add(part, F.mul(coeffs[i], st[i].val));
+        for (int i = 0; i < 4; i++) part = F.add(part, sp.mds_mul(mds_row, i, st[i].val));
         Cell o[5];
         Arg a[5] = {Arg(st[0]), Arg(st[1]), Arg(st[2]), Arg(st[3]), Arg(F.zero())};
         Sel s[6] = {{MG_SA, coeffs[0]}, {MG_SB, coeffs[1]}, {MG_SC, coeffs[2]}, {MG_SD, coeffs[3]}, {MG_SE, lay.one()}, {MG_NEXT, lay.m1()}};
         lay.row(a, 5, s, 6, o);
         const bool five = st.size() > 4;
-        const Fe total = F.add(F.add(part, five ? F.mul(coeffs[4], st[4].val) : F.zero()), constant);
+        const Fe total = F.add(F.add(part, five ? sp.mds_mul(mds_row, 4, st[4].val) : F.zero()), constant);
         Arg b[5] = {five ? Arg(st[4]) : Arg(), Arg(total), Arg(), Arg(), Arg(part)};
         Sel s2[4] = {{MG_SA, five ? coeffs[4] : F.zero()}, {MG_SB, lay.m1()}, {MG_SE, lay.one()}, {MG_CONST, constant}};
         lay.row(b, 5, s2, 4, o);
@@ -557,7 +601,7 @@ struct PoseidonRows {
             if (full) for (auto& x : s) x = pow5(x);
             else s[0] = pow5(st[0]);
             std::vector<Cell> nx;
-            for (uint32_t i = 0; i < sp.t; i++) nx.push_back(linear(s, sp.mds[i], r + 1 < rounds ? sp.constants[r + 1][i] : lay.F.zero()));
+            for (uint32_t i = 0; i < sp.t; i++) nx.push_back(linear(s, i, r + 1 < rounds ? sp.constants[r + 1][i] : lay.F.zero()));
             st = nx;
         }
         return st;
@@ -590,7 +634,10 @@ std::vector<Cell> rsa_region(Layouter& lay, const Big& n_big, uint64_t e, const 
     const std::vector<Cell> e_bits = lay.to_bits(e_cell, exp_bits);
     const std::vector<Cell> x_limbs = chip.assign_integer(x);
     const std::vector<Cell> powed = chip.pow_mod(x_limbs, e_bits, n_limbs, n_big);
-    want = big_pow_mod(x, e, n_big);
+    // the native big_pow_mod(x, e, n) the reference assigns as the expected value: the rows above hold exactly its square-and-multiply chain (every
+    // mul_mod's remainder came from the same big-integer division), so its value is read off them instead of being computed a second time
+    want = chip.to_big(powed);
+    big_trim(want);
     const std::vector<Cell> valid = chip.assign_constant(want);
     for (size_t i = 0; i < powed.size(); i++) lay.assert_equal(powed[i], valid[i]);
     return valid;
@@ -661,7 +708,8 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
     const uint32_t t = in->t ? in->t : 5, rate = in->rate ? in->rate : 4, r_f = in->r_f ? in->r_f : 8, r_p = in->r_p ? in->r_p : 57;
     if (t != 5 || rate != 4) return DEHALO_ERR_UNSUPPORTED;      // the row layout (linear()) is the T = 5 one the reference instantiates (src/lib.rs:120-121)
     if (in->message_len > 2 || (in->message_len && !in->message)) return DEHALO_ERR_INVALID;
-    Layouter lay(f, keygen_outputs);
+    const size_t n = (size_t)1 << in->k;
+    Layouter lay(f, keygen_outputs, advice, n);
     Fld F{f};
     std::vector<Fe> message;
     for (uint32_t i = 0; i < in->message_len; i++) {
@@ -724,15 +772,12 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
     inf.cipher_len = (uint32_t)std::min<size_t>(cipher_vals.size(), 3);
     if (info) *info = inf;
     // ---- into 2^k-row columns
-    const size_t n = (size_t)1 << in->k;
     const uint32_t bf = 5;      // blinding_factors of both constraint systems: max(3, 2 queries of advice column e) + 2
     const size_t u = n - (bf + 1);
     if ((size_t)lay.rows() + 1 > u) return DEHALO_ERR_INVALID;      // "not enough rows available" (upstream: Error::NotEnoughRowsAvailable)
     const size_t rows = lay.rows();
-    if (advice) {
-        memset(advice, 0, 5 * n * 32);
-        for (int c = 0; c < 5; c++) memcpy(advice + (size_t)c * n * 4, lay.adv[c].data(), rows * 32);
-    }
+    if (advice)      // (the used rows are already in place)
+        for (int c = 0; c < 5; c++) memset(advice + ((size_t)c * n + rows) * 4, 0, (n - rows) * 32);
     const uint32_t num_fixed = range_lookups ? 15 : 9;
     if (fixed) {
         memset(fixed, 0, (size_t)num_fixed * n * 32);

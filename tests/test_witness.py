@@ -300,6 +300,9 @@ def test_native_synthesize_equals_witness_py_bit_for_bit(pkg):
     # advice alone (what a proof needs) is the same array; a circuit that does not fit is refused
     adv_only = native.synthesize(native.CIRCUIT_DELAY_ENC, 14, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22])
     assert np.array_equal(adv_only["advice"], W.delay_enc_witness(p, 14, n, 0b1, x, 1, [11, 22])[0].advice)
+    # (the proving call writes the multiplication rows by a word-arithmetic fast path, the keygen call by the general one: the same rows, and zeros behind them)
+    fast = native.synthesize(native.CIRCUIT_DELAY_ENC, 16, n_big=n2, e=0b10011, x=x2, exp_bits=5, message=[123456789, p - 5])
+    assert np.array_equal(fast["advice"], nat["advice"]) and fast["rsa_result"] == nat["rsa_result"] == pow(x2, 0b10011, n2) and fast["cipher"] == nat["cipher"]
     with pytest.raises(ValueError):
         native.synthesize(native.CIRCUIT_DELAY_ENC, 13, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22])
 
