@@ -254,18 +254,30 @@ def end_to_end(st, want_proof, reps=5):
     if spec is None:
         return None
     kw = {a: b for a, b in spec.items() if a not in ("circuit", "k")}
+    import torch
+    # one page-locked buffer for the advice columns, as a host that proves repeatedly keeps: the witness generator writes its rows straight into it
+    # and the upload is one DMA from it (a fresh pageable array per proof costs the page faults of 21 MB and a staged copy: `ms_with_a_fresh_pageable_array_per_proof`)
+    pinned = torch.empty((5, 1 << spec["k"], 4), dtype=torch.int64).pin_memory()
+    buf = pinned.numpy().view(np.uint64)
     ts, tw = [], []
     for i in range(reps + 1):
         t0 = time.perf_counter()
-        nat = native.synthesize(spec["circuit"], spec["k"], **kw)
+        nat = native.synthesize(spec["circuit"], spec["k"], out=buf, **kw)
         t1 = time.perf_counter()
         proof = st.prover.create_proof(nat["advice"], [[]], prover.SeededRng(7), canonical=True).finalize()
         t2 = time.perf_counter()
         if i:
             tw.append(1e3 * (t1 - t0)); ts.append(1e3 * (t2 - t0))
     assert proof == want_proof, "the proof from the natively synthesized witness differs"
-    return {"ms": round(min(ts), 3), "ms_median": round(sorted(ts)[len(ts) // 2], 3), "witness_ms": round(min(tw), 3),
-            "what": "dehalo_synthesize (C++ witness generation on one host thread) + upload of 5 x 2^k advice values from pageable memory + dehalo_create_proof; "
+    tp = []
+    for i in range(3):      # the same with a fresh pageable array per proof (numpy's default), for comparison
+        t0 = time.perf_counter()
+        nat = native.synthesize(spec["circuit"], spec["k"], **kw)
+        proof = st.prover.create_proof(nat["advice"], [[]], prover.SeededRng(7), canonical=True).finalize()
+        tp.append(1e3 * (time.perf_counter() - t0))
+    assert proof == want_proof
+    return {"ms": round(min(ts), 3), "ms_median": round(sorted(ts)[len(ts) // 2], 3), "witness_ms": round(min(tw), 3), "ms_with_a_fresh_pageable_array_per_proof": round(min(tp), 3),
+            "what": "dehalo_synthesize (C++ witness generation on one host thread, rows written into a page-locked buffer kept across proofs) + upload of 5 x 2^k advice values from it + dehalo_create_proof; "
                     "same proof bytes as from the resident witness"}
 
 

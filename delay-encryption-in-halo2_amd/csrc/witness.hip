@@ -11,7 +11,11 @@
 // bit for bit.  Host code only (no device work): big-integer arithmetic on 64-bit limbs, field arithmetic through hostfield.hpp.
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/dehalo.h"
@@ -234,6 +238,18 @@ struct PoseidonSpec {
         return st;
     }
 };
+
+// The round constants and the MDS matrix depend on (T, R_F, R_P) only -- 325 Grain draws and 25 field inversions at the reference's parameters, 1.5 ms, most
+// of a PoseidonEnc witness -- so a process keeps each parameter set it has used (the reference rebuilds the Spec in every synthesize: src/poseidon/spec.rs).
+std::shared_ptr<const PoseidonSpec> poseidon_spec(const HostField* f, uint32_t t, uint32_t r_f, uint32_t r_p) {
+    static std::mutex mu;
+    static std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::shared_ptr<const PoseidonSpec>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() >= 16) cache.clear();      // (callers hold their own reference)
+    auto& slot = cache[std::make_tuple(t, r_f, r_p)];
+    if (!slot) slot = std::make_shared<const PoseidonSpec>(f, t, r_f, r_p);
+    return slot;
+}
 
 // ---- the MainGate / RangeChip layouter (dehalo2_amd/witness.py Layouter, row for row) ----
 enum { MG_SA = 0, MG_SB, MG_SC, MG_SD, MG_SE, MG_MUL_AB, MG_MUL_CD, MG_NEXT, MG_CONST, RC_T_TAG, RC_T_VALUE, RC_TAG_COMPOSITION, RC_TAG_OVERFLOW, RC_S_COMPOSITION, RC_S_OVERFLOW, NUM_FIX };
@@ -721,7 +737,8 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
     std::vector<Fe> cipher_vals;
     if (in->circuit == DEHALO_CIRCUIT_POSE_ENC) {
         if (!in->key) return DEHALO_ERR_INVALID;
-        const PoseidonSpec spec(f, t, r_f, r_p);
+        const std::shared_ptr<const PoseidonSpec> spec_ref = poseidon_spec(f, t, r_f, r_p);
+        const PoseidonSpec& spec = *spec_ref;
         const Fe key[2] = {fe_from(in->key), fe_from(in->key + 4)};
         for (auto& c : cipher_region(lay, spec, key, message, nullptr)) cipher_vals.push_back(c.val);
     } else {
@@ -736,7 +753,8 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         const Big wl = big_limbs(want, std::min<size_t>(num_limbs, 128));
         for (size_t i = 0; i < wl.size() && i < 128; i++) inf.rsa_result[i] = wl[i];
         if (in->circuit == DEHALO_CIRCUIT_DELAY_ENC) {
-            const PoseidonSpec spec(f, t, r_f, r_p);
+            const std::shared_ptr<const PoseidonSpec> spec_ref = poseidon_spec(f, t, r_f, r_p);
+        const PoseidonSpec& spec = *spec_ref;
             PoseidonRows rows{lay, spec};
             // hash region: limbs packed three to a field element (src/lib.rs:222-249), sponge with RATE 4 (src/hash/chip.rs:63-85)
             const Cell base1 = lay.assign_constant(F.pow2(LIMB_WIDTH));

@@ -365,10 +365,11 @@ def _limbs(x: int, count: int) -> np.ndarray:
 
 
 def synthesize(circuit: int, k: int, *, n_big: int = 0, e: int = 0, x: int = 0, exp_bits: int = 0, message: Sequence[int] = (), key: Sequence[int] = (), bits_len: int = 2048,
-               keygen: bool = False) -> dict:
+               keygen: bool = False, out=None) -> dict:
     """dehalo_synthesize: Circuit::synthesize of the reference's circuits as values, in C++ (csrc/witness.hip; src/lib.rs:164-318,
     benches/mod_pow.rs:63-110, src/encryption/chip.rs:114-204).  -> {"advice": (5, n, 4) u64 CANONICAL, "rows", "rsa_rows", "rsa_result",
-    "cipher"} and, with keygen=True, "fixed" (canonical), "mapping", "selectors"."""
+    "cipher"} and, with keygen=True, "fixed" (canonical), "mapping", "selectors".  `out`: a C-contiguous (5, n, 4) uint64 array the advice columns
+    are written into (the library writes them in place: a caller that proves repeatedly hands over one page-locked buffer and uploads from it)."""
     lib = load_library()
     nl = bits_len // 64
     inp = CCircuitInputs()
@@ -378,7 +379,12 @@ def synthesize(circuit: int, k: int, *, n_big: int = 0, e: int = 0, x: int = 0, 
     inp.n, inp.x, inp.message, inp.message_len, inp.key = keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, len(message), keep[3].ctypes.data
     n = 1 << k
     nfix = 9 if circuit == CIRCUIT_POSE_ENC else 15
-    advice = np.empty((5, n, 4), dtype=np.uint64)
+    if out is not None:
+        if out.shape != (5, n, 4) or out.dtype != np.uint64 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("synthesize: `out` must be a C-contiguous (5, %d, 4) uint64 array" % n)
+        advice = out
+    else:
+        advice = np.empty((5, n, 4), dtype=np.uint64)
     fixed = np.empty((nfix, n, 4), dtype=np.uint64) if keygen else None
     mapping = np.empty(6 * n, dtype=np.uint64) if keygen else None
     sels = [np.zeros(n, dtype=np.uint8) for _ in range(2)] if keygen and circuit != CIRCUIT_POSE_ENC else []
