@@ -16,7 +16,7 @@ SYMBOLS = [
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
     "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_lookup_h_batch_device", "dehalo_product_terms_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
-    "dehalo_intt_scaled_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
+    "dehalo_intt_scaled_device", "dehalo_lagrange_to_coeff_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_field_op_device", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_eval_polynomial_multi_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
@@ -162,6 +162,8 @@ def load_library():
     lib.dehalo_coset_ntt.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p]
     lib.dehalo_coset_intt.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p]
     lib.dehalo_intt_scaled_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, sz, P]
+    if hasattr(lib, "dehalo_lagrange_to_coeff_device"):
+        lib.dehalo_lagrange_to_coeff_device.argtypes = [P, C.c_int, u64p, u64p, u32, u64p, u64p, sz, P]
     lib.dehalo_coset_ntt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u32, u64p, u64p, sz, P]
     lib.dehalo_coset_intt_device.argtypes = [P, C.c_int, u64p, u32, u64p, u64p, u64p, sz, P]
     lib.dehalo_field_op.argtypes = [P, C.c_int, C.c_int, u64p, u64p, u64p, sz]
@@ -414,6 +416,9 @@ class Context:
 
     def intt_scaled_device(self, field: int, d_a: int, log_n: int, omega_inv, n_inv, batch: int = 1, stream: int = 0):
         self._check(self.lib.dehalo_intt_scaled_device(self.handle, field, d_a, log_n, _ptr(_u64(omega_inv, 4)), _ptr(_u64(n_inv, 4)), batch, stream or None))
+
+    def lagrange_to_coeff_device(self, field: int, d_values: int, d_coeffs: int, log_n: int, omega_inv, n_inv, batch: int = 1, stream: int = 0):
+        self._check(self.lib.dehalo_lagrange_to_coeff_device(self.handle, field, d_values, d_coeffs, log_n, _ptr(_u64(omega_inv, 4)), _ptr(_u64(n_inv, 4)), batch, stream or None))
 
     def coset_ntt_device(self, field: int, d_coeffs: int, log_n: int, d_ext: int, log_ext: int, omega_ext, zeta, batch: int = 1, stream: int = 0):
         self._check(self.lib.dehalo_coset_ntt_device(self.handle, field, d_coeffs, log_n, d_ext, log_ext, _ptr(_u64(omega_ext, 4)), _ptr(_u64(zeta, 4)), batch,

@@ -658,6 +658,15 @@ int dehalo_intt_scaled_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_
     return ntt_device_impl(ctx, field, d_a, N, N, d_a, N, log_n, omega_inv, batch, sc, stream);
 }
 
+int dehalo_lagrange_to_coeff_device(dehalo_ctx* ctx, int field, const uint64_t* d_values, uint64_t* d_coeffs, uint32_t log_n, const uint64_t omega_inv[4],
+                                    const uint64_t n_inv[4], size_t batch, void* stream) {
+    if (!n_inv) return dh_fail(ctx, DEHALO_ERR_INVALID, "lagrange_to_coeff: null n_inv");
+    NttScale sc;
+    sc.post_mode = 1; sc.post0 = fe_from_u64(n_inv);
+    uint64_t N = 1ull << (log_n & 63);
+    return ntt_device_impl(ctx, field, d_values, N, N, d_coeffs, N, log_n, omega_inv, batch, sc, stream);
+}
+
 static int form_shift_of(uint32_t flags) {   // OUT_INTERNAL: x 2^5; IN_INTERNAL: x 2^-5; both: no change of scale
     return (flags & DEHALO_FORM_OUT_INTERNAL ? 1 : 0) - (flags & DEHALO_FORM_IN_INTERNAL ? 1 : 0);
 }

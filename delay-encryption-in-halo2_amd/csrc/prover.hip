@@ -383,8 +383,7 @@ int lagrange_to_all(dehalo_pk* pk, const dehalo_params* params, const fe* values
         TRY(aff.alloc(ctx, 2 * cnt, false));
         TRY(dehalo_msm_device_affine(ctx, params->bases_gl, (const uint64_t*)values, d.n, cnt, nullptr, aff.u64(), nullptr));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(polys, values, cnt * d.n * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
-    TRY(dehalo_intt_scaled_device(ctx, pk->f->id, (uint64_t*)polys, d.k, d.omega_inv.v, d.ifft_divisor.v, cnt, nullptr));
+    TRY(dehalo_lagrange_to_coeff_device(ctx, pk->f->id, (const uint64_t*)values, (uint64_t*)polys, d.k, d.omega_inv.v, d.ifft_divisor.v, cnt, nullptr));
     TRY(dehalo_coset_ntt_form_device(ctx, pk->f->id, (const uint64_t*)polys, d.k, (uint64_t*)cosets, d.extended_k, d.ext_omega.v, d.g_coset.v, cnt, DEHALO_FORM_OUT_INTERNAL,
                                      nullptr));
     if (commitments_host) TRY(dehalo_download(ctx, aff.p, cnt * 64, commitments_host));
@@ -622,6 +621,8 @@ struct dehalo_prover {
     std::vector<uint32_t> table_rep;      // per lookup: the first lookup with the same table expressions (shares its compressed table)
     dehalo_graph *lookup_den = nullptr, *lookup_num = nullptr;
     hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_inst = nullptr, ev_side = nullptr;      // ev_ready: one per commitment phase
+    hipEvent_t ev_helper = nullptr;      // the helper thread waits for ITS work on the side stream through this event: a hipStreamSynchronize there holds the
+    uint64_t* pin_helper = nullptr;      // stream against the proving thread's launches (0.4 ms of the lookups' phase); its point lands in this page-locked slot
     // opening plan (depends on the circuit only)
     std::vector<int32_t> rots;
     std::vector<const uint64_t*> plist;
@@ -648,8 +649,9 @@ struct dehalo_prover {
         }
         if (lookup_den) (void)dehalo_graph_release(ctx, lookup_den);
         if (lookup_num) (void)dehalo_graph_release(ctx, lookup_num);
-        for (hipEvent_t e : {ev_ready[0], ev_ready[1], ev_ready[2], ev_inst, ev_side})
+        for (hipEvent_t e : {ev_ready[0], ev_ready[1], ev_ready[2], ev_inst, ev_side, ev_helper})
             if (e) (void)hipEventDestroy(e);
+        if (pin_helper) (void)hipHostFree(pin_helper);
     }
 
     const uint64_t* col_ptr(const DevMem& mem, size_t col, size_t len) const { return (const uint64_t*)mem.at(col * len); }
@@ -814,7 +816,8 @@ struct dehalo_prover {
         TRY(build_product_graphs());
         TRY(opening_plan());
         TRY(evals.alloc(ctx, eval_count + 8));
-        for (hipEvent_t* e : {&ev_ready[0], &ev_ready[1], &ev_ready[2], &ev_inst, &ev_side}) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&ev_ready[0], &ev_ready[1], &ev_ready[2], &ev_inst, &ev_side, &ev_helper}) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        HIP_TRY(ctx, hipHostMalloc((void**)&pin_helper, 128, hipHostMallocDefault));
         host_aff.resize(8 * (size_t)std::max<uint32_t>(NC, 8));
         host_jac.resize(12 * (size_t)std::max<uint32_t>(NC, 8));
         host_evals.resize(4 * eval_count);
@@ -943,16 +946,17 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
                 fe* dst = polys + (size_t)o_rand * n;
                 hipError_t e = hipSuccess;
                 if (device_rng) rc = device_draw(dst, ss);
-                else {
-                    e = hipMemcpyAsync(dst, rand_host.data(), n * 32, hipMemcpyHostToDevice, ss);
-                    if (e == hipSuccess) e = hipStreamSynchronize(ss);
-                }
+                else e = hipMemcpyAsync(dst, rand_host.data(), n * 32, hipMemcpyHostToDevice, ss);      // (rand_host lives as long as the prover)
                 if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial upload: ") + hipGetErrorString(e));
-                uint64_t rj[12];
                 if (!rc) rc = dehalo_msm_device(side, params->bases_g, (const uint64_t*)dst, n, 1, jac_side.u64(), nullptr);
                 helper_ms[1] = ms_since(th0);
-                if (!rc) rc = dehalo_download(side, jac_side.p, 96, rj);
-                if (!rc && !normalize_host(rj, 1, rand_point)) memset(rand_point, 0, sizeof rand_point);      // (the identity: refused by write_point below)
+                if (!rc) {      // read the point back and wait for it through an event of this thread's own
+                    e = hipMemcpyAsync(pin_helper, jac_side.p, 96, hipMemcpyDeviceToHost, ss);
+                    if (e == hipSuccess) e = hipEventRecord(ev_helper, ss);
+                    if (e == hipSuccess) e = hipEventSynchronize(ev_helper);
+                    if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial commitment: ") + hipGetErrorString(e));
+                }
+                if (!rc && !normalize_host(pin_helper, 1, rand_point)) memset(rand_point, 0, sizeof rand_point);      // (the identity: refused by write_point below)
                 helper_ms[2] = ms_since(th0);
             } else {
                 // without a side context only the draw is taken off the critical path; the upload is queued by the proving thread
@@ -1020,8 +1024,9 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         // polys[first..] = lagrange_to_coeff(cols[..]), ext[..] = coeff_to_extended(..) on the side context once `e` (recorded BEFORE the phase's
         // commitment was queued) has passed; the launches themselves are made after the commitment's, while this thread would only wait
         HIP_TRY(side, hipStreamWaitEvent(ss, e, 0));
-        HIP_TRY(side, hipMemcpyAsync(polys + (size_t)first * n, cols.at((size_t)first * n), (size_t)count * n * 32, hipMemcpyDeviceToDevice, ss));
-        TRY(dehalo_intt_scaled_device(side, fid, (uint64_t*)(polys + (size_t)first * n), k, d.omega_inv.v, d.ifft_divisor.v, count, nullptr));
+        // (out of place: no copy of the columns first -- a 42 MB device-to-device hipMemcpyAsync held this thread for 0.4 ms in the lookups' phase)
+        TRY(dehalo_lagrange_to_coeff_device(side, fid, (const uint64_t*)cols.at((size_t)first * n), (uint64_t*)(polys + (size_t)first * n), k, d.omega_inv.v, d.ifft_divisor.v, count,
+                                            nullptr));
         TRY(dehalo_coset_ntt_form_device(side, fid, (const uint64_t*)(polys + (size_t)first * n), k, ext.u64((size_t)first * m), ek, d.ext_omega.v, d.g_coset.v, count,
                                          DEHALO_FORM_OUT_INTERNAL, nullptr));
         return 0;

@@ -160,6 +160,10 @@ int dehalo_coset_intt(dehalo_ctx* ctx, int field, uint64_t* a, uint32_t log_ext,
 /* Device-resident forms (batch polynomials contiguous in HBM). */
 int dehalo_intt_scaled_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_n, const uint64_t omega_inv[4],
                               const uint64_t n_inv[4], size_t batch, void* stream);
+/* The same out of place: d_coeffs = lagrange_to_coeff(d_values) for `batch` contiguous columns; d_values is left as it is (the prover keeps the
+ * Lagrange values it has committed to and needs the coefficients beside them).  d_coeffs == d_values is allowed. */
+int dehalo_lagrange_to_coeff_device(dehalo_ctx* ctx, int field, const uint64_t* d_values, uint64_t* d_coeffs, uint32_t log_n, const uint64_t omega_inv[4],
+                                    const uint64_t n_inv[4], size_t batch, void* stream);
 int dehalo_coset_ntt_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, uint32_t log_n, uint64_t* d_ext_out,
                             uint32_t log_ext, const uint64_t omega_ext[4], const uint64_t zeta[4], size_t batch, void* stream);
 int dehalo_coset_intt_device(dehalo_ctx* ctx, int field, uint64_t* d_a, uint32_t log_ext, const uint64_t omega_ext_inv[4],

@@ -437,6 +437,12 @@ def test_ntt_batched_device_entry_points(pkg, po, co, ctx):
         got = d.cpu().numpy().view(np.uint64)
         for b in range(batch):
             assert np.array_equal(got[b], co.best_fft(f.id, polys[b], omega, k, 2)), (k, b)
+        # out of place (the prover's lagrange_to_coeff beside the committed values): the source stays, the result equals the in-place one
+        out = torch.zeros_like(d)
+        before = d.clone()
+        ctx.lagrange_to_coeff_device(f.id, d.data_ptr(), out.data_ptr(), k, f.encode(of.inv(of.omega(k))), f.encode(of.inv(1 << k)), batch, 0)
+        ctx.synchronize()
+        assert torch.equal(d, before) and np.array_equal(out.cpu().numpy().view(np.uint64), polys)
         ctx.intt_scaled_device(f.id, d.data_ptr(), k, f.encode(of.inv(of.omega(k))), f.encode(of.inv(1 << k)), batch, 0)
         ctx.synchronize()
         assert np.array_equal(d.cpu().numpy().view(np.uint64), polys)
