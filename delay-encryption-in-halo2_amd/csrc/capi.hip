@@ -999,8 +999,19 @@ int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, cons
                                (fe*)d_permuted_tables, pick_stream(ctx, stream));
 }
 
+static int permute_ptrs(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
+                        uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int* d_status, void* stream);
 int dehalo_permute_expression_pair_ptrs_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
                                                uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, void* stream) {
+    return permute_ptrs(ctx, field, d_inputs, d_tables, usable_rows, batch, d_permuted_inputs, d_permuted_tables, nullptr, stream);
+}
+int dehalo_permute_expression_pair_ptrs_deferred_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows,
+                                                        size_t batch, uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int32_t* d_status, void* stream) {
+    if (ctx && !d_status && batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null status array");
+    return permute_ptrs(ctx, field, d_inputs, d_tables, usable_rows, batch, d_permuted_inputs, d_permuted_tables, (int*)d_status, stream);
+}
+static int permute_ptrs(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
+                        uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int* d_status, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!d_inputs || !d_tables || !d_permuted_inputs || !d_permuted_tables) && batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
     if (batch >= 4096) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: batch too large");
@@ -1014,7 +1025,7 @@ int dehalo_permute_expression_pair_ptrs_device(dehalo_ctx* ctx, int field, const
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return lookup_permute_ptrs(ctx, field, (const fe* const*)d_inputs, (const fe* const*)d_tables, usable_rows, batch, (fe* const*)d_permuted_inputs, (fe* const*)d_permuted_tables,
-                               pick_stream(ctx, stream));
+                               pick_stream(ctx, stream), d_status);
 }
 
 int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,

@@ -203,7 +203,7 @@ int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe
                         fe* d_out_tables, hipStream_t s);
 
 int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, const fe* const* d_tables, uint64_t n, size_t batch, fe* const* d_out_inputs,
-                        fe* const* d_out_tables, hipStream_t s);
+                        fe* const* d_out_tables, hipStream_t s, int* d_status = nullptr);
 
 // quotient-numerator kernels (evalh.cuh)
 struct dehalo_graph;

@@ -398,7 +398,7 @@ __global__ void k_lp_emit(LpCols c, const fe* sorted, u64 n, u64 npad, const u32
 }
 
 template <class F>
-int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s) {
+int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s, int* d_status) {
     const u64 tiles = (n + LP_TILE - 1) / LP_TILE, npad = tiles * LP_TILE;
     const size_t pad = 256;
     const size_t bytes = 2 * ((size_t)U * npad * sizeof(fe) + pad) + 4 * ((size_t)B * n * 4 + pad) + ((size_t)B * tiles * 8 + pad) + 2 * ((size_t)B * 8 + pad) + 4096;
@@ -431,6 +431,10 @@ int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s)
     k_lp_scan_apply<<<dim3((u32)tiles, B), LP_THREADS, 0, s>>>(cnt, n, (u32)tiles, tile_sums, used_start, used_idx, lsrc);
     k_lp_emit<F><<<dim3((u32)((n + 255) / 256), B), 256, 0, s>>>(c, src, n, npad, used_start, used_idx, lsrc, totals);
     HIP_TRY(ctx, hipGetLastError());
+    if (d_status) {      // deferred: the flags stay on the device for the caller to read with whatever it reads back next; no synchronisation here
+        HIP_TRY(ctx, hipMemcpyAsync(d_status, err, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
     int host_err[LP_MAX_BATCH];
     HIP_TRY(ctx, hipMemcpyAsync(host_err, err, B * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));     // upstream returns Err(ConstraintSystemFailure) from this call: so must we
@@ -444,8 +448,11 @@ int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s)
 
 // `batch` lookups at once, given as pointer lists: lookups whose table pointers are equal share one sort.
 int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, const fe* const* d_tables, uint64_t n, size_t batch, fe* const* d_out_inputs,
-                        fe* const* d_out_tables, hipStream_t s) {
-    if (n == 0 || batch == 0) return 0;
+                        fe* const* d_out_tables, hipStream_t s, int* d_status) {
+    if (n == 0 || batch == 0) {
+        if (d_status && batch) HIP_TRY(ctx, hipMemsetAsync(d_status, 0, batch * sizeof(int), s));
+        return 0;
+    }
     if (n >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: too many rows");
     ScopedTimer timer(ctx, s, DEHALO_K_POLY);
     for (size_t first = 0; first < batch; first += LP_MAX_BATCH) {
@@ -463,10 +470,10 @@ int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, c
         }
         int rc;
         switch (field) {
-            case DEHALO_FIELD_BN254_FR: rc = lp_run<Bn254Fr>(ctx, c, B, U, n, s); break;
-            case DEHALO_FIELD_BN254_FQ: rc = lp_run<Bn254Fq>(ctx, c, B, U, n, s); break;
-            case DEHALO_FIELD_PASTA_FP: rc = lp_run<PastaFp>(ctx, c, B, U, n, s); break;
-            case DEHALO_FIELD_PASTA_FQ: rc = lp_run<PastaFq>(ctx, c, B, U, n, s); break;
+            case DEHALO_FIELD_BN254_FR: rc = lp_run<Bn254Fr>(ctx, c, B, U, n, s, d_status ? d_status + first : nullptr); break;
+            case DEHALO_FIELD_BN254_FQ: rc = lp_run<Bn254Fq>(ctx, c, B, U, n, s, d_status ? d_status + first : nullptr); break;
+            case DEHALO_FIELD_PASTA_FP: rc = lp_run<PastaFp>(ctx, c, B, U, n, s, d_status ? d_status + first : nullptr); break;
+            case DEHALO_FIELD_PASTA_FQ: rc = lp_run<PastaFq>(ctx, c, B, U, n, s, d_status ? d_status + first : nullptr); break;
             default: return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown field id");
         }
         if (rc) return rc;

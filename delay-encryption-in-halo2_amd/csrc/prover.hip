@@ -623,6 +623,8 @@ struct dehalo_prover {
     hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_inst = nullptr, ev_side = nullptr;      // ev_ready: one per commitment phase
     hipEvent_t ev_helper = nullptr;      // the helper thread waits for ITS work on the side stream through this event: a hipStreamSynchronize there holds the
     uint64_t* pin_helper = nullptr;      // stream against the proving thread's launches (0.4 ms of the lookups' phase); its point lands in this page-locked slot
+    hipStream_t hs = nullptr;            // ... and its work (upload, the random polynomial's commitment) runs on a stream of its own beside the side context's
+    uint64_t* rand_pin = nullptr;        // host-drawn random polynomial (page-locked: its upload is one DMA that holds no stream)
     // opening plan (depends on the circuit only)
     std::vector<int32_t> rots;
     std::vector<const uint64_t*> plist;
@@ -632,7 +634,7 @@ struct dehalo_prover {
     std::vector<const uint64_t*> hp_ptrs;
     size_t hpiece0 = 0, eval_count = 0;
     // host staging
-    std::vector<uint64_t> blind_host, host_aff, host_jac, host_evals, rand_host;
+    std::vector<uint64_t> blind_host, host_aff, host_jac, host_evals;
     double timings[8] = {};
     bool trace = false;      // DEHALO_PROVER_TRACE=1: host timestamps inside the phases go to stderr after each proof
     std::vector<std::pair<const char*, double>> ticks;
@@ -652,6 +654,8 @@ struct dehalo_prover {
         for (hipEvent_t e : {ev_ready[0], ev_ready[1], ev_ready[2], ev_inst, ev_side, ev_helper})
             if (e) (void)hipEventDestroy(e);
         if (pin_helper) (void)hipHostFree(pin_helper);
+        if (rand_pin) (void)hipHostFree(rand_pin);
+        if (hs) (void)hipStreamDestroy(hs);
     }
 
     const uint64_t* col_ptr(const DevMem& mem, size_t col, size_t len) const { return (const uint64_t*)mem.at(col * len); }
@@ -804,7 +808,7 @@ struct dehalo_prover {
         TRY(hfold.alloc(ctx, n));
         TRY(qbuf.alloc(ctx, 4 * n));
         TRY(wbuf.alloc(ctx, 4 * n));
-        TRY(jac.alloc(ctx, 3 * (size_t)std::max<uint32_t>(NC, 8)));
+        TRY(jac.alloc(ctx, 3 * (size_t)std::max<uint32_t>(NC, 8) + 2 + (L + 7) / 8));      // + the lookups' status flags behind a phase's points (one int32 each)
         TRY(jac_side.alloc(ctx, 3));
         // blinding values of a proof but the random polynomial, compacted: [advice rows | permuted rows | product rows]
         const size_t rows = n - u;
@@ -818,8 +822,10 @@ struct dehalo_prover {
         TRY(evals.alloc(ctx, eval_count + 8));
         for (hipEvent_t* e : {&ev_ready[0], &ev_ready[1], &ev_ready[2], &ev_inst, &ev_side, &ev_helper}) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_TRY(ctx, hipHostMalloc((void**)&pin_helper, 128, hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc((void**)&rand_pin, (size_t)n * 32, hipHostMallocDefault));
+        if (side) HIP_TRY(ctx, hipStreamCreateWithFlags(&hs, hipStreamNonBlocking));
         host_aff.resize(8 * (size_t)std::max<uint32_t>(NC, 8));
-        host_jac.resize(12 * (size_t)std::max<uint32_t>(NC, 8));
+        host_jac.resize(12 * (size_t)std::max<uint32_t>(NC, 8) + 8 + L);
         host_evals.resize(4 * eval_count);
         TRY(dehalo_ctx_synchronize(ctx));
         return 0;
@@ -855,13 +861,17 @@ struct dehalo_prover {
     }
 
     // commit `count` columns starting at `src`, read back, normalise, absorb (and append to the proof)
-    int commit(dehalo_transcript* tr, const fe* src, size_t count, bool lagrange, const std::function<int()>& before_sync = nullptr) {
+    // `flags` > 0: that many int32 status words sit behind the points in `jac` (deferred lookup permutation) and come back with them; any non-zero one fails the call
+    int commit(dehalo_transcript* tr, const fe* src, size_t count, bool lagrange, const std::function<int()>& before_sync = nullptr, size_t flags = 0) {
         TRY(dehalo_msm_device(ctx, lagrange ? params->bases_gl : params->bases_g, (const uint64_t*)src, n, count, jac.u64(), nullptr));
         tk("commit queued");
         if (before_sync) TRY(before_sync());
         tk("side work queued");
-        TRY(dehalo_download(ctx, jac.p, count * 96, host_jac.data()));
+        TRY(dehalo_download(ctx, jac.p, count * 96 + flags * 4, host_jac.data()));
         tk("points on host");
+        for (size_t i = 0; i < flags; i++)
+            if (reinterpret_cast<const int32_t*>(host_jac.data() + 12 * count)[i])
+                return dh_fail(ctx, DEHALO_ERR_NOT_IN_TABLE, "permute_expression_pair: an input value of lookup " + std::to_string(i) + " is not in the table (ConstraintSystemFailure)");
         if (!normalize_host(host_jac.data(), count, host_aff.data())) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
         for (size_t i = 0; i < count; i++)
             if (!tr->write_point(host_aff.data() + 8 * i)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
@@ -937,22 +947,21 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         const auto th0 = clk::now();
         int rc = 0;
         if (!device_rng) {
-            rand_host.resize(4 * n);
-            rc = rng_poly.scalars(rand_host.data(), n);
+            rc = rng_poly.scalars(rand_pin, n);
         }
         helper_ms[0] = ms_since(th0);
         if (!rc) {
             if (side) {
                 fe* dst = polys + (size_t)o_rand * n;
                 hipError_t e = hipSuccess;
-                if (device_rng) rc = device_draw(dst, ss);
-                else e = hipMemcpyAsync(dst, rand_host.data(), n * 32, hipMemcpyHostToDevice, ss);      // (rand_host lives as long as the prover)
+                if (device_rng) rc = device_draw(dst, hs);
+                else e = hipMemcpyAsync(dst, rand_pin, n * 32, hipMemcpyHostToDevice, hs);
                 if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial upload: ") + hipGetErrorString(e));
-                if (!rc) rc = dehalo_msm_device(side, params->bases_g, (const uint64_t*)dst, n, 1, jac_side.u64(), nullptr);
+                if (!rc) rc = dehalo_msm_device(side, params->bases_g, (const uint64_t*)dst, n, 1, jac_side.u64(), hs);      // (the side context's MSM workspace is this thread's alone)
                 helper_ms[1] = ms_since(th0);
-                if (!rc) {      // read the point back and wait for it through an event of this thread's own
-                    e = hipMemcpyAsync(pin_helper, jac_side.p, 96, hipMemcpyDeviceToHost, ss);
-                    if (e == hipSuccess) e = hipEventRecord(ev_helper, ss);
+                if (!rc) {      // read the point back and wait for it through an event of this thread's own; everything of this stream is done before the join
+                    e = hipMemcpyAsync(pin_helper, jac_side.p, 96, hipMemcpyDeviceToHost, hs);
+                    if (e == hipSuccess) e = hipEventRecord(ev_helper, hs);
                     if (e == hipSuccess) e = hipEventSynchronize(ev_helper);
                     if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial commitment: ") + hipGetErrorString(e));
                 }
@@ -1100,10 +1109,12 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             pout_in.push_back(cols.u64((size_t)(o_perm + 2 * l) * n));
             pout_tab.push_back(cols.u64((size_t)(o_perm + 2 * l + 1) * n));
         }
-        TRY(dehalo_permute_expression_pair_ptrs_device(ctx, fid, pin.data(), ptab.data(), u, L, pout_in.data(), pout_tab.data(), nullptr));
-        tk("permute returned");
+        // status flags behind the 2 L points of this phase: the stream runs from the permutation straight into the commitment, the flags come back with the points
+        TRY(dehalo_permute_expression_pair_ptrs_deferred_device(ctx, fid, pin.data(), ptab.data(), u, L, pout_in.data(), pout_tab.data(), reinterpret_cast<int32_t*>(jac.u64() + 12 * 2 * (size_t)L),
+                                                                nullptr));
+        tk("permute queued");
         if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[1], ms));
-        TRY(commit(tr, cols.at((size_t)o_perm * n), 2 * L, true, side ? std::function<int()>([&]() { return side_ntt(o_perm, 2 * L, ev_ready[1]); }) : nullptr));
+        TRY(commit(tr, cols.at((size_t)o_perm * n), 2 * L, true, side ? std::function<int()>([&]() { return side_ntt(o_perm, 2 * L, ev_ready[1]); }) : nullptr, L));
     }
     mark(1);
     const Fe beta = tr->squeeze();
@@ -1181,7 +1192,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         if (!tr->write_point(rand_point)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
     } else {
         if (device_rng) TRY(device_draw(cols.at((size_t)o_rand * n), ms));
-        else HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), rand_host.data(), n * 32, hipMemcpyHostToDevice, ms));
+        else HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), rand_pin, n * 32, hipMemcpyHostToDevice, ms));
         TRY(commit(tr, cols.at((size_t)o_rand * n), 1, false));
     }
     mark(3);

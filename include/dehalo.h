@@ -217,6 +217,11 @@ int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, cons
  * range lookups of the reference's circuit compress the same (tag, value) table expressions: one sort per proof instead of five). */
 int dehalo_permute_expression_pair_ptrs_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
                                                uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, void* stream);
+/* The same without the synchronisation: d_status (DEVICE, `batch` int32) receives one flag per lookup -- non-zero: an input value is not in the table, the call
+ * above would have returned DEHALO_ERR_NOT_IN_TABLE -- for the caller to read back with whatever it reads next (the prover: with the permuted columns' commitments),
+ * so that the stream runs from the permutation straight into the commitment. */
+int dehalo_permute_expression_pair_ptrs_deferred_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows,
+                                                        size_t batch, uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int32_t* d_status, void* stream);
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]);
 int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
                                   const uint64_t point[4], uint64_t* d_out, void* stream);

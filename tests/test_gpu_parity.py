@@ -803,6 +803,15 @@ def test_permute_expression_pair_shared_tables_and_odd_sizes(pkg, co, ctx):
         ctx.permute_expression_pair_ptrs_device(fid, [d_g.data_ptr(), d_b.data_ptr()], [d_t.data_ptr(), d_t.data_ptr()], n, [o[0].data_ptr(), o[1].data_ptr()],
                                                 [o[2].data_ptr(), o[3].data_ptr()], 0)
     assert e.value.code == -6
+    # the same call without its synchronisation: one flag per lookup on the device, the good lookup's columns as they should be
+    status = torch.full((2,), 7, dtype=torch.int32, device="cuda")
+    ctx.permute_expression_pair_ptrs_deferred_device(fid, [d_g.data_ptr(), d_b.data_ptr()], [d_t.data_ptr(), d_t.data_ptr()], n, [o[0].data_ptr(), o[1].data_ptr()],
+                                                     [o[2].data_ptr(), o[3].data_ptr()], status.data_ptr(), 0)
+    ctx.synchronize()
+    st = status.cpu().numpy()
+    assert st[0] == 0 and st[1] != 0
+    want = co.permute_expression_pair(fid, good, table, n)
+    assert np.array_equal(o[0].cpu().numpy().view(np.uint64), want[0]) and np.array_equal(o[2].cpu().numpy().view(np.uint64), want[1])
     with pytest.raises(pkg.DehaloError):      # an output aliasing an input is refused
         ctx.permute_expression_pair_ptrs_device(fid, [d_g.data_ptr()], [d_t.data_ptr()], n, [d_g.data_ptr()], [o[2].data_ptr()], 0)
 

@@ -271,6 +271,11 @@ def test_native_transcript_continues_across_proofs(pkg, po, ctx, chain, native_c
     P.release()
 
 
+def plonk_mod(pkg):
+    from dehalo2_amd import plonk
+    return plonk
+
+
 @pytest.mark.gpu
 def test_native_device_advice_and_instances(pkg, po, ctx, chain, native_chain):
     """advice as a device tensor; upstream's InvalidInstances / InstanceTooLarge; one wrong witness cell -> rejected proof."""
@@ -291,6 +296,20 @@ def test_native_device_advice_and_instances(pkg, po, ctx, chain, native_chain):
     adv = c["adv"].copy()
     adv[1, arith_row(c)] = pkg.fields.BN254_FR.encode(987654321)
     assert not oracle_verify(po, c, P.create_proof(adv, [[]], prover.SeededRng(7)).finalize(), 6)
+    P.release()
+    # a range-checked cell holding a value that is not in the table: upstream's permute_expression_pair returns Err(ConstraintSystemFailure) -- here
+    # the flag travels back with the permuted columns' commitments (no synchronisation of its own) and fails the call just the same
+    c, d = chain(9, True), native_chain(9, True)
+    P = native.Prover(d["params"], d["pk"])
+    fixed = c["circ"].fixed
+    row = next(r for r in range(c["circ"].used_rows) if np.any(fixed[plonk_mod(pkg).RC_S_COMPOSITION][r]))
+    adv = c["adv"].copy()
+    adv[0, row] = pkg.fields.BN254_FR.encode(0x1234567)
+    with pytest.raises(pkg.DehaloError) as e:
+        P.create_proof(adv, [[]], prover.SeededRng(7))
+    assert e.value.code == -6 and "not in the table" in str(e.value)
+    want, _ = oracle_proof(po, c)
+    assert P.create_proof(c["adv"], [[]], prover.SeededRng(7)).finalize() == want      # and the prover is usable afterwards
     P.release()
 
 
