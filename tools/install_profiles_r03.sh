@@ -8,7 +8,7 @@ cp $F/k1/k1_kernel_stats.csv profiles/${r}_kernel_stats_timed_region.csv
 cp $F/bench_timed_region_under_rocprof.json profiles/${r}_bench_timed_region_4_in_flight_under_rocprof.json
 cp $F/kt/kt_kernel_stats.csv profiles/${r}_kernel_stats_timed_region_4_in_flight.csv
 cp $F/kp/kp_kernel_stats.csv profiles/${r}_kernel_stats_create_proof_k17.csv
-for f in create_proof_k17_phases_under_rocprof.txt create_proof_k17_kernel_timeline.txt create_proof_k17_phases.txt create_proof_k17_host_timeline.txt create_proof_k11_phases.txt create_proof_k11_host_timeline.txt \
+for f in create_proof_k17_phases_under_rocprof.txt create_proof_k17_kernel_timeline.txt create_proof_k17_device_idle.txt create_proof_k17_phases.txt create_proof_k17_host_timeline.txt create_proof_k11_phases.txt create_proof_k11_host_timeline.txt \
          batch_throughput_by_provers.txt batch_busy_fraction.txt native_vs_python_k17.txt stream_concurrency.txt ubench_mfma_price.txt pmc_calib.txt ubench_chain.txt ntt_bench.txt clock_ramp.txt; do
   grep -v 'amdgpu.ids' $F/$f > profiles/${r}_$f || true
 done

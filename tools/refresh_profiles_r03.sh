@@ -10,6 +10,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/k
 echo "[3] kernel stats, dehalo_create_proof k=17"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kp -o kp -- python3 tools/profile_native_proof.py 17 delay_enc 40 > $out/create_proof_k17_phases_under_rocprof.txt 2> $out/kp.err
 python3 tools/timeline.py $out/kp/kp_kernel_trace.csv > $out/create_proof_k17_kernel_timeline.txt
+python3 tools/proof_gaps.py $out/kp/kp_kernel_trace.csv > $out/create_proof_k17_device_idle.txt
 echo "[3b] dehalo_create_proof k=17 and K=11, unprofiled"
 timeout -k 10 300 python tools/profile_native_proof.py 17 delay_enc 40 > $out/create_proof_k17_phases.txt 2> $out/create_proof_k17_host_timeline.txt
 timeout -k 10 300 python tools/profile_native_proof.py 11 pose_enc 40 > $out/create_proof_k11_phases.txt 2> $out/create_proof_k11_host_timeline.txt
