@@ -1,5 +1,6 @@
 #!/bin/bash
-# bucket reduction: quads against one lane per 4-bucket block, by batch size (DEHALO_MSM_RED_QUAD_MAX = lanes up to which the quad form runs)
+# bucket reduction: quads against one lane per 4-bucket block, by batch size.  NOTE: needs a build of msm.cuh that reads DEHALO_MSM_RED_QUAD_MAX (the lanes up to which the quad
+# form runs) in place of its fixed threshold -- the experiment of profiles/r03_bucket_reduction_quads_vs_lanes.txt; the shipped library ignores the variable.
 export TMPDIR=/tmp
 for b in 4 6 7 8 10 12; do
 for q in 0 1000000; do
