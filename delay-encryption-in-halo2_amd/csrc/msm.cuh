@@ -773,14 +773,14 @@ __global__ __launch_bounds__(MSM_MERGE_THREADS) void k_msm_merge_all(const u32* 
 // dependent additions / doublings on an otherwise idle chip): then every group operation is
 // quad-cooperative (ec29.cuh).  With many groups (large batches) the lanes are better spent one
 // per block (QUAD = false): quads trade 1.6x the work for 2.4x less latency.
-template <class CV, bool QUAD>
+template <class CV, bool QUAD, int RM>
 __global__ __launch_bounds__(MSM_RED_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    const u32 per_group = (nb + MSM_RED_M - 1) / MSM_RED_M;
+    const u32 per_group = (nb + RM - 1) / RM;
     u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
     if (gid >= per_group * total_groups) return;
     u32 grp = gid / per_group, t = gid % per_group;
-    u32 k0 = t * MSM_RED_M, k1 = min(k0 + MSM_RED_M, nb);
+    u32 k0 = t * RM, k1 = min(k0 + RM, nb);
     const xyzz29_rec* B = buckets + (u64)grp * nb;
     // (always_inline: left to itself hipcc emits these lambdas as real functions whose 36-word point
     // arguments travel through scratch memory -- ~230 scratch accesses per group operation)
@@ -1067,15 +1067,26 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
                 rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, only);
             if (only <= 0) break;
         }
-        // bucket reduction
-        uint64_t nblocks4 = (uint64_t)per_group * total_groups;       // 4-bucket blocks
-        if (nblocks4 * 4 <= 192 * 1024) {   // <= ~3 waves per SIMD at 4 lanes per block (two rounds of resident quads still beat one lane per block: 0.58 -> 0.28 ms for a batch of ten 2^17 MSMs)
-            k_msm_reduce_local<CV, true><<<(u32)((nblocks4 * 4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS), MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+        // bucket reduction: RM = 4 buckets per quad while the quad-waves have a SIMD each (4 columns at c = 15), 8 from there on -- half the quads, each with
+        // a chain 5 additions longer (14 + 11 doublings + <= 12 additions against 6 + 12 + <= 13), and the double-and-add weighting, most of the work,
+        // done once per 8 buckets: 2^17 x 5 / 7 / 10 columns 136 / 137 / 201 -> 105 / 107 / 178 us (3 or 4 columns: 86 -> 104, so they keep 4); batch mode
+        // 141 -> 144 proofs/s (DEHALO_MSM_RED_M=4 / 8 forces one, for A/B measurements)
+        static const int red_m_env = [] { const char* e = getenv("DEHALO_MSM_RED_M"); return e ? atoi(e) : 0; }();
+        const uint64_t quads4 = (uint64_t)((g.nb + 3) / 4) * total_groups;
+        const u32 red_m = red_m_env == 4 || red_m_env == 8 ? (u32)red_m_env : (quads4 * 4 > 65536 ? 8u : 4u);
+        const u32 per_group_r = (g.nb + red_m - 1) / red_m;
+        uint64_t nblocks4 = (uint64_t)per_group_r * total_groups;       // RM-bucket blocks
+        if (quads4 * 4 <= 192 * 1024) {   // <= ~3 waves per SIMD at 4 lanes per block (two rounds of resident quads still beat one lane per block: 0.58 -> 0.28 ms for a batch of ten 2^17 MSMs)
+            const u32 grid = (u32)((nblocks4 * 4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS);
+            if (red_m == 8) k_msm_reduce_local<CV, true, 8><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+            else k_msm_reduce_local<CV, true, 4><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
         } else {
-            k_msm_reduce_local<CV, false><<<(u32)((nblocks4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS), MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+            const u32 grid = (u32)((nblocks4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS);
+            if (red_m == 8) k_msm_reduce_local<CV, false, 8><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
+            else k_msm_reduce_local<CV, false, 4><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
         }
         const xyzz29_rec* cur = contrib;
-        u32 cnt = per_group;
+        u32 cnt = per_group_r;
         xyzz29_rec* bufs[2] = {tree, contrib};  // ping-pong: contrib is free once consumed
         int which = 0;
         bool emitted = false;

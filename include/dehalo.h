@@ -76,6 +76,7 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
  *   DEHALO_WINDOW_BITS      Pippenger window of tables registered with window_bits = 0 (4 .. 16)
  *   DEHALO_MSM_ACC_LDS      bytes of (unused) dynamic LDS per block of the bucket accumulation: caps its resident blocks per CU
  *   DEHALO_MSM_MERGE_SPLIT  1: the merge of partial sums runs one launch per bucket class (a kernel trace then shows each class's time)
+ *   DEHALO_MSM_RED_M        4 / 8: buckets per quad of the bucket reduction (default: 4 up to four 2^15-bucket columns in a launch, 8 beyond)
  *   DEHALO_NTT_SKIP         0: the first pass of a zero-padded transform (input <= N / 4) runs its two copy stages like any other
  *   DEHALO_PROVER_TRACE     dehalo_create_proof writes the host's timeline inside the phases to stderr                                        */
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
