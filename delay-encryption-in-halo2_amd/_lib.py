@@ -18,7 +18,7 @@ SYMBOLS = [
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
     "dehalo_intt_scaled_device", "dehalo_lagrange_to_coeff_device", "dehalo_coset_ntt_device", "dehalo_coset_intt_device",
     "dehalo_field_op", "dehalo_field_op_device", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
-    "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_eval_polynomial_multi_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
+    "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_eval_polynomial_multi_device", "dehalo_eval_polynomial_multi_masked_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device", "dehalo_permute_expression_pair_ptrs_device", "dehalo_permute_expression_pair_ptrs_deferred_device",
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
@@ -171,6 +171,8 @@ def load_library():
     lib.dehalo_eval_polynomial.argtypes = [P, C.c_int, u64p, sz, u64p, u64p]
     lib.dehalo_eval_polynomial_device.argtypes = [P, C.c_int, u64p, sz, sz, sz, u64p, u64p, P]
     lib.dehalo_eval_polynomial_multi_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), sz, sz, u64p, u32, u64p, P]
+    if hasattr(lib, "dehalo_eval_polynomial_multi_masked_device"):
+        lib.dehalo_eval_polynomial_multi_masked_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), sz, sz, u64p, u32, C.c_char_p, u64p, P]
     lib.dehalo_batch_invert.argtypes = [P, C.c_int, u64p, sz]
     lib.dehalo_batch_invert_device.argtypes = [P, C.c_int, u64p, sz, P]
     lib.dehalo_prefix_product_device.argtypes = [P, C.c_int, u64p, sz, u64p, P]
@@ -465,11 +467,16 @@ class Context:
     def eval_polynomial_device(self, field: int, d_coeffs: int, length: int, stride: int, batch: int, point, d_out: int, stream: int = 0):
         self._check(self.lib.dehalo_eval_polynomial_device(self.handle, field, d_coeffs, length, stride, batch, _ptr(_u64(point, 4)), d_out, stream or None))
 
-    def eval_polynomial_multi_device(self, field: int, d_polys: Sequence[int], length: int, points, d_out: int, stream: int = 0):
-        """d_out[point][polynomial] for device polynomial pointers (length coefficients each) and 1..4 points (k x 4 u64, host)."""
+    def eval_polynomial_multi_device(self, field: int, d_polys: Sequence[int], length: int, points, d_out: int, stream: int = 0, wanted: Optional[Sequence[int]] = None):
+        """d_out[point][polynomial] for device polynomial pointers (length coefficients each) and 1..4 points (k x 4 u64, host).  `wanted`: one
+        bit mask per polynomial (bit i = point i); the pairs nobody wants are written as zero and skipped."""
         pts = _u64(points, 4)
         tbl = (C.c_void_p * max(1, len(d_polys)))(*d_polys)
-        self._check(self.lib.dehalo_eval_polynomial_multi_device(self.handle, field, tbl, len(d_polys), length, _ptr(pts), pts.shape[0], d_out, stream or None))
+        if wanted is None:
+            self._check(self.lib.dehalo_eval_polynomial_multi_device(self.handle, field, tbl, len(d_polys), length, _ptr(pts), pts.shape[0], d_out, stream or None))
+        else:
+            assert len(wanted) == len(d_polys)
+            self._check(self.lib.dehalo_eval_polynomial_multi_masked_device(self.handle, field, tbl, len(d_polys), length, _ptr(pts), pts.shape[0], bytes(wanted), d_out, stream or None))
 
     def batch_invert(self, field: int, values) -> np.ndarray:
         v = np.array(values, dtype=np.uint64).reshape(-1, 4)

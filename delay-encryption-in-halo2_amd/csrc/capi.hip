@@ -145,8 +145,9 @@ int do_eval_poly(dehalo_ctx* ctx, int field, const fe* c, uint64_t len, uint64_t
     FIELD_SWITCH(ctx, field, CALL)
 #undef CALL
 }
-int do_eval_poly_multi(dehalo_ctx* ctx, int field, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s) {
-#define CALL(N) eval_poly_multi_##N(ctx, polys, count, len, pts, npts, out, s)
+int do_eval_poly_multi(dehalo_ctx* ctx, int field, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s,
+                       const uint8_t* masks = nullptr) {
+#define CALL(N) eval_poly_multi_##N(ctx, polys, count, len, pts, npts, out, s, masks)
     FIELD_SWITCH(ctx, field, CALL)
 #undef CALL
 }
@@ -822,6 +823,11 @@ int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_
 
 int dehalo_eval_polynomial_multi_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_polys, size_t count, size_t len, const uint64_t* points,
                                         uint32_t num_points, uint64_t* d_out, void* stream) {
+    return dehalo_eval_polynomial_multi_masked_device(ctx, field, d_polys, count, len, points, num_points, nullptr, d_out, stream);
+}
+
+int dehalo_eval_polynomial_multi_masked_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_polys, size_t count, size_t len, const uint64_t* points,
+                                               uint32_t num_points, const uint8_t* wanted, uint64_t* d_out, void* stream) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((count && !d_polys) || !points || !d_out) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial_multi: null argument");
     for (size_t j = 0; j < count; j++)
@@ -830,7 +836,7 @@ int dehalo_eval_polynomial_multi_device(dehalo_ctx* ctx, int field, const uint64
     if (count >= 65536) return dh_fail(ctx, DEHALO_ERR_INVALID, "eval_polynomial_multi: too many polynomials");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
-    return do_eval_poly_multi(ctx, field, (const fe* const*)d_polys, count, len, points, num_points, (fe*)d_out, pick_stream(ctx, stream));
+    return do_eval_poly_multi(ctx, field, (const fe* const*)d_polys, count, len, points, num_points, (fe*)d_out, pick_stream(ctx, stream), wanted);
 }
 
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]) {

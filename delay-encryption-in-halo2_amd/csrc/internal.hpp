@@ -184,7 +184,7 @@ DECL_NTT(pasta_fq)
 // field-vector primitives (poly.cuh), instantiated in the same per-field translation units
 #define DECL_POLY(NAME)                                                                                                                     \
     int eval_poly_##NAME(dehalo_ctx* ctx, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s); \
-    int eval_poly_multi_##NAME(dehalo_ctx* ctx, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s); \
+    int eval_poly_multi_##NAME(dehalo_ctx* ctx, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s, const uint8_t* masks); \
     int batch_invert_##NAME(dehalo_ctx* ctx, fe* v, uint64_t len, hipStream_t s);                                                           \
     int prefix_product_##NAME(dehalo_ctx* ctx, const fe* in, uint64_t len, fe* out, hipStream_t s);                                         \
     int grand_product_##NAME(dehalo_ctx* ctx, const fe* num, const fe* den, uint64_t len, size_t batch, uint64_t stride, fe* z, hipStream_t s); \

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(POLY_THREADS) void k_poly_pow_table(MultiPoints P, 
 }
 
 #define POLY_MP_POLYS 96
-struct PolyPtrs { const fe* p[POLY_MP_POLYS]; };
+struct PolyPtrs { const fe* p[POLY_MP_POLYS]; unsigned char m[POLY_MP_POLYS]; };      // m: bit i = this polynomial is wanted at point i
 template <class F>
 __global__ __launch_bounds__(POLY_THREADS) void k_poly_eval_multi(PolyPtrs polys, const fe* coeffs, u64 len, u64 stride, u64 point_stride, u32 npts, const fe* point_ptr,
                                                                   const fe* pw, fe* partials, u64 partial_stride, u64 partial_point_stride) {
@@ -164,20 +164,27 @@ __global__ __launch_bounds__(POLY_THREADS) void k_poly_eval_multi(PolyPtrs polys
         acc[ip] = f29_zero();
     }
     const fe* c0 = coeffs ? coeffs + (u64)blockIdx.y * stride : polys.p[blockIdx.y];       // level 0: one device pointer per polynomial
+    const u32 want = polys.m[blockIdx.y];                                                   // (uniform in the block) points nobody asked for are skipped
 #pragma unroll
     for (int j = POLY_EVAL_EPT - 1; j >= 0; j--) {
         const bool in = base + j < len;
         // level >= 1: every point has its own partial sums (point_stride apart); level 0: one coefficient array for all points
-        f29 cj = in ? f29_unpack(f_load(&c0[base + j])) : f29_zero();
+        f29 cj = in && !point_stride ? f29_unpack(f_load(&c0[base + j])) : f29_zero();
 #pragma unroll
         for (int ip = 0; ip < POLY_MP_MAX; ip++) {
-            if (point_stride && ip) cj = in && (u32)ip < P.count ? f29_unpack(f_load(&c0[(u64)ip * point_stride + base + j])) : f29_zero();
+            if (!((want >> ip) & 1)) continue;
+            if (point_stride) cj = in ? f29_unpack(f_load(&c0[(u64)ip * point_stride + base + j])) : f29_zero();
             acc[ip] = f29_add(f29_mul<F9>(acc[ip], x[ip]), cj);
         }
     }
 #pragma unroll
     for (int ip = 0; ip < POLY_MP_MAX; ip++) {
         if ((u32)ip >= P.count) break;
+        fe* out = &partials[(u64)ip * partial_point_stride + (u64)blockIdx.y * partial_stride + blockIdx.x];
+        if (!((want >> ip) & 1)) {
+            if (t == 0) f_store(out, f_zero());
+            continue;
+        }
         f29 term = f29_mul<F9>(f29_norm(acc[ip]), f29_unpack(f_load(&pw[ip * POLY_THREADS + t])));     // < 2p
         __syncthreads();                                     // the previous point's sums have been read
         sh[t] = term;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(POLY_THREADS) void k_poly_eval_multi(PolyPtrs polys
         }
         if (t == 0) {
             f29 r = f29_mul<F9>(sh[0], f29_one<F9>());
-            f_store(&partials[(u64)ip * partial_point_stride + (u64)blockIdx.y * partial_stride + blockIdx.x], f29_pack(f29_cond_sub(r, F9::P)));
+            f_store(out, f29_pack(f29_cond_sub(r, F9::P)));
         }
     }
 }
@@ -555,7 +562,8 @@ int eval_poly_t(dehalo_ctx* ctx, const fe* d_coeffs, uint64_t len, uint64_t stri
 // out[pt][poly] = poly_j(points[pt]) for `count` polynomials given by device pointers (len coefficients each) and npts <= POLY_MP_MAX
 // points: one table kernel for every level, then one pass per level
 template <class F>
-int eval_poly_multi_t(dehalo_ctx* ctx, const fe* const* d_polys, size_t count, uint64_t len, const uint64_t* points, uint32_t npts, fe* d_out, hipStream_t s) {
+int eval_poly_multi_t(dehalo_ctx* ctx, const fe* const* d_polys, size_t count, uint64_t len, const uint64_t* points, uint32_t npts, fe* d_out, hipStream_t s,
+                      const uint8_t* masks) {
     if (count == 0 || npts == 0) return 0;
     if (len == 0) {
         HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)npts * count * sizeof(fe), s));
@@ -586,16 +594,18 @@ int eval_poly_multi_t(dehalo_ctx* ctx, const fe* const* d_polys, size_t count, u
         const uint64_t dst_pstride = last ? count : count * nb;       // d_out is [pt][poly]; scratch is [pt][poly][block]
         const fe* lp = lvl_pts + level * POLY_MP_MAX;
         const fe* lpw = pw + (uint64_t)level * POLY_MP_MAX * POLY_THREADS;
-        if (level == 0) {
-            for (size_t first = 0; first < count; first += POLY_MP_POLYS) {
-                PolyPtrs pp{};
-                const size_t cnt = std::min<size_t>(POLY_MP_POLYS, count - first);
+        // (masks: which points each polynomial is wanted at -- a proof asks for 60 of its 47 x 4 values; the others are written as zero)
+        for (size_t first = 0; first < count; first += POLY_MP_POLYS) {
+            PolyPtrs pp{};
+            const size_t cnt = std::min<size_t>(POLY_MP_POLYS, count - first);
+            for (size_t j = 0; j < cnt; j++) pp.m[j] = masks ? masks[first + j] : 0xf;
+            if (level == 0) {
                 for (size_t j = 0; j < cnt; j++) pp.p[j] = d_polys[first + j];
                 k_poly_eval_multi<F><<<dim3((u32)nb, (u32)cnt), POLY_THREADS, 0, s>>>(pp, nullptr, cur_len, 0, 0, npts, lp, lpw, dst + first * (last ? 1 : nb), last ? 1 : nb, dst_pstride);
+            } else {
+                k_poly_eval_multi<F><<<dim3((u32)nb, (u32)cnt), POLY_THREADS, 0, s>>>(pp, cur + first * cur_len, cur_len, cur_len, count * cur_len, npts, lp, lpw, dst + first * (last ? 1 : nb),
+                                                                                          last ? 1 : nb, dst_pstride);
             }
-        } else {
-            PolyPtrs pp{};
-            k_poly_eval_multi<F><<<dim3((u32)nb, (u32)count), POLY_THREADS, 0, s>>>(pp, cur, cur_len, cur_len, count * cur_len, npts, lp, lpw, dst, last ? 1 : nb, dst_pstride);
         }
         HIP_TRY(ctx, hipGetLastError());
         cur = dst; cur_len = nb;
@@ -755,8 +765,9 @@ int kate_division_t(dehalo_ctx* ctx, const fe* d_a, uint64_t len, const uint64_t
 #define DEFINE_POLY_ENTRY(NAME, F)                                                                                                              \
     int eval_poly_##NAME(dehalo_ctx* ctx, const fe* c, uint64_t len, uint64_t stride, size_t batch, const uint64_t pt[4], fe* out, hipStream_t s) { \
         return eval_poly_t<F>(ctx, c, len, stride, batch, pt, out, s); }                                                                         \
-    int eval_poly_multi_##NAME(dehalo_ctx* ctx, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s) { \
-        return eval_poly_multi_t<F>(ctx, polys, count, len, pts, npts, out, s); }                                                            \
+    int eval_poly_multi_##NAME(dehalo_ctx* ctx, const fe* const* polys, size_t count, uint64_t len, const uint64_t* pts, uint32_t npts, fe* out, hipStream_t s, \
+                               const uint8_t* masks) {                                                                                                             \
+        return eval_poly_multi_t<F>(ctx, polys, count, len, pts, npts, out, s, masks); }                                                     \
     int batch_invert_##NAME(dehalo_ctx* ctx, fe* v, uint64_t len, hipStream_t s) { return batch_invert_t<F>(ctx, v, len, s); }                    \
     int prefix_product_##NAME(dehalo_ctx* ctx, const fe* in, uint64_t len, fe* out, hipStream_t s) {                                             \
         return prefix_product_t<F>(ctx, in, len, nullptr, 0, len, 1, out, len, s); }                                                             \

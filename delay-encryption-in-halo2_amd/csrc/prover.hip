@@ -629,6 +629,7 @@ struct dehalo_prover {
     std::vector<int32_t> rots;
     std::vector<const uint64_t*> plist;
     std::vector<int64_t> write_idx;
+    std::vector<uint8_t> eval_wanted;      // per polynomial of plist: the rotations (bits, in `rots` order) anyone reads its value at
     struct Group { int32_t rot; std::vector<const uint64_t*> ptrs; std::vector<int64_t> idx; };
     std::vector<Group> groups;
     std::vector<const uint64_t*> hp_ptrs;
@@ -779,6 +780,11 @@ struct dehalo_prover {
         if (groups.size() > 4) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "more opening points than the prover's buffers hold");
         hpiece0 = (size_t)idx(b_hp, 0, 0);
         eval_count = rots.size() * ntot;
+        eval_wanted.assign(ntot, 0);
+        auto want = [&](int64_t i) { if (i >= 0) eval_wanted[(size_t)i % ntot] |= (uint8_t)(1u << ((size_t)i / ntot)); };
+        for (int64_t i : write_idx) want(i);
+        for (auto& g : groups) for (int64_t i : g.idx) want(i);
+        for (uint32_t i = 0; i < pieces; i++) want((int64_t)hpiece0 + i);                // the pieces of h at x: the folded quotient's value
         return 0;
     }
 
@@ -1275,7 +1281,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     // ---- evaluations, in upstream's order: every opened polynomial at every rotation in ONE call
     std::vector<Fe> point(rots.size());
     for (size_t i = 0; i < rots.size(); i++) point[i] = d.rotate_omega(x, rots[i]);
-    TRY(dehalo_eval_polynomial_multi_device(ctx, fid, plist.data(), plist.size(), n, (const uint64_t*)point.data(), (uint32_t)rots.size(), evals.u64(), nullptr));
+    TRY(dehalo_eval_polynomial_multi_masked_device(ctx, fid, plist.data(), plist.size(), n, (const uint64_t*)point.data(), (uint32_t)rots.size(), eval_wanted.data(), evals.u64(), nullptr));
     // the folded quotient h(X) = sum_i x^(n i) h_i(X) (opened below; its value at x comes from the pieces' values)
     std::vector<Fe> xs(pieces);
     {

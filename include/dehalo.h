@@ -231,6 +231,10 @@ int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_
  * d_out[point][polynomial][4]. */
 int dehalo_eval_polynomial_multi_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_polys, size_t count, size_t len, const uint64_t* points,
                                         uint32_t num_points, uint64_t* d_out, void* stream);
+/* The same for a caller that needs only some (polynomial, point) pairs: wanted[j] (host, one byte per polynomial; NULL = everything) has bit i set when polynomial j
+ * is wanted at point i.  The other entries of d_out are written as zero and cost nothing (a proof asks for about 60 of its 47 x 4 values). */
+int dehalo_eval_polynomial_multi_masked_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_polys, size_t count, size_t len, const uint64_t* points,
+                                               uint32_t num_points, const uint8_t* wanted, uint64_t* d_out, void* stream);
 int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len);
 int dehalo_batch_invert_device(dehalo_ctx* ctx, int field, uint64_t* d_values, size_t len, void* stream);
 int dehalo_prefix_product_device(dehalo_ctx* ctx, int field, const uint64_t* d_in, size_t len, uint64_t* d_out, void* stream);

@@ -347,6 +347,16 @@ def test_eval_polynomial_multi_vs_oracle(pkg, co, ctx, n, fname):
         for i in range(npts):
             for b in range(batch):
                 assert np.array_equal(got[i, b], co.eval_polynomial(f.id, cols[b], pts[i], 2)), (n, npts, i, b)
+        # only some (polynomial, point) pairs wanted (a proof's case): those are the same values, the others come back as zero
+        wanted = [(0b1011, 0b0000, 0b0100, 0b1111, 0b0001)[b] & ((1 << npts) - 1) for b in range(batch)]
+        out2 = torch.full((npts, batch, 4), -1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.eval_polynomial_multi_device(f.id, [d[b].data_ptr() for b in range(batch)], n, pts[:npts], out2.data_ptr(), wanted=wanted)
+        ctx.synchronize()
+        got2 = out2.cpu().numpy().view(np.uint64)
+        for i in range(npts):
+            for b in range(batch):
+                assert np.array_equal(got2[i, b], got[i, b] if (wanted[b] >> i) & 1 else np.zeros(4, np.uint64)), (n, npts, i, b)
 
 
 @pytest.mark.gpu
