@@ -49,6 +49,13 @@ struct DevMem {
     uint64_t* u64(size_t elem = 0) const { return (uint64_t*)(p + elem); }
 };
 
+// the blinding rows of a phase's columns: column c gets `rows` elements at dst + c * dst_pitch from src + c * rows (a 2-D device copy through the
+// runtime took 10-45 us for these few hundred bytes on the proving thread's stream, right before the phase's commitment)
+__global__ void k_place_rows(fe* __restrict__ dst, uint64_t dst_pitch, const fe* __restrict__ src, uint32_t rows, uint32_t ncols) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * ncols) dst[(uint64_t)(i / rows) * dst_pitch + i % rows] = src[i];
+}
+
 __global__ void k_gather_elems(const fe* __restrict__ src, const uint64_t* __restrict__ idx, fe* __restrict__ dst, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = src[idx[i]];
@@ -1052,7 +1059,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, (flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                 ms));
     if (flags & DEHALO_PROOF_ADVICE_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, cols.u64((size_t)o_adv * n), nullptr, cols.u64((size_t)o_adv * n), (size_t)A * n, nullptr));
-    if (A) HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_adv * n + u), n * 32, bl_adv, rows * 32, rows * 32, A, hipMemcpyDeviceToDevice, ms));
+    if (A) k_place_rows<<<(unsigned)((rows * A + 255) / 256), 256, 0, ms>>>(cols.at((size_t)o_adv * n + u), n, bl_adv, (uint32_t)rows, A);
     if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[0], ms));
 
     // pointer tables of the phases
@@ -1106,7 +1113,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         TRY(dehalo_graph_evaluate_batch_device(ctx, graphs.data(), (uint32_t)graphs.size(), &e.in, k, 1, outs.data(), nullptr));
         tk("compress queued");
         // the blinding rows [u, n) first: the permutation writes rows [0, u) only and ends with a read-back
-        HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_perm * n + u), n * 32, bl_perm, rows * 32, rows * 32, 2 * L, hipMemcpyDeviceToDevice, ms));
+        k_place_rows<<<(unsigned)((rows * 2 * L + 255) / 256), 256, 0, ms>>>(cols.at((size_t)o_perm * n + u), n, bl_perm, (uint32_t)rows, 2 * L);
         std::vector<const uint64_t*> pin, ptab;
         std::vector<uint64_t*> pout_in, pout_tab;
         for (uint32_t l = 0; l < L; l++) {
@@ -1161,7 +1168,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         for (uint32_t s = 1; s < S; s++)      // z_s starts where z_{s-1} ended: z = vec![last_z]
             TRY(dehalo_scale_device(ctx, fid, cols.u64((size_t)(o_pz + s) * n), n, nullptr, 0, cols.u64((size_t)(o_pz + s - 1) * n + u), nullptr));
         // per column: bf blinding rows (n - bf .. n)
-        HIP_TRY(ctx, hipMemcpy2DAsync(cols.at((size_t)o_pz * n + (n - bf)), n * 32, bl_prod, (size_t)bf * 32, (size_t)bf * 32, S + L, hipMemcpyDeviceToDevice, ms));
+        k_place_rows<<<(unsigned)(((size_t)bf * (S + L) + 255) / 256), 256, 0, ms>>>(cols.at((size_t)o_pz * n + (n - bf)), n, bl_prod, bf, S + L);
         if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[2], ms));
         auto after_products_queued = [&]() -> int {
             TRY(side_ntt(o_pz, S + L, ev_ready[2]));
