@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves with the whole-rounds rule (0 = library default: msm_acc_points)")
     ap.add_argument("--preheat-s", type=float, default=1.0, help="untimed device work of the measured kind right before every warm-up + timed region (steps one at a time / "
                     "proofs), so that the region runs at the clocks of a busy prover instead of ramping up from idle after the host-side setup (0 = off)")
+    ap.add_argument("--in-process", action="store_true", help="measure in this process (always the case under torchrun and under a profiler); by default a one-GPU run "
+                    "measures in a child process and starts ONE more if that child is killed by a signal, see main()")
     ap.add_argument("--inflight", type=int, default=4, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
 
@@ -83,6 +85,14 @@ def preheat(fn, sync=None):
     if sync is not None:
         sync()
     return n
+
+
+def note(msg):
+    """progress on stderr (the JSON line on stdout stays the only stdout output): which section a long run -- or a failed one -- was in"""
+    print("[bench %.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
 
 
 def host_cores():
@@ -304,7 +314,9 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
     when there is one (asserted equal to the device's), otherwise against the device-made key."""
     from dehalo2_amd import prover
     threads = min(host_cores(), 256)
+    note("proof %s k = %d: setup" % (circuit, k))
     st = ProofSetup(pkg, ctx, k, circuit, threads)
+    note("proof %s k = %d: proving" % (circuit, k))
     proof = st.prove(7)
     preheat(lambda: st.prove(7))
     ts = []
@@ -314,7 +326,9 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
         ts.append(1e3 * (time.perf_counter() - t))
         assert again == proof, "the same witness, SRS and blinding gave different proof bytes"
     phases = st.prover.last_timings()
+    note("proof %s k = %d: end to end" % (circuit, k))
     e2e = end_to_end(st, proof)
+    note("proof %s k = %d: checks" % (circuit, k))
     cs = st.circ.cs
     n_evals = len(cs.advice_queries) + len(cs.fixed_queries) + 1 + len(cs.permutation_columns) + max(0, 3 * cs.num_permutation_sets() - 1) + 5 * len(cs.lookups)
     out = {"circuit": CIRCUIT_TEXT[circuit],
@@ -364,6 +378,7 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     the gathered blob to hold exactly that proof; rank 0 also puts one batch-made proof through the pairing check."""
     import torch
     from dehalo2_amd import native, prover, sharding
+    note("batch mode: setup")
     st = ProofSetup(pkg, ctx, k, "delay_enc", min(host_cores(), 256))
     mine = sharding.units_for_rank(total, rank, world)
     st.prove(1000)                                            # warm-up
@@ -373,6 +388,7 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     provers = [native.Prover(st.params, st.pk, c) for c in ctxs]
     preheat(lambda: native.create_proofs(provers, st.advice, [prover.SeededRng(999 - i) for i in range(2 * len(provers))]))      # warm-up of every prover's buffers, clocks up
     fence_all(world)
+    note("batch mode: timed region")
     t0 = time.perf_counter()
     full = native.create_proofs(provers, st.advice, [prover.SeededRng(1000 + unit) for unit in mine])          # every proof its own blinding
     blobs = [prover.proof_commitments(cs, pf) for pf in full]
@@ -382,6 +398,7 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
     assert len(allc) == total and all(len(b) == 32 * per for b in allc)
     checked = None
+    note("batch mode: checks")
     if check:
         for j, unit in enumerate(mine):                       # this rank's units, re-made alone: the gathered vector holds them at [unit]
             alone = st.prove(1000 + unit)
@@ -443,8 +460,30 @@ def fence_all(world):
         torch.cuda.synchronize()
 
 
+def under_profiler() -> bool:
+    return "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ)
+
+
+def supervise() -> int:
+    """One-GPU runs measure in a child process (nothing in this one has touched the GPU).  A child that dies by a signal -- seen once in this
+    round: `Memory access fault by GPU node` in one full run out of about ten, cause not found, DESIGN.md section 8 -- is replaced ONCE; the line
+    then carries "attempts": 2.  A child that exits by itself (any code) is final."""
+    import subprocess
+    for attempt in (1, 2):
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--in-process"], stdout=subprocess.PIPE, env=dict(os.environ, DEHALO_BENCH_ATTEMPT=str(attempt)))
+        out = p.stdout.decode()
+        if p.returncode >= 0 or attempt == 2:
+            sys.stdout.write(out)
+            sys.stdout.flush()
+            return p.returncode if p.returncode >= 0 else 128 - p.returncode
+        sys.stderr.write("[bench] the measuring process was killed by signal %d; its partial output is dropped and ONE more is started\n" % -p.returncode)
+    return 1
+
+
 def main():
     args = parse()
+    if not args.in_process and "RANK" not in os.environ and not under_profiler():
+        raise SystemExit(supervise())
     global PREHEAT_S
     PREHEAT_S = max(0.0, args.preheat_s)
     rank = int(os.environ.get("RANK", "0"))
@@ -536,6 +575,7 @@ def main():
         c.msm_device(bases, d_scalars.data_ptr(), n, 1, d_out_all[args.warmup + args.steps].data_ptr(), 0)
         c.ntt_device(field.id, d_polys[pre[0] % inflight].data_ptr(), log_n, omega, 1, 0)
         pre[0] += 1
+    note("steps: preheat, warm-up, timed region")
     preheat_steps = preheat(step_preheat, lambda: [c.synchronize() for c in ctxs]) if PREHEAT_S > 0 else 0
     for _ in range(args.warmup):
         step()
@@ -620,6 +660,7 @@ def main():
                         "what": "untimed, before the W warm-up steps: the same steps, dealt to the same contexts, for --preheat-s seconds, so that the timed region runs at a busy "
                                 "prover's clocks rather than ramping up from idle after the host-side setup (the proofs' and batch mode's regions are preceded "
                                 "by the same amount of untimed proofs); --preheat-s 0 switches it off"},
+            "attempts": int(os.environ.get("DEHALO_BENCH_ATTEMPT", "1")),      # 2: a first measuring process was killed by a signal (supervise())
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -662,6 +703,7 @@ def main():
         if ss["msm_accumulate"] > 0 and ss["ntt"] > 0:
             out["single_stream"]["valu_frac"] = {"k_msm_accum0": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (ss["msm_accumulate"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4),
                                                  "k_ntt_pass": round(ntt_muls * mads_per_mul / (ss["ntt"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4)}
+        note("roofline inputs, cpu baseline, secondary numbers")
         if world == 1 and not args.no_cpu_baseline:
             # the CPU port on rank 0's own inputs: the reported baseline AND the parity check of the measured 2^20 configuration
             out["cpu_baseline"], want_msm, want_ntt = cpu_baseline(co, po, curve, field, log_n, bases_h, scalars_h, poly_h)

@@ -6,7 +6,7 @@ rev=${1:?kernel revision (bench.py KERNEL_REV)}
 out=gpurun_out/pmc; rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/main_$c -- python3 bench.py --no-cpu-baseline --proof-k 0 --proofs 0 --steps 5 --warmup 2 --preheat-s 0 > $out/main_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/main_$c -- python3 bench.py --in-process --no-cpu-baseline --proof-k 0 --proofs 0 --steps 5 --warmup 2 --preheat-s 0 > $out/main_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/calib_$c -- ./tools/pmc_calib > $out/calib_$c.log 2>&1
 done
 mkdir -p $out/main $out/calib

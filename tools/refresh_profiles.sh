@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
 echo "[1] bench line"; timeout -k 10 600 python bench.py > $out/bench.json 2> $out/bench.err
 echo "[2] kernel stats, timed region"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --no-single-stream --no-cpu-baseline --proof-k 0 --proofs 0 > $out/bench_timed_region_under_rocprof.json 2> $out/kt.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --in-process --no-single-stream --no-cpu-baseline --proof-k 0 --proofs 0 > $out/bench_timed_region_under_rocprof.json 2> $out/kt.err
 echo "[3] kernel stats, create_proof k=17"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kp -o kp -- python3 tools/profile_proof.py 17 1 10 > $out/create_proof_k17_phases_under_rocprof.txt 2> $out/kp.err
 python3 tools/timeline.py $out/kp/kp_kernel_trace.csv > $out/create_proof_k17_kernel_timeline.txt; rm -f $out/kp/kp_kernel_trace.csv $out/kt/kt_kernel_trace.csv
