@@ -13,19 +13,6 @@ namespace {
 
 hipStream_t pick_stream(dehalo_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
-// Caller buffers of the host entry points are ordinary pageable memory (a Rust Vec<F>): large ones are pinned for the duration of the
-// call so that the copy engine reads / writes them directly instead of going through the runtime's bounce buffers (measured on
-// MI355X, profiles/r02_host_path_measurements.txt: dehalo_ntt at 2^20, 32 MiB each way, 5.73 -> 1.35 ms).  Registration failing (already pinned, exotic mapping) just leaves the pageable path.
-struct HostPin {
-    void* p = nullptr;
-    HostPin(const void* ptr, size_t bytes) {
-        if (ptr && bytes >= HOST_PIN_MIN_BYTES && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
-        else (void)hipGetLastError();
-    }
-    ~HostPin() { if (p) (void)hipHostUnregister(p); }
-    static constexpr size_t HOST_PIN_MIN_BYTES = 4u << 20;
-};
-
 // Window bits by measurement on MI355X (tools/sweep_c.py, tools/profile_prover.py with WINDOW_BITS): the bucket
 // reduction costs ~ 2^(c-1) group operations on a latency chain, the accumulation n * ceil(256 / c) additions.
 // 2^20 and up: 16; 2^17 .. 2^19: 15; 2^10 .. 2^16: 13 (prover-shaped schedule at k = 14: 2.9 ms of MSMs with

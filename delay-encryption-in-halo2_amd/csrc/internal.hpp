@@ -12,6 +12,23 @@
 #include "../../include/dehalo.h"
 #include "ec.cuh"
 
+// Caller buffers of the host entry points are ordinary pageable memory (a Rust Vec<F>): large ones are pinned for the duration of the
+// call so that the copy engine reads / writes them directly instead of going through the runtime's bounce buffers (measured on
+// MI355X, profiles/r02_host_path_measurements.txt: dehalo_ntt at 2^20, 32 MiB each way, 5.73 -> 1.35 ms), and so that the lifetime of the device's mapping of
+// caller memory is this object's and nothing else's (the pin ends only after the stream that copies has been synchronised).  Registration failing (already
+// pinned, exotic mapping) just leaves the pageable path.
+struct HostPin {
+    void* p = nullptr;
+    HostPin(const void* ptr, size_t bytes) {
+        if (ptr && bytes >= HOST_PIN_MIN_BYTES && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
+        else (void)hipGetLastError();
+    }
+    HostPin(const HostPin&) = delete;
+    HostPin& operator=(const HostPin&) = delete;
+    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+    static constexpr size_t HOST_PIN_MIN_BYTES = 4u << 20;
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;

@@ -427,6 +427,7 @@ extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const
     TRY(pk->fixed_cosets.alloc(ctx, nf * m, false));
     pk->fixed_commitments.assign(8 * nf, 0);
     if (nf) {
+        HostPin pin_fixed(fixed, nf * n * 32);
         HIP_TRY(ctx, hipMemcpyAsync(pk->fixed_values.p, fixed, nf * n * 32, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (flags & DEHALO_KEYGEN_FIXED_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, pk->fixed_values.u64(), nullptr, pk->fixed_values.u64(), nf * n, nullptr));
@@ -452,6 +453,7 @@ extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const
             dj = pk->f->mul(dj, pk->f->delta);
         }
         HIP_TRY(ctx, hipMalloc((void**)&d_map, npc * n * 8));
+        HostPin pin_map(mapping, npc * n * 8);
         hipError_t e = hipMemcpyAsync(d_map, mapping, npc * n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             k_gather_elems<<<(unsigned)((npc * n + 255) / 256), 256, 0, ctx->stream>>>(ident.p, d_map, pk->perm_values.p, npc * n);
@@ -472,6 +474,7 @@ extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const
         TRY(vals.alloc(ctx, 3 * n, false));
         TRY(polys.alloc(ctx, 3 * n, false));
         TRY(pk->l_ext.alloc(ctx, 3 * m, false));
+        HostPin pin_lag(lag.data(), 3 * n * 32);
         HIP_TRY(ctx, hipMemcpyAsync(vals.p, lag.data(), 3 * n * 32, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         TRY(lagrange_to_all(pk.get(), params, vals.p, 3, polys.p, pk->l_ext.p, nullptr));
@@ -550,6 +553,7 @@ extern "C" int dehalo_pk_read(dehalo_ctx* ctx, int curve, const dehalo_constrain
     if (nf_file != nf) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: the key's number of fixed commitments differs from the circuit's fixed columns");
     pk->num_selectors = num_selectors;
     if (len != pk->size()) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: length does not match the circuit (unexpected end of input or trailing bytes)");
+    HostPin pin_blob(bytes, len);      // every polynomial below is copied straight out of the caller's blob
     const uint8_t* p = bytes + 8;
     pk->fixed_commitments.resize(8 * nf);
     memcpy(pk->fixed_commitments.data(), p, 64 * nf);
@@ -1056,6 +1060,13 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
 
     // ---- advice: witness, blinding rows, commitments
     if (!advice) return dh_fail(ctx, DEHALO_ERR_INVALID, "null advice");
+    // a host witness is pinned until this call returns (every stream has been synchronised by then); one that is page-locked already stays as it is
+    struct PinnedUpload {      // (the copy below is asynchronous: on every way out, wait for its stream before the pin goes)
+        HostPin pin;
+        hipStream_t s;
+        PinnedUpload(const void* ptr, size_t bytes, hipStream_t s_) : pin(ptr, bytes), s(s_) {}
+        ~PinnedUpload() { if (pin.p) (void)hipStreamSynchronize(s); }
+    } pin_advice((flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? nullptr : advice, (size_t)A * n * 32, ms);
     HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, (flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                 ms));
     if (flags & DEHALO_PROOF_ADVICE_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, cols.u64((size_t)o_adv * n), nullptr, cols.u64((size_t)o_adv * n), (size_t)A * n, nullptr));
