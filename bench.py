@@ -352,7 +352,7 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
         cpu_runs = {}
         for th in sorted({threads, min(threads, 32)}):
             t2 = time.time()
-            want, _ = PO.create_proof(st.ocurve, st.srs, key, adv, [[]], prover.SeededRng(7), rep, th)
+            want, _ = PO.create_proof(st.ocurve, st.srs, key, adv, [[]], PO.ScalarStream(7), rep, th)
             cpu_runs[th] = time.time() - t2
         best_th = min(cpu_runs, key=cpu_runs.get)
         t2, t3 = 0.0, cpu_runs[best_th]

@@ -237,6 +237,21 @@ def transcript_repr(curve: po.Curve, key: dict, selectors=()) -> int:
     return int.from_bytes(h.digest(), "little") % curve.scalar.p
 
 
+class ScalarStream:
+    """The checker's own reproducible source of "random" scalars (tests and bench only): numpy's PCG64 seeded with `seed`, four 64-bit outputs per
+    scalar, least-significant word first, the top word masked to 61 bits -- a raw 253-bit value, taken as a Montgomery representation (below all
+    four moduli).  create_proof consumes it in upstream's program order (one `Scheme::Scalar::random(&mut rng)` at a time, [UPSTREAM]
+    plonk/prover.rs); the product's seeded generators (Python and C++) have to produce this same stream for the proofs to be comparable byte for byte."""
+
+    def __init__(self, seed: int):
+        self.gen = np.random.Generator(np.random.PCG64(seed))
+
+    def scalars(self, count: int) -> np.ndarray:
+        a = self.gen.integers(0, 1 << 64, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 61) - 1)
+        return a
+
+
 # ---- create_proof ---------------------------------------------------------------------------------------------
 def create_proof(curve: po.Curve, srs, key: dict, advice_mont: np.ndarray, instances: Sequence[Sequence[int]], rng, vk_repr: int, threads: int = 1):
     """-> (proof bytes, trace) -- trace holds every commitment, challenge and evaluation in order, and h's coefficients.

@@ -186,7 +186,7 @@ def test_native_proof_matches_oracle_and_verifies(pkg, po, ctx, chain, native_ch
     assert not diff, "proof items differ from the oracle's: %r" % diff[:8]
     assert oracle_verify(po, c, proof, k)
     # the caller's generator has moved past the proof's draws, exactly as far as the CPU restatement moves it
-    ref = prover.SeededRng(7)
+    ref = PO.ScalarStream(7)
     oracle_proof_rng = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], ref, c["rep"], 16)[0]
     assert oracle_proof_rng == want and np.array_equal(rng.scalars(2), ref.scalars(2))
     side = pkg.Context(0)
@@ -436,7 +436,7 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
     P = native.Prover(params, pk, ctx, side)
     proof = P.create_proof(nat["advice"], [[]], prover.SeededRng(5), canonical=True).finalize()
     adv_m = np.stack([co.field_op(0, "to_mont", nat["advice"][i]) for i in range(5)])
-    want, _ = PO.create_proof(po.BN254, srs, key, adv_m, [[]], prover.SeededRng(5), rep, 16)
+    want, _ = PO.create_proof(po.BN254, srs, key, adv_m, [[]], PO.ScalarStream(5), rep, 16)
     assert proof == want
     assert V.verify_proof(po.BN254, cs.description(), k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(s, pr.G2), [[]], proof)
     assert P.create_proof(adv_m, [[]], prover.SeededRng(5)).finalize() == want              # Montgomery input, same proof

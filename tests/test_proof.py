@@ -46,7 +46,7 @@ def oracle_proof(po, c, seed=7, threads=8):
     import plonk_oracle as PO
     from dehalo2_amd import prover
 
-    return PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(seed), c["rep"], threads)
+    return PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(seed), c["rep"], threads)
 
 
 def oracle_verify(po, c, proof, k):
@@ -170,7 +170,7 @@ def test_oracle_rejects_unsatisfied_witness(po, co, chain):
     c = chain(6, False)
     adv = c["adv"].copy()
     adv[1, arith_row(c)] = PO.Fld(po.BN254.scalar).m(123456789)      # b of a row whose a * b term is switched on
-    proof, trace = PO.create_proof(po.BN254, c["srs"], c["key"], adv, [[]], prover.SeededRng(7), c["rep"], 4)
+    proof, trace = PO.create_proof(po.BN254, c["srs"], c["key"], adv, [[]], PO.ScalarStream(7), c["rep"], 4)
     assert not oracle_verify(po, c, proof, 6)
 
 

@@ -111,7 +111,7 @@ def test_oracle_proof_of_the_real_witness_is_accepted(pkg, po, co, small_delay_w
 
     (circ, info), _, _ = small_delay_witness
     c = _oracle_chain(po, co, circ, 14, 8)
-    proof, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 8)
+    proof, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(5), c["rep"], 8)
     assert V.verify_proof(po.BN254, c["desc"], 14, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], proof)
 
 
@@ -129,7 +129,7 @@ def test_device_proof_of_the_real_pose_enc_witness(pkg, po, co, ctx):
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
     tr = transcript.Blake2bWrite(pkg.fields.BN254)
     prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
-    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 8)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(5), c["rep"], 8)
     assert tr.finalize() == want
     assert V.verify_proof(po.BN254, c["desc"], 11, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
     params.release()
@@ -153,7 +153,7 @@ def test_device_proof_of_the_real_delay_enc_witness(pkg, po, co, ctx):
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
     tr = transcript.Blake2bWrite(pkg.fields.BN254)
     prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
-    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 16)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(5), c["rep"], 16)
     assert tr.finalize() == want
     assert V.verify_proof(po.BN254, c["desc"], 16, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
     params.release()
@@ -194,7 +194,7 @@ def test_device_proof_of_the_real_mod_pow_witness(pkg, po, co, ctx):
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
     tr = transcript.Blake2bWrite(pkg.fields.BN254)
     prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
-    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(5), c["rep"], 16)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(5), c["rep"], 16)
     proof = tr.finalize()
     assert len(proof) == 2848 and proof == want
     assert V.verify_proof(po.BN254, c["desc"], k, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], proof)
@@ -229,7 +229,7 @@ def test_batch_mode_provers_make_the_proofs_a_lone_prover_makes(pkg, po, co, ctx
         lone.create_proof(c["adv"], [[]], prover.SeededRng(sd), tr)
         alone[sd] = tr.finalize()
     assert len(set(alone.values())) == len(seeds)
-    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], prover.SeededRng(seeds[3]), c["rep"], 16)
+    want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(seeds[3]), c["rep"], 16)
     assert alone[seeds[3]] == want
     ctxs = [pkg.Context(0) for _ in range(4)]
     provers = [prover.Prover(params, pk, ctx=cx) for cx in ctxs]

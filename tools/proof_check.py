@@ -33,7 +33,7 @@ def run(ctx, k, rl, verify=True, threads=16):
     tm = prover.ProofTimings()
     P.create_proof(adv, [[]], prover.SeededRng(7), tr, tm)
     proof = tr.finalize()
-    t = time.time(); want, trace = PO.create_proof(ocurve, srs, key, adv, [[]], prover.SeededRng(7), rep, threads); cpu_s = time.time() - t
+    t = time.time(); want, trace = PO.create_proof(ocurve, srs, key, adv, [[]], PO.ScalarStream(7), rep, threads); cpu_s = time.time() - t
     print("k", k, "lookups", rl, "proof bytes", len(proof), "identical to oracle:", proof == want, "cpu_s", round(cpu_s, 2), flush=True)
     if proof != want:
         for i in range(0, min(len(proof), len(want)), 32):
