@@ -48,6 +48,7 @@ struct NttPassParams {
     u32 log_c;           // log2 of columns per tile
     u32 is_final;
     u32 skip2;           // first pass of a transform whose input is zero beyond N / 4: the first two stages are copies (see the load)
+    u32 tile_log;        // log2 of the elements a workgroup owns (NTT_TILE_LOG, or one less for launches too small to fill the chip: run_ntt_t)
     u32 tw_full;         // the table holds all N powers (log_n <= ntt_full_table_log): the inter-pass twiddle is one load, no negation
     u32 r1;              // log2 of the first pass's radix (final pass store)
     u32 nrev;            // number of middle digits to reverse in the final pass
@@ -123,9 +124,10 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Lds29 L;
     L.p01 = reinterpret_cast<u64*>(smem_raw);
-    L.p23 = L.p01 + NTT_TILE; L.p45 = L.p23 + NTT_TILE; L.p67 = L.p45 + NTT_TILE;
-    L.p8 = reinterpret_cast<u32*>(L.p67 + NTT_TILE);
-    f29* ltw = reinterpret_cast<f29*>(L.p8 + NTT_TILE);  // R/2 sub-transform roots (w * 2^261), unpacked limbs
+    const u32 plane = 1u << P.tile_log, nthr = blockDim.x;
+    L.p23 = L.p01 + plane; L.p45 = L.p23 + plane; L.p67 = L.p45 + plane;
+    L.p8 = reinterpret_cast<u32*>(L.p67 + plane);
+    f29* ltw = reinterpret_cast<f29*>(L.p8 + plane);  // R/2 sub-transform roots (w * 2^261), unpacked limbs
 
     const u32 tid = threadIdx.x;
     const u32 r = P.r, log_c = P.log_c;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
     fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
 
-    for (u32 j = tid; j < (R >> 1); j += NTT_THREADS) ltw[j] = f29_unpack(f_load(&P.tw[(u64)j << (P.log_n - r)]));
+    for (u32 j = tid; j < (R >> 1); j += nthr) ltw[j] = f29_unpack(f_load(&P.tw[(u64)j << (P.log_n - r)]));
 
     // ---- tile coordinates ----
     u64 q = 0, np0 = 0;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         // 4 i of the bit-reversed order, and the first two stages -- (x, 0) -> (x, x), then (x, 0), (x, 0) -> (x, x), (x, x) -- only
         // copy: row 4 i is written to rows 4 i .. 4 i + 3 and the stages start at s = 2 (no loads of zero rows, one LDS round trip,
         // one barrier and a quarter multiplication per element less)
-        for (u32 idx = tid; idx < (tile >> 2); idx += NTT_THREADS) {
+        for (u32 idx = tid; idx < (tile >> 2); idx += nthr) {
             const u32 j = idx >> log_c, c = idx & (Cc - 1);
             const u64 g = (q << P.log_m) + ((u64)j << log_cols) + np0 + c;
             f29 v = f29_zero();
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             lds29_store(L, a0, v); lds29_store(L, a0 + Cc, v); lds29_store(L, a0 + 2 * Cc, v); lds29_store(L, a0 + 3 * Cc, v);
         }
     } else
-    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
+    for (u32 idx = tid; idx < tile; idx += nthr) {
         u32 j, c;
         u64 g;
         if (!P.is_final) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     for (; s + 1 < r; s += 2) {
         const u32 h = 1u << s;
         const u32 ngroups = tile >> 2;   // radix-4 groups in the tile
-        for (u32 gidx = tid; gidx < ngroups; gidx += NTT_THREADS) {
+        for (u32 gidx = tid; gidx < ngroups; gidx += nthr) {
             u32 c = gidx & (Cc - 1), gq = gidx >> log_c;          // gq in [0, R/4)
             u32 pos = gq & (h - 1);
             u32 i0 = ((gq >> s) << (s + 2)) | pos;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     if (s < r) {   // odd r: one last radix-2 stage
         const u32 h = 1u << s;
         const u32 nbf = tile >> 1;
-        for (u32 bidx = tid; bidx < nbf; bidx += NTT_THREADS) {
+        for (u32 bidx = tid; bidx < nbf; bidx += nthr) {
             u32 c = bidx & (Cc - 1), b = bidx >> log_c;
             u32 pos = b & (h - 1);
             u32 i0 = ((b >> s) << (s + 1)) | pos;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             mult += P.rev_r[i];
         }
     }
-    for (u32 idx = tid; idx < tile; idx += NTT_THREADS) {
+    for (u32 idx = tid; idx < tile; idx += nthr) {
         u32 k = idx >> log_c, c = idx & (Cc - 1);
         f29 v = lds29_load(L, (k << log_c) + c);
         u64 o;
@@ -406,6 +408,11 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
     const size_t lds_max = (size_t)NTT_TILE * 36 + (NTT_TILE / 2) * sizeof(f29);
     // per call: the attribute belongs to the device the context is bound to
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_ntt_pass<F>, (int)lds_max));
+    // A launch of few tiles (one 2^20 transform: 512 of 2048 elements, two per CU) leaves every CU with two workgroups that load, transform and store in
+    // lock-step; half-size tiles on half-size workgroups give it four.  Launches of up to 2^22 elements take them (measured, tools/ab_ntt_tile.sh: 22 x 2^17
+    // 0.300 -> 0.280 ms, one 2^20 0.142 -> 0.139, 23 x 2^19 unchanged either way); DEHALO_NTT_SMALL_TILE_LOG = log2 of that bound (0: never) for the A/B.
+    static const uint32_t small_log = [] { const char* e = getenv("DEHALO_NTT_SMALL_TILE_LOG"); return e ? (uint32_t)atoi(e) : 22u; }();
+    const uint32_t tile_log = L > 1 && rad[0] + 1 < NTT_TILE_LOG && batch * N <= (1ull << small_log) ? NTT_TILE_LOG - 1 : NTT_TILE_LOG;
     uint32_t log_m = log_n;
     for (uint32_t p = 0; p < L; p++) {
         NttPassParams P;
@@ -429,17 +436,18 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         uint32_t log_c;
         if (!last) {
             uint32_t log_cols = log_m - rad[p];
-            log_c = std::min<uint32_t>(NTT_TILE_LOG - rad[p], log_cols);
+            log_c = std::min<uint32_t>(tile_log - rad[p], log_cols);
         } else {
-            log_c = std::min<uint32_t>(NTT_TILE_LOG - rad[p], P.r1);
+            log_c = std::min<uint32_t>(tile_log - rad[p], P.r1);
             P.nrev = L > 2 ? L - 2 : 0;
             for (uint32_t i = 0; i < P.nrev; i++) P.rev_r[i] = rad[1 + i];
         }
         P.log_c = log_c;
+        P.tile_log = tile_log;
         uint64_t tiles = N >> (rad[p] + log_c);
         dim3 grid((uint32_t)tiles, (uint32_t)batch);
-        size_t lds = (size_t)NTT_TILE * 36 + ((size_t)1 << rad[p]) / 2 * sizeof(f29);
-        k_ntt_pass<F><<<grid, NTT_THREADS, lds, s>>>(P);
+        size_t lds = ((size_t)36 << tile_log) + ((size_t)1 << rad[p]) / 2 * sizeof(f29);
+        k_ntt_pass<F><<<grid, NTT_THREADS >> (NTT_TILE_LOG - tile_log), lds, s>>>(P);
         HIP_TRY(ctx, hipGetLastError());
         log_m -= rad[p];
     }

@@ -78,6 +78,7 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
  *   DEHALO_MSM_MERGE_SPLIT  1: the merge of partial sums runs one launch per bucket class (a kernel trace then shows each class's time)
  *   DEHALO_MSM_RED_M        4 / 8: buckets per quad of the bucket reduction (default: 4 up to four 2^15-bucket columns in a launch, 8 beyond)
  *   DEHALO_NTT_SKIP         0: the first pass of a zero-padded transform (input <= N / 4) runs its two copy stages like any other
+ *   DEHALO_NTT_SMALL_TILE_LOG  log2 of the largest transform launch (elements) that runs on half-size tiles (default 22; 0: never)
  *   DEHALO_PROVER_TRACE     dehalo_create_proof writes the host's timeline inside the phases to stderr                                        */
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
  * kernels by enqueueing it on the same stream. */
