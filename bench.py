@@ -287,7 +287,8 @@ def end_to_end(st, want_proof, reps=5):
         tp.append(1e3 * (time.perf_counter() - t0))
     assert proof == want_proof
     return {"ms": round(min(ts), 3), "ms_median": round(sorted(ts)[len(ts) // 2], 3), "witness_ms": round(min(tw), 3), "ms_with_a_fresh_pageable_array_per_proof": round(min(tp), 3),
-            "what": "dehalo_synthesize (C++ witness generation on one host thread, rows written into a page-locked buffer kept across proofs) + upload of 5 x 2^k advice values from it + dehalo_create_proof; "
+            "witness_threads": min(8, os.cpu_count() or 1) if os.environ.get("DEHALO_SYNTH_THREADS") is None else int(os.environ["DEHALO_SYNTH_THREADS"]),
+            "what": "dehalo_synthesize (C++ witness generation on the host: the RSA regions of the circuit written by up to `witness_threads` threads, the rest by one; rows go into a page-locked buffer kept across proofs) + upload of 5 x 2^k advice values from it + dehalo_create_proof; "
                     "same proof bytes as from the resident witness"}
 
 

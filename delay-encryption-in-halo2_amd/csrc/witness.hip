@@ -14,7 +14,15 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <pthread.h>
+#include <stdexcept>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <functional>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -284,6 +292,11 @@ struct Layouter {
         Fe* base = advice ? reinterpret_cast<Fe*>(advice) : own.data();
         for (int i = 0; i < 5; i++) adv[i] = base + (size_t)i * n;
     }
+    // a second cursor over the same columns, starting at row `start` (proving only: no fixed columns, no copies): the rows of independent regions whose
+    // positions are known in advance are written by several host threads at once (BigIntChip::pow_mod)
+    Layouter(const Layouter& parent, uint32_t start) : F(parent.F), want_fixed(false), cap(parent.cap), nrows(start) {
+        for (int i = 0; i < 5; i++) adv[i] = parent.adv[i];
+    }
     uint32_t rows() const { return nrows; }
 
     void row(const Arg* cells, int ncells, const Sel* sel, int nsel, Cell out[5]) {
@@ -453,6 +466,8 @@ struct Layouter {
     }
 };
 
+unsigned synth_threads();
+
 // ---- BigIntChip ----
 struct BigIntChip {
     Layouter& lay;
@@ -548,6 +563,7 @@ struct BigIntChip {
         }
         lay.assert_equal(eq_bit, lay.assign_constant(F.u(1)));
     }
+    std::vector<Cell> pow_mod_threads(std::vector<Cell> acc, std::vector<Cell> squared, const std::vector<Cell>& e_bits, const std::vector<Cell>& n, const Big& n_big);
     Big to_big(const std::vector<Cell>& limbs) const {
         Big r;
         for (auto& c : limbs) r.push_back(c.val.v[0]);
@@ -557,6 +573,10 @@ struct BigIntChip {
     std::vector<Cell> mul_mod(const std::vector<Cell>& a, const std::vector<Cell>& b, const std::vector<Cell>& n, const Big& n_big) {
         Big q_big, r_big;
         big_divmod(big_mul(to_big(a), to_big(b)), n_big, q_big, r_big);
+        return mul_mod_rows(a, b, n, q_big, r_big);
+    }
+    // the rows of a * b = q * n + r for a quotient and remainder already known
+    std::vector<Cell> mul_mod_rows(const std::vector<Cell>& a, const std::vector<Cell>& b, const std::vector<Cell>& n, const Big& q_big, const Big& r_big) {
         const size_t n1 = a.size(), n2 = b.size();
         std::vector<Cell> q, r;
         for (uint64_t v : big_limbs(q_big, n2)) q.push_back(lay.range_assign(v, LIMB_WIDTH));
@@ -572,6 +592,7 @@ struct BigIntChip {
         std::vector<Cell> acc;
         for (uint64_t v : big_limbs(Big{1}, num_limbs)) acc.push_back(lay.range_assign(v, LIMB_WIDTH));      // assign_constant_fresh(1)
         std::vector<Cell> squared = a;
+        if (!lay.want_fixed && e_bits.size() >= 3 && synth_threads() > 1) return pow_mod_threads(acc, squared, e_bits, n, n_big);
         for (auto& bit : e_bits) {
             const std::vector<Cell> muled = mul_mod(acc, squared, n, n_big);
             for (size_t j = 0; j < acc.size(); j++) acc[j] = lay.select(muled[j], acc[j], bit);
@@ -580,6 +601,135 @@ struct BigIntChip {
         return acc;
     }
 };
+
+// Proving (values only): the two multiplications of every exponent bit are regions of a fixed number of rows whose operands follow from the
+// integers alone, so the chain x^(2^i), acc_i is computed first (two 2048-bit products and divisions per bit) and the regions are then written
+// by several host threads, each through a cursor of its own at the row where the sequential order puts it -- the same rows, bit for bit
+// (tests/test_witness.py compares with the one-thread keygen path).  The first bit runs on the caller's cursor and gives the regions' lengths.
+unsigned synth_threads() {
+    static const unsigned n = [] {
+        const char* e = getenv("DEHALO_SYNTH_THREADS");
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        return e ? (unsigned)std::max(1, atoi(e)) : std::min(8u, hw);
+    }();
+    return n;
+}
+
+// Worker threads kept for the life of the process (starting seven threads costs more than the regions they would write: 25 us each against 34 us per
+// region): they sleep on a condition variable between calls.  One job at a time -- a second caller that finds the pool busy writes its regions itself.
+struct SynthPool {
+    std::mutex job_mu, mu;
+    std::condition_variable cv, done_cv;
+    const std::function<void()>* fn = nullptr;
+    uint64_t gen = 0;
+    unsigned pending = 0, workers = 0;
+    explicit SynthPool(unsigned n) : workers(n) {
+        for (unsigned i = 0; i < n; i++)
+            std::thread([this] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return gen != seen; });
+                    seen = gen;
+                    const std::function<void()>* f = fn;
+                    lk.unlock();
+                    (*f)();
+                    lk.lock();
+                    if (--pending == 0) done_cv.notify_one();
+                }
+            }).detach();
+    }
+    void run(const std::function<void()>& f) {      // f on every worker and on the caller; returns when all are back
+        { std::lock_guard<std::mutex> lk(mu); fn = &f; pending = workers; gen++; }
+        cv.notify_all();
+        f();
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+};
+// (never destroyed: its threads sleep until the process ends.  A forked child has none of them: it starts with no pool and makes its own.)
+std::atomic<SynthPool*> g_synth_pool{nullptr};
+SynthPool* synth_pool() {
+    static const int registered = pthread_atfork(nullptr, nullptr, [] { g_synth_pool.store(nullptr); });
+    (void)registered;
+    SynthPool* p = g_synth_pool.load();
+    if (!p) {
+        SynthPool* fresh = new SynthPool(synth_threads() - 1);
+        if (g_synth_pool.compare_exchange_strong(p, fresh)) p = fresh;      // (lost the race: `fresh` stays behind, asleep)
+    }
+    return p;
+}
+
+std::vector<Cell> BigIntChip::pow_mod_threads(std::vector<Cell> acc, std::vector<Cell> squared, const std::vector<Cell>& e_bits, const std::vector<Cell>& n, const Big& n_big) {
+    const size_t nb = e_bits.size();
+    auto cells_of = [&](const Big& x) {
+        std::vector<Cell> out(num_limbs);
+        const Big l = big_limbs(x, num_limbs);
+        for (size_t i = 0; i < num_limbs; i++) out[i].val = Fe{{l[i], 0, 0, 0}};      // values only: nothing of the proving path reads where a cell sits
+        return out;
+    };
+    auto T0 = std::chrono::steady_clock::now();
+    struct Step { Big acc, sq, q_mul, r_mul, q_sq, r_sq; };
+    std::vector<Step> st(nb);
+    Big a_cur = to_big(acc), s_cur = to_big(squared);
+    for (size_t i = 0; i < nb; i++) {
+        st[i].acc = a_cur; st[i].sq = s_cur;
+        big_divmod(big_mul(a_cur, s_cur), n_big, st[i].q_mul, st[i].r_mul);
+        big_divmod(big_mul(s_cur, s_cur), n_big, st[i].q_sq, st[i].r_sq);
+        if (!e_bits[i].val.is_zero()) a_cur = st[i].r_mul;
+        s_cur = st[i].r_sq;
+    }
+    auto T1 = std::chrono::steady_clock::now();
+    // bit 0 on the caller's cursor: the lengths of the two regions
+    const uint32_t r0 = lay.nrows;
+    {
+        const std::vector<Cell> muled = mul_mod_rows(acc, squared, n, st[0].q_mul, st[0].r_mul);
+        for (size_t j = 0; j < acc.size(); j++) acc[j] = lay.select(muled[j], acc[j], e_bits[0]);
+    }
+    const uint32_t len_a = lay.nrows - r0;
+    squared = mul_mod_rows(squared, squared, n, st[0].q_sq, st[0].r_sq);
+    const uint32_t len_b = lay.nrows - r0 - len_a;
+    const uint32_t base = lay.nrows;
+    auto T2 = std::chrono::steady_clock::now();
+    // regions 2 (i - 1) and 2 (i - 1) + 1 of bit i >= 1
+    const size_t tasks = 2 * (nb - 1);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+        for (;;) try {
+            const size_t t = next.fetch_add(1);
+            if (t >= tasks) return;
+            const size_t i = 1 + t / 2;
+            const uint32_t start = base + (uint32_t)(i - 1) * (len_a + len_b) + (t & 1 ? len_a : 0);
+            Layouter sub(lay, start);
+            BigIntChip chip{sub, num_limbs};
+            if (t & 1) {
+                const std::vector<Cell> sq = cells_of(st[i].sq);
+                chip.mul_mod_rows(sq, sq, n, st[i].q_sq, st[i].r_sq);
+                if (sub.nrows != start + len_b) ok = false;
+            } else {
+                const std::vector<Cell> ac = cells_of(st[i].acc), sq = cells_of(st[i].sq);
+                const std::vector<Cell> muled = chip.mul_mod_rows(ac, sq, n, st[i].q_mul, st[i].r_mul);
+                for (size_t j = 0; j < ac.size(); j++) sub.select(muled[j], ac[j], e_bits[i]);
+                if (sub.nrows != start + len_a) ok = false;
+            }
+        } catch (...) { ok = false; return; }
+    };
+    const unsigned nthreads = synth_threads();
+    {
+        SynthPool* pool = synth_pool();
+        const std::function<void()> job = work;
+        if (pool->job_mu.try_lock()) {
+            pool->run(job);
+            pool->job_mu.unlock();
+        } else work();
+    }
+    auto T3 = std::chrono::steady_clock::now();
+    if (getenv("DEHALO_SYNTH_TRACE")) fprintf(stderr, "pow_mod: chain %.3f ms, bit 0 %.3f ms, %zu regions on %u threads %.3f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count(), tasks, nthreads, std::chrono::duration<double, std::milli>(T3 - T2).count());
+    if (!ok) throw std::runtime_error("pow_mod: a region's length depends on its values");
+    lay.nrows = base + (uint32_t)(nb - 1) * (len_a + len_b);
+    return cells_of(a_cur);
+}
 
 // ---- PoseidonChip rows: x^5 as three multiplication rows, every MDS output as two rows of a five-term sum ----
 struct PoseidonRows {
@@ -725,6 +875,10 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
     if (t != 5 || rate != 4) return DEHALO_ERR_UNSUPPORTED;      // the row layout (linear()) is the T = 5 one the reference instantiates (src/lib.rs:120-121)
     if (in->message_len > 2 || (in->message_len && !in->message)) return DEHALO_ERR_INVALID;
     const size_t n = (size_t)1 << in->k;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto trace = [&](const char* what) {
+        if (getenv("DEHALO_SYNTH_TRACE")) fprintf(stderr, "synthesize: %-28s +%.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     Layouter lay(f, keygen_outputs, advice, n);
     Fld F{f};
     std::vector<Fe> message;
@@ -750,6 +904,7 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         Big want;
         const std::vector<Cell> rsa_out = rsa_region(lay, n_big, in->e, x, in->exp_bits, num_limbs, want);
         inf.rsa_rows = lay.rows();
+        trace("rsa region");
         const Big wl = big_limbs(want, std::min<size_t>(num_limbs, 128));
         for (size_t i = 0; i < wl.size() && i < 128; i++) inf.rsa_result[i] = wl[i];
         if (in->circuit == DEHALO_CIRCUIT_DELAY_ENC) {
@@ -784,6 +939,7 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
             for (auto& c : cipher_region(lay, spec, key_vals, message, key_cells)) cipher_vals.push_back(c.val);
         }
     }
+    trace("hash and cipher regions");
     inf.total_rows = lay.rows();
     if (in->circuit == DEHALO_CIRCUIT_POSE_ENC) inf.rsa_rows = 0;
     for (size_t i = 0; i < cipher_vals.size() && i < 3; i++) memcpy(inf.cipher + 4 * i, cipher_vals[i].v, 32);
@@ -796,6 +952,7 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
     const size_t rows = lay.rows();
     if (advice)      // (the used rows are already in place)
         for (int c = 0; c < 5; c++) memset(advice + ((size_t)c * n + rows) * 4, 0, (n - rows) * 32);
+    trace("unused rows zeroed");
     const uint32_t num_fixed = range_lookups ? 15 : 9;
     if (fixed) {
         memset(fixed, 0, (size_t)num_fixed * n * 32);

@@ -79,6 +79,8 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
  *   DEHALO_MSM_RED_M        4 / 8: buckets per quad of the bucket reduction (default: 4 up to four 2^15-bucket columns in a launch, 8 beyond)
  *   DEHALO_NTT_SKIP         0: the first pass of a zero-padded transform (input <= N / 4) runs its two copy stages like any other
  *   DEHALO_NTT_SMALL_TILE_LOG  log2 of the largest transform launch (elements) that runs on half-size tiles (default 22; 0: never)
+ *   DEHALO_SYNTH_THREADS    host threads dehalo_synthesize writes the RSA regions of a proving call with (default: 8, or the machine's hardware threads if fewer; 1: none)
+ *   DEHALO_SYNTH_TRACE      dehalo_synthesize writes the time of its stages to stderr
  *   DEHALO_PROVER_TRACE     dehalo_create_proof writes the host's timeline inside the phases to stderr                                        */
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
  * kernels by enqueueing it on the same stream. */

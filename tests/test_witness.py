@@ -326,6 +326,43 @@ def test_native_synthesize_is_fast_at_the_north_star_size(pkg):
     assert best < 0.5
 
 
+def test_native_synthesize_rows_do_not_depend_on_the_number_of_threads(pkg):
+    """dehalo_synthesize writes the RSA regions of a proving call from several host threads (BigIntChip::pow_mod_threads), each through a cursor at the row
+    the sequential order gives its region: k = 17, 15-bit exponent, 1 / 3 / 8 threads -- the same advice columns (digest of all 5 x 2^17 values)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    seen = set()
+    for threads in ("1", "3", "8"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "synth_bench.py")], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, DEHALO_SYNTH_THREADS=threads))
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = out.stdout.strip().splitlines()
+        assert lines[-2].endswith("True")                      # x^e mod n read off the rows
+        seen.add(lines[-1])
+    assert len(seen) == 1
+
+
+def test_native_synthesize_in_a_forked_child(pkg):
+    """The synthesis worker threads sleep between calls and do not exist in a forked child: the child makes its own and writes the same rows."""
+    from dehalo2_amd import native
+
+    v = rsa_vectors()[1]
+    n, x = int(v["n"]), int(v["signature"])
+    a = native.synthesize(native.CIRCUIT_MOD_POW, 17, n_big=n, e=0b10111, x=x, exp_bits=5)
+    pid = os.fork()
+    if pid == 0:
+        code = 3
+        try:
+            b = native.synthesize(native.CIRCUIT_MOD_POW, 17, n_big=n, e=0b10111, x=x, exp_bits=5)
+            code = 0 if np.array_equal(a["advice"], b["advice"]) else 4
+        finally:
+            os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
 def test_host_code_under_address_and_ub_sanitizers(pkg):
     """The library's host-only code -- dehalo_synthesize (big-integer division, layouter, Grain / Poseidon), hostfield, Blake2b, the random-scalar
     sources -- rebuilt by g++ with -fsanitize=address,undefined (GPU sanitizers are not available on the pool) and run on a k = 15 delay_enc circuit:
