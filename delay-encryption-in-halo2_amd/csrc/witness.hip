@@ -284,6 +284,11 @@ struct Layouter {
     Fe* adv[5];
     size_t cap;
     uint32_t nrows = 0;
+    // Proving only: what follows the exponentiation in the circuit (the expected value's rows, the hash and cipher regions) reads nothing of it but its
+    // VALUE, which the integer chain gives before any row is written -- so pow_mod may run it as one more task beside the multiplication regions, through a
+    // cursor at the row where the exponentiation will end.  Set by dehalo_synthesize; `after_pow_done` tells the sequential code behind pow_mod to skip it.
+    std::function<void(Layouter&, const std::vector<Cell>&)> after_pow;
+    bool after_pow_done = false;
     std::vector<Fe> own;
     std::vector<Fe> fix[NUM_FIX];
     std::vector<Copy> copies;
@@ -692,13 +697,26 @@ std::vector<Cell> BigIntChip::pow_mod_threads(std::vector<Cell> acc, std::vector
     const uint32_t base = lay.nrows;
     auto T2 = std::chrono::steady_clock::now();
     // regions 2 (i - 1) and 2 (i - 1) + 1 of bit i >= 1
-    const size_t tasks = 2 * (nb - 1);
+    const bool with_tail = (bool)lay.after_pow;
+    const size_t tasks = 2 * (nb - 1) + (with_tail ? 1 : 0);
+    const uint32_t end_row = base + (uint32_t)(nb - 1) * (len_a + len_b);
+    uint32_t tail_end = end_row;
+    const std::vector<Cell> powed = cells_of(a_cur);
     std::atomic<size_t> next{0};
     std::atomic<bool> ok{true};
     auto work = [&]() {
         for (;;) try {
-            const size_t t = next.fetch_add(1);
+            size_t t = next.fetch_add(1);
             if (t >= tasks) return;
+            if (with_tail) {      // the longest task first
+                if (t == 0) {
+                    Layouter sub(lay, end_row);
+                    lay.after_pow(sub, powed);
+                    tail_end = sub.nrows;
+                    continue;
+                }
+                t--;
+            }
             const size_t i = 1 + t / 2;
             const uint32_t start = base + (uint32_t)(i - 1) * (len_a + len_b) + (t & 1 ? len_a : 0);
             Layouter sub(lay, start);
@@ -727,8 +745,9 @@ std::vector<Cell> BigIntChip::pow_mod_threads(std::vector<Cell> acc, std::vector
     auto T3 = std::chrono::steady_clock::now();
     if (getenv("DEHALO_SYNTH_TRACE")) fprintf(stderr, "pow_mod: chain %.3f ms, bit 0 %.3f ms, %zu regions on %u threads %.3f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count(), tasks, nthreads, std::chrono::duration<double, std::milli>(T3 - T2).count());
     if (!ok) throw std::runtime_error("pow_mod: a region's length depends on its values");
-    lay.nrows = base + (uint32_t)(nb - 1) * (len_a + len_b);
-    return cells_of(a_cur);
+    lay.nrows = with_tail ? tail_end : end_row;
+    lay.after_pow_done = with_tail;
+    return powed;
 }
 
 // ---- PoseidonChip rows: x^5 as three multiplication rows, every MDS output as two rows of a five-term sum ----
@@ -793,6 +812,16 @@ struct NativeCipher {      // PoseidonCipher::{initial_state, encrypt} (src/encr
 };
 
 // src/lib.rs:179-206 / benches/mod_pow.rs:63-110: assign n, e, x; x^e mod n in-circuit; equal to the native big_pow_mod
+// the expected value x^e mod n as constants, constrained equal to the exponentiation's result (src/lib.rs:205-219)
+std::vector<Cell> rsa_expected_rows(Layouter& lay, const std::vector<Cell>& powed) {
+    BigIntChip chip{lay, powed.size()};
+    Big want = chip.to_big(powed);
+    big_trim(want);
+    const std::vector<Cell> valid = chip.assign_constant(want);
+    for (size_t i = 0; i < powed.size(); i++) lay.assert_equal(powed[i], valid[i]);
+    return valid;
+}
+
 std::vector<Cell> rsa_region(Layouter& lay, const Big& n_big, uint64_t e, const Big& x, unsigned exp_bits, size_t num_limbs, Big& want) {
     BigIntChip chip{lay, num_limbs};
     const std::vector<Cell> n_limbs = chip.assign_integer(n_big);
@@ -804,9 +833,8 @@ std::vector<Cell> rsa_region(Layouter& lay, const Big& n_big, uint64_t e, const 
     // mul_mod's remainder came from the same big-integer division), so its value is read off them instead of being computed a second time
     want = chip.to_big(powed);
     big_trim(want);
-    const std::vector<Cell> valid = chip.assign_constant(want);
-    for (size_t i = 0; i < powed.size(); i++) lay.assert_equal(powed[i], valid[i]);
-    return valid;
+    if (lay.after_pow_done) return powed;      // (the rows behind the exponentiation were written beside it)
+    return rsa_expected_rows(lay, powed);
 }
 
 // src/lib.rs:261-316 / src/encryption/chip.rs:72-110: the Poseidon cipher in-circuit, constrained equal to the native one
@@ -901,43 +929,52 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         Big n_big(in->n, in->n + num_limbs), x(in->x, in->x + num_limbs);
         { Big t0 = n_big; big_trim(t0); if (t0.empty()) return DEHALO_ERR_INVALID; }
         if (in->exp_bits < 64 && (in->e >> in->exp_bits)) return DEHALO_ERR_INVALID;
-        Big want;
-        const std::vector<Cell> rsa_out = rsa_region(lay, n_big, in->e, x, in->exp_bits, num_limbs, want);
-        inf.rsa_rows = lay.rows();
-        trace("rsa region");
-        const Big wl = big_limbs(want, std::min<size_t>(num_limbs, 128));
-        for (size_t i = 0; i < wl.size() && i < 128; i++) inf.rsa_result[i] = wl[i];
-        if (in->circuit == DEHALO_CIRCUIT_DELAY_ENC) {
+        // hash region: limbs packed three to a field element (src/lib.rs:222-249), sponge with RATE 4 (src/hash/chip.rs:63-85); then the cipher keyed by the digest
+        auto hash_and_cipher = [&](Layouter& L, const std::vector<Cell>& rsa_out) {
             const std::shared_ptr<const PoseidonSpec> spec_ref = poseidon_spec(f, t, r_f, r_p);
-        const PoseidonSpec& spec = *spec_ref;
-            PoseidonRows rows{lay, spec};
-            // hash region: limbs packed three to a field element (src/lib.rs:222-249), sponge with RATE 4 (src/hash/chip.rs:63-85)
-            const Cell base1 = lay.assign_constant(F.pow2(LIMB_WIDTH));
-            const Cell base2 = lay.mul(Arg(base1), Arg(base1));
+            const PoseidonSpec& spec = *spec_ref;
+            PoseidonRows rows{L, spec};
+            const Cell base1 = L.assign_constant(F.pow2(LIMB_WIDTH));
+            const Cell base2 = L.mul(Arg(base1), Arg(base1));
             std::vector<Cell> inputs;
             for (size_t i = 0; i < rsa_out.size() / 3; i++) {
-                const Cell a = lay.mul_add(Arg(rsa_out[3 * i + 1]), Arg(base1), Arg(rsa_out[3 * i]));
-                inputs.push_back(lay.mul_add(Arg(rsa_out[3 * i + 2]), Arg(base2), Arg(a)));
+                const Cell a = L.mul_add(Arg(rsa_out[3 * i + 1]), Arg(base1), Arg(rsa_out[3 * i]));
+                inputs.push_back(L.mul_add(Arg(rsa_out[3 * i + 2]), Arg(base2), Arg(a)));
             }
-            if (rsa_out.size() % 3 == 2) inputs.push_back(lay.mul_add(Arg(rsa_out[rsa_out.size() - 1]), Arg(base1), Arg(rsa_out[rsa_out.size() - 2])));
-            std::vector<Cell> state = {lay.assign_constant(F.pow2(64))};      // Poseidon::new: capacity word 2^64
-            for (uint32_t i = 1; i < t; i++) state.push_back(lay.assign_constant(F.zero()));
+            if (rsa_out.size() % 3 == 2) inputs.push_back(L.mul_add(Arg(rsa_out[rsa_out.size() - 1]), Arg(base1), Arg(rsa_out[rsa_out.size() - 2])));
+            std::vector<Cell> state = {L.assign_constant(F.pow2(64))};      // Poseidon::new: capacity word 2^64
+            for (uint32_t i = 1; i < t; i++) state.push_back(L.assign_constant(F.zero()));
             for (size_t c0 = 0; c0 < inputs.size(); c0 += rate) {
                 const size_t cnt = std::min<size_t>(rate, inputs.size() - c0);
                 std::vector<Cell> nxt = {state[0]};
-                for (uint32_t i = 0; i < rate; i++) nxt.push_back(i < cnt ? lay.add(state[1 + i], inputs[c0 + i]) : state[1 + i]);
-                if (cnt < rate) nxt[1 + cnt] = lay.add_constant(nxt[1 + cnt], F.u(1));      // padding: + 1 after the last input
+                for (uint32_t i = 0; i < rate; i++) nxt.push_back(i < cnt ? L.add(state[1 + i], inputs[c0 + i]) : state[1 + i]);
+                if (cnt < rate) nxt[1 + cnt] = L.add_constant(nxt[1 + cnt], F.u(1));      // padding: + 1 after the last input
                 state = rows.permutation(nxt);
             }
             if (inputs.size() % rate == 0) {
                 std::vector<Cell> nxt = state;
-                nxt[1] = lay.add_constant(state[1], F.u(1));
+                nxt[1] = L.add_constant(state[1], F.u(1));
                 state = rows.permutation(nxt);
             }
             const Cell key_cells[2] = {state[1], state[2]};
             const Fe key_vals[2] = {state[1].val, state[2].val};
-            for (auto& c : cipher_region(lay, spec, key_vals, message, key_cells)) cipher_vals.push_back(c.val);
-        }
+            for (auto& c : cipher_region(L, spec, key_vals, message, key_cells)) cipher_vals.push_back(c.val);
+        };
+        const bool with_hash = in->circuit == DEHALO_CIRCUIT_DELAY_ENC;
+        uint32_t rsa_rows_beside = 0;
+        if (!keygen_outputs)      // proving: everything behind the exponentiation may be written beside it (BigIntChip::pow_mod_threads)
+            lay.after_pow = [&](Layouter& sub, const std::vector<Cell>& powed) {
+                const std::vector<Cell> valid = rsa_expected_rows(sub, powed);
+                rsa_rows_beside = sub.rows();
+                if (with_hash) hash_and_cipher(sub, valid);
+            };
+        Big want;
+        const std::vector<Cell> rsa_out = rsa_region(lay, n_big, in->e, x, in->exp_bits, num_limbs, want);
+        inf.rsa_rows = lay.after_pow_done ? rsa_rows_beside : lay.rows();
+        trace(lay.after_pow_done ? "rsa, hash and cipher regions" : "rsa region");
+        const Big wl = big_limbs(want, std::min<size_t>(num_limbs, 128));
+        for (size_t i = 0; i < wl.size() && i < 128; i++) inf.rsa_result[i] = wl[i];
+        if (with_hash && !lay.after_pow_done) hash_and_cipher(lay, rsa_out);
     }
     trace("hash and cipher regions");
     inf.total_rows = lay.rows();
