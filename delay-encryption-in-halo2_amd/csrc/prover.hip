@@ -635,6 +635,7 @@ struct dehalo_prover {
     hipEvent_t ev_helper = nullptr;      // the helper thread waits for ITS work on the side stream through this event: a hipStreamSynchronize there holds the
     uint64_t* pin_helper = nullptr;      // stream against the proving thread's launches (0.4 ms of the lookups' phase); its point lands in this page-locked slot
     hipStream_t hs = nullptr;            // ... and its work (upload, the random polynomial's commitment) runs on a stream of its own beside the side context's
+    uint64_t* adv_pin = nullptr;         // dehalo_create_proof_circuit: the advice columns the witness generator writes (page-locked, kept across proofs)
     uint64_t* rand_pin = nullptr;        // host-drawn random polynomial (page-locked: its upload is one DMA that holds no stream)
     // opening plan (depends on the circuit only)
     std::vector<int32_t> rots;
@@ -667,6 +668,7 @@ struct dehalo_prover {
             if (e) (void)hipEventDestroy(e);
         if (pin_helper) (void)hipHostFree(pin_helper);
         if (rand_pin) (void)hipHostFree(rand_pin);
+        if (adv_pin) (void)hipHostFree(adv_pin);
         if (hs) (void)hipStreamDestroy(hs);
     }
 
@@ -896,7 +898,7 @@ struct dehalo_prover {
     }
 
     int run(const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns, dehalo_rng* rng_in,
-            dehalo_transcript* tr, uint32_t flags);
+            dehalo_transcript* tr, uint32_t flags, const dehalo_circuit_inputs* synth_in = nullptr, dehalo_synthesis_info* synth_info = nullptr);
 };
 
 namespace {
@@ -913,7 +915,7 @@ struct EvalIn {      // dehalo_eval_inputs with owned scalar storage
 }   // namespace
 
 int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns, dehalo_rng* rng_in,
-                       dehalo_transcript* tr, uint32_t flags) {
+                       dehalo_transcript* tr, uint32_t flags, const dehalo_circuit_inputs* synth_in, dehalo_synthesis_info* synth_info) {
     const HostCS& cs = pk->cs;
     const HostDomain& d = pk->dom;
     const int fid = f->id;
@@ -995,6 +997,19 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         ~Joiner() { if (t.joinable()) t.join(); }
     } joiner{helper};
 
+    // create_proof of a CIRCUIT (upstream's call synthesizes inside): the random polynomial's draw, upload and commitment start now, on the helper's
+    // thread and stream, and run on an otherwise idle device while this thread (and the synthesis pool) writes the advice columns
+    if (synth_in) {
+        if (synth_in->k != k || A != 5) return dh_fail(ctx, DEHALO_ERR_INVALID, "create_proof_circuit: the circuit's k / advice columns differ from the key's");
+        if (!adv_pin) HIP_TRY(ctx, hipHostMalloc((void**)&adv_pin, (size_t)A * n * 32, hipHostMallocDefault));
+        helper = std::thread(helper_body);
+        const int src = dehalo_synthesize(synth_in, adv_pin, nullptr, nullptr, nullptr, synth_info);
+        if (src) return dh_fail(ctx, src, "create_proof_circuit: the circuit's inputs are invalid or it does not fit 2^k rows");
+        advice = adv_pin;
+        flags = (flags & ~(uint32_t)DEHALO_PROOF_ADVICE_ON_DEVICE) | DEHALO_PROOF_ADVICE_CANONICAL;
+        tk("witness synthesized");
+    }
+
     // compacted blinding rows -> one upload
     {
         const size_t total = (size_t)A * rows + (size_t)2 * L * rows + (size_t)(S + L) * bf;
@@ -1066,7 +1081,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         hipStream_t s;
         PinnedUpload(const void* ptr, size_t bytes, hipStream_t s_) : pin(ptr, bytes), s(s_) {}
         ~PinnedUpload() { if (pin.p) (void)hipStreamSynchronize(s); }
-    } pin_advice((flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? nullptr : advice, (size_t)A * n * 32, ms);
+    } pin_advice((flags & DEHALO_PROOF_ADVICE_ON_DEVICE) || synth_in ? nullptr : advice, (size_t)A * n * 32, ms);
     HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, (flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                 ms));
     if (flags & DEHALO_PROOF_ADVICE_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, cols.u64((size_t)o_adv * n), nullptr, cols.u64((size_t)o_adv * n), (size_t)A * n, nullptr));
@@ -1098,7 +1113,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             e.in.y = zero.v;
             TRY(dehalo_graph_evaluate_device(side, pk->custom_gates, &e.in, ek, rot_scale, nullptr, h.u64(), nullptr));
         }
-        helper = std::thread(helper_body);      // the host is idle from here to the read-back
+        if (!synth_in) helper = std::thread(helper_body);      // the host is idle from here to the read-back
         return 0;
     };
     TRY(commit(tr, cols.at((size_t)o_adv * n), A, true, after_advice_queued));
@@ -1418,6 +1433,19 @@ extern "C" int dehalo_pk_info(const dehalo_pk* pk, uint32_t out[8]) try {
     std::sort(rs.begin(), rs.end());
     out[7] = (uint32_t)(std::unique(rs.begin(), rs.end()) - rs.begin());
     return 0;
+} catch (...) { return DEHALO_ERR_OOM; }
+
+extern "C" int dehalo_create_proof_circuit(dehalo_prover* p, const dehalo_circuit_inputs* in, dehalo_synthesis_info* info, const uint64_t* const* instances,
+                                           const size_t* instance_lens, uint32_t num_instance_columns, dehalo_rng* rng, dehalo_transcript* transcript) try {
+    if (!p || !transcript || !in) return DEHALO_ERR_INVALID;
+    if (transcript->curve != p->pk->curve) return dh_fail(p->ctx, DEHALO_ERR_INVALID, "create_proof: the transcript's curve differs from the key's");
+    std::lock_guard<std::mutex> lk(p->mu);
+    const int rc = p->run(nullptr, instances, instance_lens, num_instance_columns, rng, transcript, 0, in, info);
+    if (rc) {
+        (void)hipStreamSynchronize(p->ctx->stream);
+        if (p->side) (void)hipStreamSynchronize(p->side->stream);
+    }
+    return rc;
 } catch (...) { return DEHALO_ERR_OOM; }
 
 extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, const uint64_t* const* advice, uint32_t count, dehalo_rng* rngs, uint32_t flags,

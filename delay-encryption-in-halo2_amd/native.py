@@ -314,6 +314,25 @@ class Prover:
         rng_writeback(rng, r)
         return tr
 
+    def create_proof_circuit(self, circuit: int, instances: Sequence[Sequence[int]] = ((),), rng=None, transcript: Optional[Blake2bWrite] = None, **inputs):
+        """create_proof(&params, &pk, &[circuit], instances, rng, &mut transcript) as the reference calls it (benches/delay_enc.rs:123-131): the circuit is
+        synthesized inside the call (dehalo_create_proof_circuit).  `inputs`: n_big, e, x, exp_bits, message, key, bits_len as for synthesize().
+        -> (transcript, {"rows", "rsa_rows", "rsa_result", "cipher"})"""
+        lib = load_library()
+        tr = transcript if transcript is not None else Blake2bWrite(self.pk.curve)
+        f = self.pk.curve.scalar
+        inp, keep = circuit_inputs(circuit, self.pk.info()["k"], **inputs)
+        cols = [f.encode_many(list(v)) if len(v) else np.zeros((0, 4), dtype=np.uint64) for v in instances]
+        ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data if c.size else None for c in cols])
+        lens = (C.c_size_t * max(1, len(cols)))(*[c.shape[0] for c in cols])
+        r = rng_struct(rng)
+        info = CSynthesisInfo()
+        rc = lib.dehalo_create_proof_circuit(self.handle, C.byref(inp), C.byref(info), ptrs, lens, len(cols), C.byref(r) if r is not None else None, tr.handle)
+        if rc != 0:
+            raise DehaloError(rc, lib.dehalo_last_error(self.ctx.handle).decode())
+        rng_writeback(rng, r)
+        return tr, _info_dict(info)
+
     def last_timings(self) -> dict:
         out = (C.c_double * 8)()
         load_library().dehalo_prover_last_timings(self.handle, out)
@@ -364,6 +383,23 @@ def _limbs(x: int, count: int) -> np.ndarray:
     return np.frombuffer(int(x).to_bytes(8 * count, "little"), dtype=np.uint64).copy()
 
 
+def circuit_inputs(circuit: int, k: int, *, n_big: int = 0, e: int = 0, x: int = 0, exp_bits: int = 0, message: Sequence[int] = (), key: Sequence[int] = (), bits_len: int = 2048):
+    """-> (dehalo_circuit_inputs, the arrays it points into): the reference's circuit structs as values (DelayEncryptCircuit { n, e, x, spec, enc_key... },
+    RSACircuit, PoseidonEncCircuit)."""
+    nl = bits_len // 64
+    inp = CCircuitInputs()
+    inp.circuit, inp.k, inp.bits_len, inp.exp_bits, inp.e = circuit, k, bits_len, exp_bits, e
+    keep = [_limbs(n_big, nl), _limbs(x, nl), np.ascontiguousarray(np.frombuffer(b"".join(int(m).to_bytes(32, "little") for m in message) or bytes(32), dtype=np.uint64)),
+            np.ascontiguousarray(np.frombuffer(b"".join(int(m).to_bytes(32, "little") for m in key) or bytes(64), dtype=np.uint64))]
+    inp.n, inp.x, inp.message, inp.message_len, inp.key = keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, len(message), keep[3].ctypes.data
+    return inp, keep
+
+
+def _info_dict(info) -> dict:
+    return {"rows": int(info.total_rows), "rsa_rows": int(info.rsa_rows), "rsa_result": sum(int(v) << (64 * i) for i, v in enumerate(info.rsa_result)),
+            "cipher": [sum(int(info.cipher[4 * i + j]) << (64 * j) for j in range(4)) for i in range(info.cipher_len)]}
+
+
 def synthesize(circuit: int, k: int, *, n_big: int = 0, e: int = 0, x: int = 0, exp_bits: int = 0, message: Sequence[int] = (), key: Sequence[int] = (), bits_len: int = 2048,
                keygen: bool = False, out=None) -> dict:
     """dehalo_synthesize: Circuit::synthesize of the reference's circuits as values, in C++ (csrc/witness.hip; src/lib.rs:164-318,
@@ -371,12 +407,7 @@ def synthesize(circuit: int, k: int, *, n_big: int = 0, e: int = 0, x: int = 0, 
     "cipher"} and, with keygen=True, "fixed" (canonical), "mapping", "selectors".  `out`: a C-contiguous (5, n, 4) uint64 array the advice columns
     are written into (the library writes them in place: a caller that proves repeatedly hands over one page-locked buffer and uploads from it)."""
     lib = load_library()
-    nl = bits_len // 64
-    inp = CCircuitInputs()
-    inp.circuit, inp.k, inp.bits_len, inp.exp_bits, inp.e = circuit, k, bits_len, exp_bits, e
-    keep = [_limbs(n_big, nl), _limbs(x, nl), np.ascontiguousarray(np.frombuffer(b"".join(int(m).to_bytes(32, "little") for m in message) or bytes(32), dtype=np.uint64)),
-            np.ascontiguousarray(np.frombuffer(b"".join(int(m).to_bytes(32, "little") for m in key) or bytes(64), dtype=np.uint64))]
-    inp.n, inp.x, inp.message, inp.message_len, inp.key = keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, len(message), keep[3].ctypes.data
+    inp, keep = circuit_inputs(circuit, k, n_big=n_big, e=e, x=x, exp_bits=exp_bits, message=message, key=key, bits_len=bits_len)
     n = 1 << k
     nfix = 9 if circuit == CIRCUIT_POSE_ENC else 15
     if out is not None:
@@ -393,8 +424,7 @@ def synthesize(circuit: int, k: int, *, n_big: int = 0, e: int = 0, x: int = 0, 
     rc = lib.dehalo_synthesize(C.byref(inp), advice.ctypes.data, fixed.ctypes.data if keygen else None, mapping.ctypes.data if keygen else None, sel_ptrs, C.byref(info))
     if rc != 0:
         raise ValueError("dehalo_synthesize failed (%d): bad inputs or not enough rows available" % rc)
-    out = {"advice": advice, "rows": int(info.total_rows), "rsa_rows": int(info.rsa_rows), "rsa_result": sum(int(v) << (64 * i) for i, v in enumerate(info.rsa_result)),
-           "cipher": [sum(int(info.cipher[4 * i + j]) << (64 * j) for j in range(4)) for i in range(info.cipher_len)]}
+    out = dict(_info_dict(info), advice=advice)
     if keygen:
         out.update(fixed=fixed, mapping=mapping, selectors=[s.astype(bool) for s in sels])
     return out

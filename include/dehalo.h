@@ -520,6 +520,12 @@ typedef struct {
     uint64_t cipher[12]; uint32_t cipher_len;   /* the ciphertext (canonical), message_len + 1 elements */
 } dehalo_synthesis_info;
 int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advice, uint64_t* fixed, uint64_t* mapping, uint8_t* const* selectors, dehalo_synthesis_info* info);
+/* create_proof of a CIRCUIT -- the call the reference makes (benches/delay_enc.rs:123-131, benches/mod_pow.rs:201-209, benches/pose_enc.rs:127-135:
+ * create_proof(&params, &pk, &[circuit], instances, rng, &mut transcript) synthesizes the circuit inside): dehalo_synthesize into a page-locked buffer the
+ * prover keeps, upload, and the proof; the random polynomial's draw, upload and commitment (side context) run on the otherwise idle device meanwhile.
+ * Same proof bytes as dehalo_synthesize + dehalo_create_proof with DEHALO_PROOF_ADVICE_CANONICAL.  `info` (optional): rows, x^e mod n, ciphertext. */
+int dehalo_create_proof_circuit(dehalo_prover* prover, const dehalo_circuit_inputs* in, dehalo_synthesis_info* info, const uint64_t* const* instances,
+                                const size_t* instance_lens, uint32_t num_instance_columns, dehalo_rng* rng, dehalo_transcript* transcript);
 
 /* The grand products' per-row factors, every product of a proof in one launch [UPSTREAM plonk/permutation/prover.rs Argument::commit:
  * per set of columns  den = prod_j (value_j + beta sigma_j + gamma),  num = prod_j (value_j + delta^j beta omega^i + gamma);

@@ -440,4 +440,19 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
     assert proof == want
     assert V.verify_proof(po.BN254, cs.description(), k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(s, pr.G2), [[]], proof)
     assert P.create_proof(adv_m, [[]], prover.SeededRng(5)).finalize() == want              # Montgomery input, same proof
+    # the reference's own call shape -- create_proof(&params, &pk, &[circuit], ...) synthesizes inside (dehalo_create_proof_circuit): same proof, same
+    # summary, with and without a side context, twice in a row (the prover's page-locked advice buffer is reused), and the caller's generator moves as far
+    inputs = dict(n_big=n, e=0b10011, x=x, exp_bits=5, message=[123456789, 987654321])
+    rng, ref = prover.SeededRng(5), PO.ScalarStream(5)
+    PO.create_proof(po.BN254, srs, key, adv_m, [[]], ref, rep, 16)
+    for rep_i in range(2):
+        tr, info = P.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], rng if rep_i == 0 else prover.SeededRng(5), **inputs)
+        assert tr.finalize() == want and info["rsa_result"] == pow(x, 0b10011, n) and info["rows"] == nat["rows"] and info["cipher"] == nat["cipher"]
+    assert np.array_equal(rng.scalars(2), ref.scalars(2))
+    lone = native.Prover(params, pk, ctx, None)
+    assert lone.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], prover.SeededRng(5), **inputs)[0].finalize() == want
+    with pytest.raises(pkg.DehaloError):                                                     # a circuit that does not fit the key's 2^k rows
+        lone.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], prover.SeededRng(5), **dict(inputs, e=(1 << 14) | 1, exp_bits=15))
+    assert lone.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], prover.SeededRng(5), **inputs)[0].finalize() == want      # and the prover is usable afterwards
+    lone.release()
     P.release(); pk.release(); params.release(); side.close()
