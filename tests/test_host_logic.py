@@ -53,3 +53,21 @@ def test_domain_rejects_oversized_extension(pkg):
         pass
     with pytest.raises(ValueError):
         pkg.EvaluationDomain(NoCtx(), pkg.fields.BN254_FR, 5, 27)  # 2^29 > two-adicity 28
+
+
+def test_bench_replaces_a_measuring_process_killed_by_a_signal_once():
+    """bench.py measures in a child process; a child that exits by itself is final (here: no GPU -> exit 1 with the reason), a child killed by a signal is
+    replaced ONCE (DEHALO_BENCH_SELFTEST_KILL = the attempt that kills itself)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = lambda extra: subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=dict(env, **extra))
+    plain = run({})
+    assert "one more" not in plain.stderr.lower()
+    if plain.returncode == 0:
+        pytest.skip("a GPU is present: the no-device exit path is not reachable")
+    assert plain.returncode == 1 and "needs an MI355X" in plain.stderr
+    once = run({"DEHALO_BENCH_SELFTEST_KILL": "1"})
+    assert once.returncode == 1 and "killed by signal 6" in once.stderr and "needs an MI355X" in once.stderr and once.stdout == ""
