@@ -17,15 +17,46 @@
 // MI355X, profiles/r02_host_path_measurements.txt: dehalo_ntt at 2^20, 32 MiB each way, 5.73 -> 1.35 ms), and so that the lifetime of the device's mapping of
 // caller memory is this object's and nothing else's (the pin ends only after the stream that copies has been synchronised).  Registration failing (already
 // pinned, exotic mapping) just leaves the pageable path.
+// Several threads may hand over the SAME host buffer at once (batch proving: one witness array, four provers): the first registers it, the others count
+// themselves in, and the pages are released by whoever leaves last -- a copy that found the buffer page-locked by another thread's registration must not
+// lose that registration in flight.  A range that only partly overlaps a registered one registers (or falls back to the pageable path) independently.
+struct HostPinRegistry {
+    struct Entry { uintptr_t a, b; int refs; };
+    std::mutex mu;
+    std::vector<Entry> entries;
+};
+inline HostPinRegistry& host_pin_registry() { static HostPinRegistry r; return r; }
+
 struct HostPin {
-    void* p = nullptr;
+    void* p = nullptr;          // the caller's pointer when its pages are page-locked through this object (by its own registration or one it shares)
+    uintptr_t key = 0;          // start of the registration it holds a reference to
     HostPin(const void* ptr, size_t bytes) {
-        if (ptr && bytes >= HOST_PIN_MIN_BYTES && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
-        else (void)hipGetLastError();
+        if (!ptr || bytes < HOST_PIN_MIN_BYTES) return;
+        HostPinRegistry& reg = host_pin_registry();
+        std::lock_guard<std::mutex> lk(reg.mu);
+        const uintptr_t a = (uintptr_t)ptr, b = a + bytes;
+        for (auto& e : reg.entries)
+            if (e.a <= a && b <= e.b) { e.refs++; key = e.a; p = const_cast<void*>(ptr); return; }
+        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) {
+            reg.entries.push_back({a, b, 1});
+            key = a; p = const_cast<void*>(ptr);
+        } else (void)hipGetLastError();
     }
     HostPin(const HostPin&) = delete;
     HostPin& operator=(const HostPin&) = delete;
-    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+    ~HostPin() {
+        if (!p) return;
+        HostPinRegistry& reg = host_pin_registry();
+        std::lock_guard<std::mutex> lk(reg.mu);
+        for (size_t i = 0; i < reg.entries.size(); i++)
+            if (reg.entries[i].a == key) {
+                if (--reg.entries[i].refs == 0) {
+                    (void)hipHostUnregister((void*)key);
+                    reg.entries.erase(reg.entries.begin() + i);
+                }
+                return;
+            }
+    }
     static constexpr size_t HOST_PIN_MIN_BYTES = 4u << 20;
 };
 

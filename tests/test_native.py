@@ -455,4 +455,15 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
         lone.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], prover.SeededRng(5), **dict(inputs, e=(1 << 14) | 1, exp_bits=15))
     assert lone.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], prover.SeededRng(5), **inputs)[0].finalize() == want      # and the prover is usable afterwards
     lone.release()
+    # four provers, four library threads, ONE host witness array of 10 MiB: each call page-locks it for its upload (HostPin); the registration is shared
+    # and released by the last one out
+    ctxs = [pkg.Context(0, priority=(1, 0, -1)[i % 3]) for i in range(4)]
+    provers4 = [native.Prover(params, pk, cx) for cx in ctxs]
+    for _ in range(2):
+        got = native.create_proofs(provers4, adv_m, [prover.SeededRng(5) for _ in range(12)])
+        assert all(g == want for g in got)
+    for q in provers4:
+        q.release()
+    for cx in ctxs:
+        cx.close()
     P.release(); pk.release(); params.release(); side.close()
