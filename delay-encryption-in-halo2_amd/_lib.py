@@ -24,7 +24,7 @@ SYMBOLS = [
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
     "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device", "dehalo_kate_division_batch_device",
     "dehalo_params_create", "dehalo_params_read", "dehalo_params_size", "dehalo_params_write", "dehalo_params_release", "dehalo_params_commit_device",
-    "dehalo_create_proof_circuit", "dehalo_keygen", "dehalo_pk_read", "dehalo_pk_size", "dehalo_pk_write", "dehalo_vk_size", "dehalo_vk_write", "dehalo_pk_set_transcript_repr",
+    "dehalo_create_proof_circuit", "dehalo_create_proofs_circuit", "dehalo_keygen", "dehalo_pk_read", "dehalo_pk_size", "dehalo_pk_write", "dehalo_vk_size", "dehalo_vk_write", "dehalo_pk_set_transcript_repr",
     "dehalo_pk_get_transcript_repr", "dehalo_pk_info", "dehalo_pk_release", "dehalo_rng_scalars", "dehalo_field_info", "dehalo_synthesize",
     "dehalo_transcript_create", "dehalo_transcript_common_scalar", "dehalo_transcript_write_scalar", "dehalo_transcript_write_point",
     "dehalo_transcript_squeeze_challenge", "dehalo_transcript_len", "dehalo_transcript_finalize", "dehalo_transcript_release",
@@ -240,6 +240,7 @@ def load_library():
     lib.dehalo_prover_release.argtypes = [P]
     lib.dehalo_create_proof.argtypes = [P, u64p, C.POINTER(C.c_void_p), C.POINTER(sz), u32, C.POINTER(CRng), P, u32]
     lib.dehalo_create_proof_circuit.argtypes = [P, C.POINTER(CCircuitInputs), C.POINTER(CSynthesisInfo), C.POINTER(C.c_void_p), C.POINTER(sz), u32, C.POINTER(CRng), P]
+    lib.dehalo_create_proofs_circuit.argtypes = [C.POINTER(C.c_void_p), u32, C.POINTER(CCircuitInputs), u32, C.POINTER(CRng), C.POINTER(C.c_void_p), sz, C.POINTER(sz)]
     lib.dehalo_prover_last_timings.argtypes = [P, C.POINTER(C.c_double)]
     lib.dehalo_create_proofs.argtypes = [C.POINTER(C.c_void_p), u32, C.POINTER(C.c_void_p), u32, C.POINTER(CRng), u32, C.POINTER(C.c_void_p), sz, C.POINTER(sz)]
     lib.dehalo_timing_enable.argtypes = [P, C.c_int]

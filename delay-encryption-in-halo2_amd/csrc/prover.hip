@@ -1448,9 +1448,10 @@ extern "C" int dehalo_create_proof_circuit(dehalo_prover* p, const dehalo_circui
     return rc;
 } catch (...) { return DEHALO_ERR_OOM; }
 
-extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, const uint64_t* const* advice, uint32_t count, dehalo_rng* rngs, uint32_t flags,
-                                    uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens) try {
-    if (!provers || !num_provers || (count && (!advice || !proofs_out || !proof_lens))) return DEHALO_ERR_INVALID;
+namespace {
+// proof i on prover i mod num_provers, one library thread per prover; `one` makes proof i on prover p into `tr`
+template <class One>
+int proofs_on_threads(dehalo_prover* const* provers, uint32_t num_provers, uint32_t count, uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens, One one) {
     for (uint32_t i = 0; i < num_provers; i++)
         if (!provers[i]) return DEHALO_ERR_INVALID;
     std::vector<int> rcs(num_provers, 0);
@@ -1459,7 +1460,7 @@ extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_
         for (uint32_t i = t; i < count && !rcs[t]; i += num_provers) {
             dehalo_transcript tr;
             tr.init(p->pk->curve);
-            int rc = dehalo_create_proof(p, advice[i], nullptr, nullptr, p->I ? p->I : 0, rngs ? &rngs[i] : nullptr, &tr, flags);
+            int rc = one(p, i, &tr);
             if (!rc && tr.proof.size() > proof_cap) rc = dh_fail(p->ctx, DEHALO_ERR_INVALID, "create_proofs: proof buffer too small");
             if (!rc) {
                 memcpy(proofs_out[i], tr.proof.data(), tr.proof.size());
@@ -1475,4 +1476,22 @@ extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_
     for (int rc : rcs)
         if (rc) return rc;
     return 0;
+}
+}   // namespace
+
+extern "C" int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, const uint64_t* const* advice, uint32_t count, dehalo_rng* rngs, uint32_t flags,
+                                    uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens) try {
+    if (!provers || !num_provers || (count && (!advice || !proofs_out || !proof_lens))) return DEHALO_ERR_INVALID;
+    return proofs_on_threads(provers, num_provers, count, proofs_out, proof_cap, proof_lens, [&](dehalo_prover* p, uint32_t i, dehalo_transcript* tr) {
+        return dehalo_create_proof(p, advice[i], nullptr, nullptr, p->I ? p->I : 0, rngs ? &rngs[i] : nullptr, tr, flags);
+    });
+} catch (...) { return DEHALO_ERR_OOM; }
+
+// the same with every proof's circuit synthesized inside its call (dehalo_create_proof_circuit): inputs[i] -> proof i
+extern "C" int dehalo_create_proofs_circuit(dehalo_prover* const* provers, uint32_t num_provers, const dehalo_circuit_inputs* inputs, uint32_t count, dehalo_rng* rngs,
+                                            uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens) try {
+    if (!provers || !num_provers || (count && (!inputs || !proofs_out || !proof_lens))) return DEHALO_ERR_INVALID;
+    return proofs_on_threads(provers, num_provers, count, proofs_out, proof_cap, proof_lens, [&](dehalo_prover* p, uint32_t i, dehalo_transcript* tr) {
+        return dehalo_create_proof_circuit(p, &inputs[i], nullptr, nullptr, nullptr, p->I ? p->I : 0, rngs ? &rngs[i] : nullptr, tr);
+    });
 } catch (...) { return DEHALO_ERR_OOM; }

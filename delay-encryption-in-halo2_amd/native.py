@@ -379,6 +379,38 @@ def create_proofs(provers: Sequence[Prover], advice, rngs: Sequence, count: Opti
     return [bufs[i][:lens[i]].tobytes() for i in range(count)]
 
 
+def create_proofs_circuit(provers: Sequence[Prover], circuit: int, inputs: Sequence[dict], rngs: Sequence) -> List[bytes]:
+    """Batch mode with every proof's circuit synthesized inside its call (dehalo_create_proofs_circuit): inputs[i] = the keyword arguments of
+    synthesize() for proof i (n_big, e, x, exp_bits, message, key, bits_len)."""
+    lib = load_library()
+    count = len(inputs)
+    k = provers[0].pk.info()["k"]
+    arr = (CCircuitInputs * max(1, count))()
+    keep = []
+    for i, kw in enumerate(inputs):
+        inp, arrays = circuit_inputs(circuit, k, **kw)
+        arr[i] = inp
+        keep.append(arrays)
+    info = provers[0].pk.info()
+    cap = 32 * (info["commitments_before_evaluations"] + info["evaluations"] + info["opening_points"])
+    bufs = [np.empty(cap, dtype=np.uint8) for _ in range(count)]
+    lens = (C.c_size_t * max(1, count))()
+    rs = (CRng * max(1, count))()
+    keepalive = []
+    for i, g in enumerate(rngs):
+        r = rng_struct(g)
+        if r is None:
+            rs[i].kind = RNG_OS
+        else:
+            keepalive.append(r)
+            rs[i] = r
+    ph = (C.c_void_p * len(provers))(*[p.handle.value for p in provers])
+    rc = lib.dehalo_create_proofs_circuit(ph, len(provers), arr, count, rs, (C.c_void_p * max(1, count))(*[b.ctypes.data for b in bufs]), cap, lens)
+    if rc != 0:
+        raise DehaloError(rc, "; ".join(lib.dehalo_last_error(p.ctx.handle).decode() for p in provers))
+    return [bufs[i][:lens[i]].tobytes() for i in range(count)]
+
+
 def _limbs(x: int, count: int) -> np.ndarray:
     return np.frombuffer(int(x).to_bytes(8 * count, "little"), dtype=np.uint64).copy()
 

@@ -526,6 +526,10 @@ int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advice, uint64_
  * Same proof bytes as dehalo_synthesize + dehalo_create_proof with DEHALO_PROOF_ADVICE_CANONICAL.  `info` (optional): rows, x^e mod n, ciphertext. */
 int dehalo_create_proof_circuit(dehalo_prover* prover, const dehalo_circuit_inputs* in, dehalo_synthesis_info* info, const uint64_t* const* instances,
                                 const size_t* instance_lens, uint32_t num_instance_columns, dehalo_rng* rng, dehalo_transcript* transcript);
+/* dehalo_create_proofs with every proof's circuit synthesized inside its call: inputs[i] -> proof i on prover i mod num_provers, one library thread per
+ * prover (witness generation of one proof runs beside the device work of the others). */
+int dehalo_create_proofs_circuit(dehalo_prover* const* provers, uint32_t num_provers, const dehalo_circuit_inputs* inputs, uint32_t count, dehalo_rng* rngs,
+                                 uint8_t* const* proofs_out, size_t proof_cap, size_t* proof_lens);
 
 /* The grand products' per-row factors, every product of a proof in one launch [UPSTREAM plonk/permutation/prover.rs Argument::commit:
  * per set of columns  den = prod_j (value_j + beta sigma_j + gamma),  num = prod_j (value_j + delta^j beta omega^i + gamma);

@@ -462,6 +462,12 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
     for _ in range(2):
         got = native.create_proofs(provers4, adv_m, [prover.SeededRng(5) for _ in range(12)])
         assert all(g == want for g in got)
+    # the same with every proof's circuit synthesized inside its call; proof 3 has another exponent (its own witness), all others the one above
+    ins = [dict(inputs) for _ in range(8)]
+    ins[3] = dict(inputs, e=0b10101)
+    got = native.create_proofs_circuit(provers4, native.CIRCUIT_DELAY_ENC, ins, [prover.SeededRng(5) for _ in range(8)])
+    assert all(g == want for i, g in enumerate(got) if i != 3) and got[3] != want
+    assert got[3] == P.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], prover.SeededRng(5), **ins[3])[0].finalize()
     for q in provers4:
         q.release()
     for cx in ctxs:
