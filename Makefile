@@ -29,6 +29,9 @@ host_example: $(LIB) $(PKG)/host/halo2_backend.hpp $(PKG)/host/example.cpp
 host_sanitize: tests/native_host/host_sanitize.cpp $(CSRC)/witness.hip $(HDRS)
 	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -x c++ -o tests/native_host/host_sanitize tests/native_host/host_sanitize.cpp -x c++ $(CSRC)/witness.hip
 
+host_tsan: tests/native_host/host_sanitize.cpp $(CSRC)/witness.hip $(HDRS)
+	g++ -std=c++17 -O1 -g -fsanitize=thread -x c++ -o tests/native_host/host_tsan tests/native_host/host_sanitize.cpp -x c++ $(CSRC)/witness.hip -lpthread
+
 clean:
 	rm -rf $(LIB) $(OBJDIR) $(PKG)/host/example; $(MAKE) -C oracle clean
-.PHONY: all oracle clean host_example host_sanitize
+.PHONY: all oracle clean host_example host_sanitize host_tsan

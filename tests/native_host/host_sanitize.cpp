@@ -37,6 +37,13 @@ int main(int argc, char** argv) {
     h.update(fixed.data(), fixed.size() * 8);
     h.update(mapping.data(), mapping.size() * 8);
     h.update(s0.data(), rows); h.update(s1.data(), rows);
+    // a proving call (advice only) writes its regions from the synthesis pool's threads: the same columns
+    {
+        std::vector<uint64_t> advice2(5 * rows * 4, ~0ull);
+        dehalo_synthesis_info info2{};
+        rc = dehalo_synthesize(&in, advice2.data(), nullptr, nullptr, nullptr, &info2);
+        if (rc != 0 || advice2 != advice || info2.total_rows != info.total_rows) { printf("proving-mode advice differs from keygen-mode advice (%d)\n", rc); return 1; }
+    }
     // the too-small circuit and bad arguments are refused, not overrun
     in.k = 10;
     if (dehalo_synthesize(&in, advice.data(), nullptr, nullptr, nullptr, nullptr) == 0) { printf("k = 10 accepted\n"); return 1; }

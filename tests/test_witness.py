@@ -344,6 +344,19 @@ def test_native_synthesize_rows_do_not_depend_on_the_number_of_threads(pkg):
     assert len(seen) == 1
 
 
+def test_synthesis_threads_under_thread_sanitizer(pkg):
+    """The same host code built with -fsanitize=thread: a proving call at k = 16 with a 5-bit exponent (eight multiplication regions and the hash / cipher
+    task on eight threads) reports no data race and writes the keygen call's advice columns."""
+    import subprocess
+    from conftest import ROOT
+
+    out = subprocess.run(["make", "-C", ROOT, "host_tsan"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    run = subprocess.run([os.path.join(ROOT, "tests", "native_host", "host_tsan"), "16", "5"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, DEHALO_SYNTH_THREADS="8"))
+    assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr and "rows" in run.stdout, run.stdout + run.stderr
+
+
 def test_native_synthesize_in_a_forked_child(pkg):
     """The synthesis worker threads sleep between calls and do not exist in a forked child: the child makes its own and writes the same rows."""
     from dehalo2_amd import native
