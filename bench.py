@@ -410,7 +410,7 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     # work of the others) -- reported beside the figure above, whose witness is resident
     synth = None
     spec = getattr(st.circ, "native_spec", None)
-    if spec is not None and mine:
+    if spec is not None:      # (every rank takes this branch: the fences inside are collective)
         kw = {a: b for a, b in spec.items() if a not in ("circuit", "k")}
         fence_all(world)
         t1 = time.perf_counter()
