@@ -41,3 +41,21 @@ for r in range(rounds):
     for i, pf in enumerate(proofs):
         assert pf == first[seeds[i % len(seeds)]], "batch round %d proof %d differs" % (r, i)
 print("%d rounds of 32 proofs on four provers (one library thread each): all identical to the lone prover's" % rounds)
+# the circuit-level calls (witness synthesized inside, by the synthesis pool) and a host witness shared by four library threads (HostPin's shared registration)
+spec = getattr(circ, "native_spec", None)
+if spec is not None:
+    import numpy as np
+    kw = {a: b for a, b in spec.items() if a not in ("circuit", "k")}
+    n_c = max(50, count // 5)
+    for i in range(n_c):
+        sd = seeds[i % len(seeds)]
+        assert N.create_proof_circuit(spec["circuit"], [[]], prover.SeededRng(sd), **kw)[0].finalize() == first[sd], "create_proof_circuit %d differs" % i
+    print("%d dehalo_create_proof_circuit calls: identical" % n_c, flush=True)
+    host = native.synthesize(spec["circuit"], spec["k"], **kw)["advice"]
+    host_m = np.stack([co.field_op(curve.scalar.id, "to_mont", host[i]) for i in range(host.shape[0])])
+    for r in range(rounds):
+        proofs = native.create_proofs(provers, host_m, [prover.SeededRng(seeds[i % len(seeds)]) for i in range(32)])
+        assert all(pf == first[seeds[i % len(seeds)]] for i, pf in enumerate(proofs)), "host-witness batch round %d differs" % r
+        proofs = native.create_proofs_circuit(provers, spec["circuit"], [kw] * 32, [prover.SeededRng(seeds[i % len(seeds)]) for i in range(32)])
+        assert all(pf == first[seeds[i % len(seeds)]] for i, pf in enumerate(proofs)), "circuit batch round %d differs" % r
+    print("%d rounds of 32 proofs from one shared HOST witness array and %d rounds from circuits synthesized inside the calls, four provers: all identical" % (rounds, rounds))
