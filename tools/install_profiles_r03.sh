@@ -5,6 +5,7 @@ r=r03; F=gpurun_out/final
 cp $F/bench.json profiles/${r}_bench.json
 cp $F/bench_one_step_at_a_time_under_rocprof.json profiles/${r}_bench_timed_region_under_rocprof.json
 cp $F/k1/k1_kernel_stats.csv profiles/${r}_kernel_stats_timed_region.csv
+cp $F/accum0_launch_durations.txt profiles/${r}_accum0_launch_durations.txt
 cp $F/bench_timed_region_under_rocprof.json profiles/${r}_bench_timed_region_4_in_flight_under_rocprof.json
 cp $F/kt/kt_kernel_stats.csv profiles/${r}_kernel_stats_timed_region_4_in_flight.csv
 cp $F/kp/kp_kernel_stats.csv profiles/${r}_kernel_stats_create_proof_k17.csv

@@ -5,6 +5,7 @@ out=gpurun_out/final; rm -rf $out; mkdir -p $out
 echo "[1] bench line"; timeout -k 10 700 python bench.py > $out/bench.json 2> $out/bench.err || echo "bench failed"
 echo "[2] kernel stats, timed region one step at a time (the duration the roofline is computed from)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/k1 -o k1 -- python3 bench.py --in-process --inflight 1 --no-single-stream --no-cpu-baseline --proof-k 0 --proofs 0 > $out/bench_one_step_at_a_time_under_rocprof.json 2> $out/k1.err
+python3 tools/accum0_launches.py $out/k1/k1_kernel_trace.csv > $out/accum0_launch_durations.txt
 echo "[2b] kernel stats, timed region 4 steps in flight"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --in-process --no-single-stream --no-cpu-baseline --proof-k 0 --proofs 0 > $out/bench_timed_region_under_rocprof.json 2> $out/kt.err
 echo "[3] kernel stats, dehalo_create_proof k=17"
