@@ -603,6 +603,8 @@ def main():
         c.ntt_device(field.id, d_polys[pre[0] % inflight].data_ptr(), log_n, omega, 1, 0)
         pre[0] += 1
     note("steps: preheat, warm-up, timed region")
+    import gc
+    gc.collect(); gc.disable()      # (as timeit does: no collector pause of the interpreter inside the 30 ms region -- and none between the preheat and it)
     preheat_steps = preheat(step_preheat, lambda: [c.synchronize() for c in ctxs]) if PREHEAT_S > 0 else 0
     for _ in range(args.warmup):
         step()
@@ -611,8 +613,6 @@ def main():
     for c in ctxs:
         c.timing_enable(True)
         c.timing_reset()
-    import gc
-    gc.collect(); gc.disable()      # (as timeit does: no collector pause of the interpreter inside a 30 ms region)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
