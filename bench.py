@@ -388,7 +388,7 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     import torch
     from dehalo2_amd import native, prover, sharding
     note("batch mode: setup")
-    st = ProofSetup(pkg, ctx, k, "delay_enc", min(host_cores(), 256))
+    st = ProofSetup(pkg, ctx, k, "delay_enc", max(8, min(host_cores(), 256) // max(1, world)))      # (every rank builds the synthetic SRS on the host at once: share the cores)
     mine = sharding.units_for_rank(total, rank, world)
     st.prove(1000)                                            # warm-up
     cs = st.circ.cs
