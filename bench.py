@@ -311,7 +311,8 @@ def verify_with_device_vk(st, proof):
     import verifier as V
     from dehalo2_amd import keygen
     vk = st.vk
-    return V.verify_proof(st.ocurve, st.circ.cs.description(), st.k, keygen.decode_points(st.curve, vk.fixed_commitments),
+    import shapes
+    return V.verify_proof(st.ocurve, shapes.maingate_description(bool(st.circ.cs.lookups)), st.k, keygen.decode_points(st.curve, vk.fixed_commitments),
                           keygen.decode_points(st.curve, vk.permutation_commitments), vk.transcript_repr, (1, 2), pr.G2, pr.g2_mul(st.s, pr.G2), [[]], proof)
 
 
@@ -353,7 +354,9 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
         import plonk_oracle as PO
         import numpy as np
         t0 = time.time()
-        key = PO.keygen(st.ocurve, st.srs, cs.description(), k, st.circ.fixed, st.circ.assembly.mapping, threads)
+        import shapes
+        assert shapes.maingate_description(bool(cs.lookups)) == cs.description(), "the product's constraint system differs from the checker's statement of it"
+        key = PO.keygen(st.ocurve, st.srs, shapes.maingate_description(bool(cs.lookups)), k, st.circ.fixed, st.circ.assembly.mapping, threads)
         t1 = time.time()
         rep = PO.transcript_repr(st.ocurve, key, st.circ.selectors)
         adv = np.stack([co.field_op(st.curve.scalar.id, "to_mont", st.circ.advice[i]) for i in range(cs.num_advice)])

@@ -426,7 +426,9 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
     asm.mapping = nat["mapping"].astype(np.int64)
     s = 0x5EED5EED5EED5EED
     srs = PO.setup_srs(po.BN254, k, s, 16)
-    key = PO.keygen(po.BN254, srs, cs.description(), k, nat["fixed"], asm.mapping, 16)
+    import shapes
+    assert shapes.maingate_description(True) == cs.description()
+    key = PO.keygen(po.BN254, srs, shapes.maingate_description(True), k, nat["fixed"], asm.mapping, 16)
     rep = PO.transcript_repr(po.BN254, key, nat["selectors"])
     params = native.ParamsKZG.create(ctx, pkg.fields.BN254, k, srs["g"], srs["g_lagrange"])
     pk = native.ProvingKey.keygen(ctx, params, cs, nat["fixed"], asm, nat["selectors"])
@@ -438,7 +440,7 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
     adv_m = np.stack([co.field_op(0, "to_mont", nat["advice"][i]) for i in range(5)])
     want, _ = PO.create_proof(po.BN254, srs, key, adv_m, [[]], PO.ScalarStream(5), rep, 16)
     assert proof == want
-    assert V.verify_proof(po.BN254, cs.description(), k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(s, pr.G2), [[]], proof)
+    assert V.verify_proof(po.BN254, shapes.maingate_description(True), k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(s, pr.G2), [[]], proof)
     assert P.create_proof(adv_m, [[]], prover.SeededRng(5)).finalize() == want              # Montgomery input, same proof
     # the reference's own call shape -- create_proof(&params, &pk, &[circuit], ...) synthesizes inside (dehalo_create_proof_circuit): same proof, same
     # summary, with and without a side context, twice in a row (the prover's page-locked advice buffer is reused), and the caller's generator moves as far

@@ -326,3 +326,15 @@ def test_evalh_golden_vs_both_oracles(po, co, golden_loader):
             assert po.permute_expression_pair(f, inp, tab, v["usable"]) == want
             got = co.permute_expression_pair(fid, enc(inp), enc(tab), v["usable"])
             assert (_dec(po, f, got[0]), _dec(po, f, got[1])) == want
+
+
+def test_checker_states_the_constraint_systems_itself(pkg):
+    """oracle/shapes.py writes the two constraint systems of the reference's circuits down on its own (MainGate alone: pose_enc; MainGate + RangeChip:
+    mod_pow / delay_enc); the product's plonk.maingate_cs must describe exactly that -- columns, the gate, the five lookups, equality columns, query order."""
+    import shapes
+    from dehalo2_amd import plonk
+
+    for rl in (False, True):
+        d = shapes.maingate_description(rl)
+        assert d == plonk.maingate_cs(rl).description()
+        assert (d[0], d[1], d[2], len(d[3]), len(d[4]), len(d[5])) == (5, 15 if rl else 9, 1, 1, 5 if rl else 0, 6)

@@ -30,7 +30,9 @@ def chain(pkg, po, co):
         if (k, rl) not in cache:
             curve = po.BN254
             circ = circuits.synthesize(curve.scalar.p, k, rl, seed=3)
-            desc = circ.cs.description()
+            import shapes
+            desc = shapes.maingate_description(rl)                 # the checker's own statement of the shape ...
+            assert desc == circ.cs.description()                   # ... which the product's must equal
             srs = PO.setup_srs(curve, k, S_TOXIC, threads)
             key = PO.keygen(curve, srs, desc, k, circ.fixed, circ.assembly.mapping, threads)
             rep = PO.transcript_repr(curve, key, circ.selectors)

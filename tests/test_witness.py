@@ -96,7 +96,9 @@ def _oracle_chain(po, co, circ, k, threads):
 
     s = 0x5EED5EED5EED5EED
     srs = PO.setup_srs(po.BN254, k, s, threads)
-    desc = circ.cs.description()
+    import shapes
+    desc = shapes.maingate_description(bool(circ.cs.lookups))      # the checker's own statement of the shape; the product's must equal it
+    assert desc == circ.cs.description()
     key = PO.keygen(po.BN254, srs, desc, k, circ.fixed, circ.assembly.mapping, threads)
     rep = PO.transcript_repr(po.BN254, key, circ.selectors)
     adv = np.stack([co.field_op(0, "to_mont", circ.advice[i]) for i in range(5)])

@@ -14,7 +14,8 @@ from dehalo2_amd import plonk, circuits, prover, keygen, transcript
 def run(ctx, k, rl, verify=True, threads=16):
     curve, ocurve = pkg.fields.BN254, po.BN254
     circ = circuits.synthesize(curve.scalar.p, k, rl, seed=3)
-    desc = circ.cs.description()
+    import shapes
+    desc = shapes.maingate_description(bool(circ.cs.lookups))
     s = 0x1234567890abcdef1234567890abcdef
     t = time.time(); srs = PO.setup_srs(ocurve, k, s, threads); print("srs", round(time.time() - t, 2), flush=True)
     params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"], pr.g2_to_raw(pr.G2), pr.g2_to_raw(pr.g2_mul(s, pr.G2)))
