@@ -146,7 +146,7 @@ def secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n):
     out["table_windows"], out["table_bytes"] = b.windows, b.windows * n * 64
     b.release()
     t = time.perf_counter(); b1 = ctx.register_bases(curve.id, bases_h, 0, False); out["table_build_ms_single_row"] = round(1e3 * (time.perf_counter() - t), 2)
-    d_s = torch.from_numpy(scalars_h.view(np.int64)).cuda()
+    d_s = ctx.upload(scalars_h)
     d_o = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     ts = []
@@ -491,24 +491,72 @@ def under_profiler() -> bool:
     return "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ)
 
 
+def _section_of(stderr_tail: str) -> str:
+    """the last `[bench … s] section` marker note() printed before a measuring process died"""
+    last = ""
+    for line in stderr_tail.splitlines():
+        if line.startswith("[bench "):
+            last = line.split("] ", 1)[-1]
+    return last
+
+
 def supervise() -> int:
-    """One-GPU runs measure in a child process (nothing in this one has touched the GPU).  A child that dies by a signal -- seen once in this
-    round: `Memory access fault by GPU node` in one full run out of about ten, cause not found, DESIGN.md section 8 -- is replaced ONCE; the line
-    then carries "attempts": 2.  A child that exits by itself (any code) is final."""
+    """One-GPU runs measure in a child process (nothing in this one has touched the GPU).  A child that dies by a signal -- seen once in
+    round 3: `Memory access fault by GPU node` in one full run out of about ten, DESIGN.md section 8 -- is replaced ONCE by a FRESH child (never
+    a re-exec); the JSON line then carries "attempts": 2 and "first_attempt": {"signal", "section", "stderr_tail"} of the one that died.
+    A child that exits by itself (any code) is final."""
     import subprocess
+    import tempfile
+    first = None
     for attempt in (1, 2):
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--in-process"], stdout=subprocess.PIPE, env=dict(os.environ, DEHALO_BENCH_ATTEMPT=str(attempt)))
+        env = dict(os.environ, DEHALO_BENCH_ATTEMPT=str(attempt))
+        if first is not None:
+            env["DEHALO_BENCH_FIRST_ATTEMPT"] = json.dumps(first)
+        with tempfile.TemporaryFile() as errf:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--in-process"], stdout=subprocess.PIPE, stderr=errf, env=env)
+            errf.seek(0)
+            err = errf.read().decode(errors="replace")
+        sys.stderr.write(err)
+        sys.stderr.flush()
         out = p.stdout.decode()
         if p.returncode >= 0 or attempt == 2:
             sys.stdout.write(out)
             sys.stdout.flush()
             return p.returncode if p.returncode >= 0 else 128 - p.returncode
-        sys.stderr.write("[bench] the measuring process was killed by signal %d; its partial output is dropped and ONE more is started\n" % -p.returncode)
+        tail = [l for l in err.splitlines() if l.strip()][-6:]
+        first = {"signal": -p.returncode, "section": _section_of(err), "stderr_tail": [l[:300] for l in tail]}
+        sys.stderr.write("[bench] the measuring process was killed by signal %d in section %r; its partial output is dropped and ONE more is started\n" % (-p.returncode, first["section"]))
     return 1
+
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment (the driver's N = 1 command shape with N changed): this process has not
+    touched the GPU, so it starts `python -m torch.distributed.run --nproc-per-node N bench.py ... --in-process` as a FRESH child process (one rank per GPU
+    over RCCL), relays its output -- rank 0's single JSON line -- and returns its exit code."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--in-process"] + ["--in-process"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the pool's driver supports dmabuf IPC only (RCCL's intra-node transport)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    p = subprocess.run(cmd, env=env)
+    return p.returncode if p.returncode >= 0 else 128 - p.returncode
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1 and not args.in_process:
+        raise SystemExit(launch_ranks(args.gpus))      # a fresh torchrun child; this process never touches the GPU
     if not args.in_process and "RANK" not in os.environ and not under_profiler():
         raise SystemExit(supervise())
     if os.environ.get("DEHALO_BENCH_SELFTEST_KILL") and os.environ.get("DEHALO_BENCH_SELFTEST_KILL") == os.environ.get("DEHALO_BENCH_ATTEMPT"):
@@ -533,9 +581,16 @@ def main():
     if args.force_device >= 0:
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
+    rccl_world = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.dist_backend)  # "nccl" = RCCL over xGMI
+        # "nccl" = RCCL over xGMI.  (The timeout covers rank 0's CPU baseline and proof checks at the end, which the other ranks wait out in a barrier.)
+        dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(minutes=30))
+        seen = torch.tensor([dist.get_world_size()], dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        allseen = [torch.zeros_like(seen) for _ in range(world)]
+        dist.all_gather(allseen, seen)
+        rccl_world = {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else " (CPU rehearsal)"), "world_size_seen_by_rank": [int(t.item()) for t in allseen]}
 
     pkg = entry.load_package()
     po, co = entry.load_oracle()  # synthetic-input generators + the cpu_baseline leg only
@@ -563,8 +618,9 @@ def main():
     scalars_h = co.fill_scalars(curve.scalar.id, args.dist, n, 1000 + rank)
     poly_h = co.fill_scalars(field.id, "uniform", n, 2000 + rank)
     bases = ctx.register_bases(curve.id, bases_h, args.window_bits, True)  # resident SRS tables
-    d_scalars = torch.from_numpy(scalars_h.view(np.int64)).cuda()
-    d_polys = [torch.from_numpy(poly_h.view(np.int64)).cuda() for _ in range(inflight)]
+    # (every host array goes to HBM through the library's staged upload -- Context.upload -- never through `tensor.cuda()` of a pageable array)
+    d_scalars = ctx.upload(scalars_h)
+    d_polys = [ctx.upload(poly_h) for _ in range(inflight)]
     # one output row per step: the commitment vector of this rank (gathered once, at the end)
     d_out_all = torch.zeros((args.warmup + args.steps + 1, 12), dtype=torch.int64, device="cuda")
     d_out = d_out_all[0:1]
@@ -718,20 +774,31 @@ def main():
                          "valu": {"mads_per_launch": MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows, "peak_tmad_per_s": VMAD_PEAK_TMADS,
                                   "achieved_tmad_per_s": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (roof_ms * 1e-3) / 1e12, 2) if roof_ms > 0 else 0.0,
                                   "frac": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (roof_ms * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4) if roof_ms > 0 else 0.0}},
-            "breakdown_ms_per_step": {"msm_sort": round(sort_ms / max(sort_cnt, 1), 4), "msm_accumulate": round(acc_avg_ms, 4),
-                                      "msm_reduce": round(red_ms / max(red_cnt, 1), 4), "ntt": round(ntt_ms / max(ntt_cnt, 1), 4)},
+            # per-kernel device time of a step from the one-step-at-a-time pass (the kernels doing their work alone: sums to <= single_stream.ms_per_step);
+            # the same regions measured inside the timed region, stretched by the neighbouring steps' kernels, are printed as *_overlapped
+            "breakdown_ms_per_step": None if ss_steps == 0 else {name: round(single[kid][0] / max(single[kid][1], 1), 4) for name, kid in
+                                      (("msm_sort", _lib.K_MSM_SORT), ("msm_accumulate", _lib.K_MSM_ACCUMULATE), ("msm_reduce", _lib.K_MSM_REDUCE), ("ntt", _lib.K_NTT_PASS))},
+            "breakdown_ms_per_step_overlapped": {"msm_sort": round(sort_ms / max(sort_cnt, 1), 4), "msm_accumulate": round(acc_avg_ms, 4),
+                                                 "msm_reduce": round(red_ms / max(red_cnt, 1), 4), "ntt": round(ntt_ms / max(ntt_cnt, 1), 4),
+                                                 "note": "the same regions inside the timed region, %d steps in flight: each is stretched by the other steps' kernels sharing the chip (they sum to more than a step)" % inflight},
             "single_stream": None if ss_steps == 0 else {"ms_per_step": round(ss_ms, 4), "steps": ss_steps,
                               "kernel_ms": {name: round(single[kid][0] / max(single[kid][1], 1), 4) for name, kid in
                                             (("msm_sort", _lib.K_MSM_SORT), ("msm_accumulate", _lib.K_MSM_ACCUMULATE), ("msm_reduce", _lib.K_MSM_REDUCE), ("ntt", _lib.K_NTT_PASS))},
                               "note": "same step, one at a time (not the metric): kernel times without overlap from the %d steps in flight" % inflight},
-            "ntt_roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEM * n / (ntt_ms / max(ntt_cnt, 1) * 1e-3) / 1e9, 2) if ntt_ms > 0 else 0.0,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s"},
         }
+        # NTT: like the MSM's roofline, from the transform running ALONE (the one-at-a-time pass: its passes back to back, nothing else on the chip);
+        # the overlapped average of the timed region is printed beside it
+        ntt_over_ms = ntt_ms / max(ntt_cnt, 1)
+        ntt_alone_ms = single[_lib.K_NTT_PASS][0] / max(single[_lib.K_NTT_PASS][1], 1) if ss_steps else 0.0
+        ntt_avg_ms, ntt_src = (ntt_alone_ms, "one step at a time (single_stream pass, %d transforms)" % ss_steps) if ntt_alone_ms > 0 else \
+                              (ntt_over_ms, "timed region, %d steps in flight (overlap-inflated)" % inflight)
+        passes = 1 if log_n <= 11 else (log_n + 7) // 8
+        out["ntt_roofline"] = {"bound": "hbm", "kernel": "k_ntt_pass x %d" % passes, "achieved": round(NTT_BYTES_PER_ELEM * n / (ntt_avg_ms * 1e-3) / 1e9, 2) if ntt_avg_ms > 0 else 0.0,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_transform": NTT_BYTES_PER_ELEM * n,
+                               "avg_transform_ms": round(ntt_avg_ms, 4), "avg_transform_ms_source": ntt_src, "avg_transform_ms_overlapped": round(ntt_over_ms, 4)}
         out["ntt_roofline"]["frac"] = round(out["ntt_roofline"]["achieved"] / HBM_PEAK_GBS, 5)
         # like the MSM, a 255-bit NTT on gfx950 is bound by wide-multiply issue, not by HBM: N/2 log2 N butterfly
         # multiplications + one output multiplication per element per pass (3 passes from 2^12 up to 2^24)
-        ntt_avg_ms = ntt_ms / max(ntt_cnt, 1)
-        passes = 1 if log_n <= 11 else (log_n + 7) // 8
         ntt_muls = n * log_n // 2 + n * passes
         mads_per_mul = MADS_PER_FIELD_MUL.get(args.ntt_field, 0)
         out["ntt_roofline"]["valu"] = {"muls_per_launch": ntt_muls, "mads_per_mul": mads_per_mul, "peak_tmad_per_s": VMAD_PEAK_TMADS,
@@ -741,23 +808,28 @@ def main():
         if ss["msm_accumulate"] > 0 and ss["ntt"] > 0:
             out["single_stream"]["valu_frac"] = {"k_msm_accum0": round(MADS_PER_MIXED_ADD.get(args.curve, 0) * n * n_windows / (ss["msm_accumulate"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4),
                                                  "k_ntt_pass": round(ntt_muls * mads_per_mul / (ss["ntt"] * 1e-3) / 1e12 / VMAD_PEAK_TMADS, 4)}
+        if os.environ.get("DEHALO_BENCH_FIRST_ATTEMPT"):      # supervise(): a first measuring process died by a signal; what is known about it travels in the line
+            out["first_attempt"] = json.loads(os.environ["DEHALO_BENCH_FIRST_ATTEMPT"])
+        out["rccl_world"] = rccl_world
         note("roofline inputs, cpu baseline, secondary numbers")
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             # the CPU port on rank 0's own inputs: the reported baseline AND the parity check of the measured 2^20 configuration
             out["cpu_baseline"], want_msm, want_ntt = cpu_baseline(co, po, curve, field, log_n, bases_h, scalars_h, poly_h)
-            got = ctx.to_affine(curve.id, d_out_all[args.warmup:args.warmup + args.steps].cpu().numpy().view(np.uint64))
+            got = ctx.to_affine(curve.id, ctx.download_tensor(d_out_all[args.warmup:args.warmup + args.steps].contiguous()))
             assert all(np.array_equal(g, want_msm) for g in got), "a timed step's MSM result differs from the CPU port's"
-            chk = torch.from_numpy(poly_h.view(np.int64)).cuda()
+            chk = ctx.upload(poly_h)
             torch.cuda.synchronize()
             ctx.ntt_device(field.id, chk.data_ptr(), log_n, omega, 1, 0)
             ctx.synchronize()
-            assert np.array_equal(chk.cpu().numpy().view(np.uint64), want_ntt), "the 2^%d NTT differs from the CPU port's" % log_n
+            assert np.array_equal(ctx.download_tensor(chk), want_ntt), "the 2^%d NTT differs from the CPU port's" % log_n
             out["parity_of_timed_configuration"] = "all %d timed MSM results and the 2^%d NTT equal the CPU port's (checked after the timed region)" % (args.steps, log_n)
-            out["secondary"] = secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n)
-        if world == 1 and args.proof_k > 0:
+            if world == 1:
+                out["secondary"] = secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n)
+        if args.proof_k > 0:
             with_cpu = not args.no_cpu_baseline
             verify = not args.no_verify
             out["proof"] = proof_numbers(pkg, co, po, ctx, args.proof_k, "delay_enc", with_cpu, verify)
+        if args.proof_k > 0 and world == 1:      # (N > 1: rank 0 makes the headline proof only -- the other ranks wait at the final barrier meanwhile)
             out["proof_mod_pow"] = proof_numbers(pkg, co, po, ctx, 17, "mod_pow", with_cpu, verify)              # BASELINE configs[2]
             out["proof_pose_enc"] = proof_numbers(pkg, co, po, ctx, 11, "pose_enc", with_cpu, verify)            # BASELINE configs[0]
             # north star: k in {14, 17, 20}.  k = 14 against the CPU restatement too; k = 20 (CPU proof: a minute) by the pairing check

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SYMBOLS = [
-    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_create_with_priority", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
+    "dehalo_version", "dehalo_ctx_create", "dehalo_ctx_create_with_priority", "dehalo_ctx_destroy", "dehalo_last_error", "dehalo_ctx_synchronize", "dehalo_download", "dehalo_upload", "dehalo_ctx_stream", "dehalo_ctx_set_tuning",
     "dehalo_bases_register", "dehalo_bases_release", "dehalo_bases_len", "dehalo_bases_info",
     "dehalo_msm", "dehalo_msm_batch", "dehalo_msm_device", "dehalo_msm_device_affine", "dehalo_msm_last_shape", "dehalo_lookup_h_batch_device", "dehalo_product_terms_device", "dehalo_best_multiexp", "dehalo_to_affine", "dehalo_to_affine_device", "dehalo_point_sum_device",
     "dehalo_ntt", "dehalo_ntt_device", "dehalo_intt_scaled", "dehalo_coset_ntt", "dehalo_coset_intt",
@@ -139,6 +139,7 @@ def load_library():
     lib.dehalo_ctx_destroy.restype = None
     lib.dehalo_ctx_synchronize.argtypes = [P]
     lib.dehalo_download.argtypes = [P, P, C.c_size_t, P]
+    lib.dehalo_upload.argtypes = [P, P, C.c_size_t, P]
     lib.dehalo_ctx_set_tuning.argtypes = [P, C.c_char_p, C.c_int]
     lib.dehalo_ctx_stream.argtypes = [P]
     lib.dehalo_ctx_stream.restype = C.c_void_p
@@ -311,6 +312,24 @@ class Context:
         """(count, width) u64 from device memory, after everything queued on the context's stream (one call: copy + wait)."""
         out = np.empty((count, width), dtype=np.uint64)
         self._check(self.lib.dehalo_download(self.handle, d_src, out.nbytes, out.ctypes.data))
+        return out
+
+    def upload(self, host, dtype=None):
+        """A host array (any numpy array; 64-bit words) -> a torch tensor of the same shape in HBM, through dehalo_upload: the library's page-locked staging
+        chunks or a DMA from pages the library pins for the call -- never torch's / the HIP runtime's handling of a pageable source (`tensor.cuda()`)."""
+        import torch
+
+        a = np.ascontiguousarray(host)
+        assert a.dtype.itemsize == 8, "upload: 64-bit words expected"
+        out = torch.empty(a.shape, dtype=torch.int64 if dtype is None else dtype, device="cuda")
+        self._check(self.lib.dehalo_upload(self.handle, a.ctypes.data, a.nbytes, out.data_ptr()))
+        return out
+
+    def download_tensor(self, t) -> np.ndarray:
+        """A contiguous device tensor of 64-bit words -> numpy (uint64, same shape), through dehalo_download (staged like upload)."""
+        assert t.is_contiguous() and t.element_size() == 8
+        out = np.empty(tuple(t.shape), dtype=np.uint64)
+        self._check(self.lib.dehalo_download(self.handle, t.data_ptr(), out.nbytes, out.ctypes.data))
         return out
 
     def set_tuning(self, key: str, value: int):
@@ -666,3 +685,18 @@ class Context:
         ms, cnt = C.c_double(), C.c_uint64()
         self._check(self.lib.dehalo_timing_get(self.handle, kernel_id, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+_TRANSFER = {}
+
+
+def transfer_context() -> "Context":
+    """One context per device whose only job is moving host arrays to / from HBM through the library's staged copies (Context.upload / download_tensor) for
+    code that has no context at hand (keygen.to_device / to_host).  Its stream carries nothing else; both calls return with the copy complete."""
+    import torch
+
+    dev = torch.cuda.current_device()
+    c = _TRANSFER.get(dev)
+    if c is None or c.handle is None:
+        c = _TRANSFER[dev] = Context(dev)
+    return c

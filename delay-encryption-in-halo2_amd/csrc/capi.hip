@@ -369,9 +369,14 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     if (e != hipSuccess) { delete b; return dh_fail(ctx, DEHALO_ERR_OOM, std::string("bases table: ") + hipGetErrorString(e)); }
     HostPin pin_bases(affine_xy, n * stride_bytes);         // 64 MiB of SRS points at 2^20: DMA straight from the caller's pages
     // (contiguous points: a plain copy -- the 2-D path took 3 of the 4.1 ms of registering 2^20 points)
-    e = stride_bytes == 64 ? hipMemcpyAsync(ctx->ws_tmp_bases.p, affine_xy, n * 64, hipMemcpyHostToDevice, ctx->stream)
-                           : hipMemcpy2DAsync(ctx->ws_tmp_bases.p, 64, affine_xy, stride_bytes, 64, n, hipMemcpyHostToDevice, ctx->stream);
     int rc = 0;
+    std::vector<uint64_t> packed;      // (points with a trailing flag byte: gathered on the host, so that the upload is one contiguous copy)
+    if (stride_bytes != 64) {
+        packed.resize(n * 8);
+        for (size_t i = 0; i < n; i++) memcpy(&packed[i * 8], (const char*)affine_xy + i * stride_bytes, 64);
+    }
+    rc = dh_h2d(ctx, ctx->ws_tmp_bases.p, stride_bytes == 64 ? (const void*)affine_xy : (const void*)packed.data(), n * 64, ctx->stream);
+    if (rc != 0) { (void)hipFree(b->table); delete b; return rc; }
     if (e == hipSuccess) rc = do_build_table(ctx, b, (const affine_t*)ctx->ws_tmp_bases.p, ctx->stream);
     if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess || rc != 0) {
@@ -430,6 +435,10 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
         if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->twiddles) (void)hipFree(t.tw);
     for (auto& r : ctx->regions) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (int i = 0; i < 2; i++) {
+        if (ctx->stage.buf[i]) (void)hipHostFree(ctx->stage.buf[i]);
+        if (ctx->stage.ev[i]) (void)hipEventDestroy(ctx->stage.ev[i]);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -478,8 +487,20 @@ int dehalo_download(dehalo_ctx* ctx, const void* d_src, size_t bytes, void* host
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!d_src || !host_dst) && bytes) return dh_fail(ctx, DEHALO_ERR_INVALID, "download: null argument");
     (void)hipSetDevice(ctx->device);
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (bytes) TRY(dh_d2h(ctx, host_dst, d_src, bytes, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dehalo_upload(dehalo_ctx* ctx, const void* host_src, size_t bytes, void* d_dst) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if ((!host_src || !d_dst) && bytes) return dh_fail(ctx, DEHALO_ERR_INVALID, "upload: null argument");
+    (void)hipSetDevice(ctx->device);
+    {
+        HostPin pin(host_src, bytes);      // 4 MiB and more: one DMA from the caller's pages, released below, after the stream has drained
+        TRY(dh_h2d(ctx, d_dst, host_src, bytes, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return 0;
 }
 
@@ -557,13 +578,13 @@ int dehalo_msm_batch(dehalo_ctx* ctx, const dehalo_bases* bases, const uint64_t*
         TRY(dh_ensure(ctx, ctx->ws_out, std::max<size_t>(96, batch * 96)));
         for (size_t b = 0; b < batch && len; b++) {
             HostPin pin(scalars[b], len * 32);
-            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->ws_scalars.p + b * len * 32, scalars[b], len * 32, hipMemcpyHostToDevice, ctx->stream));
+            TRY(dh_h2d(ctx, (char*)ctx->ws_scalars.p + b * len * 32, scalars[b], len * 32, ctx->stream));
             if (pin.p) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the pin ends with this scope
         }
     }
     TRY(dehalo_msm_device(ctx, bases, (const uint64_t*)ctx->ws_scalars.p, len, batch, (uint64_t*)ctx->ws_out.p, nullptr));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipMemcpyAsync(out_jacobian, ctx->ws_out.p, batch * 96, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, out_jacobian, ctx->ws_out.p, batch * 96, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -614,9 +635,9 @@ int dehalo_to_affine(dehalo_ctx* ctx, int curve, const uint64_t* jacobian, size_
     (void)hipSetDevice(ctx->device);
     TRY(dh_ensure(ctx, ctx->ws_fop[0], count * 96));
     TRY(dh_ensure(ctx, ctx->ws_fop[1], count * 64));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_fop[0].p, jacobian, count * 96, hipMemcpyHostToDevice, ctx->stream));
+    TRY(dh_h2d(ctx, ctx->ws_fop[0].p, jacobian, count * 96, ctx->stream));
     TRY(do_to_affine(ctx, curve, (const jacobian_t*)ctx->ws_fop[0].p, (affine_t*)ctx->ws_fop[1].p, (uint32_t)count, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(affine_xy, ctx->ws_fop[1].p, count * 64, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, affine_xy, ctx->ws_fop[1].p, count * 64, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -718,11 +739,11 @@ static int with_host_io(dehalo_ctx* ctx, const uint64_t* in, size_t in_elems, ui
             TRY(dh_ensure(ctx, ctx->ws_ntt_io2, std::max<size_t>(32, out_elems * 32)));
             d_out = (uint64_t*)ctx->ws_ntt_io2.p;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(d_in, in, in_elems * 32, hipMemcpyHostToDevice, ctx->stream));
+        TRY(dh_h2d(ctx, d_in, in, in_elems * 32, ctx->stream));
     }
     TRY(fn(ctx, d_in, d_out, arg));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipMemcpyAsync(out, d_out, out_elems * 32, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, out, d_out, out_elems * 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -779,10 +800,10 @@ int dehalo_field_op(dehalo_ctx* ctx, int field, int op, const uint64_t* a, const
     TRY(dh_ensure(ctx, ctx->ws_fop[0], n * 32));
     TRY(dh_ensure(ctx, ctx->ws_fop[1], n * 32));
     TRY(dh_ensure(ctx, ctx->ws_fop[2], n * 32));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_fop[0].p, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (b) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_fop[1].p, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    TRY(dh_h2d(ctx, ctx->ws_fop[0].p, a, n * 32, ctx->stream));
+    if (b) TRY(dh_h2d(ctx, ctx->ws_fop[1].p, b, n * 32, ctx->stream));
     TRY(do_field_op(ctx, field, op, (const fe*)ctx->ws_fop[0].p, b ? (const fe*)ctx->ws_fop[1].p : nullptr, (fe*)ctx->ws_fop[2].p, n, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->ws_fop[2].p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, out, ctx->ws_fop[2].p, n * 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -836,11 +857,11 @@ int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, s
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_poly_io[0], std::max<size_t>(32, len * 32)));
         TRY(dh_ensure(ctx, ctx->ws_poly_io[1], 32));
-        if (len) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, coeffs, len * 32, hipMemcpyHostToDevice, ctx->stream));
+        if (len) TRY(dh_h2d(ctx, ctx->ws_poly_io[0].p, coeffs, len * 32, ctx->stream));
     }
     TRY(dehalo_eval_polynomial_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, len, len, 1, point, (uint64_t*)ctx->ws_poly_io[1].p, nullptr));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->ws_poly_io[1].p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, out, ctx->ws_poly_io[1].p, 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -863,11 +884,11 @@ int dehalo_batch_invert(dehalo_ctx* ctx, int field, uint64_t* values, size_t len
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_poly_io[0], len * 32));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, values, len * 32, hipMemcpyHostToDevice, ctx->stream));
+        TRY(dh_h2d(ctx, ctx->ws_poly_io[0].p, values, len * 32, ctx->stream));
     }
     TRY(dehalo_batch_invert_device(ctx, field, (uint64_t*)ctx->ws_poly_io[0].p, len, nullptr));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipMemcpyAsync(values, ctx->ws_poly_io[0].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, values, ctx->ws_poly_io[0].p, len * 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -905,13 +926,13 @@ int dehalo_grand_product(dehalo_ctx* ctx, int field, const uint64_t* num, const 
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         for (int i = 0; i < 3; i++) TRY(dh_ensure(ctx, ctx->ws_poly_io[i], len * 32));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, num, len * 32, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[1].p, den, len * 32, hipMemcpyHostToDevice, ctx->stream));
+        TRY(dh_h2d(ctx, ctx->ws_poly_io[0].p, num, len * 32, ctx->stream));
+        TRY(dh_h2d(ctx, ctx->ws_poly_io[1].p, den, len * 32, ctx->stream));
     }
     TRY(dehalo_grand_product_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, (const uint64_t*)ctx->ws_poly_io[1].p, len,
                                     (uint64_t*)ctx->ws_poly_io[2].p, nullptr));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipMemcpyAsync(z, ctx->ws_poly_io[2].p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, z, ctx->ws_poly_io[2].p, len * 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -969,9 +990,9 @@ int dehalo_kate_division(dehalo_ctx* ctx, int field, const uint64_t* a, size_t l
     (void)hipSetDevice(ctx->device);
     TRY(dh_ensure(ctx, ctx->ws_poly_io[0], len * 32));
     TRY(dh_ensure(ctx, ctx->ws_poly_io[1], len * 32));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, a, len * 32, hipMemcpyHostToDevice, ctx->stream));
+    TRY(dh_h2d(ctx, ctx->ws_poly_io[0].p, a, len * 32, ctx->stream));
     TRY(dehalo_kate_division_device(ctx, field, (const uint64_t*)ctx->ws_poly_io[0].p, len, point, (uint64_t*)ctx->ws_poly_io[1].p, nullptr));
-    HIP_TRY(ctx, hipMemcpyAsync(q, ctx->ws_poly_io[1].p, (len - 1) * 32, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, q, ctx->ws_poly_io[1].p, (len - 1) * 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -1038,15 +1059,15 @@ int dehalo_permute_expression_pair(dehalo_ctx* ctx, int field, const uint64_t* i
         (void)hipSetDevice(ctx->device);
         TRY(dh_ensure(ctx, ctx->ws_poly_io[0], usable_rows * 64));
         TRY(dh_ensure(ctx, ctx->ws_poly_io[1], usable_rows * 64));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_poly_io[0].p, input, usable_rows * 32, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->ws_poly_io[0].p + usable_rows * 32, table, usable_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+        TRY(dh_h2d(ctx, ctx->ws_poly_io[0].p, input, usable_rows * 32, ctx->stream));
+        TRY(dh_h2d(ctx, (char*)ctx->ws_poly_io[0].p + usable_rows * 32, table, usable_rows * 32, ctx->stream));
     }
     uint64_t* d_in = (uint64_t*)ctx->ws_poly_io[0].p;
     uint64_t* d_out = (uint64_t*)ctx->ws_poly_io[1].p;
     TRY(dehalo_permute_expression_pair_device(ctx, field, d_in, d_in + usable_rows * 4, usable_rows, d_out, d_out + usable_rows * 4, nullptr));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipMemcpyAsync(permuted_input, d_out, usable_rows * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(permuted_table, d_out + usable_rows * 4, usable_rows * 32, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(dh_d2h(ctx, permuted_input, d_out, usable_rows * 32, ctx->stream));
+    TRY(dh_d2h(ctx, permuted_table, d_out + usable_rows * 4, usable_rows * 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

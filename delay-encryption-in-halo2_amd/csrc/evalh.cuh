@@ -372,7 +372,7 @@ int graph_upload_t(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, 
     if (g->num_constants) {
         fe* tmp = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&tmp, (size_t)g->num_constants * sizeof(fe)));
-        hipError_t e = hipMemcpyAsync(tmp, constants, (size_t)g->num_constants * sizeof(fe), hipMemcpyHostToDevice, s);
+        hipError_t e = dh_h2d(ctx, tmp, constants, (size_t)g->num_constants * sizeof(fe), s) == 0 ? hipSuccess : hipErrorUnknown;
         if (e == hipSuccess) {
             k_evh_scalars<F><<<(g->num_constants + 127) / 128, 128, 0, s>>>(tmp, g->d_constants, g->num_constants);
             e = hipStreamSynchronize(s);

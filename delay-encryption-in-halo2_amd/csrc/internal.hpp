@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -65,6 +66,20 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Two library-owned page-locked chunks per context: every byte that travels between CALLER memory and the device either goes through them (a host memcpy
+// on one side, a DMA on the other) or moves by DMA from / to pages that are page-locked for the duration of the call (HostPin, or locked by the caller).
+// The HIP runtime's own handling of large pageable transfers -- it pins the caller's pages in place and keeps the registration in a small cache keyed by
+// (address, size) after the copy -- is never reached from this library: the device then never holds a mapping of caller memory whose lifetime the
+// library does not control ("the memory fault").
+struct HostStage {
+    static constexpr size_t CHUNK = 4u << 20;
+    static constexpr size_t DIRECT_MAX = 64u << 10;      // below this the runtime copies through its own staging buffer (a host memcpy): nothing is pinned
+    std::mutex mu;
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+};
+
 struct TwiddleEntry {
     int field;
     uint32_t log_n;
@@ -99,6 +114,7 @@ struct dehalo_ctx {
     int ntt_full_table_log = 0;    // transforms up to this size keep all N twiddles (32 B x N; one load per inter-pass twiddle), larger ones N / 2 and a
                                    // negation.  Measured equal at 23 x 2^19 with warm clocks (1.19 ms either way: the negation hides behind the load), so
                                    // the default keeps the smaller table
+    HostStage stage;
     bool timing = false;
     std::vector<TimedRegion> regions;
     double timing_ms[DEHALO_K_COUNT] = {};
@@ -161,6 +177,82 @@ inline int dh_ensure(dehalo_ctx* ctx, DevBuf& b, size_t bytes) {
     size_t want = bytes + bytes / 8 + 256;
     HIP_TRY(ctx, hipMalloc(&b.p, want));
     b.cap = want;
+    return 0;
+}
+
+inline bool dh_host_locked(const void* ptr, size_t bytes) {
+    {
+        HostPinRegistry& reg = host_pin_registry();
+        std::lock_guard<std::mutex> lk(reg.mu);
+        const uintptr_t a = (uintptr_t)ptr, b = a + bytes;
+        for (auto& e : reg.entries)
+            if (e.a <= a && b <= e.b) return true;
+    }
+    hipPointerAttribute_t at;      // page-locked by the caller (hipHostMalloc / hipHostRegister / torch's pin_memory)
+    if (hipPointerGetAttributes(&at, ptr) == hipSuccess) return at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();       // an ordinary pageable pointer is reported as an error by some runtime versions
+    return false;
+}
+
+inline int dh_stage_init(dehalo_ctx* ctx) {
+    HostStage& st = ctx->stage;
+    for (int i = 0; i < 2; i++) {
+        if (!st.buf[i]) HIP_TRY(ctx, hipHostMalloc(&st.buf[i], HostStage::CHUNK, hipHostMallocDefault));
+        if (!st.ev[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&st.ev[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// host -> device from CALLER memory, queued on `s`.  On return the source has been read in full unless it is page-locked (then the copy is an ordinary
+// asynchronous DMA from it and the caller's pin / the caller itself keeps the pages until `s` has been synchronised, as before).
+inline int dh_h2d(dehalo_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    if (!bytes) return 0;
+    if (bytes <= HostStage::DIRECT_MAX || dh_host_locked(h_src, bytes)) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    HostStage& st = ctx->stage;
+    std::lock_guard<std::mutex> lk(st.mu);
+    TRY(dh_stage_init(ctx));
+    int i = 0;
+    for (size_t off = 0; off < bytes; off += HostStage::CHUNK, i ^= 1) {
+        const size_t len = std::min(HostStage::CHUNK, bytes - off);
+        if (st.busy[i]) { HIP_TRY(ctx, hipEventSynchronize(st.ev[i])); st.busy[i] = false; }
+        memcpy(st.buf[i], (const char*)h_src + off, len);
+        HIP_TRY(ctx, hipMemcpyAsync((char*)d_dst + off, st.buf[i], len, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipEventRecord(st.ev[i], s));
+        st.busy[i] = true;
+    }
+    return 0;
+}
+
+// device -> host into CALLER memory, behind everything queued on `s`; synchronous: the data is in h_dst when this returns
+inline int dh_d2h(dehalo_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
+    if (!bytes) { HIP_TRY(ctx, hipStreamSynchronize(s)); return 0; }
+    if (bytes <= HostStage::DIRECT_MAX || dh_host_locked(h_dst, bytes)) {
+        HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        return 0;
+    }
+    HostStage& st = ctx->stage;
+    std::lock_guard<std::mutex> lk(st.mu);
+    TRY(dh_stage_init(ctx));
+    for (int i = 0; i < 2; i++)
+        if (st.busy[i]) { HIP_TRY(ctx, hipEventSynchronize(st.ev[i])); st.busy[i] = false; }
+    int i = 0;
+    size_t prev_off = 0, prev_len = 0;
+    for (size_t off = 0; off < bytes; off += HostStage::CHUNK, i ^= 1) {
+        const size_t len = std::min(HostStage::CHUNK, bytes - off);
+        HIP_TRY(ctx, hipMemcpyAsync(st.buf[i], (const char*)d_src + off, len, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipEventRecord(st.ev[i], s));
+        if (prev_len) {      // the previous chunk lands in the other buffer: hand it to the caller while this one is in flight
+            HIP_TRY(ctx, hipEventSynchronize(st.ev[i ^ 1]));
+            memcpy((char*)h_dst + prev_off, st.buf[i ^ 1], prev_len);
+        }
+        prev_off = off; prev_len = len;
+    }
+    HIP_TRY(ctx, hipEventSynchronize(st.ev[i ^ 1]));
+    memcpy((char*)h_dst + prev_off, st.buf[i ^ 1], prev_len);
     return 0;
 }
 

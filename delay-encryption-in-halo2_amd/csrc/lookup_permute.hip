@@ -436,7 +436,7 @@ int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s,
         return 0;
     }
     int host_err[LP_MAX_BATCH];
-    HIP_TRY(ctx, hipMemcpyAsync(host_err, err, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    TRY(dh_d2h(ctx, host_err, err, B * sizeof(int), s));
     HIP_TRY(ctx, hipStreamSynchronize(s));     // upstream returns Err(ConstraintSystemFailure) from this call: so must we
     for (u32 y = 0; y < B; y++)
         if (host_err[y])

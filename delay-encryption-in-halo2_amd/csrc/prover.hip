@@ -401,7 +401,7 @@ int lagrange_to_all(dehalo_pk* pk, const dehalo_params* params, const fe* values
 // (n, 4) device column of omega^i: the forward NTT of the unit vector e_1
 int omega_powers(dehalo_ctx* ctx, const HostDomain& d, fe* col) {
     HIP_TRY(ctx, hipMemsetAsync(col, 0, d.n * sizeof(fe), ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(col + (d.n > 1 ? 1 : 0), d.f->one.v, 32, hipMemcpyHostToDevice, ctx->stream));
+    TRY(dh_h2d(ctx, col + (d.n > 1 ? 1 : 0), d.f->one.v, 32, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (the source is a host object: copied before returning)
     if (d.n > 1) TRY(dehalo_ntt_device(ctx, d.f->id, (uint64_t*)col, d.k, d.omega.v, 1, nullptr));
     return 0;
@@ -428,7 +428,7 @@ extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const
     pk->fixed_commitments.assign(8 * nf, 0);
     if (nf) {
         HostPin pin_fixed(fixed, nf * n * 32);
-        HIP_TRY(ctx, hipMemcpyAsync(pk->fixed_values.p, fixed, nf * n * 32, hipMemcpyHostToDevice, ctx->stream));
+        TRY(dh_h2d(ctx, pk->fixed_values.p, fixed, nf * n * 32, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (flags & DEHALO_KEYGEN_FIXED_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, pk->fixed_values.u64(), nullptr, pk->fixed_values.u64(), nf * n, nullptr));
         TRY(lagrange_to_all(pk.get(), params, pk->fixed_values.p, nf, pk->fixed_polys.p, pk->fixed_cosets.p, pk->fixed_commitments.data()));
@@ -454,7 +454,7 @@ extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const
         }
         HIP_TRY(ctx, hipMalloc((void**)&d_map, npc * n * 8));
         HostPin pin_map(mapping, npc * n * 8);
-        hipError_t e = hipMemcpyAsync(d_map, mapping, npc * n * 8, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = dh_h2d(ctx, d_map, mapping, npc * n * 8, ctx->stream) == 0 ? hipSuccess : hipErrorUnknown;
         if (e == hipSuccess) {
             k_gather_elems<<<(unsigned)((npc * n + 255) / 256), 256, 0, ctx->stream>>>(ident.p, d_map, pk->perm_values.p, npc * n);
             e = hipStreamSynchronize(ctx->stream);
@@ -475,7 +475,7 @@ extern "C" int dehalo_keygen(dehalo_ctx* ctx, const dehalo_params* params, const
         TRY(polys.alloc(ctx, 3 * n, false));
         TRY(pk->l_ext.alloc(ctx, 3 * m, false));
         HostPin pin_lag(lag.data(), 3 * n * 32);
-        HIP_TRY(ctx, hipMemcpyAsync(vals.p, lag.data(), 3 * n * 32, hipMemcpyHostToDevice, ctx->stream));
+        TRY(dh_h2d(ctx, vals.p, lag.data(), 3 * n * 32, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         TRY(lagrange_to_all(pk.get(), params, vals.p, 3, polys.p, pk->l_ext.p, nullptr));
     }
@@ -569,7 +569,7 @@ extern "C" int dehalo_pk_read(dehalo_ctx* ctx, int curve, const dehalo_constrain
     auto poly = [&](fe* dst, size_t want, bool to_internal) -> int {
         if (get_u32_be(p) != want) return dh_fail(ctx, DEHALO_ERR_INVALID, "pk_read: polynomial length differs from the domain's");
         p += 4;
-        HIP_TRY(ctx, hipMemcpyAsync(dst, p, want * 32, hipMemcpyHostToDevice, ctx->stream));
+        TRY(dh_h2d(ctx, dst, p, want * 32, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         p += want * 32;
         if (to_internal) TRY(dehalo_convert_form_device(ctx, fid, (const uint64_t*)dst, (uint64_t*)dst, want, 1, nullptr));
@@ -1029,7 +1029,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             o += bf;
         }
         if (total) {
-            HIP_TRY(ctx, hipMemcpyAsync(blind_dev.p, packed.data(), total * 32, hipMemcpyHostToDevice, ms));
+            TRY(dh_h2d(ctx, blind_dev.p, packed.data(), total * 32, ms));
             HIP_TRY(ctx, hipStreamSynchronize(ms));      // `packed` is a local
         }
     }
@@ -1052,7 +1052,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             tr->common_scalar(v);
         }
         if (len) {
-            HIP_TRY(ctx, hipMemcpyAsync(instance.at((size_t)i * n), instances[i], len * 32, hipMemcpyHostToDevice, ms));
+            TRY(dh_h2d(ctx, instance.at((size_t)i * n), instances[i], len * 32, ms));
             HIP_TRY(ctx, hipStreamSynchronize(ms));
         }
     }
@@ -1082,8 +1082,8 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         PinnedUpload(const void* ptr, size_t bytes, hipStream_t s_) : pin(ptr, bytes), s(s_) {}
         ~PinnedUpload() { if (pin.p) (void)hipStreamSynchronize(s); }
     } pin_advice((flags & DEHALO_PROOF_ADVICE_ON_DEVICE) || synth_in ? nullptr : advice, (size_t)A * n * 32, ms);
-    HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, (flags & DEHALO_PROOF_ADVICE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                ms));
+    if (flags & DEHALO_PROOF_ADVICE_ON_DEVICE) HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, hipMemcpyDeviceToDevice, ms));
+    else TRY(dh_h2d(ctx, cols.at((size_t)o_adv * n), advice, (size_t)A * n * 32, ms));      // a DMA from the pinned pages, or staged (witness below 4 MiB)
     if (flags & DEHALO_PROOF_ADVICE_CANONICAL) TRY(dehalo_field_op_device(ctx, fid, 4, cols.u64((size_t)o_adv * n), nullptr, cols.u64((size_t)o_adv * n), (size_t)A * n, nullptr));
     if (A) k_place_rows<<<(unsigned)((rows * A + 255) / 256), 256, 0, ms>>>(cols.at((size_t)o_adv * n + u), n, bl_adv, (uint32_t)rows, A);
     if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[0], ms));
@@ -1231,7 +1231,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         if (!tr->write_point(rand_point)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
     } else {
         if (device_rng) TRY(device_draw(cols.at((size_t)o_rand * n), ms));
-        else HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), rand_pin, n * 32, hipMemcpyHostToDevice, ms));
+        else HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), rand_pin, n * 32, hipMemcpyHostToDevice, ms));      // (rand_pin: page-locked, the library's own)
         TRY(commit(tr, cols.at((size_t)o_rand * n), 1, false));
     }
     mark(3);

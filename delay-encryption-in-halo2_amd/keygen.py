@@ -46,13 +46,18 @@ def array_to_ints(arr) -> List[int]:
 
 
 def to_device(arr):
-    import torch
+    """host array of 64-bit words -> int64 tensor in HBM, through the library's staged upload (never `tensor.cuda()` of a pageable array: _lib.Context.upload)"""
+    from ._lib import transfer_context
 
-    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).cuda()
+    return transfer_context().upload(np.ascontiguousarray(arr, dtype=np.uint64))
 
 
 def to_host(t) -> np.ndarray:
-    return t.cpu().numpy().view(np.uint64)
+    import torch
+    from ._lib import transfer_context
+
+    torch.cuda.current_stream().synchronize()      # what `t.cpu()` would have waited for
+    return transfer_context().download_tensor(t.contiguous())
 
 
 _RINV: dict = {}
@@ -377,6 +382,6 @@ def _keygen(ctx: Context, params: ParamsKZG, cs: plonk.ConstraintSystem, fixed_c
 
 
 def to_device_index(idx: np.ndarray):
-    import torch
+    from ._lib import transfer_context
 
-    return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).cuda()
+    return transfer_context().upload(np.ascontiguousarray(idx, dtype=np.int64))

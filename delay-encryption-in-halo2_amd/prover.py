@@ -244,7 +244,7 @@ class Prover:
         total = sum(self.blind_counts)
         if total == 0:
             return
-        self.blind_dev[:total].copy_(self.torch.from_numpy(rng.scalars(total).view(np.int64)))
+        self.blind_dev[:total].copy_(to_device(rng.scalars(total)))
 
     def _blind_slice(self, which: int):
         off = sum(self.blind_counts[:which])

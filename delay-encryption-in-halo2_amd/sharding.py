@@ -12,16 +12,18 @@ def units_for_rank(units: int, rank: int, world: int) -> List[int]:
     return list(range(rank, units, world))
 
 
-def all_gather_commitments(local, units: int, rank: int, world: int):
+def all_gather_commitments(local, units: int, rank: int, world: int, force_collective: bool = False):
     """local: (len(units_for_rank), 12) int64 tensor on this rank's device -> (units, 12) on
-    every rank, in unit order.  backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests."""
+    every rank, in unit order.  backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests.
+    At world 1 there is nothing to exchange and no process group is needed; `force_collective` runs the collective all the same (a one-rank group
+    must be initialised): the `-m gpu` test that pushes HBM tensors through RCCL's all_gather_into_tensor on a one-GPU box."""
     import torch
     import torch.distributed as dist
 
     per = (units + world - 1) // world
     pad = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    if world == 1:
+    if world == 1 and not force_collective:
         gathered = pad.unsqueeze(0)
     else:
         out = torch.empty((world, per, local.shape[1]), dtype=local.dtype, device=local.device)
@@ -32,7 +34,7 @@ def all_gather_commitments(local, units: int, rank: int, world: int):
     return full.contiguous()
 
 
-def gather_proof_commitments(local_blobs, total: int, rank: int, world: int, device="cpu"):
+def gather_proof_commitments(local_blobs, total: int, rank: int, world: int, device="cpu", force_collective: bool = False):
     """Batch proving (BASELINE configs[4]: proof p -> rank p mod world): every rank hands in the commitment bytes of the proofs it
     made (prover.proof_commitments, equal lengths), in the order of units_for_rank, and receives all `total` blobs in proof
     order -- ONE all-gather of total x len bytes (64 proofs x 31 x 32 B = 62 KB: latency-bound over xGMI)."""
@@ -42,7 +44,7 @@ def gather_proof_commitments(local_blobs, total: int, rank: int, world: int, dev
     if len(local_blobs) != len(mine):
         raise ValueError("rank %d made %d proofs, its share is %d" % (rank, len(local_blobs), len(mine)))
     width = len(local_blobs[0]) if local_blobs else 0
-    if world > 1:                                             # ranks without a proof still need the common width
+    if world > 1 or force_collective:                         # ranks without a proof still need the common width
         import torch.distributed as dist
         w = torch.tensor([width], dtype=torch.int64, device=device)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
@@ -52,7 +54,7 @@ def gather_proof_commitments(local_blobs, total: int, rank: int, world: int, dev
     local = torch.zeros((len(mine), width // 8), dtype=torch.int64)
     for j, b in enumerate(local_blobs):
         local[j] = torch.frombuffer(bytearray(b), dtype=torch.int64)
-    full = all_gather_commitments(local.to(device), total, rank, world).cpu()
+    full = all_gather_commitments(local.to(device), total, rank, world, force_collective).cpu()
     return [full[u].numpy().tobytes() for u in range(total)]
 
 
@@ -60,7 +62,7 @@ def max_over_ranks(value: float) -> float:
     import torch
     import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=dev)
@@ -76,7 +78,7 @@ def point_range_for_rank(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def combine_partial_msm(ctx, curve_id: int, local_partial, rank: int, world: int):
+def combine_partial_msm(ctx, curve_id: int, local_partial, rank: int, world: int, force_collective: bool = False):
     """local_partial: (1, 12) int64 tensor on this rank's device (the MSM over its point range), COMPLETE on torch's current
     stream (synchronise the context that produced it first) -> (1, 12) tensor holding the whole MSM on every rank: one
     all-gather of world x 96 B, then world - 1 group additions on the device (dehalo_point_sum_device).
@@ -84,7 +86,7 @@ def combine_partial_msm(ctx, curve_id: int, local_partial, rank: int, world: int
     addition is enqueued on the context's own (non-blocking) stream: nothing else orders the two streams."""
     import torch
 
-    parts = all_gather_commitments(local_partial, world, rank, world) if world > 1 else local_partial
+    parts = all_gather_commitments(local_partial, world, rank, world, force_collective) if world > 1 or force_collective else local_partial
     parts = parts.contiguous()
     out = torch.zeros((1, 12), dtype=parts.dtype, device=parts.device)
     torch.cuda.current_stream().synchronize()

@@ -91,6 +91,12 @@ int dehalo_ctx_synchronize(dehalo_ctx* ctx);
  * of a phase's commitments / evaluations (what Blake2bWrite::write_point needs on the host, halo2_proofs/src/transcript.rs) in one
  * call instead of a synchronize followed by a separate copy. */
 int dehalo_download(dehalo_ctx* ctx, const void* d_src, size_t bytes, void* host_dst);
+/* Copies `bytes` from CALLER host memory (a `&[F]`, any ordinary pageable allocation) to device memory on the context's own stream and
+ * returns once the source has been read in full and the copy has completed: what a host does with a witness column or a polynomial it
+ * wants resident (the `Vec<F>` -> HBM step in front of every `*_device` entry point).  Like every host entry point of this library the
+ * transfer never leaves the device holding a mapping of caller memory: the bytes pass through the context's page-locked staging chunks
+ * (or move by DMA from pages that are page-locked by the caller / for the duration of the call). */
+int dehalo_upload(dehalo_ctx* ctx, const void* host_src, size_t bytes, void* d_dst);
 
 /* ---- SRS / bases ------------------------------------------------------------------------
  * Replaces the `g` / `g_lagrange` vectors of ParamsKZG / ParamsIPA

@@ -71,3 +71,36 @@ def test_bench_replaces_a_measuring_process_killed_by_a_signal_once():
     assert plain.returncode == 1 and "needs an MI355X" in plain.stderr
     once = run({"DEHALO_BENCH_SELFTEST_KILL": "1"})
     assert once.returncode == 1 and "killed by signal 6" in once.stderr and "needs an MI355X" in once.stderr and once.stdout == ""
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (the driver's N = 1 command shape with N changed, no RANK in the environment) starts torch.distributed.run itself, as a fresh
+    child process: here, without a GPU, both ranks get as far as the device check and the launcher's exit code comes back."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--force-device", "0", "--proofs", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    if r.returncode == 0:
+        import json
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["rccl_world"]["world_size_seen_by_rank"] == [2, 2]
+        return
+    assert "launch N > 1 with" not in r.stderr
+    assert r.stderr.count("needs an MI355X") >= 2, r.stderr[-2000:]      # one per rank: the ranks were started
+
+
+def test_bench_first_attempt_travels_to_the_second():
+    """supervise(): what is known about a measuring process that died (signal, last section marker, stderr tail) is handed to the one that replaces it, which
+    prints it in its JSON line as "first_attempt"."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    err = "[bench 0.1 s] steps: preheat\nnoise\n[bench 12.0 s] proof delay_enc k = 17: proving\nMemory access fault by GPU node-2\n"
+    assert bench._section_of(err) == "proof delay_enc k = 17: proving"
+    assert bench._section_of("") == ""

@@ -92,3 +92,68 @@ def test_all_gather_world_size_2(tmp_path):
             break
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+# ---- RCCL on the box's one GPU: a one-rank `nccl` process group, HBM tensors through the real collectives ---------------------------
+NCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import __graft_entry__ as entry
+import torch, torch.distributed as dist
+pkg = entry.load_package()
+po, co = entry.load_oracle()
+from dehalo2_amd import sharding
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+ctx = pkg.Context(0)
+# (1) the commitment vector of the step bench: (units, 12) int64 rows in HBM through all_gather_into_tensor
+local = torch.arange(7 * 12, dtype=torch.int64, device="cuda").reshape(7, 12) + 5
+full = sharding.all_gather_commitments(local, 7, 0, 1, force_collective=True)
+torch.cuda.synchronize()
+assert full.is_cuda and torch.equal(full, local)
+# (2) batch mode's gather of compressed commitments (31 x 32 B per proof), device tensors, width agreed by an all_reduce
+blobs = [bytes([p + 1]) * (32 * 31) for p in range(5)]
+got = sharding.gather_proof_commitments(blobs, 5, 0, 1, "cuda", force_collective=True)
+assert got == blobs
+# (3) one MSM split by point range: the library's result rows are gathered by RCCL, then summed on the context's own stream
+curve = pkg.fields.CURVES["bn254"]
+n = 3001
+g = co.synth_bases(curve.id, n)
+sc = co.fill_scalars(curve.scalar.id, "witness", n, 31)
+h = ctx.register_bases(curve.id, g, 0, True)
+d = ctx.upload(sc)
+part = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+torch.cuda.synchronize()
+ctx.msm_device(h, d.data_ptr(), n, 1, part.data_ptr(), 0)
+ctx.synchronize()
+whole = sharding.combine_partial_msm(ctx, curve.id, part, 0, 1, force_collective=True)
+want = co.to_affine(curve.id, co.best_multiexp(curve.id, sc, g, 4))
+assert np.array_equal(ctx.to_affine(curve.id, ctx.download_tensor(whole))[0], want)
+# (4) the timing helper's all_reduce(MAX) on a device scalar
+assert sharding.max_over_ranks(3.25) == 3.25
+h.release()
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+ctx.close()
+sys.stdout.write("rccl one-rank ok: %s\\n" % torch.cuda.nccl.version().__repr__())
+sys.stdout.flush()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_one_rank_all_gather_on_hbm_tensors(tmp_path):
+    """RCCL executes: a one-rank `nccl` group on the box's GPU (a one-GPU box cannot host two nccl ranks), the world-1 shortcut of sharding.py
+    switched off, device tensors through all_gather_into_tensor / all_reduce, and the stream ordering of combine_partial_msm (the gather on torch's
+    stream, the addition on the context's).  A child process of its own: one rank = one process, as under torchrun."""
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rccl one-rank ok" in r.stdout
