@@ -393,6 +393,9 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     note("batch mode: setup")
     st = ProofSetup(pkg, ctx, k, "delay_enc", max(8, min(host_cores(), 256) // max(1, world)))      # (every rank builds the synthetic SRS on the host at once: share the cores)
     mine = sharding.units_for_rank(total, rank, world)
+    if os.environ.get("DEHALO_BENCH_KEEP_TRANSFER") is None:
+        from dehalo2_amd import _lib as _l
+        _l.release_transfer_contexts()                        # (its stream would count against the pool of hardware queues the provers' streams are mapped onto)
     st.prove(1000)                                            # warm-up
     cs = st.circ.cs
     prios = (1, 0, -1) if os.environ.get("DEHALO_BENCH_FLAT_PRIORITIES") is None else (0,)      # (see main(): hardware queues are pooled per priority)

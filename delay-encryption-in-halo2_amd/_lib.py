@@ -698,5 +698,14 @@ def transfer_context() -> "Context":
     dev = torch.cuda.current_device()
     c = _TRANSFER.get(dev)
     if c is None or c.handle is None:
-        c = _TRANSFER[dev] = Context(dev)
+        c = _TRANSFER[dev] = Context(dev, priority=-1)
     return c
+
+
+def release_transfer_contexts():
+    """Closes the transfer contexts (their streams count against the runtime's pool of hardware queues: a caller about to keep several proving contexts in
+    flight drops them first; the next to_device / to_host makes a new one)."""
+    for dev in list(_TRANSFER):
+        c = _TRANSFER.pop(dev)
+        if c.handle is not None:
+            c.close()

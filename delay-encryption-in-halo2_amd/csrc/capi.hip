@@ -417,6 +417,7 @@ int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out) 
                                            : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
         if (e != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
     }
+    if (const char* e = getenv("DEHALO_MSM_ACC_BLOCK")) ctx->msm_acc_block = atoi(e) == 768 ? 768 : 128;                                      // launch geometry only
     if (const char* e = getenv("DEHALO_MSM_ACC_POINTS")) ctx->msm_acc_points = std::max(0, std::min(4096, atoi(e)));   // launch geometry only (dehalo_ctx_set_tuning)
     *out = ctx;
     return 0;
@@ -427,7 +428,7 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_out, &ctx->ws_count, &ctx->ws_counters, &ctx->ws_off, &ctx->ws_records, &ctx->ws_merge_lists,
-                      &ctx->ws_bhist, &ctx->ws_pcount, &ctx->ws_pairs, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree,
+                      &ctx->ws_bhist, &ctx->ws_pcount, &ctx->ws_pairs, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree, &ctx->ws_bred_cnt,
                       &ctx->ws_gsums, &ctx->ws_ntt_scratch, &ctx->ws_ntt_io, &ctx->ws_ntt_io2, &ctx->ws_fop[0], &ctx->ws_fop[1], &ctx->ws_fop[2],
                       &ctx->ws_tmp_bases, &ctx->ws_poly[0], &ctx->ws_poly[1], &ctx->ws_poly[2], &ctx->ws_poly[3], &ctx->ws_poly[4], &ctx->ws_poly_io[0], &ctx->ws_poly_io[1],
                       &ctx->ws_poly_io[2], &ctx->ws_evh[0], &ctx->ws_evh[1], &ctx->ws_evh[2], &ctx->ws_evh[3], &ctx->ws_lookup};
@@ -465,6 +466,11 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "msm_acc_waves")) {
         if (value < 1 || value > 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_acc_waves must be in [1, 4]");
         ctx->msm_acc_waves = value;
+        return 0;
+    }
+    if (!strcmp(key, "msm_acc_block")) {
+        if (value != 128 && value != 768) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_acc_block must be 128 or 768");
+        ctx->msm_acc_block = value;
         return 0;
     }
     if (!strcmp(key, "ntt_full_table_log")) {

@@ -103,7 +103,7 @@ struct dehalo_ctx {
     std::recursive_mutex mu;   // recursive: host-buffer entry points hold it across their device-form calls
     // workspace (grow-only)
     DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_records, ws_merge_lists, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
-        ws_contrib, ws_tree, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[5], ws_poly_io[3], ws_evh[4], ws_lookup;
+        ws_contrib, ws_tree, ws_bred_cnt, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[5], ws_poly_io[3], ws_evh[4], ws_lookup;
     std::vector<TwiddleEntry> twiddles;
     affine_t* msm_affine_out = nullptr;   // set for the duration of dehalo_msm_device_affine (under mu): k_msm_final also writes affine points
     int msm_acc_points = 48; // > 0: the accumulation's grid is 4, 6, 8, ... layers of one wave per SIMD, the fewest that leave a lane <= this many
@@ -111,6 +111,7 @@ struct dehalo_ctx {
                              // on three quarters of the wave slots -- k = 17 proof 12.6 -> 12.05 ms); 0: rounds of msm_acc_waves waves per SIMD
     int msm_acc_waves = 3;   // sizes the accumulation's points per lane (dehalo_ctx_set_tuning): 3 -> 43 points per lane at 2^20 x 16, ~1.5
                              // rounds of the 4 waves per SIMD that are resident; measured best (one round of 86 points at 3 resident waves: 1.30 ms)
+    int msm_acc_block = 128; // threads per block of k_msm_accum0: 128, or 768 = one 12-wave block per CU (3 waves per SIMD; dehalo_ctx_set_tuning / DEHALO_MSM_ACC_BLOCK)
     int ntt_full_table_log = 0;    // transforms up to this size keep all N twiddles (32 B x N; one load per inter-pass twiddle), larger ones N / 2 and a
                                    // negation.  Measured equal at 23 x 2^19 with warm clocks (1.19 ms either way: the negation hides behind the load), so
                                    // the default keeps the smaller table

@@ -32,14 +32,16 @@
 #include "internal.hpp"
 
 #define MSM_SORT_THREADS 1024
-#define MSM_ACC_THREADS 128
+#define MSM_ACC_THREADS 128        // the accumulation's default block: 2 waves (4 waves x 122 VGPRs fill a SIMD's register file)
+#define MSM_ACC_THREADS_MAX 768    // msm_acc_block = 768: ONE block of 12 waves per CU = 3 waves per SIMD and no room for a second block -- a quarter of every
+                                   // SIMD's registers (and all of the LDS) stays free for the <= 128-VGPR kernels of the other contexts
 // (measured: 2 and 3 resident waves per SIMD give the same k_msm_accum0 time -- the loop is
 // VALU-issue-bound -- and capping residency at 2 did not improve multi-stream overlap)
 #ifndef MSM_ACC_WAVES_ATTR
 #ifdef MSM_ACC_CAP
 #define MSM_ACC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MSM_ACC_CAP, MSM_ACC_CAP)))
 #else
-#define MSM_ACC_WAVES_ATTR
+#define MSM_ACC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))      // the register budget of four waves per SIMD (128), whatever the block size
 #endif
 #endif
 #ifdef MSM_HIST_VGPR64
@@ -567,7 +569,7 @@ FP_DEV aff29 load_point(const affine_t* table, u32 e, bool& is_id) {
 // kernel).  A lane whose range crosses a bucket boundary flushes its sum and starts the next
 // bucket's; L0 is chosen on the host so that the lanes fill the chip a whole number of times.
 template <class CV>
-__global__ __launch_bounds__(MSM_ACC_THREADS) MSM_ACC_WAVES_ATTR void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* nrank,
+__global__ __launch_bounds__(MSM_ACC_THREADS_MAX) MSM_ACC_WAVES_ATTR void k_msm_accum0(MsmGeom g, u32 total_buckets, const u32* idx, const u32* off, const u32* nrank,
                                                                const affine_t* table, xyzz29_rec* partial, const u32* geo) {
     typedef typename f29_of<typename CV::Base>::type F;
     const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -858,6 +860,8 @@ __global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 
     }
 }
 
+#include "msm_bred.cuh"
+
 // ---- final: window sums -> one Jacobian point per MSM -------------------------------------
 // G == 1: convert.  G == W: result = sum_w 2^(c*w) S_w; QUAD w doubles S_w c*w times (a chain of up to c (W - 1) ~ 240 doublings
 // whatever the size of the MSM: quad-cooperative, it is 2.4x shorter), then an LDS tree of quad additions (the one-shot,
@@ -979,14 +983,15 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const uint64_t resident = (uint64_t)ctx->num_cus * 4 * (lcap ? 1 : (uint64_t)ctx->msm_acc_waves) * 64;
     const uint64_t lmax = 64 * 4 / (uint64_t)ctx->msm_acc_waves;
     g.L0 = 0;
+    const uint32_t acc_block = ctx->msm_acc_block == MSM_ACC_THREADS_MAX ? MSM_ACC_THREADS_MAX : MSM_ACC_THREADS;
     uint64_t lanes_max;
     if (lcap) {
         uint64_t k = 4;
         while (Mmax > k * resident * lcap) k += 2;
-        lanes_max = k * resident + MSM_ACC_THREADS;
+        lanes_max = k * resident + acc_block;
     } else {
         const uint64_t rounds_max = std::max<uint64_t>(1, (Mmax + resident * lmax - 1) / (resident * lmax));
-        lanes_max = rounds_max * resident + MSM_ACC_THREADS;
+        lanes_max = rounds_max * resident + acc_block;
     }
     const uint64_t nt0_max = lanes_max + total_buckets;        // records: one per lane + one per non-empty bucket (upper bound)
     const u32 per_group = (g.nb + MSM_RED_M - 1) / MSM_RED_M;
@@ -1005,8 +1010,14 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
-    TRY(dh_ensure(ctx, ctx->ws_contrib, total_groups * per_group * REC));
-    TRY(dh_ensure(ctx, ctx->ws_tree, total_groups * ((per_group + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS) * REC));
+    // (the radix-2 bucket reduction keeps its node vectors in the same two buffers: BRED_VMAX records per 256-bucket block / per cluster of 16 blocks)
+    const size_t bred_blocks = std::max<size_t>(1, g.nb / BRED_BLOCK_BUCKETS);
+    TRY(dh_ensure(ctx, ctx->ws_contrib, std::max<size_t>(total_groups * per_group, total_groups * bred_blocks * BRED_VMAX) * REC));
+    TRY(dh_ensure(ctx, ctx->ws_tree, std::max<size_t>(total_groups * ((per_group + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS), total_groups * 8 * BRED_VMAX) * REC));
+    if ((size_t)total_groups * BRED_CNT_PER_GROUP * 4 > ctx->ws_bred_cnt.cap) {      // cluster / group arrival counters: zero when allocated, left zero by every launch
+        TRY(dh_ensure(ctx, ctx->ws_bred_cnt, (size_t)total_groups * BRED_CNT_PER_GROUP * 4));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ws_bred_cnt.p, 0, ctx->ws_bred_cnt.cap, s));
+    }
     TRY(dh_ensure(ctx, ctx->ws_gsums, total_groups * REC));
     u32* count = (u32*)ctx->ws_count.p;
     u32* cursor = (u32*)ctx->ws_counters.p;
@@ -1046,11 +1057,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     }
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_ACCUMULATE);
-        u32 blocks = (u32)((lanes_max + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
+        u32 blocks = (u32)((lanes_max + acc_block - 1) / acc_block);
         // DEHALO_MSM_ACC_LDS (bytes of dynamic LDS per block, unused by the kernel): caps the accumulation's resident blocks per CU so that
         // wave slots and registers stay free for the kernels of other contexts (tuning experiments; results never depend on it)
         static const unsigned acc_lds = [] { const char* e = getenv("DEHALO_MSM_ACC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-        k_msm_accum0<CV><<<blocks, MSM_ACC_THREADS, acc_lds, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + 4);
+        k_msm_accum0<CV><<<blocks, acc_block, acc_lds, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + 4);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -1058,19 +1069,35 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // partial sums -> one point per bucket (by size class)
         // (a list of <= MSM_LIGHT_QUAD_MAX buckets runs one quad per bucket, where 23 additions are still a short chain; a longer
         // list runs one LANE per bucket and is kept to 11 full-width additions)
-        const u32 c0max = tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
+        // DEHALO_MSM_MERGE2=0: the round-3 merge kernel (operands in registers, 172 VGPRs) instead of k_msm_merge2 (operands in LDS, < 128 VGPRs, quads throughout)
+        static const bool use_merge2 = [] { const char* e = getenv("DEHALO_MSM_MERGE2"); return !(e && e[0] == '0'); }();
+        const u32 c0max = use_merge2 || tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
         k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
-        // DEHALO_MSM_MERGE_SPLIT=1 (measurements, tools/merge_split.sh): one launch per class -- block, wave, 32 lanes, light -- so that a kernel trace shows each one's time
-        static const bool merge_split = [] { const char* e = getenv("DEHALO_MSM_MERGE_SPLIT"); return e && e[0] == '1'; }();
-        for (int only = merge_split ? 3 : -1; only >= -1; only--) {
-            k_msm_merge_all<CV><<<MSM_MERGE_BLOCKS_HEAVY + MSM_MERGE_BLOCKS_G64 + MSM_MERGE_BLOCKS_G32 + MSM_MERGE_BLOCKS_LIGHT, MSM_MERGE_THREADS, 0, s>>>(
-                rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, only);
-            if (only <= 0) break;
+        if (use_merge2)
+            k_msm_merge2<CV><<<MERGE2_BLOCKS_HEAVY + MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32 + MERGE2_BLOCKS_LIGHT, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        else {
+            // DEHALO_MSM_MERGE_SPLIT=1 (measurements, tools/merge_split.sh): one launch per class -- block, wave, 32 lanes, light -- so that a kernel trace shows each one's time
+            static const bool merge_split = [] { const char* e = getenv("DEHALO_MSM_MERGE_SPLIT"); return e && e[0] == '1'; }();
+            for (int only = merge_split ? 3 : -1; only >= -1; only--) {
+                k_msm_merge_all<CV><<<MSM_MERGE_BLOCKS_HEAVY + MSM_MERGE_BLOCKS_G64 + MSM_MERGE_BLOCKS_G32 + MSM_MERGE_BLOCKS_LIGHT, MSM_MERGE_THREADS, 0, s>>>(
+                    rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, only);
+                if (only <= 0) break;
+            }
         }
-        // bucket reduction: RM = 4 buckets per quad while the quad-waves have a SIMD each (4 columns at c = 15), 8 from there on -- half the quads, each with
-        // a chain 5 additions longer (14 + 11 doublings + <= 12 additions against 6 + 12 + <= 13), and the double-and-add weighting, most of the work,
-        // done once per 8 buckets: 2^17 x 5 / 7 / 10 columns 136 / 137 / 201 -> 105 / 107 / 178 us (3 or 4 columns: 86 -> 104, so they keep 4); batch mode
-        // 141 -> 144 proofs/s (DEHALO_MSM_RED_M=4 / 8 forces one, for A/B measurements)
+        // bucket reduction.  Default (round 4): ONE launch of the radix-2 recursion (msm_bred.cuh: 2 additions per bucket, operands in LDS, < 128 VGPRs; the
+        // last block of a group weights, sums and writes the result).  DEHALO_MSM_BRED=0 runs the round-3 path for A/B measurements: k_msm_reduce_local
+        // (RM = 4 / 8 buckets per quad, double-and-add weighting) + k_msm_tree_sum launches.
+        static const bool use_bred = [] { const char* e = getenv("DEHALO_MSM_BRED"); return !(e && e[0] == '0'); }();
+        bool emitted = false;
+        const xyzz29_rec* cur = contrib;
+        if (use_bred && g.nb >= 8) {
+            const u32 nblk = std::max<u32>(1, g.nb / BRED_BLOCK_BUCKETS);
+            const bool fin = g.G == 1;
+            k_msm_bred<CV><<<dim3(nblk, (u32)total_groups), BRED_THREADS, 0, s>>>(g.nb, buckets, (xyzz29_rec*)ctx->ws_contrib.p, (xyzz29_rec*)ctx->ws_tree.p, (u32*)ctx->ws_bred_cnt.p, gsums,
+                                                                                 fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
+            emitted = fin;
+            cur = gsums;
+        } else {
         static const int red_m_env = [] { const char* e = getenv("DEHALO_MSM_RED_M"); return e ? atoi(e) : 0; }();
         const uint64_t quads4 = (uint64_t)((g.nb + 3) / 4) * total_groups;
         const u32 red_m = red_m_env == 4 || red_m_env == 8 ? (u32)red_m_env : (quads4 * 4 > 65536 ? 8u : 4u);
@@ -1085,11 +1112,9 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
             if (red_m == 8) k_msm_reduce_local<CV, false, 8><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
             else k_msm_reduce_local<CV, false, 4><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
         }
-        const xyzz29_rec* cur = contrib;
         u32 cnt = per_group_r;
         xyzz29_rec* bufs[2] = {tree, contrib};  // ping-pong: contrib is free once consumed
         int which = 0;
-        bool emitted = false;
         while (cnt > 1) {
             u32 out_cnt = (cnt + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS;
             xyzz29_rec* o = out_cnt == 1 ? gsums : bufs[which];
@@ -1098,6 +1123,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
             k_msm_tree_sum<CV><<<grid, 256, 0, s>>>(cur, cnt, o, out_cnt, fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
             emitted = fin;
             cur = o; cnt = out_cnt; which ^= 1;
+        }
         }
         if (!emitted) {
             if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));

@@ -1,0 +1,375 @@
+// msm_bred.cuh -- the bucket reduction  S = sum_k (k + 1) B_k  of the Pippenger MSM (the `running_sum` loop at the end of every window of
+// upstream's multiexp_serial, halo2_proofs/src/arithmetic.rs @ v2023_04_20) as ONE launch of a radix-2 recursion.
+//
+// What it replaces (rounds 1-3): k_msm_reduce_local (a quad per 4 / 8 buckets: local running sums, then k0 * run by double-and-add -- a chain of
+// ~33 dependent group operations, ~6.5 group operations per bucket) + two k_msm_tree_sum launches.
+//
+// The recursion: write k = sum_j 2^j k_j.  Then  sum_k k B_k = sum_j 2^j A_j  with  A_j = sum of the buckets whose index has bit j set, and all A_j
+// come out of ONE binary tree over the buckets: a node covering 2^t buckets carries the vector (X, A_0 .. A_{t-1}) -- its total and its bit sums,
+// indices taken relative to the node -- and two siblings combine as
+//       X = X_lo + X_hi,    A_j = A_j(lo) + A_j(hi)  (j < t),    A_t = X_hi            (no addition: the high half IS the set with bit t),
+// t + 1 independent additions per node.  2 N additions for N buckets (against ~6.5 N), no doubling until the very end
+// (S = X + sum_j 2^j A_j: j doublings of A_j, side by side), every level's additions independent of each other.
+//
+// Mapping: a 256-thread block = 64 quads takes 256 consecutive buckets into LDS (the accumulation kernel leaves the LDS unused) and works in place;
+// every addition is QUAD-cooperative with its operands IN MEMORY (x29q_add_mem: a lane loads only the coordinate its multiplication needs and stores
+// only the coordinate it produced -- no 36-word operands in registers, no select chains), which keeps the kernel below 128 VGPRs: a wave of it fits
+// beside three resident waves of k_msm_accum0 on a SIMD.  Blocks leave their node vector (<= 9 points) in HBM; the LAST block of a cluster of 16
+// (an atomic counter per cluster, __threadfence on both sides) combines the cluster's 16 vectors, the last cluster of a group the <= 8 cluster
+// vectors, and that same block weights, sums and emits the result: one launch per MSM batch instead of three.
+#pragma once
+#include "ec29.cuh"
+
+#define BRED_THREADS 256
+#define BRED_QUADS (BRED_THREADS / 4)
+#define BRED_BLOCK_BUCKETS 256      // 4 buckets per quad
+#define BRED_FANIN 16               // node vectors one block combines in the second / third stage
+#define BRED_VMAX 17                // points per node vector in HBM: A_0 .. A_15, X
+#define BRED_CNT_PER_GROUP 16       // u32 counters per bucket group: clusters [0, 8), group [8]
+
+// ---- quad-cooperative group operations on records in memory (LDS or HBM): record = 36 words, coordinate c at words [9 c, 9 c + 9) ----
+FP_DEV f29 q_ld(const u32* rec, u32 coord) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = rec[9 * coord + i];
+    return r;
+}
+FP_DEV void q_st(u32* rec, u32 coord, const f29& v) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) rec[9 * coord + i] = v.v[i];
+}
+FP_DEV bool q_is_literal_identity(const u32* rec) {      // ZZ = 0 limb by limb: an empty bucket, x29_identity()
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= rec[18 + i];
+    return o == 0;
+}
+template <int K>
+FP_DEV u32 q_bcast_word(u32 a) {
+    u32 t = (u32)__builtin_amdgcn_update_dpp(0, (int)a, K * 0x55, 0xf, 0xf, false);
+    asm volatile("" : "+v"(t));
+    return t;
+}
+FP_DEV void x29q_copy(u32* out, const u32* src, u32 role) {
+    if (out != src) q_st(out, role, q_ld(src, role));
+}
+
+// out = 2 a  (all four lanes of the quad active, same pointers; out may be a)
+template <class F>
+FP_DEV void x29q_double_mem(u32* out, const u32* a) {
+    const u32 role = threadIdx.x & 3;
+    if (q_is_literal_identity(a)) { x29q_copy(out, a, role); return; }
+    const f29 ax = q_ld(a, 0), ay = q_ld(a, 1);
+    const f29 u = f29_dbl(ay);
+    // level 1: v = U^2 | xx = X^2
+    f29 op = (role & 1) ? ax : u;
+    f29 m = f29_mul<F>(op, op);
+    const f29 v = f29_quad_bcast<0>(m), xx = f29_quad_bcast<1>(m);
+    const f29 mm_in = f29_norm(f29_add(f29_dbl(xx), xx));
+    // level 2: w = U V | s = X V | mm = M^2 | zz3 = V ZZ
+    m = f29_mul<F>(f29_sel4(u, ax, mm_in, v, role), f29_sel4(v, v, mm_in, q_ld(a, 2), role));
+    const f29 w = f29_quad_bcast<0>(m), s = f29_quad_bcast<1>(m), mm = f29_quad_bcast<2>(m);
+    const f29 m2 = m;                                   // lane 3 keeps zz3
+    const f29 rx = f29_norm(f29_sub(mm, f29_dbl(s), F::KB));
+    const f29 t = f29_sub(s, rx, F::KA);
+    // level 3: M T | W Y | zzz3 = W ZZZ | (lane 3: spare)
+    m = f29_mul<F>(f29_sel4(mm_in, w, w, w, role), f29_sel4(t, ay, q_ld(a, 3), ay, role));
+    const f29 mt = f29_quad_bcast<0>(m), wy = f29_quad_bcast<1>(m);
+    const f29 ry = f29_norm(f29_sub(mt, wy, F::KM));
+    // lane 0 stores x, lane 1 y, lane 3 zz (its level-2 product), lane 2 zzz (its level-3 product)
+    q_st(out, role < 2 ? role : 5 - role, f29_sel4(rx, ry, m, m2, role));
+}
+
+// out = a + b  (all four lanes of the quad active, same pointers; out may be a or b).  Same arithmetic, level by level, as x29_add_quad (ec29.cuh).
+template <class F>
+FP_DEV void x29q_add_mem(u32* out, const u32* a, const u32* b) {
+    const u32 role = threadIdx.x & 3;
+    if (q_is_literal_identity(a)) { x29q_copy(out, b, role); return; }
+    if (q_is_literal_identity(b)) { x29q_copy(out, a, role); return; }
+    // level 1: u1 = X1 ZZ2 | u2 = X2 ZZ1 | s1 = Y1 ZZZ2 | s2 = Y2 ZZZ1
+    const u32* pa = (role & 1) ? b : a;
+    const u32* pb = (role & 1) ? a : b;
+    f29 m = f29_mul<F>(q_ld(pa, role >> 1), q_ld(pb, 2 + (role >> 1)));
+    const f29 u1 = f29_quad_bcast<0>(m), u2 = f29_quad_bcast<1>(m), s1 = f29_quad_bcast<2>(m), s2 = f29_quad_bcast<3>(m);
+    const f29 p = f29_norm(f29_sub(u2, u1, F::KM));
+    const f29 rr = f29_norm(f29_sub(s2, s1, F::KM));
+    // level 2: pp = P^2 | r2 = R^2 | zz12 = ZZ1 ZZ2 | zzz12 = ZZZ1 ZZZ2   (lanes 2 / 3 load their coordinate of both operands)
+    {
+        const f29 la = q_ld(a, role), lb = q_ld(b, role);
+        f29 oa, ob;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const u32 sq = (role & 1) ? rr.v[i] : p.v[i];
+            oa.v[i] = (role & 2) ? la.v[i] : sq;
+            ob.v[i] = (role & 2) ? lb.v[i] : sq;
+        }
+        m = f29_mul<F>(oa, ob);
+    }
+    const f29 pp = f29_quad_bcast<0>(m), r2 = f29_quad_bcast<1>(m);
+    const f29 keep = m;                                 // lanes 2 / 3 keep zz12 / zzz12
+    // level 3: ppp = P PP | qq = U1 PP | zz3 = zz12 PP | (lane 3: spare)
+    m = f29_mul<F>(f29_sel4(p, u1, keep, p, role), pp);
+    const f29 ppp = f29_quad_bcast<0>(m), qq = f29_quad_bcast<1>(m);
+    const f29 m3 = m;                                   // lane 2 keeps zz3
+    const u32 zz3_0 = q_bcast_word<2>(m.v[0]);
+    const f29 rx = f29_norm(f29_sub(r2, f29_add(ppp, f29_dbl(qq)), F::KB));
+    const f29 t = f29_sub(qq, rx, F::KA);
+    // level 4: R T | S1 PPP | (lane 2: spare) | zzz3 = zzz12 PPP
+    m = f29_mul<F>(f29_sel4(rr, s1, rr, keep, role), f29_sel4(t, ppp, t, ppp, role));
+    const f29 rt = f29_quad_bcast<0>(m), sp = f29_quad_bcast<1>(m);
+    const f29 ry = f29_norm(f29_sub(rt, sp, F::KM));
+    if (__builtin_expect((zz3_0 == 0) | (zz3_0 == F::P[0]), 0)) {
+        if (f29_is_zero_lt2p<F>(f29_quad_bcast<2>(m3))) {
+            // exceptional (ZZ3 = 0 mod p): an identity operand that is not all-zero limbs, P == Q, or P == -Q -- decided exactly, every lane alike
+            if (f29_is_zero_slow<F>(q_ld(a, 2))) x29q_copy(out, b, role);
+            else if (f29_is_zero_slow<F>(q_ld(b, 2))) x29q_copy(out, a, role);
+            else if (f29_is_zero_slow<F>(rr)) x29q_double_mem<F>(out, a);
+            else q_st(out, role, f29_zero());
+            return;
+        }
+    }
+    q_st(out, role, f29_sel4(rx, ry, m3, m, role));
+}
+
+// ---- the tree --------------------------------------------------------------------------------------------------------------
+// K node vectors in LDS, vector i with C base components at records aBase + i * iStride + c (c < C) and its total at xBase + i * iStride.
+// In place: after the call vector 0 holds the combined node -- base components where they were, the log2 K new ones A_{C + s} in the TOTAL slot
+// of vector 2^s, the total in the total slot of vector 0.
+template <class F>
+FP_DEV void bred_tree(u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C, u32 K) {
+    const u32 quad = threadIdx.x >> 2;
+    for (u32 t = 0; (1u << t) < K; t++) {
+        const u32 per = C + 1 + t, jobs = (K >> (t + 1)) * per;
+        for (u32 job = quad; job < jobs; job += BRED_QUADS) {
+            const u32 node = job / per, comp = job - node * per;
+            const u32 lo = node << (t + 1), hi = lo + (1u << t);
+            u32 d, s;
+            if (comp < C) { d = aBase + lo * iStride + comp; s = aBase + hi * iStride + comp; }
+            else if (comp == C) { d = xBase + lo * iStride; s = xBase + hi * iStride; }
+            else { const u32 o = 1u << (comp - C - 1); d = xBase + (lo + o) * iStride; s = xBase + (hi + o) * iStride; }
+            x29q_add_mem<F>(lds + 36 * d, lds + 36 * d, lds + 36 * s);
+        }
+        __syncthreads();
+    }
+}
+
+// the combined vector of bred_tree, in canonical order [A_0 .. A_{C + log2 K - 1}, X], copied to `dst` (LDS records)
+FP_DEV void bred_gather(u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C, u32 K, u32* dst) {
+    u32 logK = 0;
+    while ((1u << logK) < K) logK++;
+    const u32 V = C + logK + 1;
+    for (u32 e = threadIdx.x; e < V * 36; e += BRED_THREADS) {
+        const u32 v = e / 36, w = e - v * 36;
+        const u32 src = v < C ? aBase + v : (v < C + logK ? xBase + (1u << (v - C)) * iStride : xBase);
+        dst[e] = lds[36 * src + w];
+    }
+}
+
+// One thread block per 256 buckets of a group; grid (max(1, nb / 256), total_groups).  nodes1 / nodes2: BRED_VMAX records per block / per cluster.
+// counters: BRED_CNT_PER_GROUP words per group, zero on entry and left zero.  The result of group g goes to fin_out / fin_affine [g] (precomputed
+// tables: one group per MSM) or, when both are null, to gsums[g] for k_msm_final.
+template <class CV>
+__global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
+                                                          jacobian_t* fin_out, affine_t* fin_affine) {
+    typedef typename f29_of<typename CV::Base>::type F;
+    __shared__ __align__(16) u32 lds[(BRED_BLOCK_BUCKETS + 32) * 36];
+    __shared__ u32 s_last;
+    u32* const vec = lds + BRED_BLOCK_BUCKETS * 36;      // 32 records: the node vector being handed on
+    const u32 tid = threadIdx.x, quad = tid >> 2;
+    const u32 g = blockIdx.y, bx = blockIdx.x;
+    const u32 nblk = gridDim.x;
+    const u32 here = nb < BRED_BLOCK_BUCKETS ? nb : BRED_BLOCK_BUCKETS;      // buckets of this block (a power of two >= 8)
+    u32 m = 0;                                                               // log2 nb
+    while ((1u << m) < nb) m++;
+
+    // ---- stage 1: this block's buckets -> LDS; per quad the 4-bucket node (X | A_0 | A_1 in slots 0 | 1 | 2), then the tree over the quads
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(buckets + (u64)g * nb + (u64)bx * BRED_BLOCK_BUCKETS);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (u32 e = tid; e < here * 9; e += BRED_THREADS) dst[e] = src[e];
+    }
+    __syncthreads();
+    const u32 U = here / 4;
+    if (quad < U) {
+        u32* s0 = lds + 36 * (4 * quad);
+        x29q_add_mem<F>(s0, s0, s0 + 36);                  // slot 0 = B0 + B1
+        x29q_add_mem<F>(s0 + 36, s0 + 36, s0 + 108);       // slot 1 = B1 + B3 = A_0
+        x29q_add_mem<F>(s0 + 72, s0 + 72, s0 + 108);       // slot 2 = B2 + B3 = A_1
+        x29q_add_mem<F>(s0, s0, s0 + 72);                  // slot 0 = X
+    }
+    __syncthreads();
+    bred_tree<F>(lds, 1, 0, 4, 2, U);
+    bred_gather(lds, 1, 0, 4, 2, U, vec);
+    u32 V = 2 + (m < 8 ? m - 2 : 6) + 1;                   // components + total of a block's vector
+    __syncthreads();
+
+    // ---- stages 2 and 3: the last block of a cluster combines the cluster's vectors, the last cluster of a group the clusters' ----
+    u32 children = nblk;                                   // vectors still to combine for this group
+    u32 idx = bx;                                          // this block's position among them
+    xyzz29_rec* level_nodes = nodes1;
+    for (int stage = 0; stage < 2 && children > 1; stage++) {
+        const u32 fan = children < BRED_FANIN ? children : BRED_FANIN;
+        const u32 cl = idx / fan, ncl = children / fan;
+        u32* mine = reinterpret_cast<u32*>(level_nodes + ((u64)g * children + idx) * BRED_VMAX);
+        for (u32 e = tid; e < V * 36; e += BRED_THREADS) mine[e] = vec[e];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            u32* cnt = counters + (u64)g * BRED_CNT_PER_GROUP + (stage == 0 ? cl : 8);
+            const u32 old = atomicAdd(cnt, 1u);
+            s_last = old == fan - 1;
+            if (s_last) *cnt = 0;                          // (everyone else has counted already: left zero for the next launch)
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        const u32* kids = reinterpret_cast<const u32*>(level_nodes + ((u64)g * children + (u64)cl * fan) * BRED_VMAX);
+        for (u32 e = tid; e < fan * V * 36; e += BRED_THREADS) {
+            const u32 i = e / (V * 36), w = e - i * (V * 36);
+            lds[i * (V * 36) + w] = __builtin_nontemporal_load(&kids[(u64)i * BRED_VMAX * 36 + w]);
+        }
+        __syncthreads();
+        bred_tree<F>(lds, 0, V - 1, V, V - 1, fan);
+        bred_gather(lds, 0, V - 1, V, V - 1, fan, vec);
+        u32 lf = 0;
+        while ((1u << lf) < fan) lf++;
+        V += lf;
+        __syncthreads();
+        children = ncl; idx = cl; level_nodes = nodes2;
+    }
+
+    // ---- final: vec = [A_0 .. A_{m-1}, X]  ->  S = X + sum_j 2^j A_j ----
+    for (u32 e = (m + 1) * 36 + tid; e < 16 * 36; e += BRED_THREADS) vec[e] = 0;      // pad to 16 records with identities
+    __syncthreads();
+    if (quad < m)
+        for (u32 i = 0; i < quad; i++) x29q_double_mem<F>(vec + 36 * quad, vec + 36 * quad);
+    __syncthreads();
+    for (u32 half = 8; half >= 1; half >>= 1) {
+        if (quad < half) x29q_add_mem<F>(vec + 36 * quad, vec + 36 * quad, vec + 36 * (quad + half));
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const xyzz29 s = x29_load(reinterpret_cast<const xyzz29_rec*>(vec));
+        if (fin_out || fin_affine) msm_emit<F>(s, fin_out ? fin_out + g : nullptr, fin_affine ? fin_affine + g : nullptr);
+        else x29_store(&gsums[g], s);
+    }
+}
+
+// ==========================================================================================================================================
+// Merging a bucket's partial sums with operands in LDS (round 4): the same classes and sections as k_msm_merge_all (msm.cuh), every addition
+// quad-cooperative on records in LDS (x29q_add_mem) -- below 128 VGPRs, so that a wave of it fits beside three resident waves of k_msm_accum0.
+// A quad keeps its running sum in LDS record 2 q and stages the next partial sum (read from HBM one iteration ahead, nine words per lane) in
+// record 2 q + 1.  All lanes of a quad belong to one wave: LDS operations of a wave complete in order, so a record written coordinate by
+// coordinate by the four lanes is complete for every one of them at the next instruction; __builtin_amdgcn_wave_barrier() keeps the compiler from
+// moving LDS accesses across those points.
+FP_DEV void q_copy_in(u32* rec, const xyzz29_rec* src, u32 role) {      // HBM record -> LDS record, nine words per lane
+    const u32* s = reinterpret_cast<const u32*>(src) + 9 * role;
+#pragma unroll
+    for (int i = 0; i < 9; i++) rec[9 * role + i] = s[i];
+}
+FP_DEV void q_copy_out(xyzz29_rec* dst, const u32* rec, u32 role) {
+    u32* d = reinterpret_cast<u32*>(dst) + 9 * role;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = rec[9 * role + i];
+}
+
+// acc (LDS record) = sum of partial[p], p = first, first + step, ... < end  (identity if none); the next record is in flight during an addition
+template <class F>
+FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 first, u32 step, u32 end, u32 role) {
+    if (first >= end) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) acc[9 * role + i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    q_copy_in(acc, &partial[first], role);
+    u32 nxt[9];
+    u32 p = first + step;
+    if (p < end) {
+        const u32* s = reinterpret_cast<const u32*>(&partial[p]) + 9 * role;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nxt[i] = s[i];
+    }
+    while (p < end) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) inc[9 * role + i] = nxt[i];
+        p += step;
+        if (p < end) {
+            const u32* s = reinterpret_cast<const u32*>(&partial[p]) + 9 * role;
+#pragma unroll
+            for (int i = 0; i < 9; i++) nxt[i] = s[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        x29q_add_mem<F>(acc, acc, inc);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+#define MERGE2_BLOCKS_LIGHT 1024
+#define MERGE2_BLOCKS_G32 512
+#define MERGE2_BLOCKS_G64 512
+#define MERGE2_BLOCKS_HEAVY 256
+
+// grid = [heavy | 64-lane groups | 32-lane groups | light] sections of 256-thread blocks; a block whose section's list is shorter than its position
+// leaves at once.  Lists and counters as written by k_msm_merge_classify (c0max = 24: the light class always runs one quad per bucket here -- a
+// quad-cooperative addition spends 16 lane-multiplications where a single lane spends 14).
+template <class CV>
+__global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, const u32* lists, u32 cap) {
+    typedef typename f29_of<typename CV::Base>::type F;
+    __shared__ __align__(16) u32 lds[128 * 36];
+    const u32 tid = threadIdx.x, quad = tid >> 2, role = tid & 3;
+    u32* acc = lds + 36 * (2 * quad);
+    u32* inc = acc + 36;
+    u32 blk = blockIdx.x;
+    if (blk < MERGE2_BLOCKS_HEAVY) {      // a block per bucket: 64 strided quad sums, then an LDS tree over the quads
+        const u32 count = counters[3];
+        const u32* list = lists + 3 * (size_t)cap;
+        for (u32 i = blk; i < count; i += MERGE2_BLOCKS_HEAVY) {
+            const u32 b = list[i];
+            const u32 beg = rbeg[b], end = rend[b];
+            q_strided_sum<F>(acc, inc, partial, beg + quad, 64, end, role);
+            __syncthreads();
+            for (u32 d = 32; d >= 1; d >>= 1) {
+                if (quad < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
+                __syncthreads();
+            }
+            if (quad == 0) q_copy_out(&buckets[b], acc, role);
+            __syncthreads();
+        }
+        return;
+    }
+    blk -= MERGE2_BLOCKS_HEAVY;
+    if (blk < MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32) {      // a wave (16 quads) or half a wave (8 quads) per bucket: strided quad sums, then a tree inside the wave
+        const bool wide = blk < MERGE2_BLOCKS_G64;
+        if (!wide) blk -= MERGE2_BLOCKS_G64;
+        const u32 nblk = wide ? MERGE2_BLOCKS_G64 : MERGE2_BLOCKS_G32;
+        const u32 Q = wide ? 16u : 8u;                       // quads per bucket
+        const u32 count = counters[wide ? 2 : 1];
+        const u32* list = lists + (wide ? 2 : 1) * (size_t)cap;
+        const u32 groups_per_block = 64 / Q, grp = quad / Q, q = quad % Q;
+        for (u32 i = blk * groups_per_block + grp; i < count; i += nblk * groups_per_block) {
+            const u32 b = list[i];
+            const u32 beg = rbeg[b], end = rend[b];
+            q_strided_sum<F>(acc, inc, partial, beg + q, Q, end, role);
+            for (u32 d = Q >> 1; d >= 1; d >>= 1) {
+                if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (q == 0) q_copy_out(&buckets[b], acc, role);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    blk -= MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32;
+    {   // light class: one quad per bucket
+        const u32 count = counters[0];
+        for (u32 i = blk * 64 + quad; i < count; i += MERGE2_BLOCKS_LIGHT * 64) {
+            const u32 b = lists[i];
+            const u32 beg = rbeg[b], end = rend[b];
+            q_strided_sum<F>(acc, inc, partial, beg, 1, end, role);
+            q_copy_out(&buckets[b], acc, role);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}

@@ -68,11 +68,16 @@ const char* dehalo_last_error(const dehalo_ctx* ctx);
  * DEHALO_MSM_ACC_POINTS at context creation): the bucket-accumulation grid of an MSM is 4, 6, 8, ... layers of one wave per SIMD,
  * the fewest that leave a lane at most this many points; 0 selects the older rule, whole rounds of "msm_acc_waves" in [1, 4]
  * waves per SIMD (below 4 the kernel leaves wave slots and registers free for the latency-bound kernels of other contexts).
+ * "msm_acc_block" (128 or 768; DEHALO_MSM_ACC_BLOCK at context creation): threads per workgroup of the bucket accumulation.  768 = one
+ * 12-wave workgroup per compute unit, three waves per SIMD, which leaves a quarter of every SIMD's registers and all of the LDS to the
+ * kernels of other contexts that need at most 128 VGPRs (the bucket reduction, the merge, the NTT's half tiles).
  * "ntt_full_table_log" (default 0, in [0, 30]): transforms of up to 2^value points keep all N powers of omega on the device
  * (32 B x N) so that an inter-pass twiddle is one load; larger ones keep N / 2 and negate (measured equal on MI355X). */
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
 /* Environment variables read by the library (measurement and tuning only; results never depend on them):
  *   DEHALO_MSM_ACC_POINTS   default of "msm_acc_points" at context creation
+ *   DEHALO_MSM_ACC_BLOCK    default of "msm_acc_block" at context creation
+ *   DEHALO_MSM_BRED         0: the round-3 bucket reduction (k_msm_reduce_local + k_msm_tree_sum launches) instead of the one-launch radix-2 recursion
  *   DEHALO_WINDOW_BITS      Pippenger window of tables registered with window_bits = 0 (4 .. 16)
  *   DEHALO_MSM_ACC_LDS      bytes of (unused) dynamic LDS per block of the bucket accumulation: caps its resident blocks per CU
  *   DEHALO_MSM_MERGE_SPLIT  1: the merge of partial sums runs one launch per bucket class (a kernel trace then shows each class's time)
