@@ -1041,17 +1041,21 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     if (lds_hist > 48 * 1024) {
         HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_hist<FS>, (int)lds_hist));
     }
-    const size_t lds_part = 512 + (size_t)(MSM_SORT_THREADS / 64) * MSM_PART_WAVE_LDS;
+    // block sizes of the two scalar-decoding sort kernels (DEHALO_MSM_HIST_THREADS / DEHALO_MSM_PART_THREADS, 64 .. 1024): smaller blocks fit beside a
+    // resident accumulation of another context (msm_acc_block = 768 leaves one 128-VGPR wave slot per SIMD: 512 threads x 62 VGPRs, 256 x 77)
+    static const u32 hist_threads = [] { const char* e = getenv("DEHALO_MSM_HIST_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
+    static const u32 part_threads = [] { const char* e = getenv("DEHALO_MSM_PART_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
+    const size_t lds_part = 512 + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS;
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_part<FS>, (int)lds_part));
     const u32 tb = (u32)total_buckets;
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
         dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
-        k_msm_hist<FS><<<grid, MSM_SORT_THREADS, lds_hist, s>>>(g, d_scalars, bh, pc);
+        k_msm_hist<FS><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
         const u32 cs_a = (tb + 255) / 256, cs_b = ((u32)total_groups * P + 255) / 256;
         k_msm_colscan<<<cs_a + cs_b, 256, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc);
         TRY(run_scan(ctx, count, tb, cursor + 4, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend, s));
-        k_msm_part<FS><<<grid, MSM_SORT_THREADS, lds_part, s>>>(g, d_scalars, off, pc, pairs);
+        k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, 0, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
         HIP_TRY(ctx, hipGetLastError());
     }

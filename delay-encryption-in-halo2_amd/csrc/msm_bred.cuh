@@ -134,7 +134,9 @@ FP_DEV void x29q_add_mem(u32* out, const u32* a, const u32* b) {
 // ---- the tree --------------------------------------------------------------------------------------------------------------
 // K node vectors in LDS, vector i with C base components at records aBase + i * iStride + c (c < C) and its total at xBase + i * iStride.
 // In place: after the call vector 0 holds the combined node -- base components where they were, the log2 K new ones A_{C + s} in the TOTAL slot
-// of vector 2^s, the total in the total slot of vector 0.
+// of vector 2^s, the total in the total slot of vector 0.  (With C = 0 and K raw buckets this is the whole recursion from the leaves up; the same
+// call with C = 0 over any K records also just sums them into record 0.)  ONE inlined copy of the addition per kernel: the instruction cache holds
+// 64 KB and an addition is ~16 KB of code -- the first version of this kernel inlined it ten times and ran slower than what it replaced.
 template <class F>
 FP_DEV void bred_tree(u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C, u32 K) {
     const u32 quad = threadIdx.x >> 2;
@@ -154,7 +156,7 @@ FP_DEV void bred_tree(u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C, u32 K)
 }
 
 // the combined vector of bred_tree, in canonical order [A_0 .. A_{C + log2 K - 1}, X], copied to `dst` (LDS records)
-FP_DEV void bred_gather(u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C, u32 K, u32* dst) {
+FP_DEV void bred_gather(const u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C, u32 K, u32* dst) {
     u32 logK = 0;
     while ((1u << logK) < K) logK++;
     const u32 V = C + logK + 1;
@@ -168,6 +170,8 @@ FP_DEV void bred_gather(u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C, u32 
 // One thread block per 256 buckets of a group; grid (max(1, nb / 256), total_groups).  nodes1 / nodes2: BRED_VMAX records per block / per cluster.
 // counters: BRED_CNT_PER_GROUP words per group, zero on entry and left zero.  The result of group g goes to fin_out / fin_affine [g] (precomputed
 // tables: one group per MSM) or, when both are null, to gsums[g] for k_msm_final.
+// Phases of a block: 0 its 256 buckets | 1 (last block of a cluster of 16) the cluster's vectors | 2 (last cluster of the group) the clusters' vectors |
+// 3 (the block that holds the group's vector) weighting by 2^j and the final sum.  Every phase is one call of the tree -- one loop body.
 template <class CV>
 __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
                                                           jacobian_t* fin_out, affine_t* fin_affine) {
@@ -176,80 +180,65 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
     __shared__ u32 s_last;
     u32* const vec = lds + BRED_BLOCK_BUCKETS * 36;      // 32 records: the node vector being handed on
     const u32 tid = threadIdx.x, quad = tid >> 2;
-    const u32 g = blockIdx.y, bx = blockIdx.x;
-    const u32 nblk = gridDim.x;
-    const u32 here = nb < BRED_BLOCK_BUCKETS ? nb : BRED_BLOCK_BUCKETS;      // buckets of this block (a power of two >= 8)
+    const u32 g = blockIdx.y;
+    const u32 here = nb < BRED_BLOCK_BUCKETS ? nb : BRED_BLOCK_BUCKETS;      // buckets of a block (a power of two >= 8)
     u32 m = 0;                                                               // log2 nb
     while ((1u << m) < nb) m++;
 
-    // ---- stage 1: this block's buckets -> LDS; per quad the 4-bucket node (X | A_0 | A_1 in slots 0 | 1 | 2), then the tree over the quads
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(buckets + (u64)g * nb + (u64)bx * BRED_BLOCK_BUCKETS);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (u32 e = tid; e < here * 9; e += BRED_THREADS) dst[e] = src[e];
-    }
-    __syncthreads();
-    const u32 U = here / 4;
-    if (quad < U) {
-        u32* s0 = lds + 36 * (4 * quad);
-        x29q_add_mem<F>(s0, s0, s0 + 36);                  // slot 0 = B0 + B1
-        x29q_add_mem<F>(s0 + 36, s0 + 36, s0 + 108);       // slot 1 = B1 + B3 = A_0
-        x29q_add_mem<F>(s0 + 72, s0 + 72, s0 + 108);       // slot 2 = B2 + B3 = A_1
-        x29q_add_mem<F>(s0, s0, s0 + 72);                  // slot 0 = X
-    }
-    __syncthreads();
-    bred_tree<F>(lds, 1, 0, 4, 2, U);
-    bred_gather(lds, 1, 0, 4, 2, U, vec);
-    u32 V = 2 + (m < 8 ? m - 2 : 6) + 1;                   // components + total of a block's vector
-    __syncthreads();
-
-    // ---- stages 2 and 3: the last block of a cluster combines the cluster's vectors, the last cluster of a group the clusters' ----
-    u32 children = nblk;                                   // vectors still to combine for this group
-    u32 idx = bx;                                          // this block's position among them
-    xyzz29_rec* level_nodes = nodes1;
-    for (int stage = 0; stage < 2 && children > 1; stage++) {
-        const u32 fan = children < BRED_FANIN ? children : BRED_FANIN;
-        const u32 cl = idx / fan, ncl = children / fan;
-        u32* mine = reinterpret_cast<u32*>(level_nodes + ((u64)g * children + idx) * BRED_VMAX);
-        for (u32 e = tid; e < V * 36; e += BRED_THREADS) mine[e] = vec[e];
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) {
-            u32* cnt = counters + (u64)g * BRED_CNT_PER_GROUP + (stage == 0 ? cl : 8);
-            const u32 old = atomicAdd(cnt, 1u);
-            s_last = old == fan - 1;
-            if (s_last) *cnt = 0;                          // (everyone else has counted already: left zero for the next launch)
+    u32 children = gridDim.x;      // vectors still to combine for this group after the current phase
+    u32 idx = blockIdx.x;          // this block's position among them
+    u32 V = 0;                     // records of the vector in `vec`
+    for (u32 phase = 0; phase < 4; phase++) {
+        u32 C, K, xBase, iStride;
+        if (phase == 0) {          // the block's buckets -> LDS (plain records: a leaf is its own total)
+            const uint4* src = reinterpret_cast<const uint4*>(buckets + (u64)g * nb + (u64)idx * BRED_BLOCK_BUCKETS);
+            uint4* dst = reinterpret_cast<uint4*>(lds);
+            for (u32 e = tid; e < here * 9; e += BRED_THREADS) dst[e] = src[e];
+            C = 0; K = here; xBase = 0; iStride = 1;
+        } else if (phase < 3) {    // publish this block's vector; the last arrival of its cluster goes on with the cluster's vectors
+            if (children == 1) continue;
+            xyzz29_rec* level_nodes = phase == 1 ? nodes1 : nodes2;
+            const u32 fan = children < BRED_FANIN ? children : BRED_FANIN;
+            const u32 cl = idx / fan;
+            u32* mine = reinterpret_cast<u32*>(level_nodes + ((u64)g * children + idx) * BRED_VMAX);
+            for (u32 e = tid; e < V * 36; e += BRED_THREADS) mine[e] = vec[e];
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                u32* cnt = counters + (u64)g * BRED_CNT_PER_GROUP + (phase == 1 ? cl : 8);
+                const u32 old = atomicAdd(cnt, 1u);
+                s_last = old == fan - 1;
+                if (s_last) *cnt = 0;                      // (everyone else has counted already: left zero for the next launch)
+            }
+            __syncthreads();
+            if (!s_last) return;
+            __threadfence();
+            const u32* kids = reinterpret_cast<const u32*>(level_nodes + ((u64)g * children + (u64)cl * fan) * BRED_VMAX);
+            for (u32 e = tid; e < fan * V * 36; e += BRED_THREADS) {
+                const u32 i = e / (V * 36), w = e - i * (V * 36);
+                lds[e] = kids[(u64)i * BRED_VMAX * 36 + w];
+            }
+            C = V - 1; K = fan; xBase = V - 1; iStride = V;
+            children /= fan; idx = cl;
+        } else {                   // vec = [A_0 .. A_{m-1}, X]  ->  S = X + sum_j 2^j A_j: quad j doubles A_j j times, then the 16 records are summed
+            for (u32 e = tid; e < 16 * 36; e += BRED_THREADS) lds[e] = e < (m + 1) * 36 ? vec[e] : 0u;
+            __syncthreads();
+            if (quad < m)
+                for (u32 i = 0; i < quad; i++) x29q_double_mem<F>(lds + 36 * quad, lds + 36 * quad);
+            C = 0; K = 16; xBase = 0; iStride = 1;
         }
         __syncthreads();
-        if (!s_last) return;
-        __threadfence();
-        const u32* kids = reinterpret_cast<const u32*>(level_nodes + ((u64)g * children + (u64)cl * fan) * BRED_VMAX);
-        for (u32 e = tid; e < fan * V * 36; e += BRED_THREADS) {
-            const u32 i = e / (V * 36), w = e - i * (V * 36);
-            lds[i * (V * 36) + w] = __builtin_nontemporal_load(&kids[(u64)i * BRED_VMAX * 36 + w]);
+        bred_tree<F>(lds, 0, xBase, iStride, C, K);
+        if (phase < 3) {
+            bred_gather(lds, 0, xBase, iStride, C, K, vec);
+            u32 lk = 0;
+            while ((1u << lk) < K) lk++;
+            V = C + lk + 1;
+            __syncthreads();
         }
-        __syncthreads();
-        bred_tree<F>(lds, 0, V - 1, V, V - 1, fan);
-        bred_gather(lds, 0, V - 1, V, V - 1, fan, vec);
-        u32 lf = 0;
-        while ((1u << lf) < fan) lf++;
-        V += lf;
-        __syncthreads();
-        children = ncl; idx = cl; level_nodes = nodes2;
-    }
-
-    // ---- final: vec = [A_0 .. A_{m-1}, X]  ->  S = X + sum_j 2^j A_j ----
-    for (u32 e = (m + 1) * 36 + tid; e < 16 * 36; e += BRED_THREADS) vec[e] = 0;      // pad to 16 records with identities
-    __syncthreads();
-    if (quad < m)
-        for (u32 i = 0; i < quad; i++) x29q_double_mem<F>(vec + 36 * quad, vec + 36 * quad);
-    __syncthreads();
-    for (u32 half = 8; half >= 1; half >>= 1) {
-        if (quad < half) x29q_add_mem<F>(vec + 36 * quad, vec + 36 * quad, vec + 36 * (quad + half));
-        __syncthreads();
     }
     if (tid == 0) {
-        const xyzz29 s = x29_load(reinterpret_cast<const xyzz29_rec*>(vec));
+        const xyzz29 s = x29_load(reinterpret_cast<const xyzz29_rec*>(lds));
         if (fin_out || fin_affine) msm_emit<F>(s, fin_out ? fin_out + g : nullptr, fin_affine ? fin_affine + g : nullptr);
         else x29_store(&gsums[g], s);
     }
@@ -313,7 +302,8 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 
 // grid = [heavy | 64-lane groups | 32-lane groups | light] sections of 256-thread blocks; a block whose section's list is shorter than its position
 // leaves at once.  Lists and counters as written by k_msm_merge_classify (c0max = 24: the light class always runs one quad per bucket here -- a
-// quad-cooperative addition spends 16 lane-multiplications where a single lane spends 14).
+// quad-cooperative addition spends 16 lane-multiplications where a single lane spends 14).  One loop serves the four classes (Q = 64 / 16 / 8 / 1 quads
+// per bucket: strided quad sums, then a tree over the Q quads), so that the addition is inlined twice, not five times (instruction cache).
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, const u32* lists, u32 cap) {
     typedef typename f29_of<typename CV::Base>::type F;
@@ -321,55 +311,25 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     const u32 tid = threadIdx.x, quad = tid >> 2, role = tid & 3;
     u32* acc = lds + 36 * (2 * quad);
     u32* inc = acc + 36;
-    u32 blk = blockIdx.x;
-    if (blk < MERGE2_BLOCKS_HEAVY) {      // a block per bucket: 64 strided quad sums, then an LDS tree over the quads
-        const u32 count = counters[3];
-        const u32* list = lists + 3 * (size_t)cap;
-        for (u32 i = blk; i < count; i += MERGE2_BLOCKS_HEAVY) {
-            const u32 b = list[i];
-            const u32 beg = rbeg[b], end = rend[b];
-            q_strided_sum<F>(acc, inc, partial, beg + quad, 64, end, role);
-            __syncthreads();
-            for (u32 d = 32; d >= 1; d >>= 1) {
-                if (quad < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
-                __syncthreads();
-            }
-            if (quad == 0) q_copy_out(&buckets[b], acc, role);
-            __syncthreads();
+    u32 blk = blockIdx.x, cls, nblk, Q;
+    if (blk < MERGE2_BLOCKS_HEAVY) { cls = 3; nblk = MERGE2_BLOCKS_HEAVY; Q = 64; }
+    else if ((blk -= MERGE2_BLOCKS_HEAVY) < MERGE2_BLOCKS_G64) { cls = 2; nblk = MERGE2_BLOCKS_G64; Q = 16; }
+    else if ((blk -= MERGE2_BLOCKS_G64) < MERGE2_BLOCKS_G32) { cls = 1; nblk = MERGE2_BLOCKS_G32; Q = 8; }
+    else { blk -= MERGE2_BLOCKS_G32; cls = 0; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
+    const bool heavy = cls == 3;                             // the only class whose quads span several waves: block barriers (its loop is uniform over the block)
+    const u32 count = counters[cls];
+    const u32* list = lists + cls * (size_t)cap;
+    const u32 per_block = 64 / Q, grp = quad / Q, q = quad % Q;
+    for (u32 i = blk * per_block + grp; i < count; i += nblk * per_block) {
+        const u32 b = list[i];
+        const u32 beg = rbeg[b], end = rend[b];
+        q_strided_sum<F>(acc, inc, partial, beg + q, Q, end, role);
+        if (heavy) __syncthreads();
+        for (u32 d = Q >> 1; d >= 1; d >>= 1) {
+            if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
+            if (heavy) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         }
-        return;
-    }
-    blk -= MERGE2_BLOCKS_HEAVY;
-    if (blk < MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32) {      // a wave (16 quads) or half a wave (8 quads) per bucket: strided quad sums, then a tree inside the wave
-        const bool wide = blk < MERGE2_BLOCKS_G64;
-        if (!wide) blk -= MERGE2_BLOCKS_G64;
-        const u32 nblk = wide ? MERGE2_BLOCKS_G64 : MERGE2_BLOCKS_G32;
-        const u32 Q = wide ? 16u : 8u;                       // quads per bucket
-        const u32 count = counters[wide ? 2 : 1];
-        const u32* list = lists + (wide ? 2 : 1) * (size_t)cap;
-        const u32 groups_per_block = 64 / Q, grp = quad / Q, q = quad % Q;
-        for (u32 i = blk * groups_per_block + grp; i < count; i += nblk * groups_per_block) {
-            const u32 b = list[i];
-            const u32 beg = rbeg[b], end = rend[b];
-            q_strided_sum<F>(acc, inc, partial, beg + q, Q, end, role);
-            for (u32 d = Q >> 1; d >= 1; d >>= 1) {
-                if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (q == 0) q_copy_out(&buckets[b], acc, role);
-            __builtin_amdgcn_wave_barrier();
-        }
-        return;
-    }
-    blk -= MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32;
-    {   // light class: one quad per bucket
-        const u32 count = counters[0];
-        for (u32 i = blk * 64 + quad; i < count; i += MERGE2_BLOCKS_LIGHT * 64) {
-            const u32 b = lists[i];
-            const u32 beg = rbeg[b], end = rend[b];
-            q_strided_sum<F>(acc, inc, partial, beg, 1, end, role);
-            q_copy_out(&buckets[b], acc, role);
-            __builtin_amdgcn_wave_barrier();
-        }
+        if (q == 0) q_copy_out(&buckets[b], acc, role);
+        if (heavy) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     }
 }
