@@ -175,7 +175,7 @@ FP_DEV void bred_gather(const u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C
 template <class CV>
 __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
                                                           jacobian_t* fin_out, affine_t* fin_affine) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;      // lone waves of dependent operations: the latency schedule (tools/ubench_qmem.hip: 2.9 against 3.5 us per addition, 78 VGPRs either way)
     __shared__ __align__(16) u32 lds[(BRED_BLOCK_BUCKETS + 32) * 36];
     __shared__ u32 s_last;
     u32* const vec = lds + BRED_BLOCK_BUCKETS * 36;      // 32 records: the node vector being handed on
@@ -306,7 +306,7 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 // per bucket: strided quad sums, then a tree over the Q quads), so that the addition is inlined twice, not five times (instruction cache).
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, const u32* lists, u32 cap) {
-    typedef typename f29_of<typename CV::Base>::type F;
+    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;
     __shared__ __align__(16) u32 lds[128 * 36];
     const u32 tid = threadIdx.x, quad = tid >> 2, role = tid & 3;
     u32* acc = lds + 36 * (2 * quad);
