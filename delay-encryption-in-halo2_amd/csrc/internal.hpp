@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -254,6 +255,19 @@ inline int dh_d2h(dehalo_ctx* ctx, void* h_dst, const void* d_src, size_t bytes,
     }
     HIP_TRY(ctx, hipEventSynchronize(st.ev[i ^ 1]));
     memcpy((char*)h_dst + prev_off, st.buf[i ^ 1], prev_len);
+    return 0;
+}
+
+// DEHALO_CO_LDS (bytes; experiments with co-resident contexts): every latency-bound kernel that is meant to run in the wave slot a
+// 768-thread accumulation block leaves free asks for at least this much LDS per block in all (its own + unused padding), so that no two such blocks
+// fit one compute unit (> 80 KB of the 160) and the accumulation's next block always finds its three waves per SIMD.  0 = off.
+inline size_t dh_co_lds_pad(size_t own_static, size_t own_dynamic) {
+    static const size_t want = [] { const char* e = getenv("DEHALO_CO_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    if (want <= own_static + own_dynamic) return own_dynamic;
+    return want - own_static;
+}
+inline int dh_co_lds_attr(dehalo_ctx* ctx, const void* fn, size_t dyn) {
+    if (dyn > 48 * 1024) HIP_TRY(ctx, dh_func_lds(ctx, fn, (int)dyn));
     return 0;
 }
 

@@ -1045,7 +1045,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     // resident accumulation of another context (msm_acc_block = 768 leaves one 128-VGPR wave slot per SIMD: 512 threads x 62 VGPRs, 256 x 77)
     static const u32 hist_threads = [] { const char* e = getenv("DEHALO_MSM_HIST_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
     static const u32 part_threads = [] { const char* e = getenv("DEHALO_MSM_PART_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
-    const size_t lds_part = 512 + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS;
+    const size_t lds_part = dh_co_lds_pad(0, 512 + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS);
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_part<FS>, (int)lds_part));
     const u32 tb = (u32)total_buckets;
     {
@@ -1056,7 +1056,9 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_colscan<<<cs_a + cs_b, 256, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc);
         TRY(run_scan(ctx, count, tb, cursor + 4, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend, s));
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
-        k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, 0, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
+        const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
+        TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bucket, lds_bk));
+        k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, lds_bk, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -1077,9 +1079,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         static const bool use_merge2 = [] { const char* e = getenv("DEHALO_MSM_MERGE2"); return !(e && e[0] == '0'); }();
         const u32 c0max = use_merge2 || tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
         k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
-        if (use_merge2)
-            k_msm_merge2<CV><<<MERGE2_BLOCKS_HEAVY + MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32 + MERGE2_BLOCKS_LIGHT, 256, 0, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
-        else {
+        if (use_merge2) {
+            const size_t lds_m = dh_co_lds_pad(18 * 1024, 0);
+            TRY(dh_co_lds_attr(ctx, (const void*)k_msm_merge2<CV>, lds_m));
+            k_msm_merge2<CV><<<MERGE2_BLOCKS_HEAVY + MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32 + MERGE2_BLOCKS_LIGHT, 256, lds_m, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        } else {
             // DEHALO_MSM_MERGE_SPLIT=1 (measurements, tools/merge_split.sh): one launch per class -- block, wave, 32 lanes, light -- so that a kernel trace shows each one's time
             static const bool merge_split = [] { const char* e = getenv("DEHALO_MSM_MERGE_SPLIT"); return e && e[0] == '1'; }();
             for (int only = merge_split ? 3 : -1; only >= -1; only--) {
@@ -1097,7 +1101,9 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         if (use_bred && g.nb >= 8) {
             const u32 nblk = std::max<u32>(1, g.nb / BRED_BLOCK_BUCKETS);
             const bool fin = g.G == 1;
-            k_msm_bred<CV><<<dim3(nblk, (u32)total_groups), BRED_THREADS, 0, s>>>(g.nb, buckets, (xyzz29_rec*)ctx->ws_contrib.p, (xyzz29_rec*)ctx->ws_tree.p, (u32*)ctx->ws_bred_cnt.p, gsums,
+            const size_t lds_b = dh_co_lds_pad(41 * 1024, 0);
+            TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bred<CV>, lds_b));
+            k_msm_bred<CV><<<dim3(nblk, (u32)total_groups), BRED_THREADS, lds_b, s>>>(g.nb, buckets, (xyzz29_rec*)ctx->ws_contrib.p, (xyzz29_rec*)ctx->ws_tree.p, (u32*)ctx->ws_bred_cnt.p, gsums,
                                                                                  fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
             emitted = fin;
             cur = gsums;

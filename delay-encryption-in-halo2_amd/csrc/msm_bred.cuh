@@ -202,17 +202,22 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
             const u32 cl = idx / fan;
             u32* mine = reinterpret_cast<u32*>(level_nodes + ((u64)g * children + idx) * BRED_VMAX);
             for (u32 e = tid; e < V * 36; e += BRED_THREADS) mine[e] = vec[e];
-            __threadfence();
+            // ONE device-scope fence per block on either side (each is a write-back / invalidation of the XCD's whole L2: with one per wave -- 2,560 of them for
+            // ten columns -- the kernel spent more time in them than in its additions).  The block barrier's workgroup-scope release has every wave's stores in
+            // the L2 before thread 0 writes it back; the invalidation by thread 0 serves the whole block (one CU, one L1).
             __syncthreads();
             if (tid == 0) {
+                __threadfence();
                 u32* cnt = counters + (u64)g * BRED_CNT_PER_GROUP + (phase == 1 ? cl : 8);
                 const u32 old = atomicAdd(cnt, 1u);
                 s_last = old == fan - 1;
-                if (s_last) *cnt = 0;                      // (everyone else has counted already: left zero for the next launch)
+                if (s_last) {
+                    *cnt = 0;                              // (everyone else has counted already: left zero for the next launch)
+                    __threadfence();
+                }
             }
             __syncthreads();
             if (!s_last) return;
-            __threadfence();
             const u32* kids = reinterpret_cast<const u32*>(level_nodes + ((u64)g * children + (u64)cl * fan) * BRED_VMAX);
             for (u32 e = tid; e < fan * V * 36; e += BRED_THREADS) {
                 const u32 i = e / (V * 36), w = e - i * (V * 36);

@@ -447,6 +447,10 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         uint64_t tiles = N >> (rad[p] + log_c);
         dim3 grid((uint32_t)tiles, (uint32_t)batch);
         size_t lds = ((size_t)36 << tile_log) + ((size_t)1 << rad[p]) / 2 * sizeof(f29);
+        if (tile_log < NTT_TILE_LOG) {      // half tiles run in 256-thread blocks: the shape that fits beside a resident accumulation (DEHALO_CO_LDS, internal.hpp)
+            lds = dh_co_lds_pad(0, lds);
+            TRY(dh_co_lds_attr(ctx, (const void*)k_ntt_pass<F>, lds));
+        }
         k_ntt_pass<F><<<grid, NTT_THREADS >> (NTT_TILE_LOG - tile_log), lds, s>>>(P);
         HIP_TRY(ctx, hipGetLastError());
         log_m -= rad[p];
