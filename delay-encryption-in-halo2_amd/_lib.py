@@ -23,7 +23,7 @@ SYMBOLS = [
     "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device", "dehalo_permute_expression_pair_ptrs_device", "dehalo_permute_expression_pair_ptrs_deferred_device",
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
     "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device", "dehalo_kate_division_batch_device",
-    "dehalo_params_create", "dehalo_params_read", "dehalo_params_size", "dehalo_params_write", "dehalo_params_release", "dehalo_params_commit_device",
+    "dehalo_params_create", "dehalo_params_setup", "dehalo_bases_register_device", "dehalo_params_read", "dehalo_params_size", "dehalo_params_write", "dehalo_params_release", "dehalo_params_commit_device",
     "dehalo_create_proof_circuit", "dehalo_create_proofs_circuit", "dehalo_keygen", "dehalo_pk_read", "dehalo_pk_size", "dehalo_pk_write", "dehalo_vk_size", "dehalo_vk_write", "dehalo_pk_set_transcript_repr",
     "dehalo_pk_get_transcript_repr", "dehalo_pk_info", "dehalo_pk_release", "dehalo_rng_scalars", "dehalo_field_info", "dehalo_synthesize",
     "dehalo_transcript_create", "dehalo_transcript_common_scalar", "dehalo_transcript_write_scalar", "dehalo_transcript_write_point",
@@ -206,6 +206,8 @@ def load_library():
     lib.dehalo_lookup_h_batch_device.argtypes = [P, C.c_int, C.POINTER(CLookupInputs), u32, u32, u32, u64p, P]
     PP = C.POINTER(P)
     lib.dehalo_params_create.argtypes = [P, C.c_int, u32, u64p, u64p, P, P, PP]
+    lib.dehalo_params_setup.argtypes = [P, C.c_int, u32, u64p, PP]
+    lib.dehalo_bases_register_device.argtypes = [P, C.c_int, u64p, C.c_size_t, C.c_int, C.c_int, PP]
     lib.dehalo_params_read.argtypes = [P, C.c_int, P, sz, PP]
     lib.dehalo_params_size.argtypes = [P]
     lib.dehalo_params_size.restype = sz

@@ -349,7 +349,7 @@ int compile_graph(dehalo_ctx* ctx, dehalo_graph* g, const int32_t* rotations, ui
 }
 
 int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes, int window_bits, int precompute,
-                  dehalo_bases** out) {
+                  dehalo_bases** out, bool on_device = false) {
     if (!affine_xy || !out || n == 0 || stride_bytes < 64 || n >= (1ull << 30)) return dh_fail(ctx, DEHALO_ERR_INVALID, "bases_register: bad argument");
     if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return dh_fail(ctx, DEHALO_ERR_INVALID, "window_bits must be 0 or in [4, 16]");
     uint32_t c = window_bits ? (uint32_t)window_bits : (precompute ? choose_window(n) : choose_window_single(n));
@@ -361,7 +361,7 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     uint32_t W = signed_windows(scalar_modulus_words(curve), c);
     if (precompute && (uint64_t)n * W >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "precomputed table too large");
     // stage the caller's points (standard Montgomery form) on the device, then build the table
-    TRY(dh_ensure(ctx, ctx->ws_tmp_bases, n * sizeof(affine_t)));
+    if (!on_device) TRY(dh_ensure(ctx, ctx->ws_tmp_bases, n * sizeof(affine_t)));
     dehalo_bases* b = new dehalo_bases();
     b->curve = curve; b->n = n; b->c = c; b->W = W; b->precomp = precompute ? 1 : 0; b->table = nullptr;
     size_t rows = precompute ? W : 1;
@@ -371,13 +371,13 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     // (contiguous points: a plain copy -- the 2-D path took 3 of the 4.1 ms of registering 2^20 points)
     int rc = 0;
     std::vector<uint64_t> packed;      // (points with a trailing flag byte: gathered on the host, so that the upload is one contiguous copy)
-    if (stride_bytes != 64) {
+    if (stride_bytes != 64 && !on_device) {
         packed.resize(n * 8);
         for (size_t i = 0; i < n; i++) memcpy(&packed[i * 8], (const char*)affine_xy + i * stride_bytes, 64);
     }
-    rc = dh_h2d(ctx, ctx->ws_tmp_bases.p, stride_bytes == 64 ? (const void*)affine_xy : (const void*)packed.data(), n * 64, ctx->stream);
+    if (!on_device) rc = dh_h2d(ctx, ctx->ws_tmp_bases.p, stride_bytes == 64 ? (const void*)affine_xy : (const void*)packed.data(), n * 64, ctx->stream);
     if (rc != 0) { (void)hipFree(b->table); delete b; return rc; }
-    if (e == hipSuccess) rc = do_build_table(ctx, b, (const affine_t*)ctx->ws_tmp_bases.p, ctx->stream);
+    if (e == hipSuccess) rc = do_build_table(ctx, b, on_device ? (const affine_t*)affine_xy : (const affine_t*)ctx->ws_tmp_bases.p, ctx->stream);
     if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess || rc != 0) {
         (void)hipFree(b->table);
@@ -517,6 +517,14 @@ int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy,
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return register_impl(ctx, curve, affine_xy, n, stride_bytes, window_bits, precompute, out);
+}
+
+int dehalo_bases_register_device(dehalo_ctx* ctx, int curve, const uint64_t* d_affine_xy, size_t n, int window_bits, int precompute, dehalo_bases** out) {
+    if (!ctx) return DEHALO_ERR_INVALID;
+    if (curve < 0 || curve > 2) return dh_fail(ctx, DEHALO_ERR_INVALID, "unknown curve id");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return register_impl(ctx, curve, d_affine_xy, n, 64, window_bits, precompute, out, true);
 }
 
 int dehalo_bases_release(dehalo_ctx* ctx, dehalo_bases* bases) {
@@ -1140,9 +1148,25 @@ int dehalo_graph_evaluate_batch_device(dehalo_ctx* ctx, const dehalo_graph* cons
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((count && (!graphs || !d_outs)) || !in) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate_batch: null argument");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    for (uint32_t i = 0; i < count; i++)
-        TRY(dehalo_graph_evaluate_device(ctx, graphs[i], in, log_rows, rot_scale, nullptr, d_outs[i], stream));
-    return 0;
+    // DEHALO_GRAPH_BATCH=0: one staging + one evaluation launch per program, as before round 4 (A/B measurements)
+    static const bool batched = [] { const char* e = getenv("DEHALO_GRAPH_BATCH"); return !(e && e[0] == '0'); }();
+    bool same_field = count >= 2 && log_rows <= 30;
+    for (uint32_t i = 0; same_field && i < count; i++) {
+        const dehalo_graph* g = graphs[i];
+        same_field = g && d_outs[i] && g->field == graphs[0]->field && in->num_fixed >= g->max_fixed && in->num_advice >= g->max_advice && in->num_instance >= g->max_instance &&
+                     in->num_challenges >= g->max_challenge;
+    }
+    if (same_field && ((in->num_fixed && !in->fixed) || (in->num_advice && !in->advice) || (in->num_instance && !in->instance) || (in->num_challenges && !in->challenges))) same_field = false;
+    if (!batched || !same_field) {      // (the single-program entry point reports what is wrong with an argument)
+        for (uint32_t i = 0; i < count; i++)
+            TRY(dehalo_graph_evaluate_device(ctx, graphs[i], in, log_rows, rot_scale, nullptr, d_outs[i], stream));
+        return 0;
+    }
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = pick_stream(ctx, stream);
+#define CALL(N) graph_evaluate_batch_##N(ctx, graphs, count, in, log_rows, rot_scale, (fe* const*)d_outs, s)
+    FIELD_SWITCH(ctx, graphs[0]->field, CALL)
+#undef CALL
 }
 
 int dehalo_permutation_h_device(dehalo_ctx* ctx, int field, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, uint64_t* d_values,

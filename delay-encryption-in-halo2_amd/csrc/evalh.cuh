@@ -81,7 +81,7 @@ FP_DEV f29 evh_fetch(const EvhArgs& A, const EvhLds& L, const DevSrc& s, u64 row
 }
 
 template <class F>
-__global__ __launch_bounds__(EVH_THREADS) void k_graph_eval(EvhArgs A) {
+FP_DEV void graph_eval_body(const EvhArgs& A) {
     typedef typename f29_of<F>::type F9;
     extern __shared__ u32 evh_lds[];
     EvhLds L{evh_lds};
@@ -111,6 +111,16 @@ __global__ __launch_bounds__(EVH_THREADS) void k_graph_eval(EvhArgs A) {
     }
     f29 res = A.num_calcs ? evh_fetch<F9>(A, L, A.result, row) : f29_zero();
     f_store(&A.out[row], A.vals_internal ? f29_to_packed_canon<F9>(res) : f29_to_std<F9>(res));
+}
+template <class F>
+__global__ __launch_bounds__(EVH_THREADS) void k_graph_eval(EvhArgs A) { graph_eval_body<F>(A); }
+// several programs over the same rows and columns in ONE launch (grid.y = program): the lookups' compressed input / table columns of a proof were a
+// staging kernel + an evaluation kernel EACH, a dozen launches queued behind the side context's NTTs (0.6 ms of the lookups' phase at k = 17 for
+// microseconds of arithmetic).  The argument blocks live in device memory (written by k_evh_stage_batch): a block reads its own with scalar loads.
+template <class F>
+__global__ __launch_bounds__(EVH_THREADS) void k_graph_eval_batch(const EvhArgs* args) {
+    const EvhArgs A = args[blockIdx.y];
+    graph_eval_body<F>(A);
 }
 
 // standard-form scalars -> the internal packed table.  Per-call values (challenges, beta, ...)
@@ -153,6 +163,41 @@ __global__ void k_evh_stage(EvhStage st, fe* table, const void** ptr_table) {
     if (i < 4) f_store(&table[i], f29_to_packed_canon<F9>(f29_from_std<F9>(st.v[i])));
     else if (i < 4 + st.nconst) f_store(&table[i], f_load(&st.constants[i - 4]));
     else f_store(&table[i], f29_to_packed_canon<F9>(f29_from_std<F9>(st.v[4 + (i - 4 - st.nconst)])));
+}
+#define EVH_GRAPH_BATCH 8
+struct EvhStageBatch {
+    fe v[16]; u32 nchal;                                   // beta, gamma, theta, y, challenges (standard form)
+    const void* cols[EVH_ARG_COLS]; u32 ncols;
+    const fe* constants[EVH_GRAPH_BATCH]; u32 nconst[EVH_GRAPH_BATCH];
+    EvhArgs args[EVH_GRAPH_BATCH]; u32 count, tstride;     // program g's scalar table at table + g * tstride
+};
+template <class F>
+__global__ void k_evh_stage_batch(EvhStageBatch st, fe* table, const void** ptr_table, EvhArgs* args_out) {
+    typedef typename f29_of<F>::type F9;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    u32 nconst = 0; const fe* consts = nullptr;
+#pragma unroll
+    for (u32 j = 0; j < EVH_GRAPH_BATCH; j++) if (j == g) { nconst = st.nconst[j]; consts = st.constants[j]; }
+    if (g == 0 && i < st.ncols) {
+        const void* p = nullptr;
+#pragma unroll
+        for (u32 j = 0; j < EVH_ARG_COLS; j++) if (j == i) p = st.cols[j];
+        ptr_table[i] = p;
+    }
+    if (i == 0) {
+#pragma unroll
+        for (u32 j = 0; j < EVH_GRAPH_BATCH; j++) if (j == g) args_out[j] = st.args[j];
+    }
+    const u32 total = 4 + nconst + st.nchal;
+    if (i >= total) return;
+    fe* t = table + (size_t)g * st.tstride;
+    if (i < 4 || i >= 4 + nconst) {
+        fe x{};
+        const u32 k = i < 4 ? i : 4 + (i - 4 - nconst);
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) if (j == k) x = st.v[j];
+        f_store(&t[i], f29_to_packed_canon<F9>(f29_from_std<F9>(x)));
+    } else f_store(&t[i], f_load(&consts[i - 4]));
 }
 struct PtrBatch { const void* p[32]; };
 static __global__ void k_evh_ptrs(PtrBatch b, const void** out, u32 n) {
@@ -455,6 +500,67 @@ int graph_evaluate_t(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_i
     return 0;
 }
 
+// `count` programs over the same inputs, one staging launch + one evaluation launch; falls back to one pair per program when a program spills to HBM,
+// or the inputs do not fit the argument blocks
+template <class F>
+int graph_evaluate_batch_t(dehalo_ctx* ctx, const dehalo_graph* const* graphs, uint32_t count, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,
+                           fe* const* d_outs, hipStream_t s) {
+    const u32 ncol = in->num_fixed + in->num_advice + in->num_instance;
+    bool ok = count >= 2 && in->num_challenges <= 12 && ncol <= EVH_ARG_COLS;
+    u32 max_consts = 0, max_lds = 1;
+    for (u32 i = 0; ok && i < count; i++) {
+        ok = graphs[i] && graphs[i]->hbm_slots == 0;
+        if (ok) { max_consts = std::max(max_consts, graphs[i]->num_constants); max_lds = std::max(max_lds, graphs[i]->lds_slots); }
+    }
+    if (!ok) {
+        for (u32 i = 0; i < count; i++) TRY(graph_evaluate_t<F>(ctx, graphs[i], in, log_rows, rot_scale, nullptr, d_outs[i], s));
+        return 0;
+    }
+    const u64 rows = 1ull << log_rows;
+    ScopedTimer timer(ctx, s, DEHALO_K_EVAL_H);
+    const u32 tstride = 4 + max_consts + in->num_challenges + 4;
+    const uint64_t* four[4] = {in->beta, in->gamma, in->theta, in->y};
+    const size_t lds = (size_t)max_lds * EVH_SLOT_BYTES;
+    if (lds > 48 * 1024) HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_graph_eval_batch<F>, EVH_LDS_BYTES));
+    for (u32 first = 0; first < count; first += EVH_GRAPH_BATCH) {
+        const u32 cnt = std::min<u32>(EVH_GRAPH_BATCH, count - first);
+        // (the tables of consecutive groups must not overlap in time: a group of its own region each)
+        const size_t region = (size_t)(first / EVH_GRAPH_BATCH);
+        TRY(dh_ensure(ctx, ctx->ws_evh[0], (region + 1) * EVH_GRAPH_BATCH * (size_t)tstride * sizeof(fe)));
+        TRY(dh_ensure(ctx, ctx->ws_evh[2], (ncol + 1) * sizeof(void*) + (region + 1) * EVH_GRAPH_BATCH * sizeof(EvhArgs) + 64));
+    }
+    for (u32 first = 0; first < count; first += EVH_GRAPH_BATCH) {
+        const u32 cnt = std::min<u32>(EVH_GRAPH_BATCH, count - first);
+        const size_t region = (size_t)(first / EVH_GRAPH_BATCH);
+        fe* table = (fe*)ctx->ws_evh[0].p + region * EVH_GRAPH_BATCH * (size_t)tstride;
+        const void** ptrs = (const void**)ctx->ws_evh[2].p;
+        EvhArgs* dargs = reinterpret_cast<EvhArgs*>(((uintptr_t)((char*)ctx->ws_evh[2].p + (ncol + 1) * sizeof(void*)) + 63) & ~(uintptr_t)63) + region * EVH_GRAPH_BATCH;
+        EvhStageBatch st{};
+        for (int i = 0; i < 4; i++) st.v[i] = four[i] ? fe_from_u64(four[i]) : fe{};
+        for (u32 i = 0; i < in->num_challenges; i++) st.v[4 + i] = fe_from_u64(in->challenges + 4 * (size_t)i);
+        st.nchal = in->num_challenges; st.ncols = ncol; st.count = cnt; st.tstride = tstride;
+        for (u32 i = 0; i < in->num_fixed; i++) st.cols[i] = in->fixed[i];
+        for (u32 i = 0; i < in->num_advice; i++) st.cols[in->num_fixed + i] = in->advice[i];
+        for (u32 i = 0; i < in->num_instance; i++) st.cols[in->num_fixed + in->num_advice + i] = in->instance[i];
+        for (u32 j = 0; j < cnt; j++) {
+            const dehalo_graph* g = graphs[first + j];
+            st.constants[j] = g->d_constants; st.nconst[j] = g->num_constants;
+            EvhArgs& A = st.args[j];
+            A.columns = (const fe* const*)ptrs;
+            A.calcs = g->d_calcs; A.parts = g->d_parts; A.scalars = table + (size_t)j * tstride;
+            A.num_calcs = g->num_calcs; A.fixed_base = 0; A.advice_base = in->num_fixed; A.instance_base = in->num_fixed + in->num_advice;
+            A.rows_mask = (u32)(rows - 1); A.rot_scale = rot_scale;
+            A.previous = nullptr; A.out = d_outs[first + j]; A.spill = nullptr; A.rows = rows; A.result = g->result;
+            A.cols_internal = in->form_flags & DEHALO_EVAL_COLUMNS_INTERNAL; A.vals_internal = in->form_flags & DEHALO_EVAL_VALUES_INTERNAL;
+        }
+        const u32 work = std::max<u32>(tstride, ncol);
+        k_evh_stage_batch<F><<<dim3((work + 63) / 64, cnt), 64, 0, s>>>(st, table, ptrs, dargs);
+        k_graph_eval_batch<F><<<dim3((u32)((rows + EVH_THREADS - 1) / EVH_THREADS), cnt), EVH_THREADS, lds, s>>>(dargs);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 template <class F>
 int perm_h_t(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* d_values, hipStream_t s) {
     if (log_rows > (uint32_t)F::TWO_ADICITY) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "permutation_h: log_rows exceeds the field's two-adicity");
@@ -566,6 +672,8 @@ int product_terms_t(dehalo_ctx* ctx, const dehalo_product_inputs* in, uint64_t n
     int graph_upload_##NAME(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, hipStream_t s) { return graph_upload_t<F>(ctx, g, constants, s); } \
     int graph_evaluate_##NAME(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale,      \
                               const fe* prev, fe* out, hipStream_t s) { return graph_evaluate_t<F>(ctx, g, in, log_rows, rot_scale, prev, out, s); } \
+    int graph_evaluate_batch_##NAME(dehalo_ctx* ctx, const dehalo_graph* const* graphs, uint32_t count, const dehalo_eval_inputs* in, uint32_t log_rows,     \
+                                    uint32_t rot_scale, fe* const* outs, hipStream_t s) { return graph_evaluate_batch_t<F>(ctx, graphs, count, in, log_rows, rot_scale, outs, s); } \
     int perm_h_##NAME(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {             \
         return perm_h_t<F>(ctx, in, log_rows, rot_scale, v, s); }                                                                                \
     int lookup_h_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s) {         \

@@ -325,6 +325,8 @@ DECL_MSM(bn254)
 DECL_MSM(pallas)
 DECL_MSM(vesta)
 #undef DECL_MSM
+// ParamsKZG::setup's device half (setup.cuh, instantiated in msm_bn254.hip): g[i] = [s^i] G, g_lagrange[i] = [L_i(s)] G into device memory
+int kzg_setup_bn254(dehalo_ctx* ctx, uint32_t k, const uint64_t s[4], const uint64_t omega[4], const uint64_t cfac[4], affine_t* d_g, affine_t* d_gl, hipStream_t st);
 
 #define DECL_NTT(NAME)                                                                                                                       \
     int run_ntt_##NAME(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_stride, fe* dst, uint64_t dst_stride, uint32_t log_n, \
@@ -367,6 +369,8 @@ struct dehalo_graph;
     int graph_upload_##NAME(dehalo_ctx* ctx, dehalo_graph* g, const uint64_t* constants, hipStream_t s);                                   \
     int graph_evaluate_##NAME(dehalo_ctx* ctx, const dehalo_graph* g, const dehalo_eval_inputs* in, uint32_t log_rows, uint32_t rot_scale, \
                               const fe* prev, fe* out, hipStream_t s);                                                                     \
+    int graph_evaluate_batch_##NAME(dehalo_ctx* ctx, const dehalo_graph* const* graphs, uint32_t count, const dehalo_eval_inputs* in, uint32_t log_rows, \
+                                    uint32_t rot_scale, fe* const* outs, hipStream_t s);                                                   \
     int perm_h_##NAME(dehalo_ctx* ctx, const dehalo_perm_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s);         \
     int lookup_h_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s);    \
     int lookup_h_batch_##NAME(dehalo_ctx* ctx, const dehalo_lookup_inputs* in, uint32_t count, uint32_t log_rows, uint32_t rot_scale, fe* v, hipStream_t s); \

@@ -135,6 +135,107 @@ extern "C" int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, cons
     return 0;
 } catch (...) { return DEHALO_ERR_OOM; }
 
+// ---- ParamsKZG::setup: the two G2 points on the host (O(1): one 254-bit scalar multiplication over Fq2 = Fq[i] / (i^2 + 1)) -------------------
+namespace {
+struct Fq2 { Fe a, b; };
+struct G2Host {
+    const HostField* q;
+    explicit G2Host(const HostField* f) : q(f) {}
+    Fq2 add(const Fq2& x, const Fq2& y) const { return {q->add(x.a, y.a), q->add(x.b, y.b)}; }
+    Fq2 sub(const Fq2& x, const Fq2& y) const { return {q->sub(x.a, y.a), q->sub(x.b, y.b)}; }
+    Fq2 mul(const Fq2& x, const Fq2& y) const { return {q->sub(q->mul(x.a, y.a), q->mul(x.b, y.b)), q->add(q->mul(x.a, y.b), q->mul(x.b, y.a))}; }
+    Fq2 inv(const Fq2& x) const {
+        const Fe d = q->invert(q->add(q->sqr(x.a), q->sqr(x.b)));
+        return {q->mul(x.a, d), q->neg(q->mul(x.b, d))};
+    }
+    bool is_zero(const Fq2& x) const { return x.a.is_zero() && x.b.is_zero(); }
+    struct Pt { Fq2 x, y; bool inf; };
+    Pt padd(const Pt& P, const Pt& Q) const {      // affine chord-and-tangent (a = 0): 381 inversions for one scalar multiplication are nothing here
+        if (P.inf) return Q;
+        if (Q.inf) return P;
+        Fq2 lam;
+        if (is_zero(sub(P.x, Q.x))) {
+            if (is_zero(add(P.y, Q.y))) return Pt{{}, {}, true};
+            const Fq2 xx = mul(P.x, P.x);
+            lam = mul(add(add(xx, xx), xx), inv(add(P.y, P.y)));
+        } else lam = mul(sub(Q.y, P.y), inv(sub(Q.x, P.x)));
+        Pt R;
+        R.inf = false;
+        R.x = sub(sub(mul(lam, lam), P.x), Q.x);
+        R.y = sub(mul(lam, sub(P.x, R.x)), P.y);
+        return R;
+    }
+    Pt scalar_mul(const uint64_t k_canonical[4], Pt P) const {
+        Pt acc{{}, {}, true};
+        for (int i = 0; i < 256; i++) {
+            if ((k_canonical[i >> 6] >> (i & 63)) & 1) acc = padd(acc, P);
+            P = padd(P, P);
+        }
+        return acc;
+    }
+    void to_raw(const Pt& P, uint8_t out[128]) const {      // G2Affine RawBytes: x.c0 | x.c1 | y.c0 | y.c1, Montgomery limbs; all zero = identity
+        memset(out, 0, 128);
+        if (P.inf) return;
+        memcpy(out, P.x.a.v, 32); memcpy(out + 32, P.x.b.v, 32); memcpy(out + 64, P.y.a.v, 32); memcpy(out + 96, P.y.b.v, 32);
+    }
+};
+// the generator of BN254's G2 (halo2curves bn256::G2Affine::generator(); canonical limbs)
+const uint64_t BN254_G2_GEN[4][4] = {{0x46debd5cd992f6edull, 0x674322d4f75edaddull, 0x426a00665e5c4479ull, 0x1800deef121f1e76ull},
+                                     {0x97e485b7aef312c2ull, 0xf1aa493335a9e712ull, 0x7260bfb731fb5d25ull, 0x198e9393920d483aull},
+                                     {0x4ce6cc0166fa7daaull, 0xe3d1e7690c43d37bull, 0x4aab71808dcb408full, 0x12c85ea5db8c6debull},
+                                     {0x55acdadcd122975bull, 0xbc4b313370b38ef3ull, 0xec9e99ad690c3395ull, 0x090689d0585ff075ull}};
+}   // namespace
+
+extern "C" int dehalo_params_setup(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t s[4], dehalo_params** out) try {
+    if (!ctx || !out || !s) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: null argument");
+    if (curve != DEHALO_CURVE_BN254_G1) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "params_setup: ParamsKZG needs a pairing: BN254 only");
+    const HostField* f = host_field(curve_scalar_field(curve));
+    if (k > f->two_adicity || k > 26) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: k out of range");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    Fe sm;
+    memcpy(sm.v, s, 32);
+    const size_t n = (size_t)1 << k;
+    // omega = ROOT_OF_UNITY^(2^(S - k));  (s^n - 1) / n
+    Fe omega = f->root_of_unity;
+    for (uint32_t i = k; i < f->two_adicity; i++) omega = f->sqr(omega);
+    Fe sn = sm;
+    for (uint32_t i = 0; i < k; i++) sn = f->sqr(sn);
+    const Fe cfac = f->mul(f->sub(sn, f->one), f->invert(f->from_u64((uint64_t)n)));
+    std::unique_ptr<dehalo_params> p(new dehalo_params);
+    p->ctx = ctx; p->curve = curve; p->k = k; p->n = n;
+    DevMem dg, dgl;
+    TRY(dg.alloc(ctx, 2 * n, false));
+    TRY(dgl.alloc(ctx, 2 * n, false));
+    TRY(kzg_setup_bn254(ctx, k, sm.v, omega.v, cfac.v, (affine_t*)dg.p, (affine_t*)dgl.p, ctx->stream));
+    TRY(dehalo_bases_register_device(ctx, curve, dg.u64(), n, 0, 1, &p->bases_g));
+    int rc = dehalo_bases_register_device(ctx, curve, dgl.u64(), n, 0, 1, &p->bases_gl);
+    if (rc == 0) {
+        p->g.resize(8 * n); p->g_lagrange.resize(8 * n);
+        rc = dehalo_download(ctx, dg.p, 64 * n, p->g.data());
+        if (rc == 0) rc = dehalo_download(ctx, dgl.p, 64 * n, p->g_lagrange.data());
+    }
+    if (rc) {
+        (void)dehalo_bases_release(ctx, p->bases_g);
+        if (p->bases_gl) (void)dehalo_bases_release(ctx, p->bases_gl);
+        return rc;
+    }
+    {   // g2 = the generator, s_g2 = [s] g2
+        const HostField* q = host_field(curve_base_field(curve));
+        G2Host g2(q);
+        G2Host::Pt G;
+        G.inf = false;
+        Fe c[4];
+        for (int i = 0; i < 4; i++) { memcpy(c[i].v, BN254_G2_GEN[i], 32); c[i] = q->from_canonical(c[i]); }
+        G.x = {c[0], c[1]}; G.y = {c[2], c[3]};
+        const Fe sc = f->to_canonical(sm);
+        g2.to_raw(G, p->g2);
+        g2.to_raw(g2.scalar_mul(sc.v, G), p->s_g2);
+    }
+    *out = p.release();
+    return 0;
+} catch (...) { return DEHALO_ERR_OOM; }
+
 extern "C" int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out) try {
     if (!ctx || !bytes || !out) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: null argument");
     if (len < 4) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_read: unexpected end of input");

@@ -116,6 +116,18 @@ class ParamsKZG:
         return cls(ctx, curve, h)
 
     @classmethod
+    def setup(cls, ctx: Context, curve: CurveSpec, k: int, s: Optional[int] = None) -> "ParamsKZG":
+        """ParamsKZG::setup(k, rng) (benches/delay_enc.rs:43): the SRS for the secret `s` (a field element; None = drawn from OS entropy, as the reference's OsRng
+        does), generated on the device -- dehalo_params_setup."""
+        if s is None:
+            import secrets
+            s = secrets.randbelow(curve.scalar.p - 2) + 2
+        h = C.c_void_p()
+        sm = curve.scalar.encode(s % curve.scalar.p)
+        _check(ctx, load_library().dehalo_params_setup(ctx.handle, curve.id, k, sm.ctypes.data, C.byref(h)))
+        return cls(ctx, curve, h)
+
+    @classmethod
     def read(cls, ctx: Context, curve: CurveSpec, data: bytes) -> "ParamsKZG":
         h = C.c_void_p()
         buf = np.frombuffer(data, dtype=np.uint8)

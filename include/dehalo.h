@@ -116,6 +116,9 @@ int dehalo_upload(dehalo_ctx* ctx, const void* host_src, size_t bytes, void* d_d
  */
 int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes,
                           int window_bits, int precompute, dehalo_bases** out);
+/* The same for points that are in device memory already (n x {x, y}, 64 bytes apart, standard Montgomery form): an SRS generated on the device
+ * (dehalo_params_setup) or left there by the caller.  The points are read before the call returns. */
+int dehalo_bases_register_device(dehalo_ctx* ctx, int curve, const uint64_t* d_affine_xy, size_t n, int window_bits, int precompute, dehalo_bases** out);
 int dehalo_bases_release(dehalo_ctx* ctx, dehalo_bases* bases);
 size_t dehalo_bases_len(const dehalo_bases* bases);
 /* The Pippenger window c chosen for these bases, the number of windows ceil(256 / c) and whether their multiples are stored. */
@@ -400,6 +403,10 @@ typedef struct dehalo_transcript dehalo_transcript; /* Blake2bWrite<Vec<u8>, C, 
  * k: u32 LE | g | g_lagrange | g2 | s_g2  (what benches/delay_enc.rs:45,54 write and read). */
 int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, const uint8_t* g2, const uint8_t* s_g2,
                          dehalo_params** out);
+/* ParamsKZG::setup(k, rng) with the rng's draw handed over: `s` is the toxic waste as a Montgomery scalar (what `<E::Scalar>::random(rng)` returns).  g[i] = [s^i] G
+ * and g_lagrange[i] = [L_i(s)] G are made on the device (fixed-base table multiplication, one batch inversion), g2 / s_g2 on the host: the reference's
+ * `ParamsKZG::<Bn256>::setup(K, OsRng)` (benches/delay_enc.rs:43).  BN254 only (a KZG SRS needs the pairing). */
+int dehalo_params_setup(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t s[4], dehalo_params** out);
 int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out);
 size_t dehalo_params_size(const dehalo_params* params);
 int dehalo_params_write(const dehalo_params* params, uint8_t* out, size_t cap);

@@ -475,3 +475,52 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
     for cx in ctxs:
         cx.close()
     P.release(); pk.release(); params.release(); side.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [6, 11, 17])
+def test_params_setup_on_the_device_equals_the_cpu_restatement(pkg, po, ctx, k):
+    """ParamsKZG::setup (benches/delay_enc.rs:43) through dehalo_params_setup: g[i] = [s^i] G and g_lagrange[i] = [L_i(s)] G by fixed-base table multiplication
+    on the device, g2 / s_g2 on the host.  The RawBytes serialisation must equal, byte for byte, the one assembled from oracle/plonk_oracle.setup_srs and
+    oracle/pairing.py (the generator of G2 and [s] G2) for the same s; and a commitment made with the device-made tables equals the CPU's."""
+    import time
+    import pairing as pr
+    import plonk_oracle as PO
+    from dehalo2_amd import native
+
+    curve = pkg.fields.BN254
+    s = 0x64656C6179656E63 * 0x9E3779B97F4A7C15 % curve.scalar.p
+    t0 = time.perf_counter()
+    params = native.ParamsKZG.setup(ctx, curve, k, s)
+    dt = time.perf_counter() - t0
+    got = params.write()
+    srs = PO.setup_srs(po.BN254, k, s, 8)
+    want = (k.to_bytes(4, "little") + np.ascontiguousarray(srs["g"]).tobytes() + np.ascontiguousarray(srs["g_lagrange"]).tobytes() +
+            pr.g2_to_raw(pr.G2) + pr.g2_to_raw(pr.g2_mul(s, pr.G2)))
+    assert len(got) == len(want) == 4 + 128 * (1 << k) + 256
+    assert got[:4] == want[:4]
+    n = 1 << k
+    assert got[4:4 + 64 * n] == want[4:4 + 64 * n], "g differs"
+    assert got[4 + 64 * n:4 + 128 * n] == want[4 + 64 * n:4 + 128 * n], "g_lagrange differs"
+    assert got[4 + 128 * n:] == want[4 + 128 * n:], "g2 / s_g2 differ"
+    print("dehalo_params_setup k = %d: %.1f ms" % (k, 1e3 * dt))
+    params.release()
+
+
+@pytest.mark.gpu
+def test_params_setup_k20_is_fast(pkg, ctx):
+    """The largest north-star size: 2 x 2^20 fixed-base multiplications, the tables of both vectors and the download of the points for write()."""
+    import time
+    from dehalo2_amd import native
+
+    curve = pkg.fields.BN254
+    native.ParamsKZG.setup(ctx, curve, 10, 12345).release()          # (first use: code objects, workspace)
+    t0 = time.perf_counter()
+    params = native.ParamsKZG.setup(ctx, curve, 20, 0x1234567890ABCDEF)
+    dt = time.perf_counter() - t0
+    print("dehalo_params_setup k = 20: %.1f ms" % (1e3 * dt))
+    assert len(params.write()) == 4 + 128 * (1 << 20) + 256
+    params.release()
+    assert dt < 0.5
+    with pytest.raises(Exception):
+        native.ParamsKZG.setup(ctx, pkg.fields.CURVES["pallas"], 6, 3)      # no pairing: not a KZG curve
