@@ -1282,7 +1282,9 @@ int dehalo_msm_last_shape(dehalo_ctx* ctx, uint32_t out[6]) {
     memset(out, 0, 6 * sizeof(uint32_t));
     if (!ctx->ws_counters.p) return 0;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->ws_counters.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t raw[10];      // eight merge-class counters (light: 2 | 3-4 | 5-8 | 9-16 | 17-24 records; 8 quads; 16 quads; a block), L0, M
+    HIP_TRY(ctx, hipMemcpy(raw, ctx->ws_counters.p, sizeof(raw), hipMemcpyDeviceToHost));
+    out[0] = raw[0] + raw[1] + raw[2] + raw[3] + raw[4]; out[1] = raw[5]; out[2] = raw[6]; out[3] = raw[7]; out[4] = raw[8]; out[5] = raw[9];
     return 0;
 }
 

@@ -49,6 +49,7 @@
 #else
 #define MSM_HIST_ATTR
 #endif
+#define MSM_MERGE_COUNTERS 8   // merge-class counters in ws_counters, in front of [L0 | M]
 #define MSM_RED_M 4        // buckets per lane in the bucket reduction
 #ifndef MSM_RED_THREADS
 #define MSM_RED_THREADS 256   // one wave per SIMD per block: with 128-thread blocks the second block on a CU shared SIMDs with the first (3-4 columns at c = 15: 134 -> 86 us)
@@ -268,7 +269,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_item
         if (threadIdx.x == SCAN_THREADS - 1) { carry_i += s_i[threadIdx.x]; carry_t += s_t[threadIdx.x]; }
         __syncthreads();
     }
-    if (threadIdx.x < 4) geo[(int)threadIdx.x - 4] = 0;     // the four merge-class counters sit just below geo (ws_counters): zeroed here, no fill launch
+    if (threadIdx.x < MSM_MERGE_COUNTERS) geo[(int)threadIdx.x - MSM_MERGE_COUNTERS] = 0;     // the merge-class counters sit just below geo (ws_counters): zeroed here, no fill launch
     if (threadIdx.x == 0) {
         const u64 M = carry_i;
         u64 L;
@@ -998,7 +999,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const size_t REC = sizeof(xyzz29_rec);
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
-    TRY(dh_ensure(ctx, ctx->ws_counters, 32));                                   // 4 merge-class counters | L0 | M
+    TRY(dh_ensure(ctx, ctx->ws_counters, 64));                                   // 8 merge-class counters | L0 | M
     TRY(dh_ensure(ctx, ctx->ws_bhist, total_buckets * (size_t)g.slices * 4));   // per-block histograms
     const u32 sub_bits = g.c - 1 < 8 ? g.c - 1 : 8, P = g.nb >> sub_bits;
     TRY(dh_ensure(ctx, ctx->ws_pcount, total_groups * (size_t)g.slices * P * 4));   // per-(slice, partition) counts
@@ -1006,7 +1007,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
     TRY(dh_ensure(ctx, ctx->ws_records, (total_buckets + 1) * 4 * 3));           // nrank | rbeg | rend
     const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / 2 + 1);
-    TRY(dh_ensure(ctx, ctx->ws_merge_lists, (size_t)merge_cap * 4 * 4));   // merge-class lists
+    TRY(dh_ensure(ctx, ctx->ws_merge_lists, (size_t)merge_cap * MSM_MERGE_COUNTERS * 4));   // merge-class lists
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
@@ -1054,7 +1055,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_hist<FS><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
         const u32 cs_a = (tb + 255) / 256, cs_b = ((u32)total_groups * P + 255) / 256;
         k_msm_colscan<<<cs_a + cs_b, 256, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc);
-        TRY(run_scan(ctx, count, tb, cursor + 4, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend, s));
+        TRY(run_scan(ctx, count, tb, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend, s));
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
         TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bucket, lds_bk));
@@ -1067,7 +1068,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // DEHALO_MSM_ACC_LDS (bytes of dynamic LDS per block, unused by the kernel): caps the accumulation's resident blocks per CU so that
         // wave slots and registers stay free for the kernels of other contexts (tuning experiments; results never depend on it)
         static const unsigned acc_lds = [] { const char* e = getenv("DEHALO_MSM_ACC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-        k_msm_accum0<CV><<<blocks, acc_block, acc_lds, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + 4);
+        k_msm_accum0<CV><<<blocks, acc_block, acc_lds, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + MSM_MERGE_COUNTERS);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -1078,7 +1079,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // DEHALO_MSM_MERGE2=0: the round-3 merge kernel (operands in registers, 172 VGPRs) instead of k_msm_merge2 (operands in LDS, < 128 VGPRs, quads throughout)
         static const bool use_merge2 = [] { const char* e = getenv("DEHALO_MSM_MERGE2"); return !(e && e[0] == '0'); }();
         const u32 c0max = use_merge2 || tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
-        k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
+        if (use_merge2) k_msm_merge_classify2<<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
+        else k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
         if (use_merge2) {
             const size_t lds_m = dh_co_lds_pad(18 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_merge2<CV>, lds_m));

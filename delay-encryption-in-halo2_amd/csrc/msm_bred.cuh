@@ -304,11 +304,43 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 #define MERGE2_BLOCKS_G32 512
 #define MERGE2_BLOCKS_G64 512
 #define MERGE2_BLOCKS_HEAVY 256
+#define MERGE2_LIGHT_CLASSES 5      // 2 | 3-4 | 5-8 | 9-16 | 17-24 partial sums
 
-// grid = [heavy | 64-lane groups | 32-lane groups | light] sections of 256-thread blocks; a block whose section's list is shorter than its position
-// leaves at once.  Lists and counters as written by k_msm_merge_classify (c0max = 24: the light class always runs one quad per bucket here -- a
-// quad-cooperative addition spends 16 lane-multiplications where a single lane spends 14).  One loop serves the four classes (Q = 64 / 16 / 8 / 1 quads
-// per bucket: strided quad sums, then a tree over the Q quads), so that the addition is inlined twice, not five times (instruction cache).
+// classification for k_msm_merge2: one lane per bucket; S = 0 -> identity, S = 1 -> copy, otherwise the bucket is queued in the list of its class
+// (one atomic per wave and class).  EIGHT classes: the light ones -- a quad walks the bucket's records one after the other -- are split by length, because
+// a wave of 16 quads runs as long as its longest bucket: with one light class of 2 .. 24 records the waves of a witness commitment (most buckets 2-4
+// records, some 20) waited 80 % of their time (merge 0.18 ms for 0.24 M additions that fill the chip for 0.04).  Classes 5 / 6 / 7: 8 quads, 16 quads, a block.
+FP_DEV u32 merge2_class(u32 S) { return S <= 2 ? 0u : S <= 4 ? 1u : S <= 8 ? 2u : S <= 16 ? 3u : S <= 24 ? 4u : S <= 128 ? 5u : S <= 512 ? 6u : 7u; }
+static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_buckets, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
+                                                                   u32* counters, u32* lists, u32 cap) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = b < total_buckets;
+    const u32 beg = in ? rbeg[b] : 0, end = in ? rend[b] : 0;
+    const u32 S = end - beg;
+    const u32 cls = !in || S <= 1 ? 8u : merge2_class(S);
+    const u32 lane = threadIdx.x & 63;
+    for (u32 c = 0; c < 8; c++) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (mask == 0) continue;
+        const u32 leader = (u32)__ffsll((long long)mask) - 1;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
+        base = __shfl(base, (int)leader);
+        if (cls == c) lists[(size_t)c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
+    }
+    if (!in || cls != 8u) return;
+    xyzz29_rec rec;
+    if (S == 1) rec = partial[beg];
+    else {
+#pragma unroll
+        for (int i = 0; i < 36; i++) rec.w[i] = 0;
+    }
+    buckets[b] = rec;
+}
+
+// grid = [heavy | 16-quad groups | 8-quad groups | light] sections of 256-thread blocks; a block whose section's list is shorter than its position
+// leaves at once.  One loop serves all classes (Q = 64 / 16 / 8 / 1 quads per bucket: strided quad sums, then a tree over the Q quads), so that the
+// addition is inlined twice, not five times (instruction cache); the light section walks its five lists longest buckets first.
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, const u32* lists, u32 cap) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;
@@ -317,24 +349,26 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     u32* acc = lds + 36 * (2 * quad);
     u32* inc = acc + 36;
     u32 blk = blockIdx.x, cls, nblk, Q;
-    if (blk < MERGE2_BLOCKS_HEAVY) { cls = 3; nblk = MERGE2_BLOCKS_HEAVY; Q = 64; }
-    else if ((blk -= MERGE2_BLOCKS_HEAVY) < MERGE2_BLOCKS_G64) { cls = 2; nblk = MERGE2_BLOCKS_G64; Q = 16; }
-    else if ((blk -= MERGE2_BLOCKS_G64) < MERGE2_BLOCKS_G32) { cls = 1; nblk = MERGE2_BLOCKS_G32; Q = 8; }
-    else { blk -= MERGE2_BLOCKS_G32; cls = 0; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
-    const bool heavy = cls == 3;                             // the only class whose quads span several waves: block barriers (its loop is uniform over the block)
-    const u32 count = counters[cls];
-    const u32* list = lists + cls * (size_t)cap;
+    if (blk < MERGE2_BLOCKS_HEAVY) { cls = 7; nblk = MERGE2_BLOCKS_HEAVY; Q = 64; }
+    else if ((blk -= MERGE2_BLOCKS_HEAVY) < MERGE2_BLOCKS_G64) { cls = 6; nblk = MERGE2_BLOCKS_G64; Q = 16; }
+    else if ((blk -= MERGE2_BLOCKS_G64) < MERGE2_BLOCKS_G32) { cls = 5; nblk = MERGE2_BLOCKS_G32; Q = 8; }
+    else { blk -= MERGE2_BLOCKS_G32; cls = MERGE2_LIGHT_CLASSES - 1; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
+    const bool heavy = cls == 7;                             // the only class whose quads span several waves: block barriers (its loop is uniform over the block)
     const u32 per_block = 64 / Q, grp = quad / Q, q = quad % Q;
-    for (u32 i = blk * per_block + grp; i < count; i += nblk * per_block) {
-        const u32 b = list[i];
-        const u32 beg = rbeg[b], end = rend[b];
-        q_strided_sum<F>(acc, inc, partial, beg + q, Q, end, role);
-        if (heavy) __syncthreads();
-        for (u32 d = Q >> 1; d >= 1; d >>= 1) {
-            if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
+    for (u32 pass = 0; pass < (Q == 1 ? (u32)MERGE2_LIGHT_CLASSES : 1u); pass++, cls--) {
+        const u32 count = counters[cls];
+        const u32* list = lists + cls * (size_t)cap;
+        for (u32 i = blk * per_block + grp; i < count; i += nblk * per_block) {
+            const u32 b = list[i];
+            const u32 beg = rbeg[b], end = rend[b];
+            q_strided_sum<F>(acc, inc, partial, beg + q, Q, end, role);
+            if (heavy) __syncthreads();
+            for (u32 d = Q >> 1; d >= 1; d >>= 1) {
+                if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
+                if (heavy) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            }
+            if (q == 0) q_copy_out(&buckets[b], acc, role);
             if (heavy) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         }
-        if (q == 0) q_copy_out(&buckets[b], acc, role);
-        if (heavy) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     }
 }
