@@ -226,12 +226,11 @@ class ProofSetup:
         t0 = time.time()
         self.circ, self.witness = real_witness(self.curve.scalar.p, k, circuit)
         tw = time.time()
-        self.srs = PO.setup_srs(self.ocurve, k, self.s, threads)
-        t1 = time.time()
-        raw = (k.to_bytes(4, "little") + np.ascontiguousarray(self.srs["g"]).tobytes() + np.ascontiguousarray(self.srs["g_lagrange"]).tobytes() +
-               pr.g2_to_raw(pr.G2) + pr.g2_to_raw(pr.g2_mul(self.s, pr.G2)))
-        self.params = native.ParamsKZG.read(ctx, self.curve, raw)
-        t2 = time.time()
+        # ParamsKZG::setup (benches/delay_enc.rs:43) on the device: dehalo_params_setup.  The CPU restatement builds ITS OWN SRS from the same secret when a
+        # CPU leg asks for it (`srs` below), and the two are compared there: the product takes nothing from oracle/.
+        self.params = native.ParamsKZG.setup(ctx, self.curve, k, self.s)
+        t1 = t2 = time.time()
+        self._threads, self._srs = threads, None
         self.pk = native.ProvingKey.keygen(ctx, self.params, self.circ.cs, self.circ.fixed, self.circ.assembly, self.circ.selectors)
         ctx.synchronize()
         t3 = time.time()
@@ -245,8 +244,20 @@ class ProofSetup:
             self.advice = keygen.to_device(self.circ.advice)          # the witness, resident in HBM (Montgomery form)
             ctx.field_op_device(self.curve.scalar.id, "to_mont", self.advice.data_ptr(), 0, self.advice.data_ptr(), self.advice.numel() // 4, 0)
         ctx.synchronize()
-        self.setup_s = {"witness_python": round(tw - t0, 2), "srs_cpu": round(t1 - tw, 2), "params_read_and_tables": round(t2 - t1, 2), "keygen_gpu": round(t3 - t2, 3)}
+        self.setup_s = {"witness_python": round(tw - t0, 2), "params_setup_gpu": round(t1 - tw, 3), "keygen_gpu": round(t3 - t2, 3)}
         self.witness_ms = round(1e3 * (tw - t0), 1)
+
+    @property
+    def srs(self):
+        """the CPU restatement's SRS for the same secret (checker legs only), asserted equal to the device-made one"""
+        if self._srs is None:
+            import numpy as np
+            import plonk_oracle as PO
+            self._srs = PO.setup_srs(self.ocurve, self.k, self.s, self._threads)
+            raw, n = self.params.write(), 1 << self.k
+            assert raw[4:4 + 64 * n] == np.ascontiguousarray(self._srs["g"]).tobytes() and raw[4 + 64 * n:4 + 128 * n] == np.ascontiguousarray(self._srs["g_lagrange"]).tobytes(), \
+                "dehalo_params_setup's SRS differs from the CPU restatement's"
+        return self._srs
 
     def prove(self, seed, which=None):
         from dehalo2_amd import prover

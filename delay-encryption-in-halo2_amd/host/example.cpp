@@ -1,8 +1,9 @@
-// example.cpp -- the reference's bench flow (benches/pose_enc.rs:41-135: read params, keygen_vk / keygen_pk, write and re-read the
-// proving key, create_proof into a Blake2bWrite transcript) from C++ over the C ABI, with no interpreter anywhere.
+// example.cpp -- the reference's bench flow (benches/pose_enc.rs:41-135: ParamsKZG::setup when no params file is cached, else read it; keygen_vk /
+// keygen_pk, write and re-read the proving key, create_proof into a Blake2bWrite transcript) from C++ over the C ABI, with no interpreter anywhere.
 //
 //   example                 build / link check: one tiny best_fft (needs a GPU to run)
-//   example <dir>           <dir>/params.bin   ParamsKZG RawBytes
+//   example <dir>           <dir>/params.bin   ParamsKZG RawBytes; when it does not exist it is MADE (ParamsKZG::setup on the device) from
+//                                              <dir>/secret.bin (32 B: the scalar the reference would draw from OsRng, Montgomery form) and written
 //                           <dir>/circuit.bin  u32 k | fixed columns (9 x 2^k x 32 B, Montgomery) | permutation mapping (6 x 2^k u64) |
 //                                              advice (5 x 2^k x 32 B, Montgomery) | transcript_repr (32 B) | PCG64 state, inc (2 x 16 B)
 //                           -> <dir>/pk.bin (ProvingKey RawBytes), <dir>/vk.bin, <dir>/proof.bin
@@ -11,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 
 #include "halo2_backend.hpp"
 
@@ -55,10 +57,20 @@ int main(int argc, char** argv) {
             return 0;
         }
         const std::string dir = argv[1];
-        ParamsKZG params(be, DEHALO_CURVE_BN254_G1, slurp(dir + "/params.bin"));
         const std::vector<uint8_t> c = slurp(dir + "/circuit.bin");
         uint32_t k;
         memcpy(&k, c.data(), 4);
+        std::unique_ptr<ParamsKZG> params_owner;
+        if (std::ifstream(dir + "/params.bin", std::ios::binary)) params_owner.reset(new ParamsKZG(be, DEHALO_CURVE_BN254_G1, slurp(dir + "/params.bin")));
+        else {      // benches/pose_enc.rs:44-54: no cached file -> setup, write
+            const std::vector<uint8_t> sb = slurp(dir + "/secret.bin");
+            if (sb.size() != 32) throw std::runtime_error("secret.bin: 32 bytes expected");
+            Fe s;
+            memcpy(s.data(), sb.data(), 32);
+            params_owner.reset(new ParamsKZG(be, DEHALO_CURVE_BN254_G1, k, s));
+            dump(dir + "/params.bin", params_owner->write());
+        }
+        ParamsKZG& params = *params_owner;
         const size_t n = (size_t)1 << k;
         if (c.size() != 4 + 9 * n * 32 + 6 * n * 8 + 5 * n * 32 + 32 + 32) throw std::runtime_error("circuit.bin: unexpected size");
         std::vector<Fe> fixed(9 * n), advice(5 * n);

@@ -233,6 +233,8 @@ class ParamsKZG {
     ParamsKZG(const Backend& be, dehalo_curve curve, const std::vector<uint8_t>& raw_bytes) : be_(be) {      // ParamsKZG::read (RawBytes)
         be_.check(dehalo_params_read(be_.raw(), curve, raw_bytes.data(), raw_bytes.size(), &p_));
     }
+    // ParamsKZG::setup(k, rng) with the rng's draw handed over: `s` = the secret scalar in Montgomery form (benches/delay_enc.rs:43); made on the device
+    ParamsKZG(const Backend& be, dehalo_curve curve, uint32_t k, const Fe& s) : be_(be) { be_.check(dehalo_params_setup(be_.raw(), curve, k, s.data(), &p_)); }
     ~ParamsKZG() { dehalo_params_release(be_.raw(), p_); }
     ParamsKZG(const ParamsKZG&) = delete;
     std::vector<uint8_t> write() const {

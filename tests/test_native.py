@@ -387,8 +387,10 @@ def test_cpp_host_example_proves_without_an_interpreter(pkg, po, ctx, chain, tmp
     c = chain(k, False)
     f = pkg.fields.BN254_FR
     n = 1 << k
-    (tmp_path / "params.bin").write_bytes(k.to_bytes(4, "little") + np.ascontiguousarray(c["srs"]["g"]).tobytes() + np.ascontiguousarray(c["srs"]["g_lagrange"]).tobytes() +
-                                          pr.g2_to_raw(pr.G2) + pr.g2_to_raw(c["s_g2"]))
+    # no params.bin: the program makes the SRS itself (ParamsKZG::setup on the device) from the secret and caches it, as the reference's bench does
+    want_params = (k.to_bytes(4, "little") + np.ascontiguousarray(c["srs"]["g"]).tobytes() + np.ascontiguousarray(c["srs"]["g_lagrange"]).tobytes() +
+                   pr.g2_to_raw(pr.G2) + pr.g2_to_raw(c["s_g2"]))
+    (tmp_path / "secret.bin").write_bytes(f.encode(S_TOXIC).tobytes())
     fixed_m = np.stack([ctx.field_op(f.id, "to_mont", c["circ"].fixed[i]) for i in range(9)])
     st = prover.SeededRng(7).gen.bit_generator.state["state"]
     (tmp_path / "circuit.bin").write_bytes(k.to_bytes(4, "little") + fixed_m.tobytes() + np.ascontiguousarray(c["circ"].assembly.mapping, dtype=np.uint64).tobytes() +
@@ -398,7 +400,10 @@ def test_cpp_host_example_proves_without_an_interpreter(pkg, po, ctx, chain, tmp
     assert out.returncode == 0, out.stdout + out.stderr
     want, _ = oracle_proof(po, c)
     proof = (tmp_path / "proof.bin").read_bytes()
+    assert (tmp_path / "params.bin").read_bytes() == want_params, "the SRS the program made differs from the CPU restatement's"
     assert proof == want and oracle_verify(po, c, proof, k)
+    out2 = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)      # second run: params.bin is read, same proof
+    assert out2.returncode == 0 and (tmp_path / "proof.bin").read_bytes() == want
     assert (tmp_path / "vk.bin").read_bytes() == PO.vk_bytes(po.BN254, c["key"], c["circ"].selectors)
     assert len((tmp_path / "pk.bin").read_bytes()) == keygen.pk_size(c["circ"].cs, k, 0, f)
 
