@@ -36,7 +36,7 @@ NTT_BYTES_PER_ELEM = 64  # read once + write once
 # peak of that instruction on MI355X (profiles/r01_ubench_instruction_rates.txt)
 MADS_PER_MIXED_ADD = {"pallas": 1224, "vesta": 1224, "bn254": 1467}
 VMAD_PEAK_TMADS = 30.5
-KERNEL_REV = "r02b"   # bumped whenever k_msm_accum0 changes: a PMC traffic figure measured on another revision is not reported
+KERNEL_REV = "r04a"   # bumped whenever k_msm_accum0 changes: a PMC traffic figure measured on another revision is not reported
 MADS_PER_FIELD_MUL = {"pasta_fp": 135, "pasta_fq": 135, "bn254_fr": 162, "bn254_fq": 162}   # f29_mul, ISA count
 
 
