@@ -427,7 +427,7 @@ void dehalo_ctx_destroy(dehalo_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_out, &ctx->ws_count, &ctx->ws_counters, &ctx->ws_off, &ctx->ws_records, &ctx->ws_merge_lists,
+    DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_out, &ctx->ws_count, &ctx->ws_counters, &ctx->ws_off, &ctx->ws_records, &ctx->ws_merge_lists, &ctx->ws_merge_parts,
                       &ctx->ws_bhist, &ctx->ws_pcount, &ctx->ws_pairs, &ctx->ws_bsum, &ctx->ws_idx, &ctx->ws_partial0, &ctx->ws_buckets, &ctx->ws_contrib, &ctx->ws_tree, &ctx->ws_bred_cnt,
                       &ctx->ws_gsums, &ctx->ws_ntt_scratch, &ctx->ws_ntt_io, &ctx->ws_ntt_io2, &ctx->ws_fop[0], &ctx->ws_fop[1], &ctx->ws_fop[2],
                       &ctx->ws_tmp_bases, &ctx->ws_poly[0], &ctx->ws_poly[1], &ctx->ws_poly[2], &ctx->ws_poly[3], &ctx->ws_poly[4], &ctx->ws_poly_io[0], &ctx->ws_poly_io[1],
@@ -1282,9 +1282,9 @@ int dehalo_msm_last_shape(dehalo_ctx* ctx, uint32_t out[6]) {
     memset(out, 0, 6 * sizeof(uint32_t));
     if (!ctx->ws_counters.p) return 0;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t raw[10];      // eight merge-class counters (light: 2 | 3-4 | 5-8 | 9-16 | 17-24 records; 8 quads; 16 quads; a block), L0, M
+    uint32_t raw[10];      // eight merge-class counters (k_msm_merge_classify2: 2 | 3-4 | 5-8 | 9-64 | 65-512 records, parts of heavy buckets, heavy buckets, unused), L0, M
     HIP_TRY(ctx, hipMemcpy(raw, ctx->ws_counters.p, sizeof(raw), hipMemcpyDeviceToHost));
-    out[0] = raw[0] + raw[1] + raw[2] + raw[3] + raw[4]; out[1] = raw[5]; out[2] = raw[6]; out[3] = raw[7]; out[4] = raw[8]; out[5] = raw[9];
+    out[0] = raw[0] + raw[1] + raw[2]; out[1] = raw[3]; out[2] = raw[4]; out[3] = raw[6]; out[4] = raw[8]; out[5] = raw[9];      // light (2-8 records) | 9-64 | 65-512 | > 512
     return 0;
 }
 

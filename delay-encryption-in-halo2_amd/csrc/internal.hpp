@@ -103,7 +103,7 @@ struct dehalo_ctx {
     std::mutex err_mu;
     std::recursive_mutex mu;   // recursive: host-buffer entry points hold it across their device-form calls
     // workspace (grow-only)
-    DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_records, ws_merge_lists, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
+    DevBuf ws_scalars, ws_out, ws_count, ws_counters, ws_off, ws_records, ws_merge_lists, ws_merge_parts, ws_bhist, ws_pcount, ws_pairs, ws_bsum, ws_idx, ws_partial0, ws_buckets,
         ws_contrib, ws_tree, ws_bred_cnt, ws_gsums, ws_ntt_scratch, ws_ntt_io, ws_ntt_io2, ws_fop[3], ws_tmp_bases, ws_poly[5], ws_poly_io[3], ws_evh[4], ws_lookup;
     std::vector<TwiddleEntry> twiddles;
     affine_t* msm_affine_out = nullptr;   // set for the duration of dehalo_msm_device_affine (under mu): k_msm_final also writes affine points

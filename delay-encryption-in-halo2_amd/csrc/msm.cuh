@@ -473,10 +473,10 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
 // cursors already stand at slice k + 1's first positions -- no re-initialisation.
 #define MSM_BUCKET_SLICES 4
 static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 slices, const u32* off, const u32* bh, const u32* pc,
-                                                          const unsigned long long* pairs, u32* idx_out) {
+                                                          const unsigned long long* pairs, u32* idx_out, u32 per_block) {
     __shared__ u32 lcur[256];
     const u32 sub = msm_sub_bits(c), P = nb >> sub, nsub = 1u << sub;
-    const u32 chunks = (slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES;
+    const u32 chunks = (slices + per_block - 1) / per_block;      // per_block: consecutive slices one block walks (MSM_BUCKET_SLICES, or fewer: run_msm_t)
     const u64 gidx = blockIdx.y;
     u32 p, ch;
     if ((P & 7) == 0) {   // blocks of one partition on one XCD: id = 8 * j + (p mod 8)
@@ -487,7 +487,7 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
         p = blockIdx.x / chunks;
         ch = blockIdx.x % chunks;
     }
-    const u32 k0 = ch * MSM_BUCKET_SLICES, k1 = min(k0 + MSM_BUCKET_SLICES, slices);
+    const u32 k0 = ch * per_block, k1 = min(k0 + per_block, slices);
     const u32* goff = off + gidx * nb + ((u64)p << sub);
     const u32* rel = bh + (gidx * slices + k0) * nb + ((u64)p << sub);
     for (u32 j = threadIdx.x; j < nsub; j += blockDim.x) lcur[j] = goff[j] + rel[j];
@@ -1018,7 +1018,9 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_pairs, Mmax * 8));                                   // partition-sorted (sub-bucket, reference) pairs
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
     TRY(dh_ensure(ctx, ctx->ws_records, (total_buckets + 1) * 4 * 3));           // nrank | rbeg | rend
-    const u32 merge_cap = (u32)std::min<uint64_t>(total_buckets, nt0_max / 2 + 1);
+    // merge-class lists: `cap` words per class -- a bucket index per listed bucket, or (classes 5 / 6 of k_msm_merge2) 2 words per 512-record part and 4 per heavy bucket
+    const u32 merge_cap = (u32)std::max<uint64_t>(std::min<uint64_t>(total_buckets, nt0_max / 2 + 1), 4 * (nt0_max / MERGE2_CHUNK + 2));
+    TRY(dh_ensure(ctx, ctx->ws_merge_parts, (2 * (nt0_max / MERGE2_CHUNK) + 4) * sizeof(xyzz29_rec)));   // part sums of the heavy buckets
     TRY(dh_ensure(ctx, ctx->ws_merge_lists, (size_t)merge_cap * MSM_MERGE_COUNTERS * 4));   // merge-class lists
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
@@ -1071,7 +1073,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
         TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bucket, lds_bk));
-        k_msm_bucket<<<dim3(P * ((g.slices + MSM_BUCKET_SLICES - 1) / MSM_BUCKET_SLICES), (u32)total_groups), 256, lds_bk, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx);
+        // slices per block: 4 (measured best on dense columns) unless DEHALO_MSM_BUCKET_SLICES says otherwise (1 / 2 / 4 / 8: A/B measurements on the
+        // skewed columns of a proof, where a block's run can be 17 windows x 4 slices of ONE value)
+        static const u32 bucket_slices = [] { const char* e = getenv("DEHALO_MSM_BUCKET_SLICES"); const int v = e ? atoi(e) : MSM_BUCKET_SLICES; return (u32)(v >= 1 && v <= 16 ? v : MSM_BUCKET_SLICES); }();
+        k_msm_bucket<<<dim3(P * ((g.slices + bucket_slices - 1) / bucket_slices), (u32)total_groups), 256, lds_bk, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx, bucket_slices);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -1096,7 +1101,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         if (use_merge2) {
             const size_t lds_m = dh_co_lds_pad(18 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_merge2<CV>, lds_m));
-            k_msm_merge2<CV><<<MERGE2_BLOCKS_HEAVY + MERGE2_BLOCKS_G64 + MERGE2_BLOCKS_G32 + MERGE2_BLOCKS_LIGHT, 256, lds_m, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
+            k_msm_merge2<CV><<<MERGE2_GRID, 256, lds_m, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, (xyzz29_rec*)ctx->ws_merge_parts.p);
         } else {
             // DEHALO_MSM_MERGE_SPLIT=1 (measurements, tools/merge_split.sh): one launch per class -- block, wave, 32 lanes, light -- so that a kernel trace shows each one's time
             static const bool merge_split = [] { const char* e = getenv("DEHALO_MSM_MERGE_SPLIT"); return e && e[0] == '1'; }();

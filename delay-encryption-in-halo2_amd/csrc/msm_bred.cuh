@@ -300,17 +300,23 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
     __builtin_amdgcn_wave_barrier();
 }
 
-#define MERGE2_BLOCKS_LIGHT 1024
-#define MERGE2_BLOCKS_G32 512
-#define MERGE2_BLOCKS_G64 512
-#define MERGE2_BLOCKS_HEAVY 256
-#define MERGE2_LIGHT_CLASSES 5      // 2 | 3-4 | 5-8 | 9-16 | 17-24 partial sums
+#define MERGE2_BLOCKS_LIGHT 1024     // per light class
+#define MERGE2_BLOCKS_Q8 512
+#define MERGE2_BLOCKS_BLOCK 512
+#define MERGE2_BLOCKS_PARTS 1024
+#define MERGE2_CHUNK 512             // records of one part of a heavy bucket
+#define MERGE2_GRID (MERGE2_BLOCKS_PARTS + MERGE2_BLOCKS_BLOCK + MERGE2_BLOCKS_Q8 + 3 * MERGE2_BLOCKS_LIGHT)
 
 // classification for k_msm_merge2: one lane per bucket; S = 0 -> identity, S = 1 -> copy, otherwise the bucket is queued in the list of its class
-// (one atomic per wave and class).  EIGHT classes: the light ones -- a quad walks the bucket's records one after the other -- are split by length, because
-// a wave of 16 quads runs as long as its longest bucket: with one light class of 2 .. 24 records the waves of a witness commitment (most buckets 2-4
-// records, some 20) waited 80 % of their time (merge 0.18 ms for 0.24 M additions that fill the chip for 0.04).  Classes 5 / 6 / 7: 8 quads, 16 quads, a block.
-FP_DEV u32 merge2_class(u32 S) { return S <= 2 ? 0u : S <= 4 ? 1u : S <= 8 ? 2u : S <= 16 ? 3u : S <= 24 ? 4u : S <= 128 ? 5u : S <= 512 ? 6u : 7u; }
+// (one atomic per wave and class).  The classes are cut so that no chain is longer than ~14 additions whatever S is:
+//   0 | 1 | 2   S = 2 | 3-4 | 5-8: one quad walks the bucket's records (three lists, three grid sections side by side: a wave of 16 quads runs as long as its
+//               longest bucket, and sections that ran one after the other inside a block added their latencies up -- 80 us for the trivial merge of a K = 11 proof);
+//   3           S = 9 .. 64: 8 quads (strided quad sums, then a tree inside the wave);
+//   4           S = 65 .. 512: a block of 64 quads (LDS tree);
+//   5 / 6       S > 512: the bucket is cut into parts of 512 records, list 5 holds one entry (slot, part) per part, list 6 one entry (bucket, first part, parts,
+//               arrival counter) per such bucket; a block sums one part into the parts buffer and the LAST block of a bucket to arrive sums its parts.  (One block per
+//               bucket, as before round 4, walked S / 64 records per quad: 0.3 ms for the 10^4-record buckets of a permuted lookup column.)
+FP_DEV u32 merge2_class(u32 S) { return S <= 2 ? 0u : S <= 4 ? 1u : S <= 8 ? 2u : S <= 64 ? 3u : S <= MERGE2_CHUNK ? 4u : 5u; }
 static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_buckets, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
                                                                    u32* counters, u32* lists, u32 cap) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,7 +325,7 @@ static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_bu
     const u32 S = end - beg;
     const u32 cls = !in || S <= 1 ? 8u : merge2_class(S);
     const u32 lane = threadIdx.x & 63;
-    for (u32 c = 0; c < 8; c++) {
+    for (u32 c = 0; c < 5; c++) {
         const unsigned long long mask = __ballot(cls == c);
         if (mask == 0) continue;
         const u32 leader = (u32)__ffsll((long long)mask) - 1;
@@ -327,6 +333,16 @@ static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_bu
         if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
         base = __shfl(base, (int)leader);
         if (cls == c) lists[(size_t)c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
+    }
+    if (cls == 5u) {      // rare: its own atomics
+        const u32 parts = (S + MERGE2_CHUNK - 1) / MERGE2_CHUNK;
+        const u32 slot = atomicAdd(&counters[6], 1u), first = atomicAdd(&counters[5], parts);
+        u32* hb = lists + (size_t)6 * cap + 4 * (size_t)slot;
+        hb[0] = b; hb[1] = first; hb[2] = parts; hb[3] = 0;
+        for (u32 p = 0; p < parts; p++) {
+            lists[(size_t)5 * cap + 2 * (size_t)(first + p)] = slot;
+            lists[(size_t)5 * cap + 2 * (size_t)(first + p) + 1] = p;
+        }
     }
     if (!in || cls != 8u) return;
     xyzz29_rec rec;
@@ -338,37 +354,62 @@ static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_bu
     buckets[b] = rec;
 }
 
-// grid = [heavy | 16-quad groups | 8-quad groups | light] sections of 256-thread blocks; a block whose section's list is shorter than its position
-// leaves at once.  One loop serves all classes (Q = 64 / 16 / 8 / 1 quads per bucket: strided quad sums, then a tree over the Q quads), so that the
-// addition is inlined twice, not five times (instruction cache); the light section walks its five lists longest buckets first.
+// grid = [parts of heavy buckets | block class | 8-quad class | light 5-8 | light 3-4 | light 2] sections of 256-thread blocks; a block whose section's list is
+// shorter than its position leaves at once.  One loop body serves all classes (Q = 64 / 64 / 8 / 1 quads per unit: strided quad sums, then a tree over the
+// Q quads), so that the addition is inlined twice, not five times (instruction cache).
 template <class CV>
-__global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, const u32* lists, u32 cap) {
+__global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, u32* lists, u32 cap,
+                                                   xyzz29_rec* parts_buf) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;
     __shared__ __align__(16) u32 lds[128 * 36];
+    __shared__ u32 s_last;
     const u32 tid = threadIdx.x, quad = tid >> 2, role = tid & 3;
     u32* acc = lds + 36 * (2 * quad);
     u32* inc = acc + 36;
     u32 blk = blockIdx.x, cls, nblk, Q;
-    if (blk < MERGE2_BLOCKS_HEAVY) { cls = 7; nblk = MERGE2_BLOCKS_HEAVY; Q = 64; }
-    else if ((blk -= MERGE2_BLOCKS_HEAVY) < MERGE2_BLOCKS_G64) { cls = 6; nblk = MERGE2_BLOCKS_G64; Q = 16; }
-    else if ((blk -= MERGE2_BLOCKS_G64) < MERGE2_BLOCKS_G32) { cls = 5; nblk = MERGE2_BLOCKS_G32; Q = 8; }
-    else { blk -= MERGE2_BLOCKS_G32; cls = MERGE2_LIGHT_CLASSES - 1; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
-    const bool heavy = cls == 7;                             // the only class whose quads span several waves: block barriers (its loop is uniform over the block)
+    if (blk < MERGE2_BLOCKS_PARTS) { cls = 5; nblk = MERGE2_BLOCKS_PARTS; Q = 64; }
+    else if ((blk -= MERGE2_BLOCKS_PARTS) < MERGE2_BLOCKS_BLOCK) { cls = 4; nblk = MERGE2_BLOCKS_BLOCK; Q = 64; }
+    else if ((blk -= MERGE2_BLOCKS_BLOCK) < MERGE2_BLOCKS_Q8) { cls = 3; nblk = MERGE2_BLOCKS_Q8; Q = 8; }
+    else { blk -= MERGE2_BLOCKS_Q8; cls = 2 - blk / MERGE2_BLOCKS_LIGHT; blk %= MERGE2_BLOCKS_LIGHT; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
+    const bool wide = Q == 64;                               // quads of one unit span several waves: block barriers (these loops are uniform over the block)
     const u32 per_block = 64 / Q, grp = quad / Q, q = quad % Q;
-    for (u32 pass = 0; pass < (Q == 1 ? (u32)MERGE2_LIGHT_CLASSES : 1u); pass++, cls--) {
-        const u32 count = counters[cls];
-        const u32* list = lists + cls * (size_t)cap;
-        for (u32 i = blk * per_block + grp; i < count; i += nblk * per_block) {
+    const u32 count = counters[cls];
+    const u32* list = lists + cls * (size_t)cap;
+    for (u32 i = blk * per_block + grp; i < count; i += nblk * per_block) {
+        const xyzz29_rec* src = partial;
+        xyzz29_rec* dst;
+        u32 beg, end;
+        u32* hb = nullptr;
+        if (cls == 5) {                                      // one part of a heavy bucket -> the parts buffer
+            hb = lists + (size_t)6 * cap + 4 * (size_t)list[2 * i];
+            const u32 part = list[2 * i + 1], b = hb[0];
+            beg = rbeg[b] + part * MERGE2_CHUNK;
+            end = min(rend[b], beg + MERGE2_CHUNK);
+            dst = &parts_buf[hb[1] + part];
+        } else {
             const u32 b = list[i];
-            const u32 beg = rbeg[b], end = rend[b];
-            q_strided_sum<F>(acc, inc, partial, beg + q, Q, end, role);
-            if (heavy) __syncthreads();
+            beg = rbeg[b]; end = rend[b];
+            dst = &buckets[b];
+        }
+        for (u32 round = 0; round < 2; round++) {            // (round 1: only the last block of a heavy bucket, over the bucket's parts)
+            q_strided_sum<F>(acc, inc, src, beg + q, Q, end, role);
+            if (wide) __syncthreads();
             for (u32 d = Q >> 1; d >= 1; d >>= 1) {
                 if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
-                if (heavy) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+                if (wide) __syncthreads(); else __builtin_amdgcn_wave_barrier();
             }
-            if (q == 0) q_copy_out(&buckets[b], acc, role);
-            if (heavy) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if (q == 0) q_copy_out(dst, acc, role);
+            if (wide) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if (cls != 5 || round == 1) break;
+            // the part is in HBM: count this block in; the last one to arrive sums the bucket's parts (one device-scope fence per block on either side, msm_bred above)
+            if (tid == 0) {
+                __threadfence();
+                s_last = atomicAdd(&hb[3], 1u) == hb[2] - 1;
+                if (s_last) __threadfence();
+            }
+            __syncthreads();
+            if (!s_last) break;
+            src = parts_buf; beg = hb[1]; end = hb[1] + hb[2]; dst = &buckets[hb[0]];
         }
     }
 }
