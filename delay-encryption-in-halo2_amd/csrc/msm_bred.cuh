@@ -371,9 +371,14 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     else if ((blk -= MERGE2_BLOCKS_PARTS) < MERGE2_BLOCKS_BLOCK) { cls = 4; nblk = MERGE2_BLOCKS_BLOCK; Q = 64; }
     else if ((blk -= MERGE2_BLOCKS_BLOCK) < MERGE2_BLOCKS_Q8) { cls = 3; nblk = MERGE2_BLOCKS_Q8; Q = 8; }
     else { blk -= MERGE2_BLOCKS_Q8; cls = 2 - blk / MERGE2_BLOCKS_LIGHT; blk %= MERGE2_BLOCKS_LIGHT; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
+    const u32 count = counters[cls];
+    // Wide groups buy latency with idle lanes (a tree level keeps half of the group's quads busy): right for the few hundred skewed buckets of a witness column,
+    // wrong when EVERY bucket of a large dense MSM lands in the class (2^20 uniform scalars: 32768 buckets of ~13 records -- eight sweeps of 8-quad groups
+    // against one sweep of single quads, step 1.37 -> 1.50 ms).  So a populous class falls back to narrower groups.
+    if (cls == 3 && count > MERGE2_BLOCKS_Q8 * 8 * 2) Q = 1;
+    if (cls == 4 && count > MERGE2_BLOCKS_BLOCK * 4) Q = 8;
     const bool wide = Q == 64;                               // quads of one unit span several waves: block barriers (these loops are uniform over the block)
     const u32 per_block = 64 / Q, grp = quad / Q, q = quad % Q;
-    const u32 count = counters[cls];
     const u32* list = lists + cls * (size_t)cap;
     for (u32 i = blk * per_block + grp; i < count; i += nblk * per_block) {
         const xyzz29_rec* src = partial;
