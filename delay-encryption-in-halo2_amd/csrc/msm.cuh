@@ -125,6 +125,27 @@ struct DigitStream {
 // second-level split of the bucket index: buckets = partitions x 2^sub sub-buckets
 FP_DEV u32 msm_sub_bits(u32 c) { return c - 1 < 8 ? c - 1 : 8; }
 
+// Groups of equal scalars inside a wave.  A grand-product column over unused rows, a permuted lookup column's runs of equal inputs and a sorted table hand a
+// wave ONE value -- or two or three where runs meet; lanes that hold the same scalar have the same digits, so per window one lane per GROUP counts / reserves
+// for all of them (64 LDS atomics on one word per digit otherwise: 5 ms of k_msm_hist on the grand products of a k = 20 proof before the one-value case was
+// caught in round 2, and still 0.23 ms of k_msm_part on the permuted columns of a k = 17 proof, whose waves straddle two runs, until round 4).
+// -> false when the active lanes hold more than `max_groups` distinct values (the general path then); leader / cnt / rank describe the lane's group.
+FP_DEV bool wave_value_groups(const fe& s, bool active, u32 lane, u32 max_groups, u32& leader, u32& cnt, u32& rank) {
+    unsigned long long rem = __ballot(active);
+    leader = lane; cnt = 1; rank = 0;
+    for (u32 n = 0; rem; n++) {
+        if (n == max_groups) return false;
+        const int ld = __ffsll((long long)rem) - 1;
+        bool eq = active;
+#pragma unroll
+        for (int w = 0; w < 8; w++) eq &= s.v[w] == (u32)__shfl((int)s.v[w], ld);
+        const unsigned long long m = __ballot(eq);
+        if (eq) { leader = (u32)ld; cnt = (u32)__popcll(m); rank = (u32)__popcll(m & ((1ull << lane) - 1)); }
+        rem &= ~m;
+    }
+    return true;
+}
+
 // ---- sort step 1: per-block histograms ----------------------------------------------------
 // grid (slices, G, batch); dynamic LDS nb * 4 B.  Each block stores its whole local histogram
 // (plain coalesced stores): bh[group][slice][bucket].  No global atomics anywhere in the sort:
@@ -154,13 +175,10 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
             // A wave whose 64 consecutive rows hold ONE value (a grand-product column over unused rows, a permuted column's run of
             // equal inputs) would send 64 atomics to the same LDS word for every digit; one lane adds the count instead.
             // (k = 20 grand products, 7 columns: this kernel 5.2 ms -> see DESIGN.md)
-            const unsigned long long act = __ballot(valid);
-            bool same = true;
-#pragma unroll
-            for (int w = 0; w < 8; w++) same &= s4[j].v[w] == (u32)__builtin_amdgcn_readfirstlane((int)s4[j].v[w]);
-            const bool uniform = act != 0 && __ballot(valid && !same) == 0 && __popcll(act) > 1;
-            const u32 weight = uniform ? (u32)__popcll(act) : 1u;
-            const bool counts = uniform ? (threadIdx.x & 63) == (u32)(__ffsll((long long)act) - 1) : valid;
+            u32 gl, weight, grank;
+            const bool grouped = wave_value_groups(s4[j], valid, threadIdx.x & 63, 4, gl, weight, grank);
+            if (!grouped) weight = 1;
+            const bool counts = grouped ? valid && (threadIdx.x & 63) == gl : valid;
             if (counts)
                 for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool) { atomicAdd(&lhist[(one ? 0u : (w - w_lo) * g.nb) + bucket], weight); });
         }
@@ -388,26 +406,21 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
         if (actm == 0) continue;
         DigitStream ds;
         if (nonzero) ds.template init<FS>(s_cur, g.c);
-        {   // the wave's rows hold ONE value (see k_msm_hist): every lane has the same digits, so a window's 64 pairs go to one
-            // partition run -- one reservation per window by the first lane, positions by lane rank, no staging
-            bool same = true;
-#pragma unroll
-            for (int w = 0; w < 8; w++) same &= s_cur.v[w] == (u32)__builtin_amdgcn_readfirstlane((int)s_cur.v[w]);
-            if (__ballot(have && !same) == 0 && actm == __ballot(have) && __popcll(actm) > 1) {
-                const u32 cnt = (u32)__popcll(actm), rank = (u32)__popcll(actm & ((1ull << lane) - 1));
-                const int first = __ffsll((long long)actm) - 1;
+        {   // few distinct values in the wave (wave_value_groups above): the lanes of a group have the same digits, so a window's pairs of a group go to one
+            // partition run -- one reservation per window by the group's first lane, positions by rank inside the group, no staging
+            u32 gl, gcnt, grank;
+            if (__popcll(actm) > 1 && wave_value_groups(s_cur, nonzero, lane, 4, gl, gcnt, grank)) {
                 for (u32 w = 0; w < w_hi; w++) {
-                    u32 bk; bool ng1;
-                    ds.next(bk, ng1);                                     // (uniform across the wave)
-                    if (w >= w_lo && bk != 0xffffffffu) {
-                        const u32 q = (one ? 0u : (w - w_lo) * P) + (bk >> sub);
-                        u32 g0 = 0;
-                        if ((int)lane == first) g0 = atomicAdd(&pcur[q], cnt);
-                        g0 = (u32)__shfl((int)g0, first);
-                        const u32 tidx = one ? w * g.table_n + i : i;
-                        if (nonzero) pairs[g0 + rank] = ((unsigned long long)(bk & submask) << 32) | (tidx | (ng1 ? 0x80000000u : 0u));
-                    }
-                    if (ds.exhausted()) break;
+                    if (__ballot(nonzero && !ds.exhausted()) == 0) break;
+                    u32 bk = 0xffffffffu; bool ng1 = false;
+                    if (nonzero) ds.next(bk, ng1);                       // (uniform across a group; an exhausted stream yields no digit)
+                    const bool put = nonzero && w >= w_lo && bk != 0xffffffffu;
+                    const u32 q = put ? (one ? 0u : (w - w_lo) * P) + (bk >> sub) : 0u;
+                    u32 g0 = 0;
+                    if (put && lane == gl) g0 = atomicAdd(&pcur[q], gcnt);
+                    g0 = (u32)__shfl((int)g0, (int)gl);
+                    const u32 tidx = one ? w * g.table_n + i : i;
+                    if (put) pairs[g0 + grank] = ((unsigned long long)(bk & submask) << 32) | (tidx | (ng1 ? 0x80000000u : 0u));
                 }
                 continue;
             }
@@ -511,7 +524,13 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
         for (int j = 0; j < 8; j++) {
             u32 i = r0 + tid + j * 256;
             pr[j] = i < rend ? pairs[i] : ~0ull;
-            if (pr[j] != ~0ull) atomicAdd(&cnt[(u32)(pr[j] >> 32)], 1u);
+            // (a wave whose 64 pairs all go to ONE sub-bucket -- rows of a constant or sorted column -- counts once: 64 atomics on one LDS word otherwise)
+            const bool v = pr[j] != ~0ull;
+            const u32 sb = (u32)(pr[j] >> 32);
+            const unsigned long long act = __ballot(v);
+            if (act && __ballot(v && sb != (u32)__builtin_amdgcn_readfirstlane((int)sb)) == 0 && ((act & 1ull) != 0)) {
+                if (lane == 0) atomicAdd(&cnt[sb], (u32)__popcll(act));
+            } else if (v) atomicAdd(&cnt[sb], 1u);
         }
         __syncthreads();
         {   // exclusive scan of the (<= 256) counts: one per thread
@@ -526,13 +545,20 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (pr[j] != ~0ull) {
-                const u32 sb = (u32)(pr[j] >> 32);
-                const u32 pos = atomicAdd(&scur[sb], 1u);
+        for (int j = 0; j < 8; j++) {
+            const bool v = pr[j] != ~0ull;
+            const u32 sb = (u32)(pr[j] >> 32);
+            const unsigned long long act = __ballot(v);
+            u32 pos = 0;
+            if (act && __ballot(v && sb != (u32)__builtin_amdgcn_readfirstlane((int)sb)) == 0 && ((act & 1ull) != 0)) {
+                if (lane == 0) pos = atomicAdd(&scur[sb], (u32)__popcll(act));
+                pos = (u32)__shfl((int)pos, 0) + (u32)__popcll(act & ((1ull << lane) - 1));
+            } else if (v) pos = atomicAdd(&scur[sb], 1u);
+            if (v) {
                 stage[pos] = (u32)pr[j];
                 stageq[pos] = (unsigned short)sb;
             }
+        }
         __syncthreads();
         const u32 total = rend - r0;
         for (u32 e = tid; e < total; e += 256) {

@@ -201,6 +201,18 @@ def test_device_proof_of_the_real_mod_pow_witness(pkg, po, co, ctx):
     assert len(proof) == 2848 and proof == want
     assert V.verify_proof(po.BN254, c["desc"], k, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], proof)
     params.release()
+    # the same witness through the whole-call C ABI (dehalo_params_setup -> dehalo_keygen -> dehalo_create_proof, with a side context), and with the circuit
+    # synthesized inside the call (dehalo_create_proof_circuit): the same bytes
+    from dehalo2_amd import native
+    side = pkg.Context(0)
+    nparams = native.ParamsKZG.setup(ctx, pkg.fields.BN254, k, c["s"])
+    npk = native.ProvingKey.keygen(ctx, nparams, circ.cs, circ.fixed, circ.assembly, circ.selectors)
+    npk.transcript_repr = c["rep"]
+    nprover = native.Prover(nparams, npk, ctx, side)
+    assert nprover.create_proof(c["adv"], [[]], prover.SeededRng(5)).finalize() == want
+    tr2, info2 = nprover.create_proof_circuit(native.CIRCUIT_MOD_POW, [[]], prover.SeededRng(5), n_big=n, e=e, x=x, exp_bits=5)
+    assert tr2.finalize() == want and info2["rows"] == info.total_rows
+    nprover.release(); npk.release(); nparams.release(); side.close()
 
 
 @pytest.mark.gpu
