@@ -1052,6 +1052,12 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     std::thread helper;
     double helper_ms[3] = {};
     const bool device_rng = rng.kind == DEHALO_RNG_OS;      // the large draw comes from a ChaCha20 kernel keyed with this proof's entropy
+    // The random polynomial's commitment.  Committing COEFFICIENTS over g equals committing their forward transform (the values on the domain) over g_lagrange,
+    // and upstream writes the point right behind the grand products' commitments with no challenge in between: so (round 4, with a side context) the helper only
+    // draws and uploads, and the polynomial rides as ONE MORE COLUMN of the products' MSM launch -- a whole sort / accumulate / merge / reduce pipeline per proof
+    // less, and none running beside the lookups' phase.  DEHALO_PROVER_RANDOM_SEPARATE=1: the helper commits it with an MSM of its own, as in round 3 (A/B measurements).
+    static const bool random_separate_env = [] { const char* e = getenv("DEHALO_PROVER_RANDOM_SEPARATE"); return e && e[0] == '1'; }();
+    const bool random_separate = random_separate_env;
     auto device_draw = [&](fe* dst, hipStream_t st) -> int {
         ChaKey ck;
         memcpy(ck.k, rng.key, 32);
@@ -1077,15 +1083,15 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
                 if (device_rng) rc = device_draw(dst, hs);
                 else e = hipMemcpyAsync(dst, rand_pin, n * 32, hipMemcpyHostToDevice, hs);
                 if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial upload: ") + hipGetErrorString(e));
-                if (!rc) rc = dehalo_msm_device(side, params->bases_g, (const uint64_t*)dst, n, 1, jac_side.u64(), hs);      // (the side context's MSM workspace is this thread's alone)
+                if (!rc && random_separate) rc = dehalo_msm_device(side, params->bases_g, (const uint64_t*)dst, n, 1, jac_side.u64(), hs);      // (the side context's MSM workspace is this thread's alone)
                 helper_ms[1] = ms_since(th0);
-                if (!rc) {      // read the point back and wait for it through an event of this thread's own; everything of this stream is done before the join
-                    e = hipMemcpyAsync(pin_helper, jac_side.p, 96, hipMemcpyDeviceToHost, hs);
+                if (!rc) {      // wait for this stream through an event of this thread's own: the coefficients (and the point) are there before the join
+                    if (random_separate) e = hipMemcpyAsync(pin_helper, jac_side.p, 96, hipMemcpyDeviceToHost, hs);
                     if (e == hipSuccess) e = hipEventRecord(ev_helper, hs);
                     if (e == hipSuccess) e = hipEventSynchronize(ev_helper);
-                    if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial commitment: ") + hipGetErrorString(e));
+                    if (e != hipSuccess) rc = dh_fail(side, DEHALO_ERR_HIP, std::string("random polynomial: ") + hipGetErrorString(e));
                 }
-                if (!rc && !normalize_host(pin_helper, 1, rand_point)) memset(rand_point, 0, sizeof rand_point);      // (the identity: refused by write_point below)
+                if (!rc && random_separate && !normalize_host(pin_helper, 1, rand_point)) memset(rand_point, 0, sizeof rand_point);      // (the identity: refused by write_point below)
                 helper_ms[2] = ms_since(th0);
             } else {
                 // without a side context only the draw is taken off the critical path; the upload is queued by the proving thread
@@ -1263,6 +1269,27 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
 
     // ---- grand products: permutation sets, then lookups; one batched inversion
     const uint32_t npc = (uint32_t)cs.perm_cols.size();
+    const uint32_t extra = random_separate ? 0u : 1u;      // the random polynomial's values as the launch's last column (cols[o_rand] sits right behind the products)
+    if (extra) {
+        if (helper.joinable()) helper.join();              // (long finished: the draw takes 0.5 ms at k = 17 and started before the advice commitment)
+        tk("helper joined");
+        if (helper_rc.load()) return helper_rc.load();
+        fe* rl = cols.at((size_t)o_rand * n);
+        if (side) HIP_TRY(ctx, hipMemcpyAsync(rl, polys + (size_t)o_rand * n, n * sizeof(fe), hipMemcpyDeviceToDevice, ms));      // (the helper put the coefficients there)
+        else {      // without a side context the coefficient forms live in `cols` itself: keep a copy for after the commitment
+            if (device_rng) TRY(device_draw(rl, ms));
+            else HIP_TRY(ctx, hipMemcpyAsync(rl, rand_pin, n * 32, hipMemcpyHostToDevice, ms));      // (rand_pin: page-locked, the library's own)
+            HIP_TRY(ctx, hipMemcpyAsync(wbuf.p, rl, n * sizeof(fe), hipMemcpyDeviceToDevice, ms));
+        }
+        TRY(dehalo_ntt_device(ctx, fid, (uint64_t*)rl, k, d.omega.v, 1, nullptr));
+    }
+    auto restore_random = [&]() -> int {      // (queued behind the MSM's kernels on the same stream)
+        if (extra && !side) HIP_TRY(ctx, hipMemcpyAsync(cols.at((size_t)o_rand * n), wbuf.p, n * sizeof(fe), hipMemcpyDeviceToDevice, ms));
+        return 0;
+    };
+    if (S + L == 0 && extra) {
+        TRY(commit(tr, cols.at((size_t)o_rand * n), 1, true, [&]() { return restore_random(); }));
+    }
     if (S + L) {
         std::vector<Fe> chal(std::max<uint32_t>(npc, 1));
         Fe dj = beta;
@@ -1298,6 +1325,8 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         k_place_rows<<<(unsigned)(((size_t)bf * (S + L) + 255) / 256), 256, 0, ms>>>(cols.at((size_t)o_pz * n + (n - bf)), n, bl_prod, bf, S + L);
         if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[2], ms));
         auto after_products_queued = [&]() -> int {
+            TRY(restore_random());
+            if (!side) return 0;
             TRY(side_ntt(o_pz, S + L, ev_ready[2]));
             // the lookups' (compressed input + beta)(compressed table + gamma) over the extended domain need theta, beta, gamma and the advice /
             // fixed cosets: all there -- on the side context, beside the products' commitment, instead of after y
@@ -1313,7 +1342,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             }
             return 0;
         };
-        TRY(commit(tr, cols.at((size_t)o_pz * n), S + L, true, side ? std::function<int()>(after_products_queued) : nullptr));
+        TRY(commit(tr, cols.at((size_t)o_pz * n), S + L + extra, true, std::function<int()>(after_products_queued)));
     }
     mark(2);
 
@@ -1328,7 +1357,9 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
         uint64_t blind[4];
         TRY(rng.scalars(blind, 1));      // random_blind (unused by KZG)
     }
-    if (side) {
+    if (!random_separate) {
+        // (written with the products' commitments above)
+    } else if (side) {
         if (!tr->write_point(rand_point)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
     } else {
         if (device_rng) TRY(device_draw(cols.at((size_t)o_rand * n), ms));

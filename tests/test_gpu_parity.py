@@ -1142,3 +1142,39 @@ def test_product_terms_vs_python_integers(pkg, co, ctx, fname):
         assert f.decode_many(got_n[sets + l, :n]) == [(A[i] + beta) * (Sx[i] + gamma) % f.p for i in range(n)]
         assert f.decode_many(got_d[sets + l, :n]) == [(a_[i] + beta) * (s_[i] + gamma) % f.p for i in range(n)]
     assert not got_n[:, n:].any() and not got_d[:, n:].any()      # the padding between columns is untouched
+
+
+@pytest.mark.gpu
+def test_staged_upload_and_download_of_caller_memory(pkg, ctx):
+    """dehalo_upload / dehalo_download: every byte between caller memory and the device goes through the context's page-locked staging chunks (4 MiB, two of
+    them) or moves by DMA from pages the library pins for the call -- sizes around the thresholds (64 KiB direct, 4 MiB pin), not multiples of a chunk, an
+    unaligned source, a source the caller page-locked itself."""
+    import torch
+    rng = np.random.default_rng(7)
+    for words in (1, 8191, 8192, 8193, (4 << 20) // 8 - 1, (4 << 20) // 8 + 5, 3 * (4 << 20) // 8 + 12345, (9 << 20) // 8):
+        a = rng.integers(0, 1 << 63, size=words + 1, dtype=np.int64).view(np.uint64)
+        for src in (a[:words], a[1:]):                       # 8-byte aligned, and 8 bytes into the allocation
+            src = np.ascontiguousarray(src) if src.base is None else src
+            d = ctx.upload(src)
+            assert np.array_equal(ctx.download_tensor(d), src)
+            assert np.array_equal(d.cpu().numpy().view(np.uint64), src)
+    pinned = torch.empty((3 << 20,), dtype=torch.int64).pin_memory()
+    pinned.copy_(torch.from_numpy(rng.integers(0, 1 << 62, size=3 << 20, dtype=np.int64)))
+    host = pinned.numpy().view(np.uint64)
+    d = ctx.upload(host)
+    assert np.array_equal(ctx.download_tensor(d), host)
+    # the same staging chunks serve two threads at once (one context, serialised inside)
+    import threading
+    errs = []
+    def worker(seed):
+        try:
+            r = np.random.default_rng(seed)
+            for _ in range(4):
+                x = r.integers(0, 1 << 63, size=(1 << 20) + seed, dtype=np.int64).view(np.uint64)
+                if not np.array_equal(ctx.download_tensor(ctx.upload(x)), x):
+                    errs.append("mismatch in thread %d" % seed)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(s,)) for s in (1, 2, 3)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
