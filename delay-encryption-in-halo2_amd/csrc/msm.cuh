@@ -55,6 +55,18 @@
 #define MSM_RED_THREADS 256   // one wave per SIMD per block: with 128-thread blocks the second block on a CU shared SIMDs with the first (3-4 columns at c = 15: 134 -> 86 us)
 #endif
 
+// The MSM's latency-bound kernels (sort, scans, merge, bucket reduction) raise their waves' issue priority: beside another stream's throughput kernels (the side
+// context's NTTs in a proof, a neighbour step's accumulation) the SIMD's arbiter then takes their instructions first -- they are few and someone waits for them
+// (DEHALO_MSM_PRIO=0 as a build flag -DMSM_TAIL_PRIO=0 switches it off for A/B measurements).
+#ifndef MSM_TAIL_PRIO
+#define MSM_TAIL_PRIO 2
+#endif
+FP_DEV void msm_tail_prio() {
+#if MSM_TAIL_PRIO > 0
+    __builtin_amdgcn_s_setprio(MSM_TAIL_PRIO);
+#endif
+}
+
 struct MsmGeom {
     u32 n;          // scalars per MSM
     u32 table_n;    // registered points (row pitch of the window tables)
@@ -152,6 +164,7 @@ FP_DEV bool wave_value_groups(const fe& s, bool active, u32 lane, u32 max_groups
 // 256 blocks claiming runs in the same 2^15 counters with returning atomics cost 0.2 ms.
 template <class FS>
 __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(MsmGeom g, const fe* scalars, u32* bh, u32* pc) {
+    msm_tail_prio();
     extern __shared__ u32 lhist[];
     // G == 1: the block counts every window into the one bucket set.  G == W: it covers windows [w_lo, w_hi), one bucket set each
     // (a scalar is decoded once per block, not once per window: ceil(W / wb) passes over the scalars instead of W).
@@ -232,6 +245,7 @@ FP_DEV void colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* cou
     if (count) count[gb] = run;
 }
 static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 blocks_a, u32 P, u32 total_parts, u32* pc) {
+    msm_tail_prio();
     if (blockIdx.x < blocks_a) colscan_one(nb, slices, total_buckets, bh, count, blockIdx.x * blockDim.x + threadIdx.x);
     else colscan_one(P, slices, total_parts, pc, nullptr, (blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
 }
@@ -244,6 +258,7 @@ static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32*
 #define SCAN_BLOCK (SCAN_THREADS * SCAN_PER_THREAD)
 
 static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u32* cnt, u32 total, u32 L, u32* bsum_items, u32* bsum_tasks) {
+    msm_tail_prio();
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
     u32 si = 0, st = 0;
@@ -267,6 +282,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u
 // rounds = ceil(M / (resident * lmax)), at least 4; geo[1] = M.  (Sized from the upper bound on the host, a sparse column left most
 // lanes idle and the rest with full-length chains: advice columns took half the time of dense ones with a fifth of the points.)
 static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident, u32 lmax, u32 lcap) {
+    msm_tail_prio();
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     __shared__ u32 carry_i, carry_t;
     if (threadIdx.x == 0) { carry_i = 0; carry_t = 0; }
@@ -311,6 +327,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_item
 // for the lanes of one bucket.  rbeg/rend[b] = that bucket's record range (equal when empty).
 static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32 total, const u32* geo, const u32* bsum_items, const u32* bsum_tasks,
                                                                     u32* off, u32* nrank, u32* rbeg, u32* rend) {
+    msm_tail_prio();
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     const u32 L = geo[0];
     u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
@@ -365,6 +382,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* c
 #define MSM_PART_WAVE_LDS (4 * 128 * 4 + 512 * 8 + 512 * 2)
 template <class FS>
 __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const fe* scalars, const u32* off, const u32* pc, unsigned long long* pairs) {
+    msm_tail_prio();
     extern __shared__ __align__(8) unsigned char part_smem[];
     const u32 bat = blockIdx.z;
     const u32 sub = msm_sub_bits(g.c), P = g.nb >> sub, submask = (1u << sub) - 1;
@@ -487,6 +505,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
 #define MSM_BUCKET_SLICES 4
 static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 slices, const u32* off, const u32* bh, const u32* pc,
                                                           const unsigned long long* pairs, u32* idx_out, u32 per_block) {
+    msm_tail_prio();
     __shared__ u32 lcur[256];
     const u32 sub = msm_sub_bits(c), P = nb >> sub, nsub = 1u << sub;
     const u32 chunks = (slices + per_block - 1) / per_block;      // per_block: consecutive slices one block walks (MSM_BUCKET_SLICES, or fewer: run_msm_t)

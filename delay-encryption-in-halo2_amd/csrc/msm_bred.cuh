@@ -175,6 +175,7 @@ FP_DEV void bred_gather(const u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C
 template <class CV>
 __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
                                                           jacobian_t* fin_out, affine_t* fin_affine) {
+    msm_tail_prio();
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;      // lone waves of dependent operations: the latency schedule (tools/ubench_qmem.hip: 2.9 against 3.5 us per addition, 78 VGPRs either way)
     __shared__ __align__(16) u32 lds[(BRED_BLOCK_BUCKETS + 32) * 36];
     __shared__ u32 s_last;
@@ -319,6 +320,7 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 FP_DEV u32 merge2_class(u32 S) { return S <= 2 ? 0u : S <= 4 ? 1u : S <= 8 ? 2u : S <= 64 ? 3u : S <= MERGE2_CHUNK ? 4u : 5u; }
 static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_buckets, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
                                                                    u32* counters, u32* lists, u32 cap) {
+    msm_tail_prio();
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = b < total_buckets;
     const u32 beg = in ? rbeg[b] : 0, end = in ? rend[b] : 0;
@@ -360,6 +362,7 @@ static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_bu
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, u32* lists, u32 cap,
                                                    xyzz29_rec* parts_buf) {
+    msm_tail_prio();
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;
     __shared__ __align__(16) u32 lds[128 * 36];
     __shared__ u32 s_last;

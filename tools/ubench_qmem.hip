@@ -5,6 +5,7 @@
 #include <cstdio>
 #include "ec29.cuh"
 template <class F> __device__ void msm_emit(const xyzz29&, jacobian_t*, affine_t*) {}
+__device__ __forceinline__ void msm_tail_prio() {}
 #include "msm_bred.cuh"
 
 template <class CV>
