@@ -55,11 +55,12 @@
 #define MSM_RED_THREADS 256   // one wave per SIMD per block: with 128-thread blocks the second block on a CU shared SIMDs with the first (3-4 columns at c = 15: 134 -> 86 us)
 #endif
 
-// The MSM's latency-bound kernels (sort, scans, merge, bucket reduction) raise their waves' issue priority: beside another stream's throughput kernels (the side
-// context's NTTs in a proof, a neighbour step's accumulation) the SIMD's arbiter then takes their instructions first -- they are few and someone waits for them
-// (DEHALO_MSM_PRIO=0 as a build flag -DMSM_TAIL_PRIO=0 switches it off for A/B measurements).
+// Experiment, off (round 4): the MSM's latency-bound kernels (sort, scans, merge, bucket reduction) raising their waves' issue priority with s_setprio, so that beside
+// another stream's throughput kernels (the side context's NTTs in a proof, a neighbour step's accumulation) the SIMD's arbiter takes their instructions first.
+// Measured with -DMSM_TAIL_PRIO=2 against 0 on one box: the kernels ALONE got slower (sort 0.194 -> 0.216 ms, merge + reduction 0.253 -> 0.277 at 2^20), the step, a
+// k = 17 proof (7.58-7.60 against 7.48-7.54 ms) and batch mode (154.3-154.9 against 153.9-154.7 proofs/s) did not move.
 #ifndef MSM_TAIL_PRIO
-#define MSM_TAIL_PRIO 2
+#define MSM_TAIL_PRIO 0
 #endif
 FP_DEV void msm_tail_prio() {
 #if MSM_TAIL_PRIO > 0
