@@ -359,7 +359,7 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     }
     if (c < 4) c = 4;
     uint32_t W = signed_windows(scalar_modulus_words(curve), c);
-    if (precompute && (uint64_t)n * W >= (1ull << 31)) return dh_fail(ctx, DEHALO_ERR_INVALID, "precomputed table too large");
+    if (precompute && (uint64_t)n * W >= (1ull << 30)) return dh_fail(ctx, DEHALO_ERR_INVALID, "precomputed table too large");      // 30-bit table indices in the sorted list (msm.cuh)
     // stage the caller's points (standard Montgomery form) on the device, then build the table
     if (!on_device) TRY(dh_ensure(ctx, ctx->ws_tmp_bases, n * sizeof(affine_t)));
     dehalo_bases* b = new dehalo_bases();

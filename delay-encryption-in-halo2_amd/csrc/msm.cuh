@@ -27,6 +27,8 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #include "ec29.cuh"
 #include "internal.hpp"
@@ -67,6 +69,9 @@ FP_DEV void msm_tail_prio() {
     __builtin_amdgcn_s_setprio(MSM_TAIL_PRIO);
 #endif
 }
+
+#define MSM_IDX_FIRST 0x40000000u     // sorted entry, bit 30: first point of its bucket
+#define MSM_IDX_MASK 0x3fffffffu      // table index (precomputed tables: window * table_n + point < 2^30, checked at registration)
 
 struct MsmGeom {
     u32 n;          // scalars per MSM
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
 static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 slices, const u32* off, const u32* bh, const u32* pc,
                                                           const unsigned long long* pairs, u32* idx_out, u32 per_block) {
     msm_tail_prio();
-    __shared__ u32 lcur[256];
+    __shared__ u32 lcur[256], lfirst[256];
     const u32 sub = msm_sub_bits(c), P = nb >> sub, nsub = 1u << sub;
     const u32 chunks = (slices + per_block - 1) / per_block;      // per_block: consecutive slices one block walks (MSM_BUCKET_SLICES, or fewer: run_msm_t)
     const u64 gidx = blockIdx.y;
@@ -523,7 +528,7 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
     const u32 k0 = ch * per_block, k1 = min(k0 + per_block, slices);
     const u32* goff = off + gidx * nb + ((u64)p << sub);
     const u32* rel = bh + (gidx * slices + k0) * nb + ((u64)p << sub);
-    for (u32 j = threadIdx.x; j < nsub; j += blockDim.x) lcur[j] = goff[j] + rel[j];
+    for (u32 j = threadIdx.x; j < nsub; j += blockDim.x) { lcur[j] = goff[j] + rel[j]; lfirst[j] = goff[j]; }
     // the run of slices [k0, k1) inside the partition: partition base + prefix over earlier slices
     const u32 pbase = goff[0];
     const u32 beg = pbase + pc[(gidx * slices + k0) * P + p];
@@ -583,7 +588,8 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
         const u32 total = rend - r0;
         for (u32 e = tid; e < total; e += 256) {
             const u32 sb = stageq[e];
-            idx_out[lcur[sb] + (e - sbase[sb])] = stage[e];
+            const u32 at = lcur[sb] + (e - sbase[sb]);
+            idx_out[at] = stage[e] | (at == lfirst[sb] ? MSM_IDX_FIRST : 0u);     // bit 30: the first point of its bucket (k_msm_accum0 starts a new sum there)
         }
         __syncthreads();
         if (tid < nsub) lcur[tid] += cnt[tid];     // the next round continues where this one ended
@@ -603,7 +609,7 @@ FP_DEV u32 find_segment(const u32* off, u32 total, u32 t) {
 // table entry -> (affine limbs, is_identity); bit 31 of the reference negates y
 template <class F>
 FP_DEV aff29 load_point(const affine_t* table, u32 e, bool& is_id) {
-    affine_t pk = aff_load(&table[e & 0x7fffffffu]);
+    affine_t pk = aff_load(&table[e & MSM_IDX_MASK]);
     is_id = aff_is_identity(pk);
     aff29 q = a29_from_packed(pk);
     if (e >> 31) q.y = f29_sub(f29_zero(), q.y, F::KN);   // 2p - y, limbs < 2^30
@@ -626,14 +632,16 @@ __global__ __launch_bounds__(MSM_ACC_THREADS_MAX) MSM_ACC_WAVES_ATTR void k_msm_
     if (beg64 >= M) return;
     const u32 beg = (u32)beg64;
     const u32 end = (u32)min((u64)M, beg64 + L0);
-    u32 b = find_segment(off, total_buckets, beg);      // the (non-empty) bucket holding point `beg`
-    u32 next = off[b + 1];
-    u32 rec = lane + nrank[b];
+    // Sorted entry = table index | bit 31 (negate y) | bit 30 (first point of its bucket, set by k_msm_bucket).  Only non-empty buckets appear in the
+    // sorted list, so the record of the next bucket's sum is the next record: a boundary costs one store and no look-up (until round 4 the lane searched
+    // `off` for the next non-empty bucket and fetched its record rank: two or three dependent loads in a branch that some lane of the wave takes in
+    // a fifth of the iterations at 2^20 and in a third of them at 2^17).
+    u32 rec = lane + nrank[find_segment(off, total_buckets, beg)];      // (the bucket holding point `beg`: non-empty)
     // the next point's index is fetched one iteration ahead (dependent idx -> table[idx] chain);
     // measured twice (also after the product-scanning multiplication): prefetching the 64-B point
     // one iteration ahead too changes nothing, although SQ_WAIT_ANY is 24 % of the wave cycles
-    affine_t pk = aff_load(&table[idx[beg] & 0x7fffffffu]);
     u32 e = idx[beg];
+    affine_t pk = aff_load(&table[e & MSM_IDX_MASK]);
     bool is_id = aff_is_identity(pk);
     aff29 q = a29_from_packed(pk);
     if (e >> 31) q.y = f29_sub(f29_zero(), q.y, F::KN);
@@ -642,28 +650,14 @@ __global__ __launch_bounds__(MSM_ACC_THREADS_MAX) MSM_ACC_WAVES_ATTR void k_msm_
     u32 e_next = beg + 1 < end ? idx[beg + 1] : 0;
     for (u32 p = beg + 1; p < end; p++) {
         e = e_next;
-        pk = aff_load(&table[e & 0x7fffffffu]);
+        pk = aff_load(&table[e & MSM_IDX_MASK]);
         e_next = p + 1 < end ? idx[p + 1] : 0;
         is_id = aff_is_identity(pk);
         q = a29_from_packed(pk);
         if (e >> 31) q.y = f29_sub(f29_zero(), q.y, F::KN);   // 2p - y, limbs < 2^30
-        if (p == next) {                                      // bucket boundary inside the range
+        if (e & MSM_IDX_FIRST) {                              // bucket boundary inside the range
             x29_store(&partial[rec], acc);
-            // the next NON-EMPTY bucket: the largest b' > b with off[b'] <= p.  A galloping search -- one probe when the neighbour is not empty (dense columns),
-            // log2(gap) dependent loads when thousands of empty buckets lie between (a permuted lookup column's few hundred distinct values leave most of the
-            // 16384 buckets of every window empty: walking them one load at a time made this kernel take 0.25 ms for 0.6 M points, round 4)
-            {
-                u32 lo = b + 1, step = 1;                     // off[lo] == p
-                while (lo + step <= total_buckets && off[lo + step] <= p) { lo += step; step <<= 1; }
-                u32 hi = min(lo + step, total_buckets);       // off[hi] > p  (off[total_buckets] = M > p)
-                while (hi - lo > 1) {
-                    const u32 mid = (lo + hi) >> 1;
-                    if (off[mid] <= p) lo = mid; else hi = mid;
-                }
-                b = lo;
-            }
-            next = off[b + 1];
-            rec = lane + nrank[b];
+            rec++;
             acc = x29_from_affine<F>(q, is_id);
             if (!is_id) acc.y = f29_norm(acc.y);
         } else if (!is_id) acc = x29_add_mixed<F>(acc, q);
@@ -1147,7 +1141,37 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         if (use_merge2) {
             const size_t lds_m = dh_co_lds_pad(18 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_merge2<CV>, lds_m));
+            static const bool merge_stamps = getenv("DEHALO_MSM_MERGE_STAMPS") != nullptr;
+            static const int merge_q3 = [] { const char* e = getenv("DEHALO_MSM_MERGE_Q3"); return e ? atoi(e) : 0; }();
+            static bool merge_q3_set = false;
+            if (merge_q3 && !merge_q3_set) { HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_merge2_q3), &merge_q3, sizeof(int))); merge_q3_set = true; }
+            if (merge_stamps) { const int on = 1; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_merge2_stamps_on), &on, sizeof(on))); }
             k_msm_merge2<CV><<<MERGE2_GRID, 256, lds_m, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, (xyzz29_rec*)ctx->ws_merge_parts.p);
+            if (merge_stamps) {
+                std::vector<unsigned long long> st(MERGE2_GRID * 3); std::vector<u32> info(MERGE2_GRID * 3);
+                HIP_TRY(ctx, hipStreamSynchronize(s));
+                HIP_TRY(ctx, hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_merge2_stamps), st.size() * 8));
+                HIP_TRY(ctx, hipMemcpyFromSymbol(info.data(), HIP_SYMBOL(g_merge2_info), info.size() * 4));
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (u32 b = 0; b < MERGE2_GRID; b++) { t0 = std::min(t0, st[3 * b]); t1 = std::max(t1, st[3 * b + 2]); }
+                fprintf(stderr, "k_msm_merge2 %u buckets: %.1f us from the first block's start to the last block's end;", tb, (double)(t1 - t0) / 100.0);
+                for (u32 c = 0; c < 6; c++) {
+                    u32 nb_ = 0, q_ = 0, umax = 0; unsigned long long usum = 0; double smax = 0, cmax = 0, emax = 0, longest = 0;
+                    for (u32 b = 0; b < MERGE2_GRID; b++) {
+                        if (info[3 * b] != c || info[3 * b + 2] == 0) continue;
+                        nb_++; q_ = info[3 * b + 1]; umax = std::max(umax, info[3 * b + 2]); usum += info[3 * b + 2];
+                        smax = std::max(smax, (double)(st[3 * b] - t0) / 100.0); cmax = std::max(cmax, (double)(st[3 * b + 1] - t0) / 100.0);
+                        emax = std::max(emax, (double)(st[3 * b + 2] - t0) / 100.0); longest = std::max(longest, (double)(st[3 * b + 2] - st[3 * b + 1]) / 100.0);
+                    }
+                    if (nb_) fprintf(stderr, " class %u: Q %u, %u blocks with work (%llu units, <= %u per block), latest start %.1f, latest count read %.1f, latest end %.1f, longest block %.1f us;",
+                                     c, q_, nb_, usum, umax, smax, cmax, emax, longest);
+                }
+                unsigned long long it[64];
+                HIP_TRY(ctx, hipMemcpyFromSymbol(it, HIP_SYMBOL(g_merge2_iter), sizeof(it)));
+                fprintf(stderr, " | one quad's walk of class 3, us per iteration:");
+                for (int i = 1; i < 62 && it[i]; i++) fprintf(stderr, " %.1f", (double)(it[i] - it[i - 1]) / 100.0);
+                fprintf(stderr, "\n");
+            }
         } else {
             // DEHALO_MSM_MERGE_SPLIT=1 (measurements, tools/merge_split.sh): one launch per class -- block, wave, 32 lanes, light -- so that a kernel trace shows each one's time
             static const bool merge_split = [] { const char* e = getenv("DEHALO_MSM_MERGE_SPLIT"); return e && e[0] == '1'; }();
@@ -1168,10 +1192,24 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
             const bool fin = g.G == 1;
             const size_t lds_b = dh_co_lds_pad(41 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bred<CV>, lds_b));
+            static const bool bred_stamps = getenv("DEHALO_MSM_BRED_STAMPS") != nullptr;
+            if (bred_stamps) {
+                const int on = 1; unsigned long long init[8] = {0, 0, 0, 0, 0, 0, 0, ~0ull};
+                HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps_on), &on, sizeof(on)));
+                HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps), init, sizeof(init)));
+            }
             k_msm_bred<CV><<<dim3(nblk, (u32)total_groups), BRED_THREADS, lds_b, s>>>(g.nb, buckets, (xyzz29_rec*)ctx->ws_contrib.p, (xyzz29_rec*)ctx->ws_tree.p, (u32*)ctx->ws_bred_cnt.p, gsums,
                                                                                  fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
             emitted = fin;
             cur = gsums;
+            if (bred_stamps) {
+                unsigned long long st[8];
+                HIP_TRY(ctx, hipStreamSynchronize(s));
+                HIP_TRY(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_bred_stamps), sizeof(st)));
+                auto us = [&](int i) { return (double)(st[i] - st[7]) / 100.0; };
+                fprintf(stderr, "k_msm_bred nb %u groups %u, us after the first block's start (the block that finishes group 0): its start %.1f | phase 0 tree done %.1f | phase 1 %.1f | phase 2 %.1f | "
+                        "doublings done %.1f | final tree %.1f | result written %.1f\n", g.nb, (unsigned)total_groups, us(0), us(1), st[2] ? us(2) : 0.0, st[3] ? us(3) : 0.0, us(5), us(4), us(6));
+            }
         } else {
         static const int red_m_env = [] { const char* e = getenv("DEHALO_MSM_RED_M"); return e ? atoi(e) : 0; }();
         const uint64_t quads4 = (uint64_t)((g.nb + 3) / 4) * total_groups;

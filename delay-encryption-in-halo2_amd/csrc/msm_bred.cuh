@@ -172,6 +172,12 @@ FP_DEV void bred_gather(const u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C
 // tables: one group per MSM) or, when both are null, to gsums[g] for k_msm_final.
 // Phases of a block: 0 its 256 buckets | 1 (last block of a cluster of 16) the cluster's vectors | 2 (last cluster of the group) the clusters' vectors |
 // 3 (the block that holds the group's vector) weighting by 2^j and the final sum.  Every phase is one call of the tree -- one loop body.
+// measurement only (DEHALO_MSM_BRED_STAMPS=1): wall-clock stamps (100 MHz) of the block that finishes group 0 -- [0] its start, [1 + phase] the end of each phase's
+// tree, [5] the doublings of phase 3 done, [6] the result written; [7] the earliest start of any block
+__device__ unsigned long long g_bred_stamps[8];
+__device__ int g_bred_stamps_on;
+#define BRED_STAMP(i) do { if (stamps_on && tid == 0 && g == 0) my_stamps[i] = wall_clock64(); } while (0)
+
 template <class CV>
 __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
                                                           jacobian_t* fin_out, affine_t* fin_affine) {
@@ -185,6 +191,10 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
     const u32 here = nb < BRED_BLOCK_BUCKETS ? nb : BRED_BLOCK_BUCKETS;      // buckets of a block (a power of two >= 8)
     u32 m = 0;                                                               // log2 nb
     while ((1u << m) < nb) m++;
+    const bool stamps_on = g_bred_stamps_on != 0;
+    unsigned long long my_stamps[7] = {0, 0, 0, 0, 0, 0, 0};
+    BRED_STAMP(0);
+    if (stamps_on && tid == 0 && g == 0) atomicMin(&g_bred_stamps[7], my_stamps[0]);
 
     u32 children = gridDim.x;      // vectors still to combine for this group after the current phase
     u32 idx = blockIdx.x;          // this block's position among them
@@ -234,7 +244,9 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
             C = 0; K = 16; xBase = 0; iStride = 1;
         }
         __syncthreads();
+        if (phase == 3) BRED_STAMP(5);
         bred_tree<F>(lds, 0, xBase, iStride, C, K);
+        BRED_STAMP(1 + phase);
         if (phase < 3) {
             bred_gather(lds, 0, xBase, iStride, C, K, vec);
             u32 lk = 0;
@@ -247,6 +259,10 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
         const xyzz29 s = x29_load(reinterpret_cast<const xyzz29_rec*>(lds));
         if (fin_out || fin_affine) msm_emit<F>(s, fin_out ? fin_out + g : nullptr, fin_affine ? fin_affine + g : nullptr);
         else x29_store(&gsums[g], s);
+        if (stamps_on && g == 0) {
+            my_stamps[6] = wall_clock64();
+            for (int i = 0; i < 7; i++) g_bred_stamps[i] = my_stamps[i];
+        }
     }
 }
 
@@ -269,8 +285,9 @@ FP_DEV void q_copy_out(xyzz29_rec* dst, const u32* rec, u32 role) {
 }
 
 // acc (LDS record) = sum of partial[p], p = first, first + step, ... < end  (identity if none); the next record is in flight during an addition
+__device__ unsigned long long g_merge2_iter[64];      // measurement only: the iterations of one quad's walk (first block of class 3, quad 0)
 template <class F>
-FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 first, u32 step, u32 end, u32 role) {
+FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 first, u32 step, u32 end, u32 role, unsigned long long* iter_stamps = nullptr) {
     if (first >= end) {
 #pragma unroll
         for (int i = 0; i < 9; i++) acc[9 * role + i] = 0;
@@ -285,7 +302,10 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 #pragma unroll
         for (int i = 0; i < 9; i++) nxt[i] = s[i];
     }
+    u32 it = 0;
+    if (iter_stamps) iter_stamps[it++] = wall_clock64();
     while (p < end) {
+        if (iter_stamps && it < 60) iter_stamps[it++] = wall_clock64();
 #pragma unroll
         for (int i = 0; i < 9; i++) inc[9 * role + i] = nxt[i];
         p += step;
@@ -298,6 +318,7 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
         x29q_add_mem<F>(acc, acc, inc);
         __builtin_amdgcn_wave_barrier();
     }
+    if (iter_stamps && it < 62) { iter_stamps[it++] = wall_clock64(); iter_stamps[it] = 0; }
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -359,6 +380,16 @@ static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_bu
 // grid = [parts of heavy buckets | block class | 8-quad class | light 5-8 | light 3-4 | light 2] sections of 256-thread blocks; a block whose section's list is
 // shorter than its position leaves at once.  One loop body serves all classes (Q = 64 / 64 / 8 / 1 quads per unit: strided quad sums, then a tree over the
 // Q quads), so that the addition is inlined twice, not five times (instruction cache).
+// (Round 4, measured and removed: summing a populous class -- every bucket of a dense MSM in one class, 16384 x ~15 or 32768 x ~13 partial sums -- by plain lanes,
+// T lanes per bucket with register operands and shuffle folds, instead of quads.  A lane's own addition is 14 multiplications one after the other, ~3,800
+// instructions against ~1,300 for the quad-cooperative one, so a wave-step takes 8-16 us against 3.6 and the four-fold lane economy is spent: the kernel took
+// ~95 us where the quads take 100 at 2^17 and the whole MSM got 20-70 us longer; a k = 17 proof +0.1-0.2 ms.  profiles/r04_merge_lanes_ab.txt)
+// measurement only (DEHALO_MSM_MERGE_STAMPS=1): per block [start, its section's count read, end] wall-clock stamps (100 MHz) and [class, Q, units it summed]
+__device__ unsigned long long g_merge2_stamps[MERGE2_GRID * 3];
+__device__ u32 g_merge2_info[MERGE2_GRID * 3];
+__device__ int g_merge2_stamps_on;
+__device__ int g_merge2_q3;
+
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, u32* lists, u32 cap,
                                                    xyzz29_rec* parts_buf) {
@@ -374,11 +405,23 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     else if ((blk -= MERGE2_BLOCKS_PARTS) < MERGE2_BLOCKS_BLOCK) { cls = 4; nblk = MERGE2_BLOCKS_BLOCK; Q = 64; }
     else if ((blk -= MERGE2_BLOCKS_BLOCK) < MERGE2_BLOCKS_Q8) { cls = 3; nblk = MERGE2_BLOCKS_Q8; Q = 8; }
     else { blk -= MERGE2_BLOCKS_Q8; cls = 2 - blk / MERGE2_BLOCKS_LIGHT; blk %= MERGE2_BLOCKS_LIGHT; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
+    const bool stamps_on = g_merge2_stamps_on != 0;
+    if (stamps_on && tid == 0) g_merge2_stamps[3 * blockIdx.x] = wall_clock64();
     const u32 count = counters[cls];
+    if (stamps_on && tid == 0) g_merge2_stamps[3 * blockIdx.x + 1] = wall_clock64();
+    u32 units = 0;
     // Wide groups buy latency with idle lanes (a tree level keeps half of the group's quads busy): right for the few hundred skewed buckets of a witness column,
     // wrong when EVERY bucket of a large dense MSM lands in the class (2^20 uniform scalars: 32768 buckets of ~13 records -- eight sweeps of 8-quad groups
     // against one sweep of single quads, step 1.37 -> 1.50 ms).  So a populous class falls back to narrower groups.
-    if (cls == 3 && count > MERGE2_BLOCKS_Q8 * 8 * 2) Q = 1;
+    // Class 3 takes the widest group that still gives every bucket its group in ONE sweep of the section (512 blocks x 64 quads): 8 quads up to 4096
+    // buckets, 4 up to 8192, 2 up to 16384 (three 2^14 columns: 12288 buckets of ~20 records, 200 -> 150 us; a lone 2^17 column 106 -> 99), single quads beyond (2^20).
+    // What bounds a populous class is issue slots, not latency: a lone wave of quad additions takes 3.6-3.8 us per step here and fills its SIMD; two per SIMD take 7.
+    if (cls == 3) {
+        static_assert(MERGE2_BLOCKS_Q8 == 512, "");
+        const u32 q_env = (u32)g_merge2_q3;
+        if (q_env) Q = count > MERGE2_BLOCKS_Q8 * 8 * 2 ? 1 : 8;                  // (DEHALO_MSM_MERGE_Q3=1: the two-way choice of the first version, for the A/B)
+        else while (Q > 1 && count * Q > MERGE2_BLOCKS_Q8 * 64) Q >>= 1;
+    }
     if (cls == 4 && count > MERGE2_BLOCKS_BLOCK * 4) Q = 8;
     const bool wide = Q == 64;                               // quads of one unit span several waves: block barriers (these loops are uniform over the block)
     const u32 per_block = 64 / Q, grp = quad / Q, q = quad % Q;
@@ -400,7 +443,7 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
             dst = &buckets[b];
         }
         for (u32 round = 0; round < 2; round++) {            // (round 1: only the last block of a heavy bucket, over the bucket's parts)
-            q_strided_sum<F>(acc, inc, src, beg + q, Q, end, role);
+            q_strided_sum<F>(acc, inc, src, beg + q, Q, end, role, stamps_on && tid == 0 && blockIdx.x == MERGE2_BLOCKS_PARTS + MERGE2_BLOCKS_BLOCK && units == 0 ? g_merge2_iter : nullptr);
             if (wide) __syncthreads();
             for (u32 d = Q >> 1; d >= 1; d >>= 1) {
                 if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
@@ -419,5 +462,10 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
             if (!s_last) break;
             src = parts_buf; beg = hb[1]; end = hb[1] + hb[2]; dst = &buckets[hb[0]];
         }
+        units++;
+    }
+    if (stamps_on && tid == 0) {
+        g_merge2_stamps[3 * blockIdx.x + 2] = wall_clock64();
+        g_merge2_info[3 * blockIdx.x] = cls; g_merge2_info[3 * blockIdx.x + 1] = Q; g_merge2_info[3 * blockIdx.x + 2] = units;
     }
 }

@@ -28,6 +28,8 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #include "fp29.cuh"
 #include "internal.hpp"
@@ -61,6 +63,9 @@ struct NttPassParams {
     int form_shift;      // +1 / -1: fold 2^5 / 2^-5 into the output multiplication (internal <-> standard form, see dehalo.h)
     fe pre_z;
     fe post0, post_z;
+    unsigned long long* stamps;   // measurement only (DEHALO_NTT_STAMPS=1): 4 wall-clock stamps per workgroup -- start, tile in LDS, stages done, stores issued
+    u32 prio_mode;       // experiment (DEHALO_NTT_PRIO): issue priority by the workgroup's slot on its CU, so co-resident workgroups leave lock-step
+    u32 prio_shift;
 };
 
 FP_DEV u32 bitrev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -133,6 +138,14 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     const u32 r = P.r, log_c = P.log_c;
     const u32 R = 1u << r, Cc = 1u << log_c;
     const u32 tile = R << log_c;
+    unsigned long long* stamp = P.stamps ? P.stamps + 4 * ((u64)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+    if (stamp && tid == 0) stamp[0] = wall_clock64();
+    if (P.prio_mode) {
+        const u32 slot = (P.prio_mode == 1 ? blockIdx.x >> 3 : blockIdx.x >> P.prio_shift) & 3;
+        if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 3) __builtin_amdgcn_s_setprio(3);
+    }
     const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
     fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
 
@@ -205,6 +218,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         lds29_store(L, (bitrev32(j, r) << log_c) + c, v);
     }
     __syncthreads();
+    if (stamp && tid == 0) stamp[1] = wall_clock64();
 
     // ---- DIT stages, two per round ----
     u32 s = P.skip2 ? 2 : 0;
@@ -248,6 +262,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         __syncthreads();
     }
 
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
     // ---- store: row k holds output digit k; one multiplication brings every element below 2p ----
     f29 post0m = f29_one<F9>(), post1m = f29_zero(), post2m = f29_zero();
     if (P.is_final && (P.post_mode || P.form_shift)) {
@@ -295,6 +310,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         f29 t = f29_mul<F9>(v, w);   // < 30p * p / 2^261 + p < 2p
         f_store(&dst[o], f29_pack(f29_cond_sub(t, F9::P)));
     }
+    if (stamp && tid == 0) stamp[3] = wall_clock64();
 }
 
 // tw[j] = omega^j * 2^261 mod p (canonical, packed), j < half (`half` = the table's length: N for a full table).  Thread t fills a run of 64
@@ -376,6 +392,26 @@ int get_twiddles(dehalo_ctx* ctx, uint32_t log_n, const uint64_t omega[4], hipSt
     return 0;
 }
 
+// measurement only: phases of the workgroups of one pass from their wall-clock stamps (100 MHz), relative to the first workgroup's start
+static inline void ntt_report_stamps(dehalo_ctx* ctx, unsigned long long* d, uint64_t nblk, uint32_t pass, uint32_t r, uint32_t tile_log, hipStream_t s) {
+    std::vector<unsigned long long> h(nblk * 4);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(h.data(), d, nblk * 32, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d); return; }
+    (void)hipFree(d);
+    unsigned long long t0 = ~0ull;
+    for (uint64_t i = 0; i < nblk; i++) t0 = std::min(t0, h[4 * i]);
+    const char* names[4] = {"start", "tile in LDS", "stages done", "stores issued"};
+    fprintf(stderr, "ntt pass %u (radix 2^%u, tile 2^%u, %llu workgroups), us after the first workgroup's start: ", pass, r, tile_log, (unsigned long long)nblk);
+    for (int k = 0; k < 4; k++) {
+        std::vector<double> v(nblk);
+        for (uint64_t i = 0; i < nblk; i++) v[i] = (double)(h[4 * i + k] - t0) / 100.0;
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "%s min %.1f median %.1f p90 %.1f max %.1f | ", names[k], v[0], v[nblk / 2], v[nblk * 9 / 10], v[nblk - 1]);
+    }
+    double dl = 0, dc = 0, ds = 0;
+    for (uint64_t i = 0; i < nblk; i++) { dl += (double)(h[4 * i + 1] - h[4 * i]); dc += (double)(h[4 * i + 2] - h[4 * i + 1]); ds += (double)(h[4 * i + 3] - h[4 * i + 2]); }
+    fprintf(stderr, "mean per workgroup: load %.1f us, stages %.1f us, store %.1f us\n", dl / nblk / 100.0, dc / nblk / 100.0, ds / nblk / 100.0);
+}
+
 // Transforms `batch` polynomials: src (src_len valid elements each, zero-extended to 2^log_n,
 // src_stride apart) -> dst (dst_stride apart).  src == dst allowed.
 template <class F>
@@ -451,8 +487,17 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
             lds = dh_co_lds_pad(0, lds);
             TRY(dh_co_lds_attr(ctx, (const void*)k_ntt_pass<F>, lds));
         }
+        static const int prio_mode = [] { const char* e = getenv("DEHALO_NTT_PRIO"); return e ? atoi(e) : 0; }();
+        if (prio_mode && tile_log < NTT_TILE_LOG) {
+            P.prio_mode = (u32)prio_mode;
+            u32 lg = 0; while ((2ull << lg) <= tiles) lg++;
+            P.prio_shift = lg >= 2 ? lg - 2 : 0;
+        }
+        static const bool stamps_on = getenv("DEHALO_NTT_STAMPS") != nullptr;
+        if (stamps_on) HIP_TRY(ctx, hipMalloc((void**)&P.stamps, tiles * batch * 4 * sizeof(unsigned long long)));
         k_ntt_pass<F><<<grid, NTT_THREADS >> (NTT_TILE_LOG - tile_log), lds, s>>>(P);
         HIP_TRY(ctx, hipGetLastError());
+        if (stamps_on) ntt_report_stamps(ctx, P.stamps, tiles * batch, p, rad[p], tile_log, s);
         log_m -= rad[p];
     }
     return 0;
