@@ -227,8 +227,8 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
 
 // column scan: for every bucket, exclusive prefix over the slices (in place) and the total count.  One launch covers two tables:
 // blocks [0, blocks_a) the per-bucket histograms (bh, counts out), the rest the per-partition counts (pc, no totals).
-FP_DEV void colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 gb) {
-    if (gb >= total_buckets) return;
+FP_DEV u32 colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 gb) {
+    if (gb >= total_buckets) return 0;
     u32 grp = gb / nb, b = gb - grp * nb;
     u32* col = bh + (u64)grp * slices * nb + b;
     u32 run = 0;
@@ -249,124 +249,91 @@ FP_DEV void colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* cou
         run += v;
     }
     if (count) count[gb] = run;
+    return run;
 }
-static __global__ void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 blocks_a, u32 P, u32 total_parts, u32* pc) {
-    msm_tail_prio();
-    if (blockIdx.x < blocks_a) colscan_one(nb, slices, total_buckets, bh, count, blockIdx.x * blockDim.x + threadIdx.x);
-    else colscan_one(P, slices, total_parts, pc, nullptr, (blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
-}
-
-// ---- scans (3 kernels): point offsets and record ranges -----------------------------------
-// in: cnt[total]; out: off[total + 1] = exclusive scan of cnt, nrank[total + 1] = exclusive count of
-// non-empty buckets, and each bucket's range of partial-sum records.  Blocks of SCAN_BLOCK entries.
+// (256 threads.)  A block of the first table also leaves the sums of its 256 buckets -- points and non-empty buckets -- for the scan below:
+// bsum_items / bsum_tasks [blockIdx] (until round 4 a launch of its own, k_scan_block_sums).
 #define SCAN_THREADS 256
-#define SCAN_PER_THREAD 8
-#define SCAN_BLOCK (SCAN_THREADS * SCAN_PER_THREAD)
-
-static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u32* cnt, u32 total, u32 L, u32* bsum_items, u32* bsum_tasks) {
+static __global__ __launch_bounds__(SCAN_THREADS) void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 blocks_a, u32 P, u32 total_parts, u32* pc,
+                                                                     u32* bsum_items, u32* bsum_tasks) {
     msm_tail_prio();
-    __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
-    u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    u32 si = 0, st = 0;
-    for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
-        u32 idx = base + k;
-        u32 v = idx < total ? cnt[idx] : 0;
-        si += v; st += v ? 1u : 0u;
+    if (blockIdx.x >= blocks_a) {
+        colscan_one(P, slices, total_parts, pc, nullptr, (blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
+        return;
     }
-    s_i[threadIdx.x] = si; s_t[threadIdx.x] = st;
+    const u32 v = colscan_one(nb, slices, total_buckets, bh, count, blockIdx.x * blockDim.x + threadIdx.x);
+    u32 si = v, st = v ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { si += __shfl_down(si, d); st += __shfl_down(st, d); }
+    __shared__ u32 w_i[SCAN_THREADS / 64], w_t[SCAN_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) { w_i[threadIdx.x >> 6] = si; w_t[threadIdx.x >> 6] = st; }
     __syncthreads();
-    for (u32 d = SCAN_THREADS / 2; d > 0; d >>= 1) {
-        if (threadIdx.x < d) { s_i[threadIdx.x] += s_i[threadIdx.x + d]; s_t[threadIdx.x] += s_t[threadIdx.x + d]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { bsum_items[blockIdx.x] = s_i[0]; bsum_tasks[blockIdx.x] = s_t[0]; }
-}
-
-// single block: exclusive scan of the block sums in place (nblocks <= a few thousand)
-// It also fixes the accumulation's points per lane from the ACTUAL number of sorted points M (zero digits are never sorted: a
-// witness column of small values has a fraction of batch * n * W): geo[0] = L = ceil(M / (rounds * resident)) with
-// rounds = ceil(M / (resident * lmax)), at least 4; geo[1] = M.  (Sized from the upper bound on the host, a sparse column left most
-// lanes idle and the rest with full-length chains: advice columns took half the time of dense ones with a fifth of the points.)
-static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(u32* bsum_items, u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident, u32 lmax, u32 lcap) {
-    msm_tail_prio();
-    __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
-    __shared__ u32 carry_i, carry_t;
-    if (threadIdx.x == 0) { carry_i = 0; carry_t = 0; }
-    __syncthreads();
-    for (u32 base = 0; base < nblocks; base += SCAN_THREADS) {
-        u32 idx = base + threadIdx.x;
-        u32 vi = idx < nblocks ? bsum_items[idx] : 0, vt = idx < nblocks ? bsum_tasks[idx] : 0;
-        s_i[threadIdx.x] = vi; s_t[threadIdx.x] = vt;
-        __syncthreads();
-        for (u32 d = 1; d < SCAN_THREADS; d <<= 1) {  // Hillis-Steele inclusive
-            u32 ai = threadIdx.x >= d ? s_i[threadIdx.x - d] : 0, at = threadIdx.x >= d ? s_t[threadIdx.x - d] : 0;
-            __syncthreads();
-            s_i[threadIdx.x] += ai; s_t[threadIdx.x] += at;
-            __syncthreads();
-        }
-        if (idx < nblocks) { bsum_items[idx] = carry_i + s_i[threadIdx.x] - vi; bsum_tasks[idx] = carry_t + s_t[threadIdx.x] - vt; }
-        __syncthreads();
-        if (threadIdx.x == SCAN_THREADS - 1) { carry_i += s_i[threadIdx.x]; carry_t += s_t[threadIdx.x]; }
-        __syncthreads();
-    }
-    if (threadIdx.x < MSM_MERGE_COUNTERS) geo[(int)threadIdx.x - MSM_MERGE_COUNTERS] = 0;     // the merge-class counters sit just below geo (ws_counters): zeroed here, no fill launch
     if (threadIdx.x == 0) {
-        const u64 M = carry_i;
-        u64 L;
-        if (lcap) {   // layers of one wave per SIMD (`resident` lanes each): 4 (a full chip), 6, 8, ... until a lane has <= lcap points
-            u64 k = 4;
-            while (M > k * resident * lcap) k += 2;
-            L = max((u64)4, (M + k * resident - 1) / (k * resident));
-        } else {
-            const u64 rounds = max((u64)1, (M + (u64)resident * lmax - 1) / ((u64)resident * lmax));
-            L = (M + rounds * resident - 1) / (rounds * resident);
-            L = min((u64)lmax, max((u64)4, L));
-        }
-        geo[0] = (u32)L;
-        geo[1] = (u32)M;
+        u32 a = 0, b = 0;
+        for (u32 w = 0; w < SCAN_THREADS / 64; w++) { a += w_i[w]; b += w_t[w]; }
+        bsum_items[blockIdx.x] = a; bsum_tasks[blockIdx.x] = b;
     }
 }
 
-// off[b] = points before bucket b.  The accumulation cuts the sorted list into ranges of L points,
-// one per lane, regardless of bucket boundaries; lane g writes one partial sum per bucket its
-// range touches, at record  g + (number of non-empty buckets before that bucket)  -- consecutive
-// for the lanes of one bucket.  rbeg/rend[b] = that bucket's record range (equal when empty).
-static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* cnt, u32 total, const u32* geo, const u32* bsum_items, const u32* bsum_tasks,
-                                                                    u32* off, u32* nrank, u32* rbeg, u32* rend) {
+// ---- the scan: point offsets and record ranges, ONE launch after the column scan (round 4; three before: block sums, a one-block scan of them, apply) --------
+// in: cnt[total] and the sums of its blocks of 256 (k_msm_colscan); out: off[total + 1] = exclusive scan of cnt, nrank[total + 1] = exclusive count of non-empty
+// buckets, each bucket's range of partial-sum records, and geo.  Every block adds up the block sums before it and all of them itself (a few hundred to a few
+// thousand words from the L2: cheaper than a launch that does it once), so every block knows M and derives the same L.
+// geo[0] = L fixes the accumulation's points per lane from the ACTUAL number of sorted points M (zero digits are never sorted: a witness column of small values
+// has a fraction of batch * n * W): L = ceil(M / (rounds * resident)) with rounds = ceil(M / (resident * lmax)), at least 4; geo[1] = M.  (Sized from the upper
+// bound on the host, a sparse column left most lanes idle and the rest with full-length chains: advice columns took half the time of dense ones with a fifth of
+// the points.)  off[b] = points before bucket b.  The accumulation cuts the sorted list into ranges of L points, one per lane, regardless of bucket boundaries;
+// lane g writes one partial sum per bucket its range touches, at record  g + (number of non-empty buckets before that bucket)  -- consecutive for the lanes of
+// one bucket.  rbeg/rend[b] = that bucket's record range (equal when empty).
+static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32* cnt, u32 total, const u32* bsum_items, const u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident,
+                                                                      u32 lmax, u32 lcap, u32* off, u32* nrank, u32* rbeg, u32* rend) {
     msm_tail_prio();
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
-    const u32 L = geo[0];
-    u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    u32 vi[SCAN_PER_THREAD], vt[SCAN_PER_THREAD];
-    u32 si = 0, st = 0;
-#pragma unroll
-    for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
-        u32 idx = base + k;
-        u32 v = idx < total ? cnt[idx] : 0;
-        vi[k] = v; vt[k] = v ? 1u : 0u;
-        si += vi[k]; st += vt[k];
+    __shared__ u32 w4[4][SCAN_THREADS / 64];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 bi = 0, bt = 0, ti = 0;                      // points / non-empty buckets in the blocks before this one; points in all blocks
+    for (u32 j = tid; j < nblocks; j += SCAN_THREADS) {
+        const u32 a = bsum_items[j];
+        ti += a;
+        if (j < blockIdx.x) { bi += a; bt += bsum_tasks[j]; }
     }
-    s_i[threadIdx.x] = si; s_t[threadIdx.x] = st;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { bi += __shfl_down(bi, d); bt += __shfl_down(bt, d); ti += __shfl_down(ti, d); }
+    if (lane == 0) { w4[0][wave] = bi; w4[1][wave] = bt; w4[2][wave] = ti; }
+    const u32 idx = blockIdx.x * SCAN_THREADS + tid;
+    const u32 vi = idx < total ? cnt[idx] : 0, vt = vi ? 1u : 0u;
+    s_i[tid] = vi; s_t[tid] = vt;
     __syncthreads();
+    bi = 0; bt = 0; ti = 0;
+    for (u32 w = 0; w < SCAN_THREADS / 64; w++) { bi += w4[0][w]; bt += w4[1][w]; ti += w4[2][w]; }
+    const u64 M = ti;
+    u64 L;
+    if (lcap) {   // layers of one wave per SIMD (`resident` lanes each): 4 (a full chip), 6, 8, ... until a lane has <= lcap points
+        u64 k = 4;
+        while (M > k * resident * lcap) k += 2;
+        L = max((u64)4, (M + k * resident - 1) / (k * resident));
+    } else {
+        const u64 rounds = max((u64)1, (M + (u64)resident * lmax - 1) / ((u64)resident * lmax));
+        L = (M + rounds * resident - 1) / (rounds * resident);
+        L = min((u64)lmax, max((u64)4, L));
+    }
+    if (blockIdx.x == 0) {
+        if (tid < MSM_MERGE_COUNTERS) geo[(int)tid - MSM_MERGE_COUNTERS] = 0;     // the merge-class counters sit just below geo (ws_counters): zeroed here, no fill launch
+        if (tid == 0) { geo[0] = (u32)L; geo[1] = (u32)M; }
+    }
     for (u32 d = 1; d < SCAN_THREADS; d <<= 1) {
-        u32 ai = threadIdx.x >= d ? s_i[threadIdx.x - d] : 0, at = threadIdx.x >= d ? s_t[threadIdx.x - d] : 0;
+        const u32 ai = tid >= d ? s_i[tid - d] : 0, at = tid >= d ? s_t[tid - d] : 0;
         __syncthreads();
-        s_i[threadIdx.x] += ai; s_t[threadIdx.x] += at;
+        s_i[tid] += ai; s_t[tid] += at;
         __syncthreads();
     }
-    u32 ri = bsum_items[blockIdx.x] + s_i[threadIdx.x] - si;
-    u32 rt = bsum_tasks[blockIdx.x] + s_t[threadIdx.x] - st;
-#pragma unroll
-    for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
-        u32 idx = base + k;
-        if (idx < total) {
-            off[idx] = ri; nrank[idx] = rt;
-            u32 b0 = ri / L + rt;
-            rbeg[idx] = b0;
-            rend[idx] = vi[k] ? (ri + vi[k] - 1) / L + rt + 1 : b0;
-        }
-        ri += vi[k]; rt += vt[k];
-        if (idx + 1 == total) { off[total] = ri; nrank[total] = rt; }
+    const u32 ri = bi + s_i[tid] - vi, rt = bt + s_t[tid] - vt;
+    if (idx < total) {
+        off[idx] = ri; nrank[idx] = rt;
+        const u32 b0 = (u32)(ri / L) + rt;
+        rbeg[idx] = b0;
+        rend[idx] = vi ? (u32)((ri + vi - 1) / L) + rt + 1 : b0;
+        if (idx + 1 == total) { off[total] = ri + vi; nrank[total] = rt + vt; }
     }
 }
 
@@ -994,17 +961,6 @@ __global__ void k_jac_to_affine(const jacobian_t* in, affine_t* out, u32 count) 
 // ==========================================================================================
 // host driver (instantiated once per curve in msm_<curve>.hip)
 // ==========================================================================================
-static int run_scan(dehalo_ctx* ctx, const u32* cnt, u32 total, u32* geo, u32 resident, u32 lmax, u32 lcap, u32* off, u32* nrank, u32* rbeg, u32* rend, hipStream_t s) {
-    u32 nblocks = (total + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)nblocks * 2 * sizeof(u32)));
-    u32* bs_i = (u32*)ctx->ws_bsum.p;
-    u32* bs_t = bs_i + nblocks;
-    k_scan_block_sums<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, 0, bs_i, bs_t);
-    k_scan_top<<<1, SCAN_THREADS, 0, s>>>(bs_i, bs_t, nblocks, geo, resident, lmax, lcap);
-    k_scan_apply<<<nblocks, SCAN_THREADS, 0, s>>>(cnt, total, geo, bs_i, bs_t, off, nrank, rbeg, rend);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
-}
 
 template <class CV>
 int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, size_t len, size_t batch, jacobian_t* d_out, hipStream_t s) {
@@ -1031,7 +987,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     if (Mmax >= (1ull << 32) || total_buckets >= (1ull << 31))
         return dh_fail(ctx, DEHALO_ERR_INVALID, "batch * len * windows too large for one launch");
     // points per lane: the lanes fill the chip (msm_acc_waves waves per SIMD of k_msm_accum0) a whole number of times.  The value is
-    // fixed ON THE DEVICE from the number of points actually sorted (k_scan_top); the host only bounds the lane count.
+    // fixed ON THE DEVICE from the number of points actually sorted (k_scan_offsets); the host only bounds the lane count.
     const uint32_t lcap = (uint32_t)ctx->msm_acc_points;
     const uint64_t resident = (uint64_t)ctx->num_cus * 4 * (lcap ? 1 : (uint64_t)ctx->msm_acc_waves) * 64;
     const uint64_t lmax = 64 * 4 / (uint64_t)ctx->msm_acc_waves;
@@ -1108,8 +1064,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
         k_msm_hist<FS><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
         const u32 cs_a = (tb + 255) / 256, cs_b = ((u32)total_groups * P + 255) / 256;
-        k_msm_colscan<<<cs_a + cs_b, 256, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc);
-        TRY(run_scan(ctx, count, tb, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend, s));
+        TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)cs_a * 2 * sizeof(u32)));
+        u32* bs_i = (u32*)ctx->ws_bsum.p;
+        u32* bs_t = bs_i + cs_a;
+        k_msm_colscan<<<cs_a + cs_b, SCAN_THREADS, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc, bs_i, bs_t);
+        k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend);
+        HIP_TRY(ctx, hipGetLastError());
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
         TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bucket, lds_bk));

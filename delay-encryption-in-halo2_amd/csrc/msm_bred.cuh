@@ -20,6 +20,9 @@
 #pragma once
 #include "ec29.cuh"
 
+#ifndef DEHALO_PHASE_STAMPS
+#define DEHALO_PHASE_STAMPS 1        // 0: the measurement hooks (DEHALO_MSM_BRED_STAMPS, DEHALO_MSM_MERGE_STAMPS, DEHALO_MSM_MERGE_Q3) compiled out, for the A/B of their cost
+#endif
 #define BRED_THREADS 256
 #define BRED_QUADS (BRED_THREADS / 4)
 #define BRED_BLOCK_BUCKETS 256      // 4 buckets per quad
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
     const u32 here = nb < BRED_BLOCK_BUCKETS ? nb : BRED_BLOCK_BUCKETS;      // buckets of a block (a power of two >= 8)
     u32 m = 0;                                                               // log2 nb
     while ((1u << m) < nb) m++;
-    const bool stamps_on = g_bred_stamps_on != 0;
+    const bool stamps_on = DEHALO_PHASE_STAMPS && g_bred_stamps_on != 0;
     unsigned long long my_stamps[7] = {0, 0, 0, 0, 0, 0, 0};
     BRED_STAMP(0);
     if (stamps_on && tid == 0 && g == 0) atomicMin(&g_bred_stamps[7], my_stamps[0]);
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     else if ((blk -= MERGE2_BLOCKS_PARTS) < MERGE2_BLOCKS_BLOCK) { cls = 4; nblk = MERGE2_BLOCKS_BLOCK; Q = 64; }
     else if ((blk -= MERGE2_BLOCKS_BLOCK) < MERGE2_BLOCKS_Q8) { cls = 3; nblk = MERGE2_BLOCKS_Q8; Q = 8; }
     else { blk -= MERGE2_BLOCKS_Q8; cls = 2 - blk / MERGE2_BLOCKS_LIGHT; blk %= MERGE2_BLOCKS_LIGHT; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
-    const bool stamps_on = g_merge2_stamps_on != 0;
+    const bool stamps_on = DEHALO_PHASE_STAMPS && g_merge2_stamps_on != 0;
     if (stamps_on && tid == 0) g_merge2_stamps[3 * blockIdx.x] = wall_clock64();
     const u32 count = counters[cls];
     if (stamps_on && tid == 0) g_merge2_stamps[3 * blockIdx.x + 1] = wall_clock64();
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     // What bounds a populous class is issue slots, not latency: a lone wave of quad additions takes 3.6-3.8 us per step here and fills its SIMD; two per SIMD take 7.
     if (cls == 3) {
         static_assert(MERGE2_BLOCKS_Q8 == 512, "");
-        const u32 q_env = (u32)g_merge2_q3;
+        const u32 q_env = DEHALO_PHASE_STAMPS ? (u32)g_merge2_q3 : 0u;
         if (q_env) Q = count > MERGE2_BLOCKS_Q8 * 8 * 2 ? 1 : 8;                  // (DEHALO_MSM_MERGE_Q3=1: the two-way choice of the first version, for the A/B)
         else while (Q > 1 && count * Q > MERGE2_BLOCKS_Q8 * 64) Q >>= 1;
     }
