@@ -70,6 +70,10 @@ FP_DEV void msm_tail_prio() {
 #endif
 }
 
+// classes of k_msm_merge2 (msm_bred.cuh) by the number S of partial sums of a bucket; S > MERGE2_CHUNK: cut into parts of MERGE2_CHUNK records
+#define MERGE2_CHUNK 512
+FP_DEV u32 merge2_class(u32 S) { return S <= 2 ? 0u : S <= 4 ? 1u : S <= 8 ? 2u : S <= 64 ? 3u : S <= MERGE2_CHUNK ? 4u : 5u; }
+
 #define MSM_IDX_FIRST 0x40000000u     // sorted entry, bit 30: first point of its bucket
 #define MSM_IDX_MASK 0x3fffffffu      // table index (precomputed tables: window * table_n + point < 2^30, checked at registration)
 
@@ -255,8 +259,9 @@ FP_DEV u32 colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* coun
 // bsum_items / bsum_tasks [blockIdx] (until round 4 a launch of its own, k_scan_block_sums).
 #define SCAN_THREADS 256
 static __global__ __launch_bounds__(SCAN_THREADS) void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 blocks_a, u32 P, u32 total_parts, u32* pc,
-                                                                     u32* bsum_items, u32* bsum_tasks) {
+                                                                     u32* bsum_items, u32* bsum_tasks, u32* merge_counters) {
     msm_tail_prio();
+    if (blockIdx.x == 0 && threadIdx.x < MSM_MERGE_COUNTERS) merge_counters[threadIdx.x] = 0;      // (k_scan_offsets counts the merge classes: zero before it starts, no fill launch)
     if (blockIdx.x >= blocks_a) {
         colscan_one(P, slices, total_parts, pc, nullptr, (blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
         return;
@@ -285,8 +290,12 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_msm_colscan(u32 nb, u32
 // the points.)  off[b] = points before bucket b.  The accumulation cuts the sorted list into ranges of L points, one per lane, regardless of bucket boundaries;
 // lane g writes one partial sum per bucket its range touches, at record  g + (number of non-empty buckets before that bucket)  -- consecutive for the lanes of
 // one bucket.  rbeg/rend[b] = that bucket's record range (equal when empty).
+// It also queues every bucket with S >= 2 partial sums in the list of its merge class (k_msm_merge2; `lists` null: not wanted) -- S follows from the offsets alone, so
+// the lists are ready before the accumulation starts instead of in a launch between it and the merge: one lane per bucket, one atomic per wave and class.
+//   classes 0 .. 4: lists[class][..] = bucket;   S > MERGE2_CHUNK: list 5 holds one entry (slot, part) per part of MERGE2_CHUNK records, list 6 one entry
+//   (bucket, first part, parts, arrival counter) per such bucket.
 static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32* cnt, u32 total, const u32* bsum_items, const u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident,
-                                                                      u32 lmax, u32 lcap, u32* off, u32* nrank, u32* rbeg, u32* rend) {
+                                                                      u32 lmax, u32 lcap, u32* off, u32* nrank, u32* rbeg, u32* rend, u32* lists, u32 cap) {
     msm_tail_prio();
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     __shared__ u32 w4[4][SCAN_THREADS / 64];
@@ -317,10 +326,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32*
         L = (M + rounds * resident - 1) / (rounds * resident);
         L = min((u64)lmax, max((u64)4, L));
     }
-    if (blockIdx.x == 0) {
-        if (tid < MSM_MERGE_COUNTERS) geo[(int)tid - MSM_MERGE_COUNTERS] = 0;     // the merge-class counters sit just below geo (ws_counters): zeroed here, no fill launch
-        if (tid == 0) { geo[0] = (u32)L; geo[1] = (u32)M; }
-    }
+    if (blockIdx.x == 0 && tid == 0) { geo[0] = (u32)L; geo[1] = (u32)M; }
     for (u32 d = 1; d < SCAN_THREADS; d <<= 1) {
         const u32 ai = tid >= d ? s_i[tid - d] : 0, at = tid >= d ? s_t[tid - d] : 0;
         __syncthreads();
@@ -328,12 +334,37 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32*
         __syncthreads();
     }
     const u32 ri = bi + s_i[tid] - vi, rt = bt + s_t[tid] - vt;
+    u32 S = 0;
     if (idx < total) {
         off[idx] = ri; nrank[idx] = rt;
         const u32 b0 = (u32)(ri / L) + rt;
+        const u32 b1 = vi ? (u32)((ri + vi - 1) / L) + rt + 1 : b0;
         rbeg[idx] = b0;
-        rend[idx] = vi ? (u32)((ri + vi - 1) / L) + rt + 1 : b0;
+        rend[idx] = b1;
+        S = b1 - b0;
         if (idx + 1 == total) { off[total] = ri + vi; nrank[total] = rt + vt; }
+    }
+    if (!lists) return;
+    u32* counters = geo - MSM_MERGE_COUNTERS;      // the merge-class counters sit just below geo (ws_counters); zeroed by k_msm_colscan
+    const u32 cls = S <= 1 ? 8u : merge2_class(S);
+    for (u32 c = 0; c < 5; c++) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (mask == 0) continue;
+        const u32 leader = (u32)__ffsll((long long)mask) - 1;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
+        base = __shfl(base, (int)leader);
+        if (cls == c) lists[(size_t)c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = idx;
+    }
+    if (cls == 5u) {      // rare: its own atomics
+        const u32 parts = (S + MERGE2_CHUNK - 1) / MERGE2_CHUNK;
+        const u32 slot = atomicAdd(&counters[6], 1u), first = atomicAdd(&counters[5], parts);
+        u32* hb = lists + (size_t)6 * cap + 4 * (size_t)slot;
+        hb[0] = idx; hb[1] = first; hb[2] = parts; hb[3] = 0;
+        for (u32 p = 0; p < parts; p++) {
+            lists[(size_t)5 * cap + 2 * (size_t)(first + p)] = slot;
+            lists[(size_t)5 * cap + 2 * (size_t)(first + p) + 1] = p;
+        }
     }
 }
 
@@ -1059,6 +1090,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     const size_t lds_part = dh_co_lds_pad(0, 512 + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS);
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_part<FS>, (int)lds_part));
     const u32 tb = (u32)total_buckets;
+    // DEHALO_MSM_MERGE2=0: the round-3 merge kernels (operands in registers, 172 VGPRs, their own classification launch) instead of k_msm_merge2, for A/B measurements
+    static const bool use_merge2 = [] { const char* e = getenv("DEHALO_MSM_MERGE2"); return !(e && e[0] == '0'); }();
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
         dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
@@ -1067,8 +1100,9 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)cs_a * 2 * sizeof(u32)));
         u32* bs_i = (u32*)ctx->ws_bsum.p;
         u32* bs_t = bs_i + cs_a;
-        k_msm_colscan<<<cs_a + cs_b, SCAN_THREADS, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc, bs_i, bs_t);
-        k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend);
+        k_msm_colscan<<<cs_a + cs_b, SCAN_THREADS, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc, bs_i, bs_t, merge_counters);
+        k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend,
+                                                     use_merge2 ? merge_lists : nullptr, merge_cap);
         HIP_TRY(ctx, hipGetLastError());
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
@@ -1094,10 +1128,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // (a list of <= MSM_LIGHT_QUAD_MAX buckets runs one quad per bucket, where 23 additions are still a short chain; a longer
         // list runs one LANE per bucket and is kept to 11 full-width additions)
         // DEHALO_MSM_MERGE2=0: the round-3 merge kernel (operands in registers, 172 VGPRs) instead of k_msm_merge2 (operands in LDS, < 128 VGPRs, quads throughout)
-        static const bool use_merge2 = [] { const char* e = getenv("DEHALO_MSM_MERGE2"); return !(e && e[0] == '0'); }();
         const u32 c0max = use_merge2 || tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
-        if (use_merge2) k_msm_merge_classify2<<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap);
-        else k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
+        if (!use_merge2) k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
         if (use_merge2) {
             const size_t lds_m = dh_co_lds_pad(18 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_merge2<CV>, lds_m));
@@ -1106,18 +1138,18 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
             static bool merge_q3_set = false;
             if (merge_q3 && !merge_q3_set) { HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_merge2_q3), &merge_q3, sizeof(int))); merge_q3_set = true; }
             if (merge_stamps) { const int on = 1; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_merge2_stamps_on), &on, sizeof(on))); }
-            k_msm_merge2<CV><<<MERGE2_GRID, 256, lds_m, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, (xyzz29_rec*)ctx->ws_merge_parts.p);
+            k_msm_merge2<CV><<<MERGE2_GRID, 256, lds_m, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, (xyzz29_rec*)ctx->ws_merge_parts.p, tb);
             if (merge_stamps) {
                 std::vector<unsigned long long> st(MERGE2_GRID * 3); std::vector<u32> info(MERGE2_GRID * 3);
                 HIP_TRY(ctx, hipStreamSynchronize(s));
                 HIP_TRY(ctx, hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_merge2_stamps), st.size() * 8));
                 HIP_TRY(ctx, hipMemcpyFromSymbol(info.data(), HIP_SYMBOL(g_merge2_info), info.size() * 4));
                 unsigned long long t0 = ~0ull, t1 = 0;
-                for (u32 b = 0; b < MERGE2_GRID; b++) { t0 = std::min(t0, st[3 * b]); t1 = std::max(t1, st[3 * b + 2]); }
+                for (u32 b = 0; b < MERGE2_GRID_SUMS; b++) { t0 = std::min(t0, st[3 * b]); t1 = std::max(t1, st[3 * b + 2]); }
                 fprintf(stderr, "k_msm_merge2 %u buckets: %.1f us from the first block's start to the last block's end;", tb, (double)(t1 - t0) / 100.0);
                 for (u32 c = 0; c < 6; c++) {
                     u32 nb_ = 0, q_ = 0, umax = 0; unsigned long long usum = 0; double smax = 0, cmax = 0, emax = 0, longest = 0;
-                    for (u32 b = 0; b < MERGE2_GRID; b++) {
+                    for (u32 b = 0; b < MERGE2_GRID_SUMS; b++) {
                         if (info[3 * b] != c || info[3 * b + 2] == 0) continue;
                         nb_++; q_ = info[3 * b + 1]; umax = std::max(umax, info[3 * b + 2]); usum += info[3 * b + 2];
                         smax = std::max(smax, (double)(st[3 * b] - t0) / 100.0); cmax = std::max(cmax, (double)(st[3 * b + 1] - t0) / 100.0);

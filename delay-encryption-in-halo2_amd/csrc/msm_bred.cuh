@@ -329,8 +329,9 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 #define MERGE2_BLOCKS_Q8 512
 #define MERGE2_BLOCKS_BLOCK 512
 #define MERGE2_BLOCKS_PARTS 1024
-#define MERGE2_CHUNK 512             // records of one part of a heavy bucket
-#define MERGE2_GRID (MERGE2_BLOCKS_PARTS + MERGE2_BLOCKS_BLOCK + MERGE2_BLOCKS_Q8 + 3 * MERGE2_BLOCKS_LIGHT)
+#define MERGE2_BLOCKS_COPY 256        // buckets with one partial sum (copied) or none (identity): one lane per bucket, the last section of the grid
+#define MERGE2_GRID_SUMS (MERGE2_BLOCKS_PARTS + MERGE2_BLOCKS_BLOCK + MERGE2_BLOCKS_Q8 + 3 * MERGE2_BLOCKS_LIGHT)
+#define MERGE2_GRID (MERGE2_GRID_SUMS + MERGE2_BLOCKS_COPY)
 
 // classification for k_msm_merge2: one lane per bucket; S = 0 -> identity, S = 1 -> copy, otherwise the bucket is queued in the list of its class
 // (one atomic per wave and class).  The classes are cut so that no chain is longer than ~14 additions whatever S is:
@@ -341,44 +342,8 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 //   5 / 6       S > 512: the bucket is cut into parts of 512 records, list 5 holds one entry (slot, part) per part, list 6 one entry (bucket, first part, parts,
 //               arrival counter) per such bucket; a block sums one part into the parts buffer and the LAST block of a bucket to arrive sums its parts.  (One block per
 //               bucket, as before round 4, walked S / 64 records per quad: 0.3 ms for the 10^4-record buckets of a permuted lookup column.)
-FP_DEV u32 merge2_class(u32 S) { return S <= 2 ? 0u : S <= 4 ? 1u : S <= 8 ? 2u : S <= 64 ? 3u : S <= MERGE2_CHUNK ? 4u : 5u; }
-static __global__ __launch_bounds__(256) void k_msm_merge_classify2(u32 total_buckets, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
-                                                                   u32* counters, u32* lists, u32 cap) {
-    msm_tail_prio();
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = b < total_buckets;
-    const u32 beg = in ? rbeg[b] : 0, end = in ? rend[b] : 0;
-    const u32 S = end - beg;
-    const u32 cls = !in || S <= 1 ? 8u : merge2_class(S);
-    const u32 lane = threadIdx.x & 63;
-    for (u32 c = 0; c < 5; c++) {
-        const unsigned long long mask = __ballot(cls == c);
-        if (mask == 0) continue;
-        const u32 leader = (u32)__ffsll((long long)mask) - 1;
-        u32 base = 0;
-        if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
-        base = __shfl(base, (int)leader);
-        if (cls == c) lists[(size_t)c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
-    }
-    if (cls == 5u) {      // rare: its own atomics
-        const u32 parts = (S + MERGE2_CHUNK - 1) / MERGE2_CHUNK;
-        const u32 slot = atomicAdd(&counters[6], 1u), first = atomicAdd(&counters[5], parts);
-        u32* hb = lists + (size_t)6 * cap + 4 * (size_t)slot;
-        hb[0] = b; hb[1] = first; hb[2] = parts; hb[3] = 0;
-        for (u32 p = 0; p < parts; p++) {
-            lists[(size_t)5 * cap + 2 * (size_t)(first + p)] = slot;
-            lists[(size_t)5 * cap + 2 * (size_t)(first + p) + 1] = p;
-        }
-    }
-    if (!in || cls != 8u) return;
-    xyzz29_rec rec;
-    if (S == 1) rec = partial[beg];
-    else {
-#pragma unroll
-        for (int i = 0; i < 36; i++) rec.w[i] = 0;
-    }
-    buckets[b] = rec;
-}
+// (the lists are built by k_scan_offsets, msm.cuh, from the record ranges alone -- before the accumulation runs; until round 4 a launch of its own between the
+// accumulation and this kernel, k_msm_merge_classify2, which also copied the S <= 1 buckets: the last grid section below does that now)
 
 // grid = [parts of heavy buckets | block class | 8-quad class | light 5-8 | light 3-4 | light 2] sections of 256-thread blocks; a block whose section's list is
 // shorter than its position leaves at once.  One loop body serves all classes (Q = 64 / 64 / 8 / 1 quads per unit: strided quad sums, then a tree over the
@@ -395,7 +360,7 @@ __device__ int g_merge2_q3;
 
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, u32* lists, u32 cap,
-                                                   xyzz29_rec* parts_buf) {
+                                                   xyzz29_rec* parts_buf, u32 total_buckets) {
     msm_tail_prio();
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;
     __shared__ __align__(16) u32 lds[128 * 36];
@@ -404,6 +369,20 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     u32* acc = lds + 36 * (2 * quad);
     u32* inc = acc + 36;
     u32 blk = blockIdx.x, cls, nblk, Q;
+    if (blk >= MERGE2_GRID_SUMS) {                           // S <= 1: nothing to add
+        for (u32 b = (blk - MERGE2_GRID_SUMS) * 256 + tid; b < total_buckets; b += MERGE2_BLOCKS_COPY * 256) {
+            const u32 beg = rbeg[b], S = rend[b] - beg;
+            if (S > 1) continue;
+            xyzz29_rec rec;
+            if (S == 1) rec = partial[beg];
+            else {
+#pragma unroll
+                for (int i = 0; i < 36; i++) rec.w[i] = 0;
+            }
+            buckets[b] = rec;
+        }
+        return;
+    }
     if (blk < MERGE2_BLOCKS_PARTS) { cls = 5; nblk = MERGE2_BLOCKS_PARTS; Q = 64; }
     else if ((blk -= MERGE2_BLOCKS_PARTS) < MERGE2_BLOCKS_BLOCK) { cls = 4; nblk = MERGE2_BLOCKS_BLOCK; Q = 64; }
     else if ((blk -= MERGE2_BLOCKS_BLOCK) < MERGE2_BLOCKS_Q8) { cls = 3; nblk = MERGE2_BLOCKS_Q8; Q = 8; }
