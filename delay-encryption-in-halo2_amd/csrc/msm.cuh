@@ -1006,6 +1006,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     g.G = bases->precomp ? 1 : g.W;
     g.batch = (u32)batch;
     g.slices = (u32)std::min<size_t>(256, std::max<size_t>(1, len / 2048));
+    {   // small precomputed-table launches: 2048 scalars a sort block leave a 2^14 column 8 blocks and a 2^11 column ONE for k_msm_hist / k_msm_part (21 + 34 us of
+        // latency where the work is 2); down to 256 scalars a block until ~128 blocks are there (DEHALO_MSM_SMALL_SLICES=0: the A/B)
+        static const bool small_slices = [] { const char* e = getenv("DEHALO_MSM_SMALL_SLICES"); return !(e && e[0] == '0'); }();
+        if (small_slices && g.G == 1 && (size_t)g.slices * batch < 128)
+            g.slices = (u32)std::max<size_t>(g.slices, std::min<size_t>(std::max<size_t>(1, len / 256), (128 + batch - 1) / batch));
+    }
     {   // single-row tables: windows per sort block -- the block's histograms fit 128 KiB of LDS and its (group, partition) runs the 128 staging lists
         const u32 sb = g.c - 1 < 8 ? g.c - 1 : 8, Pg = g.nb >> sb;
         const u32 fit = std::min<u32>(std::min<u32>(g.W, 128 / Pg), (128u * 1024 / 4) / g.nb);
@@ -1110,7 +1116,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         // slices per block: 4 (measured best on dense columns) unless DEHALO_MSM_BUCKET_SLICES says otherwise (1 / 2 / 4 / 8: A/B measurements on the
         // skewed columns of a proof, where a block's run can be 17 windows x 4 slices of ONE value)
         static const u32 bucket_slices = [] { const char* e = getenv("DEHALO_MSM_BUCKET_SLICES"); const int v = e ? atoi(e) : MSM_BUCKET_SLICES; return (u32)(v >= 1 && v <= 16 ? v : MSM_BUCKET_SLICES); }();
-        k_msm_bucket<<<dim3(P * ((g.slices + bucket_slices - 1) / bucket_slices), (u32)total_groups), 256, lds_bk, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx, bucket_slices);
+        // ... and fewer while the grid would not give every CU a block (2^14: 16 partitions x 8 slices -- 32 blocks of 10 k pairs each took 49 us a column, round 4)
+        u32 bslices = bucket_slices;
+        static const bool bucket_fill = [] { const char* e = getenv("DEHALO_MSM_BUCKET_FILL"); return !(e && e[0] == '0'); }();
+        while (bucket_fill && bslices > 1 && (uint64_t)P * ((g.slices + bslices - 1) / bslices) * total_groups < (uint64_t)ctx->num_cus) bslices >>= 1;
+        k_msm_bucket<<<dim3(P * ((g.slices + bslices - 1) / bslices), (u32)total_groups), 256, lds_bk, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx, bslices);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
