@@ -417,6 +417,7 @@ int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out) 
                                            : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
         if (e != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
     }
+    if (const char* e = getenv("DEHALO_HOST_SPIN_US")) ctx->host_wait_spin_us = std::max(0, std::min(1000000, atoi(e)));
     if (const char* e = getenv("DEHALO_MSM_ACC_BLOCK")) ctx->msm_acc_block = atoi(e) == 768 ? 768 : 128;                                      // launch geometry only
     if (const char* e = getenv("DEHALO_MSM_ACC_POINTS")) ctx->msm_acc_points = std::max(0, std::min(4096, atoi(e)));   // launch geometry only (dehalo_ctx_set_tuning)
     *out = ctx;
@@ -468,6 +469,11 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value) {
         ctx->msm_acc_waves = value;
         return 0;
     }
+    if (!strcmp(key, "host_wait_spin_us")) {
+        if (value < 0 || value > 1000000) return dh_fail(ctx, DEHALO_ERR_INVALID, "host_wait_spin_us must be in [0, 1000000]");
+        ctx->host_wait_spin_us = value;
+        return 0;
+    }
     if (!strcmp(key, "msm_acc_block")) {
         if (value != 128 && value != 768) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_acc_block must be 128 or 768");
         ctx->msm_acc_block = value;
@@ -494,7 +500,7 @@ int dehalo_download(dehalo_ctx* ctx, const void* d_src, size_t bytes, void* host
     if ((!d_src || !host_dst) && bytes) return dh_fail(ctx, DEHALO_ERR_INVALID, "download: null argument");
     (void)hipSetDevice(ctx->device);
     if (bytes) TRY(dh_d2h(ctx, host_dst, d_src, bytes, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, dh_stream_wait(ctx, ctx->stream));
     return 0;
 }
 

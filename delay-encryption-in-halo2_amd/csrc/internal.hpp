@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -112,6 +113,9 @@ struct dehalo_ctx {
                              // on three quarters of the wave slots -- k = 17 proof 12.6 -> 12.05 ms); 0: rounds of msm_acc_waves waves per SIMD
     int msm_acc_waves = 3;   // sizes the accumulation's points per lane (dehalo_ctx_set_tuning): 3 -> 43 points per lane at 2^20 x 16, ~1.5
                              // rounds of the 4 waves per SIMD that are resident; measured best (one round of 86 points at 3 resident waves: 1.30 ms)
+    int host_wait_spin_us = 400; // > 0: a host wait for this context's stream polls hipStreamQuery for up to this many microseconds before it blocks (dh_stream_wait;
+                               // dehalo_ctx_set_tuning "host_wait_spin_us" / DEHALO_HOST_SPIN_US): the runtime's blocking wait wakes the thread ~15 us after the stream
+                               // drained -- five waits of a K = 11 proof: 1.73 -> 1.65 ms; waits longer than this (a k = 17 commitment) block as before, where it was measured to make no difference
     int msm_acc_block = 128; // threads per block of k_msm_accum0: 128, or 768 = one 12-wave block per CU (3 waves per SIMD; dehalo_ctx_set_tuning / DEHALO_MSM_ACC_BLOCK)
     int ntt_full_table_log = 0;    // transforms up to this size keep all N twiddles (32 B x N; one load per inter-pass twiddle), larger ones N / 2 and a
                                    // negation.  Measured equal at 23 x 2^19 with warm clocks (1.19 ms either way: the negation hides behind the load), so
@@ -229,11 +233,26 @@ inline int dh_h2d(dehalo_ctx* ctx, void* d_dst, const void* h_src, size_t bytes,
 }
 
 // device -> host into CALLER memory, behind everything queued on `s`; synchronous: the data is in h_dst when this returns
+// Host wait for a stream.  With host_wait_spin_us set the thread first polls (a transcript round trip of the prover: the few commitments of a phase come back and
+// the next phase's launches wait for the challenge hashed from them -- five to seven such waits a proof), then blocks as hipStreamSynchronize always does.
+inline hipError_t dh_stream_wait(dehalo_ctx* ctx, hipStream_t s) {
+    if (ctx->host_wait_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipErrorNotReady) return q;
+            for (int i = 0; i < 64; i++) __builtin_ia32_pause();
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= ctx->host_wait_spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(s);
+}
+
 inline int dh_d2h(dehalo_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
-    if (!bytes) { HIP_TRY(ctx, hipStreamSynchronize(s)); return 0; }
+    if (!bytes) { HIP_TRY(ctx, dh_stream_wait(ctx, s)); return 0; }
     if (bytes <= HostStage::DIRECT_MAX || dh_host_locked(h_dst, bytes)) {
         HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        HIP_TRY(ctx, dh_stream_wait(ctx, s));
         return 0;
     }
     HostStage& st = ctx->stage;

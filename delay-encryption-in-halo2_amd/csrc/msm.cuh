@@ -1058,10 +1058,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_idx, Mmax * 4));
     TRY(dh_ensure(ctx, ctx->ws_partial0, nt0_max * REC));
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
-    // (the radix-2 bucket reduction keeps its node vectors in the same two buffers: BRED_VMAX records per 256-bucket block / per cluster of 16 blocks)
-    const size_t bred_blocks = std::max<size_t>(1, g.nb / BRED_BLOCK_BUCKETS);
+    // (the radix-2 bucket reduction keeps its node vectors in the same two buffers: BRED_VMAX records per block of 128 / 256 buckets / per cluster of 16 blocks)
+    const size_t bred_blocks = std::max<size_t>(1, g.nb / BRED_BLOCK_BUCKETS_MIN);
     TRY(dh_ensure(ctx, ctx->ws_contrib, std::max<size_t>(total_groups * per_group, total_groups * bred_blocks * BRED_VMAX) * REC));
-    TRY(dh_ensure(ctx, ctx->ws_tree, std::max<size_t>(total_groups * ((per_group + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS), total_groups * 8 * BRED_VMAX) * REC));
+    TRY(dh_ensure(ctx, ctx->ws_tree, std::max<size_t>(total_groups * ((per_group + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS), total_groups * 16 * BRED_VMAX) * REC));
     if ((size_t)total_groups * BRED_CNT_PER_GROUP * 4 > ctx->ws_bred_cnt.cap) {      // cluster / group arrival counters: zero when allocated, left zero by every launch
         TRY(dh_ensure(ctx, ctx->ws_bred_cnt, (size_t)total_groups * BRED_CNT_PER_GROUP * 4));
         HIP_TRY(ctx, hipMemsetAsync(ctx->ws_bred_cnt.p, 0, ctx->ws_bred_cnt.cap, s));
@@ -1190,7 +1190,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         bool emitted = false;
         const xyzz29_rec* cur = contrib;
         if (use_bred && g.nb >= 8) {
-            const u32 nblk = std::max<u32>(1, g.nb / BRED_BLOCK_BUCKETS);
+            // buckets per block: 128 up to 2^13 buckets (the kernel alone 119 -> 107 us at 4096 buckets, 134 -> 125 at 16384, 153 -> 153 at 32768 where the third level costs
+            // what the shorter first one saves); 256 above: measured on k = 17 proofs the 128-bucket blocks -- twice as many, beside the side context's transforms -- cost
+            // 0.1 ms (profiles/r04_bred_block_buckets.txt).  DEHALO_MSM_BRED_BLOCK = 128 | 256 forces one.
+            static const u32 bred_bb_env = [] { const char* e = getenv("DEHALO_MSM_BRED_BLOCK"); const int v = e ? atoi(e) : 0; return v == 128 || v == 256 ? (u32)v : 0u; }();
+            const u32 bred_bb = bred_bb_env ? bred_bb_env : (g.nb <= 8192 ? 128u : 256u);
+            const u32 nblk = std::max<u32>(1, g.nb / bred_bb);
             const bool fin = g.G == 1;
             const size_t lds_b = dh_co_lds_pad(41 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bred<CV>, lds_b));
@@ -1200,7 +1205,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
                 HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps_on), &on, sizeof(on)));
                 HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps), init, sizeof(init)));
             }
-            k_msm_bred<CV><<<dim3(nblk, (u32)total_groups), BRED_THREADS, lds_b, s>>>(g.nb, buckets, (xyzz29_rec*)ctx->ws_contrib.p, (xyzz29_rec*)ctx->ws_tree.p, (u32*)ctx->ws_bred_cnt.p, gsums,
+            k_msm_bred<CV><<<dim3(nblk, (u32)total_groups), BRED_THREADS, lds_b, s>>>(g.nb, bred_bb, buckets, (xyzz29_rec*)ctx->ws_contrib.p, (xyzz29_rec*)ctx->ws_tree.p, (u32*)ctx->ws_bred_cnt.p, gsums,
                                                                                  fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
             emitted = fin;
             cur = gsums;

@@ -25,10 +25,11 @@
 #endif
 #define BRED_THREADS 256
 #define BRED_QUADS (BRED_THREADS / 4)
-#define BRED_BLOCK_BUCKETS 256      // 4 buckets per quad
+#define BRED_BLOCK_BUCKETS 256      // buckets of a block at most (the LDS array): 4 per quad
+#define BRED_BLOCK_BUCKETS_MIN 128  // ... and at least (sizes the node buffers); run_msm_t picks (msm_bred_block)
 #define BRED_FANIN 16               // node vectors one block combines in the second / third stage
 #define BRED_VMAX 17                // points per node vector in HBM: A_0 .. A_15, X
-#define BRED_CNT_PER_GROUP 16       // u32 counters per bucket group: clusters [0, 8), group [8]
+#define BRED_CNT_PER_GROUP 32       // u32 counters per bucket group: clusters [0, 16), group [16]
 
 // ---- quad-cooperative group operations on records in memory (LDS or HBM): record = 36 words, coordinate c at words [9 c, 9 c + 9) ----
 FP_DEV f29 q_ld(const u32* rec, u32 coord) {
@@ -170,7 +171,8 @@ FP_DEV void bred_gather(const u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C
     }
 }
 
-// One thread block per 256 buckets of a group; grid (max(1, nb / 256), total_groups).  nodes1 / nodes2: BRED_VMAX records per block / per cluster.
+// One thread block per bb (= 128 or 256) buckets of a group; grid (max(1, nb / bb), total_groups).  (128: the block's tree is 7 rounds of additions instead of 11
+// -- a level with fewer nodes than quads costs a round all the same -- for one more level further up.)  nodes1 / nodes2: BRED_VMAX records per block / per cluster.
 // counters: BRED_CNT_PER_GROUP words per group, zero on entry and left zero.  The result of group g goes to fin_out / fin_affine [g] (precomputed
 // tables: one group per MSM) or, when both are null, to gsums[g] for k_msm_final.
 // Phases of a block: 0 its 256 buckets | 1 (last block of a cluster of 16) the cluster's vectors | 2 (last cluster of the group) the clusters' vectors |
@@ -182,7 +184,7 @@ __device__ int g_bred_stamps_on;
 #define BRED_STAMP(i) do { if (stamps_on && tid == 0 && g == 0) my_stamps[i] = wall_clock64(); } while (0)
 
 template <class CV>
-__global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
+__global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
                                                           jacobian_t* fin_out, affine_t* fin_affine) {
     msm_tail_prio();
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;      // lone waves of dependent operations: the latency schedule (tools/ubench_qmem.hip: 2.9 against 3.5 us per addition, 78 VGPRs either way)
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
     u32* const vec = lds + BRED_BLOCK_BUCKETS * 36;      // 32 records: the node vector being handed on
     const u32 tid = threadIdx.x, quad = tid >> 2;
     const u32 g = blockIdx.y;
-    const u32 here = nb < BRED_BLOCK_BUCKETS ? nb : BRED_BLOCK_BUCKETS;      // buckets of a block (a power of two >= 8)
+    const u32 here = nb < bb ? nb : bb;      // buckets of a block (a power of two >= 8)
     u32 m = 0;                                                               // log2 nb
     while ((1u << m) < nb) m++;
     const bool stamps_on = DEHALO_PHASE_STAMPS && g_bred_stamps_on != 0;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
     for (u32 phase = 0; phase < 4; phase++) {
         u32 C, K, xBase, iStride;
         if (phase == 0) {          // the block's buckets -> LDS (plain records: a leaf is its own total)
-            const uint4* src = reinterpret_cast<const uint4*>(buckets + (u64)g * nb + (u64)idx * BRED_BLOCK_BUCKETS);
+            const uint4* src = reinterpret_cast<const uint4*>(buckets + (u64)g * nb + (u64)idx * bb);
             uint4* dst = reinterpret_cast<uint4*>(lds);
             for (u32 e = tid; e < here * 9; e += BRED_THREADS) dst[e] = src[e];
             C = 0; K = here; xBase = 0; iStride = 1;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, const xyzz29_
             __syncthreads();
             if (tid == 0) {
                 __threadfence();
-                u32* cnt = counters + (u64)g * BRED_CNT_PER_GROUP + (phase == 1 ? cl : 8);
+                u32* cnt = counters + (u64)g * BRED_CNT_PER_GROUP + (phase == 1 ? cl : 16);
                 const u32 old = atomicAdd(cnt, 1u);
                 s_last = old == fan - 1;
                 if (s_last) {
