@@ -72,11 +72,21 @@ const char* dehalo_last_error(const dehalo_ctx* ctx);
  * 12-wave workgroup per compute unit, three waves per SIMD, which leaves a quarter of every SIMD's registers and all of the LDS to the
  * kernels of other contexts that need at most 128 VGPRs (the bucket reduction, the merge, the NTT's half tiles).
  * "ntt_full_table_log" (default 0, in [0, 30]): transforms of up to 2^value points keep all N powers of omega on the device
- * (32 B x N) so that an inter-pass twiddle is one load; larger ones keep N / 2 and negate (measured equal on MI355X). */
+ * (32 B x N) so that an inter-pass twiddle is one load; larger ones keep N / 2 and negate (measured equal on MI355X).
+ * "host_wait_spin_us" (default 400, in [0, 1000000]; DEHALO_HOST_SPIN_US at context creation): a host wait for the context's stream
+ * (dehalo_download and the calls built on it: every transcript round trip of a proof) polls for up to this many microseconds before it
+ * blocks in the runtime, whose wake-up comes ~15 us after the stream has drained; 0: block at once (no CPU spent waiting). */
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
 /* Environment variables read by the library (measurement and tuning only; results never depend on them):
  *   DEHALO_MSM_ACC_POINTS   default of "msm_acc_points" at context creation
  *   DEHALO_MSM_ACC_BLOCK    default of "msm_acc_block" at context creation
+ *   DEHALO_HOST_SPIN_US     default of "host_wait_spin_us" at context creation
+ *   DEHALO_MSM_BRED_BLOCK   128 / 256: buckets per workgroup of the bucket reduction (default: 128 up to 2^13 buckets, 256 above)
+ *   DEHALO_MSM_SMALL_SLICES 0: sort workgroups of 2048 scalars whatever the launch size (default: down to 256 until ~128 workgroups are there)
+ *   DEHALO_MSM_BUCKET_FILL  0: k_msm_bucket workgroups of 4 slices whatever the launch size (default: fewer until every compute unit has one)
+ *   DEHALO_MSM_MERGE_Q3     1: the merge's 9..64-record class as 8 quads or 1 (the first version's choice) instead of the widest group that fits one sweep
+ *   DEHALO_MSM_BRED_STAMPS / DEHALO_MSM_MERGE_STAMPS / DEHALO_NTT_STAMPS   1: the kernel's workgroups stamp their phases with the wall clock; a report per launch on stderr (synchronises)
+ *   DEHALO_NTT_PRIO         1 / 2: workgroups of a half-tile transform pass take issue priorities by slot (experiment: flat)
  *   DEHALO_MSM_BRED         0: the round-3 bucket reduction (k_msm_reduce_local + k_msm_tree_sum launches) instead of the one-launch radix-2 recursion
  *   DEHALO_WINDOW_BITS      Pippenger window of tables registered with window_bits = 0 (4 .. 16)
  *   DEHALO_MSM_ACC_LDS      bytes of (unused) dynamic LDS per block of the bucket accumulation: caps its resident blocks per CU
