@@ -347,14 +347,25 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32*
     if (!lists) return;
     u32* counters = geo - MSM_MERGE_COUNTERS;      // the merge-class counters sit just below geo (ws_counters); zeroed by k_msm_colscan
     const u32 cls = S <= 1 ? 8u : merge2_class(S);
+    // one atomic per BLOCK and class (per wave and class, 256 blocks of a four-column 2^17 launch sent 5,000 atomics to five words: 25 us of this kernel)
+    __shared__ u32 wcnt[5][SCAN_THREADS / 64], cbase[5];
+    unsigned long long mine = 0;
     for (u32 c = 0; c < 5; c++) {
         const unsigned long long mask = __ballot(cls == c);
-        if (mask == 0) continue;
-        const u32 leader = (u32)__ffsll((long long)mask) - 1;
-        u32 base = 0;
-        if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
-        base = __shfl(base, (int)leader);
-        if (cls == c) lists[(size_t)c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = idx;
+        if (cls == c) mine = mask;
+        if (lane == 0) wcnt[c][wave] = (u32)__popcll(mask);
+    }
+    __syncthreads();
+    if (tid < 5) {
+        u32 tot = 0;
+        for (u32 w = 0; w < SCAN_THREADS / 64; w++) tot += wcnt[tid][w];
+        cbase[tid] = tot ? atomicAdd(&counters[tid], tot) : 0u;
+    }
+    __syncthreads();
+    if (cls < 5) {
+        u32 pos = cbase[cls] + (u32)__popcll(mine & ((1ull << lane) - 1));
+        for (u32 w = 0; w < wave; w++) pos += wcnt[cls][w];
+        lists[(size_t)cls * cap + pos] = idx;
     }
     if (cls == 5u) {      // rare: its own atomics
         const u32 parts = (S + MERGE2_CHUNK - 1) / MERGE2_CHUNK;
