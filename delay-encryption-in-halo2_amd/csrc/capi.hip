@@ -417,6 +417,7 @@ int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out) 
                                            : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
         if (e != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
     }
+    if (const char* e = getenv("DEHALO_MSM_ACC_MIN_LAYERS")) ctx->msm_acc_min_layers = std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("DEHALO_HOST_SPIN_US")) ctx->host_wait_spin_us = std::max(0, std::min(1000000, atoi(e)));
     if (const char* e = getenv("DEHALO_MSM_ACC_BLOCK")) ctx->msm_acc_block = atoi(e) == 768 ? 768 : 128;                                      // launch geometry only
     if (const char* e = getenv("DEHALO_MSM_ACC_POINTS")) ctx->msm_acc_points = std::max(0, std::min(4096, atoi(e)));   // launch geometry only (dehalo_ctx_set_tuning)

@@ -295,7 +295,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_msm_colscan(u32 nb, u32
 //   classes 0 .. 4: lists[class][..] = bucket;   S > MERGE2_CHUNK: list 5 holds one entry (slot, part) per part of MERGE2_CHUNK records, list 6 one entry
 //   (bucket, first part, parts, arrival counter) per such bucket.
 static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32* cnt, u32 total, const u32* bsum_items, const u32* bsum_tasks, u32 nblocks, u32* geo, u32 resident,
-                                                                      u32 lmax, u32 lcap, u32* off, u32* nrank, u32* rbeg, u32* rend, u32* lists, u32 cap) {
+                                                                      u32 lmax, u32 lcap, u32 kmin, u32* off, u32* nrank, u32* rbeg, u32* rend, u32* lists, u32 cap) {
     msm_tail_prio();
     __shared__ u32 s_i[SCAN_THREADS], s_t[SCAN_THREADS];
     __shared__ u32 w4[4][SCAN_THREADS / 64];
@@ -317,9 +317,9 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32*
     for (u32 w = 0; w < SCAN_THREADS / 64; w++) { bi += w4[0][w]; bt += w4[1][w]; ti += w4[2][w]; }
     const u64 M = ti;
     u64 L;
-    if (lcap) {   // layers of one wave per SIMD (`resident` lanes each): 4 (a full chip), 6, 8, ... until a lane has <= lcap points
-        u64 k = 4;
-        while (M > k * resident * lcap) k += 2;
+    if (lcap) {   // layers of one wave per SIMD (`resident` lanes each): kmin, ..., 4 (a full chip), 6, 8, ... until a lane has <= lcap points
+        u64 k = kmin;
+        while (M > k * resident * lcap) k += k < 4 ? 1 : 2;
         L = max((u64)4, (M + k * resident - 1) / (k * resident));
     } else {
         const u64 rounds = max((u64)1, (M + (u64)resident * lmax - 1) / ((u64)resident * lmax));
@@ -1118,7 +1118,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         u32* bs_i = (u32*)ctx->ws_bsum.p;
         u32* bs_t = bs_i + cs_a;
         k_msm_colscan<<<cs_a + cs_b, SCAN_THREADS, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc, bs_i, bs_t, merge_counters);
-        k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, off, nrank, rbeg, rend,
+        k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, (u32)ctx->msm_acc_min_layers, off, nrank, rbeg, rend,
                                                      use_merge2 ? merge_lists : nullptr, merge_cap);
         HIP_TRY(ctx, hipGetLastError());
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);

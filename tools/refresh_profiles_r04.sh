@@ -38,6 +38,10 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACT
 done
 python3 tools/sq_summary.py $out/sq_step_SQ_WAVE_CYCLES $out/sq_step_SQ_ACTIVE_INST_ANY > $out/sq_counters_step.txt
 python3 tools/sq_summary.py $out/sq_ntt_SQ_WAVE_CYCLES $out/sq_ntt_SQ_ACTIVE_INST_ANY --group-by-launch 3 > $out/ntt_sq_counters.txt
+echo "[6b] the MSM's kernels by shape, the bucket reduction's phases, a K = 11 kernel timeline"
+tools/accum_eff.sh > $out/msm_kernels_by_shape.txt 2>&1
+for k in 11 17 20; do echo "== k $k"; DEHALO_MSM_BRED_STAMPS=1 timeout -k 10 120 python tools/accum_eff.py $k 1,4 2>&1 | grep "k_msm_bred" | awk "NR%4==0"; done > $out/bred_phase_stamps.txt 2>&1
+tools/trace_k11.sh > $out/trace_k11.log 2>&1; cp gpurun_out/trace_k11/proof_timeline.txt $out/create_proof_k11_kernel_timeline.txt
 echo "[7] microbenchmarks"; timeout -k 5 100 ./tools/ubench_qmem > $out/ubench_qmem.txt 2>&1; timeout -k 10 200 python tools/ntt_bench.py > $out/ntt_bench.txt 2>/dev/null
 echo "[8] N = 2 from the bare command (two ranks on this one GPU, gloo for the gather), and the one-rank RCCL test"
 timeout -k 10 400 python3 bench.py --gpus 2 --dist-backend gloo --force-device 0 --proofs 8 > $out/bench_gpus2_bare_command.json 2> $out/bench_gpus2_bare_command.err; echo "rc=$?" >> $out/bench_gpus2_bare_command.err
