@@ -309,6 +309,30 @@ def test_msm_every_merge_class(pkg, co, ctx):
     h.release()
 
 
+@pytest.mark.parametrize("log_n, batch", [(11, 1), (11, 5), (14, 1), (14, 2), (14, 3), (14, 6), (16, 1)])
+def test_msm_small_launch_geometry_and_populous_merge_classes(pkg, co, ctx, log_n, batch):
+    """Dense columns at the sizes where the launch geometry adapts (round 4): sort blocks of 256 scalars and k_msm_bucket blocks of fewer slices for launches too small
+    to fill the chip, 128-bucket blocks in the bucket reduction up to 2^13 buckets, and the merge's 9 .. 64-record class taking 8 / 4 / 2 / 1 quads a bucket by how many
+    buckets it holds (2^14 uniform columns: ~20 partial sums in every one of 4096 buckets a column -- one column 8 quads, two 4, three 2, six 1).  Also with the
+    host-wait knob at both ends."""
+    spec = pkg.fields.BN254
+    n = 1 << log_n
+    bases = co.synth_bases(spec.id, n)
+    h = ctx.register_bases(spec.id, bases, 0, True)
+    cols = [co.fill_scalars(spec.scalar.id, "uniform", n, 300 + 7 * j + log_n) for j in range(batch)]
+    want = [co.to_affine(spec.id, co.best_multiexp(spec.id, c, bases, 8)) for c in cols]
+    for spin in (0, 400):
+        ctx.set_tuning("host_wait_spin_us", spin)
+        got = ctx.to_affine(spec.id, ctx.msm_batch(h, cols))
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    # a prefix of the registered bases (commit() of a shorter polynomial): another slice count over the same table
+    m = n - n // 3
+    got = ctx.to_affine(spec.id, ctx.msm(h, cols[0][:m]))[0]
+    assert np.array_equal(got, co.to_affine(spec.id, co.best_multiexp(spec.id, cols[0][:m], bases[:m], 8)))
+    h.release()
+
+
 @pytest.mark.parametrize("cname", ["pallas", "bn254"])
 def test_msm_full_size_2_20(pkg, co, ctx, cname):
     """BASELINE config #2: 2^20 points.  Direct comparison with the C restatement of
