@@ -20,7 +20,7 @@ SYMBOLS = [
     "dehalo_field_op", "dehalo_field_op_device", "dehalo_timing_enable", "dehalo_timing_reset", "dehalo_timing_get",
     "dehalo_eval_polynomial", "dehalo_eval_polynomial_device", "dehalo_eval_polynomial_multi_device", "dehalo_eval_polynomial_multi_masked_device", "dehalo_batch_invert", "dehalo_batch_invert_device",
     "dehalo_prefix_product_device", "dehalo_grand_product", "dehalo_grand_product_device", "dehalo_grand_product_batch_device",
-    "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device", "dehalo_permute_expression_pair_ptrs_device", "dehalo_permute_expression_pair_ptrs_deferred_device",
+    "dehalo_permute_expression_pair", "dehalo_permute_expression_pair_device", "dehalo_permute_expression_pair_batch_device", "dehalo_permute_expression_pair_ptrs_device", "dehalo_permute_expression_pair_distinct_device", "dehalo_permute_expression_pair_ptrs_deferred_device",
     "dehalo_convert_form_device", "dehalo_coset_ntt_form_device", "dehalo_coset_intt_form_device",
     "dehalo_lincomb_device", "dehalo_scale_device", "dehalo_kate_division", "dehalo_kate_division_device", "dehalo_kate_division_batch_device",
     "dehalo_params_create", "dehalo_params_setup", "dehalo_bases_register_device", "dehalo_params_read", "dehalo_params_size", "dehalo_params_write", "dehalo_params_release", "dehalo_params_commit_device",
@@ -185,6 +185,9 @@ def load_library():
     lib.dehalo_permute_expression_pair_batch_device.argtypes = [P, C.c_int, u64p, u64p, sz, sz, sz, u64p, u64p, P]
     if hasattr(lib, "dehalo_permute_expression_pair_ptrs_deferred_device"):
         lib.dehalo_permute_expression_pair_ptrs_deferred_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), sz, sz, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), P, P]
+    if hasattr(lib, "dehalo_permute_expression_pair_distinct_device"):
+        lib.dehalo_permute_expression_pair_distinct_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), sz, sz, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), P, P]
     if hasattr(lib, "dehalo_permute_expression_pair_ptrs_device"):      # (absent from an older build loaded through DEHALO_LIBRARY)
         lib.dehalo_permute_expression_pair_ptrs_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), sz, sz, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), P]
     lib.dehalo_lincomb_device.argtypes = [P, C.c_int, C.POINTER(C.c_void_p), u64p, sz, sz, u64p, u64p, P]
@@ -586,6 +589,15 @@ class Context:
         arr = lambda xs: (C.c_void_p * max(1, len(xs)))(*xs)
         self._check(self.lib.dehalo_permute_expression_pair_ptrs_deferred_device(self.handle, field, arr(d_inputs), arr(d_tables), usable_rows, len(d_inputs), arr(d_permuted_inputs),
                                                                                  arr(d_permuted_tables), d_status, stream or None))
+
+    def permute_expression_pair_distinct_device(self, field: int, d_inputs: Sequence[int], d_tables: Sequence[int], usable_rows: int, d_permuted_inputs: Sequence[int],
+                                                d_permuted_tables: Sequence[int], d_rep_rows: Sequence[int], d_multiplicities: Sequence[int], distinct_counts: Sequence[int],
+                                                d_status: int = 0, stream: int = 0):
+        """tables of fixed columns given as distinct rows: per lookup a device array of representative row indices, one of multiplicities (uint32 each) and their number"""
+        arr = lambda xs: (C.c_void_p * max(1, len(xs)))(*xs)
+        cnt = (C.c_uint32 * max(1, len(distinct_counts)))(*distinct_counts)
+        self._check(self.lib.dehalo_permute_expression_pair_distinct_device(self.handle, field, arr(d_inputs), arr(d_tables), usable_rows, len(d_inputs), arr(d_permuted_inputs),
+                                                                            arr(d_permuted_tables), arr(d_rep_rows), arr(d_multiplicities), cnt, d_status or None, stream or None))
 
     def permute_expression_pair_device(self, field: int, d_input: int, d_table: int, usable_rows: int, d_permuted_input: int, d_permuted_table: int, stream: int = 0):
         self._check(self.lib.dehalo_permute_expression_pair_device(self.handle, field, d_input, d_table, usable_rows, d_permuted_input, d_permuted_table, stream or None))

@@ -1035,18 +1035,18 @@ int dehalo_permute_expression_pair_batch_device(dehalo_ctx* ctx, int field, cons
 }
 
 static int permute_ptrs(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
-                        uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int* d_status, void* stream);
+                        uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int* d_status, void* stream, const LookupDistinct* distinct);
 int dehalo_permute_expression_pair_ptrs_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
                                                uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, void* stream) {
-    return permute_ptrs(ctx, field, d_inputs, d_tables, usable_rows, batch, d_permuted_inputs, d_permuted_tables, nullptr, stream);
+    return permute_ptrs(ctx, field, d_inputs, d_tables, usable_rows, batch, d_permuted_inputs, d_permuted_tables, nullptr, stream, nullptr);
 }
 int dehalo_permute_expression_pair_ptrs_deferred_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows,
                                                         size_t batch, uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int32_t* d_status, void* stream) {
     if (ctx && !d_status && batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null status array");
-    return permute_ptrs(ctx, field, d_inputs, d_tables, usable_rows, batch, d_permuted_inputs, d_permuted_tables, (int*)d_status, stream);
+    return permute_ptrs(ctx, field, d_inputs, d_tables, usable_rows, batch, d_permuted_inputs, d_permuted_tables, (int*)d_status, stream, nullptr);
 }
 static int permute_ptrs(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
-                        uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int* d_status, void* stream) {
+                        uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int* d_status, void* stream, const LookupDistinct* distinct) {
     if (!ctx) return DEHALO_ERR_INVALID;
     if ((!d_inputs || !d_tables || !d_permuted_inputs || !d_permuted_tables) && batch) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: null argument");
     if (batch >= 4096) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair: batch too large");
@@ -1060,7 +1060,22 @@ static int permute_ptrs(dehalo_ctx* ctx, int field, const uint64_t* const* d_inp
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return lookup_permute_ptrs(ctx, field, (const fe* const*)d_inputs, (const fe* const*)d_tables, usable_rows, batch, (fe* const*)d_permuted_inputs, (fe* const*)d_permuted_tables,
-                               pick_stream(ctx, stream), d_status);
+                               pick_stream(ctx, stream), d_status, distinct);
+}
+int dehalo_permute_expression_pair_distinct_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
+                                                   uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, const uint32_t* const* d_rep_rows,
+                                                   const uint32_t* const* d_multiplicities, const uint32_t* distinct_count, int32_t* d_status, void* stream) {
+    if (ctx && batch && (!d_rep_rows || !d_multiplicities || !distinct_count)) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair_distinct: null argument");
+    std::vector<LookupDistinct> dist(batch);
+    for (size_t y = 0; y < batch; y++) {
+        dist[y] = LookupDistinct{d_rep_rows[y], d_multiplicities[y], distinct_count[y]};
+        if (distinct_count[y] && (!d_rep_rows[y] || !d_multiplicities[y])) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair_distinct: null distinct-row array");
+        if (distinct_count[y] > usable_rows) return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair_distinct: more distinct rows than usable rows");
+        for (size_t z = 0; z < y; z++)      // lookups of one table must describe it alike
+            if (d_tables && d_tables[z] == d_tables[y] && (d_rep_rows[z] != d_rep_rows[y] || d_multiplicities[z] != d_multiplicities[y] || distinct_count[z] != distinct_count[y]))
+                return dh_fail(ctx, DEHALO_ERR_INVALID, "permute_expression_pair_distinct: lookups that share a table must pass the same distinct-row arrays");
+    }
+    return permute_ptrs(ctx, field, d_inputs, d_tables, usable_rows, batch, d_permuted_inputs, d_permuted_tables, (int*)d_status, stream, dist.data());
 }
 
 int dehalo_permute_expression_pair_device(dehalo_ctx* ctx, int field, const uint64_t* d_input, const uint64_t* d_table, size_t usable_rows,

@@ -379,8 +379,11 @@ DECL_POLY(pasta_fq)
 int lookup_permute_impl(dehalo_ctx* ctx, int field, const fe* d_inputs, const fe* d_tables, uint64_t n, size_t batch, uint64_t stride, fe* d_out_inputs,
                         fe* d_out_tables, hipStream_t s);
 
+// per lookup of a call (null array: none): its table as distinct rows -- representative row indices and multiplicities on the device, their number (0 or more
+// than 2048: the general path); lookups that share a table carry the same arrays
+struct LookupDistinct { const uint32_t* d_rep_rows; const uint32_t* d_mult; uint32_t count; };
 int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, const fe* const* d_tables, uint64_t n, size_t batch, fe* const* d_out_inputs,
-                        fe* const* d_out_tables, hipStream_t s, int* d_status = nullptr);
+                        fe* const* d_out_tables, hipStream_t s, int* d_status = nullptr, const LookupDistinct* distinct = nullptr);
 
 // quotient-numerator kernels (evalh.cuh)
 struct dehalo_graph;

@@ -17,6 +17,12 @@
 // position by binary search (a miss is the error), positions are counted, and A' / S' are WRITTEN from the counts -- A' is the sorted
 // table with every entry repeated as often as it was looked up, S' the first occurrences plus the unused entries from the end.
 // Everything is hand-written here (round 3 replaced the rocPRIM radix sort and scans this file used to call).
+//
+// Tables of fixed columns (round 4): when every table expression of a lookup reads fixed columns only, WHICH rows of the table are equal does not depend on
+// theta -- only the order of the compressed values does.  The prover hands over, per table, one representative row of every distinct tuple and its
+// multiplicity (computed once per proving key: the range tables of the delay-encryption circuit have 339 distinct rows among 131,066).  Then only the
+// distinct keys are sorted -- one LDS tile instead of 64 tiles and six merge passes --, the full sorted table is written out from (key, multiplicity) and the
+// inputs search the distinct keys.  Same A' and S' (tests/test_gpu_parity.py compares both paths with the CPU restatement).
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,6 +44,9 @@ struct LpCols {      // per lookup: its input column, its outputs, which sorted 
     fe* out_tab[LP_MAX_BATCH];
     const fe* tab[LP_MAX_BATCH];      // distinct tables
     u32 table_of[LP_MAX_BATCH];
+    const u32* rep[LP_MAX_BATCH];     // per distinct table, or null: a representative row of every distinct tuple (< LP_TILE of them) ...
+    const u32* mult[LP_MAX_BATCH];    // ... and how many of the usable rows hold it
+    u32 ndist[LP_MAX_BATCH];
 };
 
 FP_DEV int lp_cmp(const fe& a, const fe& b) {          // canonical integers, most significant word first
@@ -191,6 +200,159 @@ __global__ void __launch_bounds__(LP_MERGE_THREADS) k_lp_merge(const fe* in, fe*
             if (hb) kb = key(na + bi);
         }
     }
+}
+
+// ---- tables given as distinct rows + multiplicities -------------------------------------------------------------------------------------
+// canonical keys of the distinct rows of table t, one tile per table, padded with +infinity
+template <class F>
+__global__ void k_lp_distinct_keys(LpCols c, fe* keys) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (i >= LP_TILE) return;
+    fe k;
+    if (i < c.ndist[t]) k = f_from_mont<F>(f_load(&c.tab[t][c.rep[t][i]]));
+    else {
+#pragma unroll
+        for (int w = 0; w < 8; w++) k.v[w] = 0xFFFFFFFFu;
+    }
+    f_store(&keys[(u64)t * LP_TILE + i], k);
+}
+FP_DEV u32 lp_lower_bound_tile(const fe* T, const fe& a) {      // first index in the sorted tile with T[index] >= a (the +infinity padding is above every value)
+    u32 lo = 0;
+    for (u32 len = LP_TILE; len > 1;) {
+        const u32 half = len >> 1;
+        if (lp_cmp(f_load(&T[lo + half - 1]), a) < 0) lo += half;
+        len -= half;
+    }
+    if (lp_cmp(f_load(&T[lo]), a) < 0) lo++;
+    return lo;
+}
+// one block per table: the multiplicity of every SORTED distinct key (a tuple finds its key's first position; tuples whose compressed values coincide add up
+// there, as equal values of the multiset do) and its exclusive scan = the key's first position in the full sorted table: dstart[t][0 .. LP_TILE]
+template <class F>
+__global__ void __launch_bounds__(1024) k_lp_distinct_starts(LpCols c, const fe* dsorted, u32* dstart) {
+    __shared__ u32 sm[LP_TILE], part[1024];
+    const u32 t = blockIdx.x, tid = threadIdx.x;
+    const fe* T = dsorted + (u64)t * LP_TILE;
+    for (u32 i = tid; i < LP_TILE; i += 1024) sm[i] = 0;
+    __syncthreads();
+    for (u32 d = tid; d < c.ndist[t]; d += 1024) {
+        const fe key = f_from_mont<F>(f_load(&c.tab[t][c.rep[t][d]]));
+        atomicAdd(&sm[lp_lower_bound_tile(T, key)], c.mult[t][d]);
+    }
+    __syncthreads();
+    constexpr u32 PER = LP_TILE / 1024;
+    u32 v[PER], sum = 0;
+    for (u32 k = 0; k < PER; k++) { v[k] = sm[tid * PER + k]; sum += v[k]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        const u32 a = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += a;
+        __syncthreads();
+    }
+    u32 run = part[tid] - sum;
+    for (u32 k = 0; k < PER; k++) { dstart[(u64)t * (LP_TILE + 1) + tid * PER + k] = run; run += v[k]; }
+    if (tid == 1023) dstart[(u64)t * (LP_TILE + 1) + LP_TILE] = run;
+}
+// Every input value's distinct key: counted, cnt[y][position among the sorted distinct keys].  The block keeps the table's sorted distinct keys in LDS (64 KB:
+// eleven search steps on LDS words instead of seventeen on 32-byte loads from a 4 MB table) and a histogram of its 2048 inputs; a wave whose 64 inputs are
+// one value (the zero rows of an unused region) counts once.
+template <class F>
+__global__ void __launch_bounds__(LP_SORT_THREADS) k_lp_rank_distinct(LpCols c, const fe* dsorted, u64 n, u32* cnt, int* err) {
+    extern __shared__ u32 lds[];                      // [8 planes of LP_TILE key words | LP_TILE counters]
+    u32* hist = lds + 8 * LP_TILE;
+    constexpr u32 RP = LP_TILE / LP_SORT_THREADS;     // 2 inputs per thread
+    const u32 y = blockIdx.y, t = c.table_of[y], nd = c.ndist[t];
+    const fe* T = dsorted + (u64)t * LP_TILE;
+    for (u32 i = threadIdx.x; i < LP_TILE; i += LP_SORT_THREADS) { lds_put(lds, i, f_load(&T[i])); hist[i] = 0; }
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * LP_TILE;
+    bool miss = false;
+    for (u32 k = 0; k < RP; k++) {
+        const u64 i = base + threadIdx.x + k * LP_SORT_THREADS;
+        const bool have = i < n;
+        u32 lo = 0;
+        if (have) {
+            const fe a = f_from_mont<F>(f_load(&c.in[y][i]));
+            for (u32 len = LP_TILE; len > 1;) {       // lower bound among the tile's keys (the +infinity padding is above every value)
+                const u32 half = len >> 1;
+                if (lp_cmp(lds_key(lds, lo + half - 1), a) < 0) lo += half;
+                len -= half;
+            }
+            if (lp_cmp(lds_key(lds, lo), a) < 0) lo++;
+            if (lo >= nd || lp_cmp(lds_key(lds, lo), a) != 0) { miss = true; lo = 0xFFFFFFFFu; }
+        } else lo = 0xFFFFFFFFu;
+        const bool count = lo != 0xFFFFFFFFu;
+        const unsigned long long act = __ballot(count);
+        if (act && __ballot(count && lo != (u32)__builtin_amdgcn_readfirstlane((int)lo)) == 0 && (act & 1ull)) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&hist[lo], (u32)__popcll(act));
+        } else if (count) atomicAdd(&hist[lo], 1u);
+    }
+    if (miss) atomicExch(&err[y], 1);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nd; i += LP_SORT_THREADS)
+        if (hist[i]) atomicAdd(&cnt[(u64)y * LP_TILE + i], hist[i]);
+}
+// one block per lookup, over the <= LP_TILE sorted distinct keys p of its table: exclusive scans of the looked-up counts (-> rowstart[p], the first output row
+// of key p), of "looked up at all" (-> usedbefore[p]: first-occurrence rows before key p's) and of the leftover copies  multiplicity - looked up at all
+// (-> leftstart[p]: the key's rank among the leftovers, ascending).  Each array has LP_TILE + 1 entries (the last: the total).
+__global__ void __launch_bounds__(1024) k_lp_scan_distinct(LpCols c, const u32* cnt, const u32* dstart, u32* rowstart, u32* usedbefore, u32* leftstart) {
+    __shared__ u32 part[3][1024];
+    constexpr u32 PER = LP_TILE / 1024;
+    const u32 y = blockIdx.x, t = c.table_of[y], tid = threadIdx.x;
+    u32 v[3][PER], sum[3] = {0, 0, 0};
+    for (u32 k = 0; k < PER; k++) {
+        const u32 p = tid * PER + k;
+        const u32 cn = cnt[(u64)y * LP_TILE + p], mult = dstart[(u64)t * (LP_TILE + 1) + p + 1] - dstart[(u64)t * (LP_TILE + 1) + p];
+        v[0][k] = cn; v[1][k] = cn ? 1u : 0u; v[2][k] = mult - (cn ? 1u : 0u);
+        for (int a = 0; a < 3; a++) sum[a] += v[a][k];
+    }
+    for (int a = 0; a < 3; a++) part[a][tid] = sum[a];
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        u32 x[3];
+        for (int a = 0; a < 3; a++) x[a] = tid >= d ? part[a][tid - d] : 0;
+        __syncthreads();
+        for (int a = 0; a < 3; a++) part[a][tid] += x[a];
+        __syncthreads();
+    }
+    u32* out[3] = {rowstart + (u64)y * (LP_TILE + 1), usedbefore + (u64)y * (LP_TILE + 1), leftstart + (u64)y * (LP_TILE + 1)};
+    for (int a = 0; a < 3; a++) {
+        u32 run = part[a][tid] - sum[a];
+        for (u32 k = 0; k < PER; k++) { out[a][tid * PER + k] = run; run += v[a][k]; }
+        if (tid == 1023) out[a][LP_TILE] = run;
+    }
+}
+FP_DEV u32 lp_last_le_lds(const u32* a, u32 x) {      // the last index in [0, LP_TILE) with a[index] <= x (a non-decreasing, a[0] = 0)
+    u32 lo = 0, hi = LP_TILE;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+// output row i of lookup y: A'[i] = the key p whose rows [rowstart[p], rowstart[p + 1]) hold i; on the key's first row S' = A'; otherwise the row is the r-th
+// repeated one, r = i - (first-occurrence rows up to i), and takes the (m - 1 - r)-th leftover, ascending (m = leftovers = repeated rows).
+template <class F>
+__global__ void __launch_bounds__(256) k_lp_emit_distinct(LpCols c, const fe* dsorted, u64 n, const u32* rowstart, const u32* usedbefore, const u32* leftstart, const int* err) {
+    __shared__ u32 rs[LP_TILE + 1], ls[LP_TILE + 1];
+    const u32 y = blockIdx.y;
+    if (err[y]) return;                                   // a missing input value: the call fails, nothing meaningful to write
+    for (u32 i = threadIdx.x; i <= LP_TILE; i += 256) { rs[i] = rowstart[(u64)y * (LP_TILE + 1) + i]; ls[i] = leftstart[(u64)y * (LP_TILE + 1) + i]; }
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const fe* T = dsorted + (u64)c.table_of[y] * LP_TILE;
+    const u32 p = lp_last_le_lds(rs, (u32)i);
+    const fe a = f_to_mont<F>(f_load(&T[p]));
+    f_store(&c.out_in[y][i], a);
+    if (rs[p] == (u32)i) {
+        f_store(&c.out_tab[y][i], a);
+        return;
+    }
+    const u32 r = (u32)i - (usedbefore[(u64)y * (LP_TILE + 1) + p] + 1), m = ls[LP_TILE];
+    f_store(&c.out_tab[y][i], f_to_mont<F>(f_load(&T[lp_last_le_lds(ls, m - 1 - r)])));
 }
 
 // Every input value's position in its sorted table (first copy): counted.  A tile's positions are sorted in LDS and run-length encoded,
@@ -401,35 +563,59 @@ template <class F>
 int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s, int* d_status) {
     const u64 tiles = (n + LP_TILE - 1) / LP_TILE, npad = tiles * LP_TILE;
     const size_t pad = 256;
-    const size_t bytes = 2 * ((size_t)U * npad * sizeof(fe) + pad) + 4 * ((size_t)B * n * 4 + pad) + ((size_t)B * tiles * 8 + pad) + 2 * ((size_t)B * 8 + pad) + 4096;
+    const size_t bytes = 2 * ((size_t)U * npad * sizeof(fe) + pad) + 4 * ((size_t)B * std::max<size_t>(n, LP_TILE + 1) * 4 + pad) + ((size_t)B * tiles * 8 + pad) + 2 * ((size_t)B * 8 + pad) + 4096 +
+                         2 * ((size_t)U * LP_TILE * sizeof(fe) + pad) + ((size_t)U * (LP_TILE + 1) * 4 + pad);
     TRY(dh_ensure(ctx, ctx->ws_lookup, bytes));
     char* p = (char*)ctx->ws_lookup.p;
     auto take = [&](size_t b) { char* r = p; p += (b + 255) & ~(size_t)255; return r; };
     fe* k0 = (fe*)take((size_t)U * npad * sizeof(fe));
     fe* k1 = (fe*)take((size_t)U * npad * sizeof(fe));
-    u32* cnt = (u32*)take((size_t)B * n * 4);
-    u32* used_start = (u32*)take((size_t)B * n * 4);
-    u32* used_idx = (u32*)take((size_t)B * n * 4);
-    u32* lsrc = (u32*)take((size_t)B * n * 4);
+    const size_t per_lookup = std::max<size_t>(n, LP_TILE + 1);      // (the distinct-rows path keeps LP_TILE + 1 words per lookup in these, whatever n is)
+    u32* cnt = (u32*)take((size_t)B * per_lookup * 4);
+    u32* used_start = (u32*)take((size_t)B * per_lookup * 4);
+    u32* used_idx = (u32*)take((size_t)B * per_lookup * 4);
+    u32* lsrc = (u32*)take((size_t)B * per_lookup * 4);
     u32* tile_sums = (u32*)take((size_t)B * tiles * 8);
     u32* totals = (u32*)take((size_t)B * 8);
     int* err = (int*)take((size_t)B * 4);
+    fe* dk0 = (fe*)take((size_t)U * LP_TILE * sizeof(fe));
+    fe* dk1 = (fe*)take((size_t)U * LP_TILE * sizeof(fe));
+    u32* dstart = (u32*)take((size_t)U * (LP_TILE + 1) * 4);
     const int lds_keys = LP_TILE * 32;
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_lp_tile_sort, lds_keys));
-    k_lp_canon_tables<F><<<dim3((u32)((npad + 255) / 256), U), 256, 0, s>>>(c, n, npad, k0);
-    k_lp_tile_sort<<<dim3((u32)tiles, U), LP_SORT_THREADS, lds_keys, s>>>(k0, k1, npad);
-    fe *src = k1, *dst = k0;
-    for (u64 run = LP_TILE; run < npad; run <<= 1) {
-        k_lp_merge<<<dim3((u32)(npad / LP_MERGE_OUT), U), LP_MERGE_THREADS, 0, s>>>(src, dst, npad, run);
-        std::swap(src, dst);
-    }
-    HIP_TRY(ctx, hipMemsetAsync(cnt, 0, (size_t)B * n * 4, s));
+    bool distinct = true;
+    for (u32 t = 0; t < U; t++) distinct = distinct && c.rep[t] && c.mult[t] && c.ndist[t] > 0 && c.ndist[t] <= LP_TILE;
     HIP_TRY(ctx, hipMemsetAsync(err, 0, (size_t)B * 4, s));
-    k_lp_rank<F><<<dim3((u32)tiles, B), LP_SORT_THREADS, 0, s>>>(c, src, n, npad, cnt, err);
-    k_lp_scan_tiles<<<dim3((u32)tiles, B), LP_THREADS, 0, s>>>(cnt, n, (u32)tiles, tile_sums);
-    k_lp_scan_top<<<B, 1024, 0, s>>>(tile_sums, (u32)tiles, totals);
-    k_lp_scan_apply<<<dim3((u32)tiles, B), LP_THREADS, 0, s>>>(cnt, n, (u32)tiles, tile_sums, used_start, used_idx, lsrc);
-    k_lp_emit<F><<<dim3((u32)((n + 255) / 256), B), 256, 0, s>>>(c, src, n, npad, used_start, used_idx, lsrc, totals);
+    if (distinct) {
+        // tables given as distinct rows: everything after the (one-tile) sort runs over the <= LP_TILE distinct keys instead of the n table positions
+        u32* dcnt = cnt;                                   // [B][LP_TILE]
+        u32* rowstart = used_start;                        // [B][LP_TILE + 1] each (the buffers hold max(n, LP_TILE + 1) words per lookup)
+        u32* usedbefore = used_idx;
+        u32* leftstart = lsrc;
+        const int lds_rank = LP_TILE * 32 + LP_TILE * 4;
+        HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_lp_rank_distinct<F>, lds_rank));
+        k_lp_distinct_keys<F><<<dim3(LP_TILE / 256, U), 256, 0, s>>>(c, dk0);
+        k_lp_tile_sort<<<dim3(1, U), LP_SORT_THREADS, lds_keys, s>>>(dk0, dk1, LP_TILE);
+        k_lp_distinct_starts<F><<<U, 1024, 0, s>>>(c, dk1, dstart);
+        HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, (size_t)B * LP_TILE * 4, s));
+        k_lp_rank_distinct<F><<<dim3((u32)tiles, B), LP_SORT_THREADS, lds_rank, s>>>(c, dk1, n, dcnt, err);
+        k_lp_scan_distinct<<<B, 1024, 0, s>>>(c, dcnt, dstart, rowstart, usedbefore, leftstart);
+        k_lp_emit_distinct<F><<<dim3((u32)((n + 255) / 256), B), 256, 0, s>>>(c, dk1, n, rowstart, usedbefore, leftstart, err);
+    } else {
+        fe *src = k1, *dst = k0;
+        k_lp_canon_tables<F><<<dim3((u32)((npad + 255) / 256), U), 256, 0, s>>>(c, n, npad, k0);
+        k_lp_tile_sort<<<dim3((u32)tiles, U), LP_SORT_THREADS, lds_keys, s>>>(k0, k1, npad);
+        for (u64 run = LP_TILE; run < npad; run <<= 1) {
+            k_lp_merge<<<dim3((u32)(npad / LP_MERGE_OUT), U), LP_MERGE_THREADS, 0, s>>>(src, dst, npad, run);
+            std::swap(src, dst);
+        }
+        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, (size_t)B * n * 4, s));
+        k_lp_rank<F><<<dim3((u32)tiles, B), LP_SORT_THREADS, 0, s>>>(c, src, n, npad, cnt, err);
+        k_lp_scan_tiles<<<dim3((u32)tiles, B), LP_THREADS, 0, s>>>(cnt, n, (u32)tiles, tile_sums);
+        k_lp_scan_top<<<B, 1024, 0, s>>>(tile_sums, (u32)tiles, totals);
+        k_lp_scan_apply<<<dim3((u32)tiles, B), LP_THREADS, 0, s>>>(cnt, n, (u32)tiles, tile_sums, used_start, used_idx, lsrc);
+        k_lp_emit<F><<<dim3((u32)((n + 255) / 256), B), 256, 0, s>>>(c, src, n, npad, used_start, used_idx, lsrc, totals);
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (d_status) {      // deferred: the flags stay on the device for the caller to read with whatever it reads back next; no synchronisation here
         HIP_TRY(ctx, hipMemcpyAsync(d_status, err, B * sizeof(int), hipMemcpyDeviceToDevice, s));
@@ -448,7 +634,7 @@ int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s,
 
 // `batch` lookups at once, given as pointer lists: lookups whose table pointers are equal share one sort.
 int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, const fe* const* d_tables, uint64_t n, size_t batch, fe* const* d_out_inputs,
-                        fe* const* d_out_tables, hipStream_t s, int* d_status) {
+                        fe* const* d_out_tables, hipStream_t s, int* d_status, const LookupDistinct* distinct) {
     if (n == 0 || batch == 0) {
         if (d_status && batch) HIP_TRY(ctx, hipMemsetAsync(d_status, 0, batch * sizeof(int), s));
         return 0;
@@ -465,7 +651,10 @@ int lookup_permute_ptrs(dehalo_ctx* ctx, int field, const fe* const* d_inputs, c
             c.out_tab[y] = d_out_tables[first + y];
             u32 t = 0;
             while (t < U && c.tab[t] != d_tables[first + y]) t++;
-            if (t == U) c.tab[U++] = d_tables[first + y];
+            if (t == U) {
+                if (distinct) { c.rep[U] = distinct[first + y].d_rep_rows; c.mult[U] = distinct[first + y].d_mult; c.ndist[U] = distinct[first + y].count; }
+                c.tab[U++] = d_tables[first + y];
+            }
             c.table_of[y] = t;
         }
         int rc;

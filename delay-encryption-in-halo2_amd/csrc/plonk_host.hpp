@@ -94,6 +94,24 @@ struct HostCS {
             default: return expr_equal(x.a, y.a) && expr_equal(x.b, y.b);
         }
     }
+    bool expr_fixed_only(uint32_t i) const {      // no advice / instance query anywhere below: the expression's values belong to the proving key
+        const dehalo_expr_node& e = nodes[i];
+        switch (e.kind) {
+            case DEHALO_EXPR_CONSTANT: case DEHALO_EXPR_FIXED: return true;
+            case DEHALO_EXPR_ADVICE: case DEHALO_EXPR_INSTANCE: return false;
+            case DEHALO_EXPR_NEGATED: case DEHALO_EXPR_SCALED: return expr_fixed_only(e.a);
+            default: return expr_fixed_only(e.a) && expr_fixed_only(e.b);
+        }
+    }
+    void expr_fixed_columns(uint32_t i, std::vector<uint32_t>& out) const {      // the fixed columns an expression reads
+        const dehalo_expr_node& e = nodes[i];
+        switch (e.kind) {
+            case DEHALO_EXPR_FIXED: if (std::find(out.begin(), out.end(), e.a) == out.end()) out.push_back(e.a); break;
+            case DEHALO_EXPR_NEGATED: case DEHALO_EXPR_SCALED: expr_fixed_columns(e.a, out); break;
+            case DEHALO_EXPR_SUM: case DEHALO_EXPR_PRODUCT: expr_fixed_columns(e.a, out); expr_fixed_columns(e.b, out); break;
+            default: break;
+        }
+    }
     // the first lookup whose table expressions equal lookup l's (l itself if none before it): their theta-compressed table columns are
     // the same column, computed and sorted once
     uint32_t table_representative(uint32_t l) const {

@@ -13,6 +13,7 @@
 #include <functional>
 #include <memory>
 #include <thread>
+#include <unordered_map>
 
 #include "blake2b.hpp"
 #include "hostrng.hpp"
@@ -731,6 +732,10 @@ struct dehalo_prover {
     fe* polys = nullptr;      // coefficient forms: polys_own with a side context, cols (in place) without
     std::vector<std::pair<dehalo_graph*, dehalo_graph*>> perm_graphs;      // per set: (denominator, numerator)
     std::vector<uint32_t> table_rep;      // per lookup: the first lookup with the same table expressions (shares its compressed table)
+    // tables of fixed columns as distinct rows (lookup_permute.hip): per representative lookup one row index per distinct tuple of its table expressions' values over
+    // the usable rows and the tuple's multiplicity, on the device; count 0: not such a table, or more distinct rows than the permutation's one-tile path takes
+    struct TableRows { uint32_t* d_rep = nullptr; uint32_t* d_mult = nullptr; uint32_t count = 0; };
+    std::vector<TableRows> table_rows;
     dehalo_graph *lookup_den = nullptr, *lookup_num = nullptr;
     hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_inst = nullptr, ev_side = nullptr;      // ev_ready: one per commitment phase
     hipEvent_t ev_helper = nullptr;      // the helper thread waits for ITS work on the side stream through this event: a hipStreamSynchronize there holds the
@@ -771,6 +776,10 @@ struct dehalo_prover {
         if (rand_pin) (void)hipHostFree(rand_pin);
         if (adv_pin) (void)hipHostFree(adv_pin);
         if (hs) (void)hipStreamDestroy(hs);
+        for (auto& t : table_rows) {
+            if (t.d_rep) (void)hipFree(t.d_rep);
+            if (t.d_mult) (void)hipFree(t.d_mult);
+        }
     }
 
     const uint64_t* col_ptr(const DevMem& mem, size_t col, size_t len) const { return (const uint64_t*)mem.at(col * len); }
@@ -937,6 +946,7 @@ struct dehalo_prover {
         TRY(omega_powers(ctx, d, omega_col.p));
         table_rep.clear();
         for (uint32_t l = 0; l < L; l++) table_rep.push_back(cs.table_representative(l));
+        TRY(find_table_rows());
         TRY(build_product_graphs());
         TRY(opening_plan());
         TRY(evals.alloc(ctx, eval_count + 8));
@@ -948,6 +958,66 @@ struct dehalo_prover {
         host_jac.resize(12 * (size_t)std::max<uint32_t>(NC, 8) + 8 + L);
         host_evals.resize(4 * eval_count);
         TRY(dehalo_ctx_synchronize(ctx));
+        return 0;
+    }
+
+    // Which rows of a lookup table are equal does not depend on theta when its expressions read fixed columns only: evaluate them once, on the host, over the usable
+    // rows and keep one representative row per distinct tuple + its multiplicity (the delay-encryption circuit's (tag, value) range table: 339 tuples in 131,066 rows).
+    Fe eval_fixed_expr(uint32_t node, size_t row, const std::vector<std::vector<Fe>>& colv) const {
+        const HostCS& cs = pk->cs;
+        const dehalo_expr_node& e = cs.nodes[node];
+        switch (e.kind) {
+            case DEHALO_EXPR_CONSTANT: return cs.constants[e.a];
+            case DEHALO_EXPR_FIXED: return colv[e.a][(size_t)(((int64_t)row + e.rotation) % (int64_t)n + (int64_t)n) % n];
+            case DEHALO_EXPR_NEGATED: return f->neg(eval_fixed_expr(e.a, row, colv));
+            case DEHALO_EXPR_SCALED: return f->mul(eval_fixed_expr(e.a, row, colv), cs.constants[e.b]);
+            case DEHALO_EXPR_SUM: return f->add(eval_fixed_expr(e.a, row, colv), eval_fixed_expr(e.b, row, colv));
+            default: return f->mul(eval_fixed_expr(e.a, row, colv), eval_fixed_expr(e.b, row, colv));
+        }
+    }
+    int find_table_rows() {
+        const HostCS& cs = pk->cs;
+        table_rows.assign(L, TableRows{});
+        static const bool enabled = [] { const char* e = getenv("DEHALO_PROVER_TABLE_ROWS"); return !(e && e[0] == '0'); }();      // (0: every table sorted in full, for the A/B)
+        if (!enabled) return 0;
+        std::vector<std::vector<Fe>> colv(cs.num_fixed);
+        for (uint32_t l = 0; l < L; l++) {
+            if (table_rep[l] != l) continue;
+            bool fixed_only = true;
+            std::vector<uint32_t> need;
+            for (uint32_t e : cs.lookups[l].tables) { fixed_only = fixed_only && cs.expr_fixed_only(e); cs.expr_fixed_columns(e, need); }
+            if (!fixed_only) continue;
+            for (uint32_t c : need)
+                if (colv[c].empty()) {
+                    colv[c].resize(n);
+                    TRY(dehalo_download(ctx, pk->fixed_values.at((size_t)c * n), n * 32, colv[c].data()));
+                }
+            const size_t T = cs.lookups[l].tables.size();
+            struct Key { std::vector<uint64_t> w; bool operator==(const Key& o) const { return w == o.w; } };
+            struct Hash { size_t operator()(const Key& k) const { uint64_t h = 0x9e3779b97f4a7c15ull; for (uint64_t x : k.w) { h ^= x + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); } return (size_t)h; } };
+            std::unordered_map<Key, uint32_t, Hash> seen;
+            std::vector<uint32_t> rep, mult;
+            bool too_many = false;
+            Key key;
+            key.w.resize(4 * T);
+            for (size_t i = 0; i < u && !too_many; i++) {
+                for (size_t t = 0; t < T; t++) {
+                    const Fe v = eval_fixed_expr(cs.lookups[l].tables[t], i, colv);
+                    memcpy(&key.w[4 * t], v.v, 32);
+                }
+                auto it = seen.find(key);
+                if (it != seen.end()) mult[it->second]++;
+                else if (rep.size() == 2048) too_many = true;
+                else { seen.emplace(key, (uint32_t)rep.size()); rep.push_back((uint32_t)i); mult.push_back(1); }
+            }
+            if (too_many || rep.empty()) continue;
+            TableRows& tr = table_rows[l];
+            HIP_TRY(ctx, hipMalloc((void**)&tr.d_rep, rep.size() * 4));
+            HIP_TRY(ctx, hipMalloc((void**)&tr.d_mult, rep.size() * 4));
+            TRY(dehalo_upload(ctx, rep.data(), rep.size() * 4, tr.d_rep));
+            TRY(dehalo_upload(ctx, mult.data(), mult.size() * 4, tr.d_mult));
+            tr.count = (uint32_t)rep.size();
+        }
         return 0;
     }
 
@@ -1256,8 +1326,14 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
             pout_tab.push_back(cols.u64((size_t)(o_perm + 2 * l + 1) * n));
         }
         // status flags behind the 2 L points of this phase: the stream runs from the permutation straight into the commitment, the flags come back with the points
-        TRY(dehalo_permute_expression_pair_ptrs_deferred_device(ctx, fid, pin.data(), ptab.data(), u, L, pout_in.data(), pout_tab.data(), reinterpret_cast<int32_t*>(jac.u64() + 12 * 2 * (size_t)L),
-                                                                nullptr));
+        std::vector<const uint32_t*> trep, tmult;
+        std::vector<uint32_t> tcount;
+        for (uint32_t l = 0; l < L; l++) {
+            const TableRows& t = table_rows[table_rep[l]];
+            trep.push_back(t.d_rep); tmult.push_back(t.d_mult); tcount.push_back(t.count);
+        }
+        TRY(dehalo_permute_expression_pair_distinct_device(ctx, fid, pin.data(), ptab.data(), u, L, pout_in.data(), pout_tab.data(), trep.data(), tmult.data(), tcount.data(),
+                                                           reinterpret_cast<int32_t*>(jac.u64() + 12 * 2 * (size_t)L), nullptr));
         tk("permute queued");
         if (side) HIP_TRY(ctx, hipEventRecord(ev_ready[1], ms));
         TRY(commit(tr, cols.at((size_t)o_perm * n), 2 * L, true, side ? std::function<int()>([&]() { return side_ntt(o_perm, 2 * L, ev_ready[1]); }) : nullptr, L));

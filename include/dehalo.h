@@ -250,6 +250,15 @@ int dehalo_permute_expression_pair_ptrs_device(dehalo_ctx* ctx, int field, const
  * so that the stream runs from the permutation straight into the commitment. */
 int dehalo_permute_expression_pair_ptrs_deferred_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows,
                                                         size_t batch, uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, int32_t* d_status, void* stream);
+/* The same for tables of FIXED columns (every table expression of the lookup reads fixed columns only -- the reference circuit's range tables): which rows of such
+ * a table are equal does not depend on theta, only the order of the compressed values does.  Per lookup y the caller passes one representative row (an index
+ * < usable_rows) of every distinct table tuple and how many of the usable rows hold that tuple (DEVICE arrays of distinct_count[y] uint32 each; the multiplicities add
+ * up to usable_rows; lookups that share a table pass the same arrays).  Then only the distinct compressed values are sorted -- 339 instead of 131,066 for the
+ * delay-encryption circuit at k = 17 -- and the sorted table is written out from (value, multiplicity): the same A' and S'.  distinct_count[y] == 0 or > 2048 for any
+ * lookup of the call: the general path.  d_status as above, or null: the call synchronises and returns DEHALO_ERR_NOT_IN_TABLE itself. */
+int dehalo_permute_expression_pair_distinct_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
+                                                   uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables, const uint32_t* const* d_rep_rows,
+                                                   const uint32_t* const* d_multiplicities, const uint32_t* distinct_count, int32_t* d_status, void* stream);
 int dehalo_eval_polynomial(dehalo_ctx* ctx, int field, const uint64_t* coeffs, size_t len, const uint64_t point[4], uint64_t out[4]);
 int dehalo_eval_polynomial_device(dehalo_ctx* ctx, int field, const uint64_t* d_coeffs, size_t len, size_t stride_elems, size_t batch,
                                   const uint64_t point[4], uint64_t* d_out, void* stream);

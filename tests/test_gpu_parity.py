@@ -840,6 +840,79 @@ def test_permute_expression_pair_shared_tables_and_odd_sizes(pkg, co, ctx):
         ctx.permute_expression_pair_ptrs_device(fid, [d_g.data_ptr()], [d_t.data_ptr()], n, [d_g.data_ptr()], [o[2].data_ptr()], 0)
 
 
+def test_permute_expression_pair_tables_given_as_distinct_rows(pkg, co, ctx):
+    """dehalo_permute_expression_pair_distinct_device: a table of fixed columns handed over as one representative row per distinct value + multiplicities (what the
+    prover computes once per proving key); only the distinct keys are sorted.  Same A' and S' as the CPU restatement on the full table: few distinct values among
+    many rows (the range tables' shape), up to the 2048-key tile, two tables in one call, one table shared by several lookups, a table with more than 2048 distinct
+    values (the general path), values that repeat with wildly different multiplicities, an input that is not in the table."""
+    import torch
+    fid = 0
+    rng = np.random.default_rng(23)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    dev32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32)).cuda()
+
+    def distinct_rows(table):
+        _, first, counts = np.unique(table, axis=0, return_index=True, return_counts=True)
+        order = rng.permutation(len(first))                      # representative rows in no particular order
+        return first[order].astype(np.uint32), counts[order].astype(np.uint32)
+
+    def table_of(n, d, skew):
+        vals = co.fill_scalars(fid, "uniform", d, 900 + d)
+        if skew:   # one value fills most of the table (the padding row of a range table), the rest appear once or a few times
+            idx = np.concatenate([np.arange(d), rng.integers(0, min(d, 3), size=max(0, n - d - n // 2)), np.zeros(n // 2, dtype=np.int64)])[:n]
+            idx[:d] = np.arange(d) if d <= n else idx[:d]
+        else:
+            idx = rng.integers(0, d, size=n)
+            idx[:min(d, n)] = np.arange(min(d, n))
+        return vals[rng.permutation(idx)]
+
+    for n, d1, d2 in ((5000, 339, 7), (2048, 2048, 1), (100003, 1500, 2047), (6000, 3000, 40), (1, 1, 1), (70000, 2, 300)):
+        d1, d2 = min(d1, n), min(d2, n)
+        t1, t2 = table_of(n, d1, True), table_of(n, d2, False)
+        B = 5
+        tabs_h = [t1, t2, t1, t1, t2]
+        ins = [tabs_h[y][rng.integers(0, max(1, n // (y + 1)), size=n)] for y in range(B)]
+        r1, m1 = distinct_rows(t1)
+        r2, m2 = distinct_rows(t2)
+        assert int(m1.sum()) == n and int(m2.sum()) == n
+        d_t1, d_t2 = dev(t1), dev(t2)
+        d_r = {1: dev32(r1), 2: dev32(r2)}
+        d_m = {1: dev32(m1), 2: dev32(m2)}
+        which = [1, 2, 1, 1, 2]
+        d_ins = [dev(a) for a in ins]
+        outs_i = [torch.zeros((n, 4), dtype=torch.int64, device="cuda") for _ in range(B)]
+        outs_t = [torch.zeros((n, 4), dtype=torch.int64, device="cuda") for _ in range(B)]
+        status = torch.full((B,), 9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.permute_expression_pair_distinct_device(fid, [a.data_ptr() for a in d_ins], [(d_t1 if w == 1 else d_t2).data_ptr() for w in which], n,
+                                                    [o.data_ptr() for o in outs_i], [o.data_ptr() for o in outs_t], [d_r[w].data_ptr() for w in which],
+                                                    [d_m[w].data_ptr() for w in which], [len(r1) if w == 1 else len(r2) for w in which], status.data_ptr(), 0)
+        ctx.synchronize()
+        assert not status.cpu().numpy().any()
+        for y in range(B):
+            want = co.permute_expression_pair(fid, ins[y], tabs_h[y], n)
+            assert want is not None
+            assert np.array_equal(outs_i[y].cpu().numpy().view(np.uint64), want[0]), (n, d1, d2, y)
+            assert np.array_equal(outs_t[y].cpu().numpy().view(np.uint64), want[1]), (n, d1, d2, y)
+    # an input value that is not in the table: the synchronous form of the call says so
+    n = 4000
+    table = table_of(n, 50, True)
+    r, m = distinct_rows(table)
+    good = table[rng.integers(0, n, size=n)]
+    bad = good.copy()
+    bad[17] = co.fill_scalars(fid, "uniform", 1, 77)[0]
+    d_t, d_g, d_b, d_rr, d_mm = dev(table), dev(good), dev(bad), dev32(r), dev32(m)
+    o = [torch.zeros((n, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.DehaloError) as e:
+        ctx.permute_expression_pair_distinct_device(fid, [d_g.data_ptr(), d_b.data_ptr()], [d_t.data_ptr()] * 2, n, [o[0].data_ptr(), o[1].data_ptr()], [o[2].data_ptr(), o[3].data_ptr()],
+                                                    [d_rr.data_ptr()] * 2, [d_mm.data_ptr()] * 2, [len(r)] * 2, 0, 0)
+    assert e.value.code == -6
+    with pytest.raises(pkg.DehaloError):      # lookups of one table must describe it alike
+        ctx.permute_expression_pair_distinct_device(fid, [d_g.data_ptr(), d_g.data_ptr()], [d_t.data_ptr()] * 2, n, [o[0].data_ptr(), o[1].data_ptr()], [o[2].data_ptr(), o[3].data_ptr()],
+                                                    [d_rr.data_ptr()] * 2, [d_mm.data_ptr()] * 2, [len(r), len(r) - 1], 0, 0)
+
+
 def test_permute_expression_pair_small_values(pkg, co, ctx):
     """Range-table shaped columns (values < 2^16): the sort skips the limbs that are zero everywhere."""
     fid, n = 0, 40000
