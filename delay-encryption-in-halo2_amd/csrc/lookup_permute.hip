@@ -203,6 +203,50 @@ __global__ void __launch_bounds__(LP_MERGE_THREADS) k_lp_merge(const fe* in, fe*
 }
 
 // ---- tables given as distinct rows + multiplicities -------------------------------------------------------------------------------------
+// inclusive scan over the 1024 threads of a block: shuffles inside a wave, one LDS round trip across the 16 waves (a Hillis-Steele scan in LDS is ten steps of
+// two barriers each: 50 us for a kernel whose whole work is this scan)
+FP_DEV u32 lp_block_scan_1024(u32 v, u32* wave_sums /* 16 words of LDS */) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(v, d); if ((int)lane >= d) v += x; }
+    if (lane == 63) wave_sums[wave] = v;
+    __syncthreads();
+    u32 before = 0;
+    for (u32 w = 0; w < wave; w++) before += wave_sums[w];
+    __syncthreads();
+    return v + before;
+}
+// up to 512 keys sorted by counting, for every key, the keys below it (ties by position): one pass instead of the bitonic network's 66 stages of two barriers
+// each.  One block per table; only the table's `ndist` keys take part (the +infinity padding behind them stays where it is).  NO LDS: key j is the same address
+// for every lane, so the loop reads the keys through the scalar cache -- a block that needs 16 KB of LDS (let alone the bitonic tile's 64 KB) waits until a CU
+// whose LDS is held by two NTT tiles of the side context gives one up: 160-270 us in a proof for 5 us of work.  (Nor do the top 64 bits alone order the keys:
+// the compressed values theta * tag + value of one tag differ in their LOW bits only.)
+__global__ void __launch_bounds__(512) k_lp_small_sort(LpCols c, const fe* in, fe* out) {
+    const u32 tb = blockIdx.y, len = c.ndist[tb];
+    const fe* K = in + (u64)tb * LP_TILE;
+    fe* O = out + (u64)tb * LP_TILE;
+    const u32 t = threadIdx.x;
+    for (u32 i = len + t; i < LP_TILE; i += 512) f_store(&O[i], f_load(&K[i]));
+    if (t >= len) return;
+    const fe mine = f_load(&K[t]);
+    u32 rank = 0;
+    for (u32 j0 = 0; j0 < len; j0 += 8) {                 // eight keys' loads in flight at a time (one per comparison: 339 round trips to the cache, 0.4 us each)
+        fe cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cur[q] = f_load(&K[j0 + q < len ? j0 + q : len - 1]);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            int cmp = 0;                                  // all eight words, no early exit (an early-exit compare turns into eight dependent loads)
+#pragma unroll
+            for (int w = 7; w >= 0; w--) {
+                const int d = cur[q].v[w] < mine.v[w] ? -1 : (cur[q].v[w] > mine.v[w] ? 1 : 0);
+                cmp = cmp ? cmp : d;
+            }
+            if (j0 + q < len) rank += cmp < 0 || (cmp == 0 && j0 + q < t);      // equal keys: by position
+        }
+    }
+    f_store(&O[rank], mine);
+}
 // canonical keys of the distinct rows of table t, one tile per table, padded with +infinity
 template <class F>
 __global__ void k_lp_distinct_keys(LpCols c, fe* keys) {
@@ -230,7 +274,7 @@ FP_DEV u32 lp_lower_bound_tile(const fe* T, const fe& a) {      // first index i
 // there, as equal values of the multiset do) and its exclusive scan = the key's first position in the full sorted table: dstart[t][0 .. LP_TILE]
 template <class F>
 __global__ void __launch_bounds__(1024) k_lp_distinct_starts(LpCols c, const fe* dsorted, u32* dstart) {
-    __shared__ u32 sm[LP_TILE], part[1024];
+    __shared__ u32 sm[LP_TILE], part[16];
     const u32 t = blockIdx.x, tid = threadIdx.x;
     const fe* T = dsorted + (u64)t * LP_TILE;
     for (u32 i = tid; i < LP_TILE; i += 1024) sm[i] = 0;
@@ -243,51 +287,57 @@ __global__ void __launch_bounds__(1024) k_lp_distinct_starts(LpCols c, const fe*
     constexpr u32 PER = LP_TILE / 1024;
     u32 v[PER], sum = 0;
     for (u32 k = 0; k < PER; k++) { v[k] = sm[tid * PER + k]; sum += v[k]; }
-    part[tid] = sum;
-    __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {
-        const u32 a = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += a;
-        __syncthreads();
-    }
-    u32 run = part[tid] - sum;
+    u32 run = lp_block_scan_1024(sum, part) - sum;
     for (u32 k = 0; k < PER; k++) { dstart[(u64)t * (LP_TILE + 1) + tid * PER + k] = run; run += v[k]; }
     if (tid == 1023) dstart[(u64)t * (LP_TILE + 1) + LP_TILE] = run;
 }
-// Every input value's distinct key: counted, cnt[y][position among the sorted distinct keys].  The block keeps the table's sorted distinct keys in LDS (64 KB:
-// eleven search steps on LDS words instead of seventeen on 32-byte loads from a 4 MB table) and a histogram of its 2048 inputs; a wave whose 64 inputs are
-// one value (the zero rows of an unused region) counts once.
+// Every input value's distinct key: counted, cnt[y][position among the sorted distinct keys].  The block keeps the table's sorted distinct keys in LDS as eight
+// planes of dlen words (16 KB for up to 512 keys: nine search steps on LDS words instead of seventeen 32-byte loads from a 4 MB table) and a histogram of its
+// 2048 inputs; a wave whose 64 inputs are one value (the zero rows of an unused region) counts once.
 template <class F>
-__global__ void __launch_bounds__(LP_SORT_THREADS) k_lp_rank_distinct(LpCols c, const fe* dsorted, u64 n, u32* cnt, int* err) {
-    extern __shared__ u32 lds[];                      // [8 planes of LP_TILE key words | LP_TILE counters]
-    u32* hist = lds + 8 * LP_TILE;
+__global__ void __launch_bounds__(LP_SORT_THREADS) k_lp_rank_distinct(LpCols c, const fe* dsorted, u64 n, u32* cnt, int* err, u32 dlen) {      // dlen: a power of two >= every table's distinct rows
+    extern __shared__ u32 lds[];                      // [8 planes of dlen key words | dlen counters]
+    u32* hist = lds + 8 * dlen;
     constexpr u32 RP = LP_TILE / LP_SORT_THREADS;     // 2 inputs per thread
     const u32 y = blockIdx.y, t = c.table_of[y], nd = c.ndist[t];
     const fe* T = dsorted + (u64)t * LP_TILE;
-    for (u32 i = threadIdx.x; i < LP_TILE; i += LP_SORT_THREADS) { lds_put(lds, i, f_load(&T[i])); hist[i] = 0; }
+    for (u32 i = threadIdx.x; i < dlen; i += LP_SORT_THREADS) {
+        const fe k = f_load(&T[i]);
+#pragma unroll
+        for (int w = 0; w < 8; w++) lds[w * dlen + i] = k.v[w];
+        hist[i] = 0;
+    }
     __syncthreads();
+    auto cmp_at = [&](u32 m, const fe& a) {           // key[m] against a, words from the top
+        int cmp = 0;
+#pragma unroll
+        for (int w = 7; w >= 0; w--) {
+            const u32 x = lds[w * dlen + m];
+            if (cmp == 0 && x != a.v[w]) cmp = x < a.v[w] ? -1 : 1;
+        }
+        return cmp;
+    };
     const u64 base = (u64)blockIdx.x * LP_TILE;
     bool miss = false;
     for (u32 k = 0; k < RP; k++) {
         const u64 i = base + threadIdx.x + k * LP_SORT_THREADS;
-        const bool have = i < n;
-        u32 lo = 0;
-        if (have) {
+        u32 pos = 0xFFFFFFFFu;
+        if (i < n) {
             const fe a = f_from_mont<F>(f_load(&c.in[y][i]));
-            for (u32 len = LP_TILE; len > 1;) {       // lower bound among the tile's keys (the +infinity padding is above every value)
+            u32 l = 0;
+            for (u32 len = dlen; len > 1;) {          // lower bound among the first dlen keys of the tile (the +infinity padding is above every value)
                 const u32 half = len >> 1;
-                if (lp_cmp(lds_key(lds, lo + half - 1), a) < 0) lo += half;
+                if (cmp_at(l + half - 1, a) < 0) l += half;
                 len -= half;
             }
-            if (lp_cmp(lds_key(lds, lo), a) < 0) lo++;
-            if (lo >= nd || lp_cmp(lds_key(lds, lo), a) != 0) { miss = true; lo = 0xFFFFFFFFu; }
-        } else lo = 0xFFFFFFFFu;
-        const bool count = lo != 0xFFFFFFFFu;
+            if (cmp_at(l, a) < 0) l++;
+            if (l < nd && l < dlen && cmp_at(l, a) == 0) pos = l; else miss = true;
+        }
+        const bool count = pos != 0xFFFFFFFFu;
         const unsigned long long act = __ballot(count);
-        if (act && __ballot(count && lo != (u32)__builtin_amdgcn_readfirstlane((int)lo)) == 0 && (act & 1ull)) {
-            if ((threadIdx.x & 63) == 0) atomicAdd(&hist[lo], (u32)__popcll(act));
-        } else if (count) atomicAdd(&hist[lo], 1u);
+        if (act && __ballot(count && pos != (u32)__builtin_amdgcn_readfirstlane((int)pos)) == 0 && (act & 1ull)) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&hist[pos], (u32)__popcll(act));
+        } else if (count) atomicAdd(&hist[pos], 1u);
     }
     if (miss) atomicExch(&err[y], 1);
     __syncthreads();
@@ -298,7 +348,7 @@ __global__ void __launch_bounds__(LP_SORT_THREADS) k_lp_rank_distinct(LpCols c, 
 // of key p), of "looked up at all" (-> usedbefore[p]: first-occurrence rows before key p's) and of the leftover copies  multiplicity - looked up at all
 // (-> leftstart[p]: the key's rank among the leftovers, ascending).  Each array has LP_TILE + 1 entries (the last: the total).
 __global__ void __launch_bounds__(1024) k_lp_scan_distinct(LpCols c, const u32* cnt, const u32* dstart, u32* rowstart, u32* usedbefore, u32* leftstart) {
-    __shared__ u32 part[3][1024];
+    __shared__ u32 part[3][16];
     constexpr u32 PER = LP_TILE / 1024;
     const u32 y = blockIdx.x, t = c.table_of[y], tid = threadIdx.x;
     u32 v[3][PER], sum[3] = {0, 0, 0};
@@ -308,18 +358,11 @@ __global__ void __launch_bounds__(1024) k_lp_scan_distinct(LpCols c, const u32* 
         v[0][k] = cn; v[1][k] = cn ? 1u : 0u; v[2][k] = mult - (cn ? 1u : 0u);
         for (int a = 0; a < 3; a++) sum[a] += v[a][k];
     }
-    for (int a = 0; a < 3; a++) part[a][tid] = sum[a];
-    __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {
-        u32 x[3];
-        for (int a = 0; a < 3; a++) x[a] = tid >= d ? part[a][tid - d] : 0;
-        __syncthreads();
-        for (int a = 0; a < 3; a++) part[a][tid] += x[a];
-        __syncthreads();
-    }
+    u32 incl[3];
+    for (int a = 0; a < 3; a++) incl[a] = lp_block_scan_1024(sum[a], part[a]);
     u32* out[3] = {rowstart + (u64)y * (LP_TILE + 1), usedbefore + (u64)y * (LP_TILE + 1), leftstart + (u64)y * (LP_TILE + 1)};
     for (int a = 0; a < 3; a++) {
-        u32 run = part[a][tid] - sum[a];
+        u32 run = incl[a] - sum[a];
         for (u32 k = 0; k < PER; k++) { out[a][tid * PER + k] = run; run += v[a][k]; }
         if (tid == 1023) out[a][LP_TILE] = run;
     }
@@ -592,13 +635,17 @@ int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s,
         u32* rowstart = used_start;                        // [B][LP_TILE + 1] each (the buffers hold max(n, LP_TILE + 1) words per lookup)
         u32* usedbefore = used_idx;
         u32* leftstart = lsrc;
-        const int lds_rank = LP_TILE * 32 + LP_TILE * 4;
-        HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_lp_rank_distinct<F>, lds_rank));
+        u32 dlen = 64;                                     // a power of two >= every table's distinct rows: what the sort and the searches run over
+        for (u32 t = 0; t < U; t++) while (dlen < c.ndist[t]) dlen <<= 1;
         k_lp_distinct_keys<F><<<dim3(LP_TILE / 256, U), 256, 0, s>>>(c, dk0);
-        k_lp_tile_sort<<<dim3(1, U), LP_SORT_THREADS, lds_keys, s>>>(dk0, dk1, LP_TILE);
+        if (dlen <= 512) {
+            k_lp_small_sort<<<dim3(1, U), 512, 0, s>>>(c, dk0, dk1);
+        } else k_lp_tile_sort<<<dim3(1, U), LP_SORT_THREADS, lds_keys, s>>>(dk0, dk1, LP_TILE);
         k_lp_distinct_starts<F><<<U, 1024, 0, s>>>(c, dk1, dstart);
         HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, (size_t)B * LP_TILE * 4, s));
-        k_lp_rank_distinct<F><<<dim3((u32)tiles, B), LP_SORT_THREADS, lds_rank, s>>>(c, dk1, n, dcnt, err);
+        const int lds_rank = (int)(36 * dlen);
+        if (lds_rank > 48 * 1024) HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_lp_rank_distinct<F>, lds_rank));
+        k_lp_rank_distinct<F><<<dim3((u32)tiles, B), LP_SORT_THREADS, lds_rank, s>>>(c, dk1, n, dcnt, err, dlen);
         k_lp_scan_distinct<<<B, 1024, 0, s>>>(c, dcnt, dstart, rowstart, usedbefore, leftstart);
         k_lp_emit_distinct<F><<<dim3((u32)((n + 255) / 256), B), 256, 0, s>>>(c, dk1, n, rowstart, usedbefore, leftstart, err);
     } else {
