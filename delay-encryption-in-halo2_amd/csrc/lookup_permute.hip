@@ -249,11 +249,11 @@ __global__ void __launch_bounds__(512) k_lp_small_sort(LpCols c, const fe* in, f
 }
 // canonical keys of the distinct rows of table t, one tile per table, padded with +infinity
 template <class F>
-__global__ void k_lp_distinct_keys(LpCols c, fe* keys) {
+__global__ void k_lp_distinct_keys(LpCols c, u64 n, fe* keys) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
     if (i >= LP_TILE) return;
     fe k;
-    if (i < c.ndist[t]) k = f_from_mont<F>(f_load(&c.tab[t][c.rep[t][i]]));
+    if (i < c.ndist[t]) k = f_from_mont<F>(f_load(&c.tab[t][min((u64)c.rep[t][i], n - 1)]));      // (a row index is the caller's: never read past the column)
     else {
 #pragma unroll
         for (int w = 0; w < 8; w++) k.v[w] = 0xFFFFFFFFu;
@@ -273,15 +273,15 @@ FP_DEV u32 lp_lower_bound_tile(const fe* T, const fe& a) {      // first index i
 // one block per table: the multiplicity of every SORTED distinct key (a tuple finds its key's first position; tuples whose compressed values coincide add up
 // there, as equal values of the multiset do) and its exclusive scan = the key's first position in the full sorted table: dstart[t][0 .. LP_TILE]
 template <class F>
-__global__ void __launch_bounds__(1024) k_lp_distinct_starts(LpCols c, const fe* dsorted, u32* dstart) {
+__global__ void __launch_bounds__(1024) k_lp_distinct_starts(LpCols c, u64 n, const fe* dsorted, u32* dstart) {
     __shared__ u32 sm[LP_TILE], part[16];
     const u32 t = blockIdx.x, tid = threadIdx.x;
     const fe* T = dsorted + (u64)t * LP_TILE;
     for (u32 i = tid; i < LP_TILE; i += 1024) sm[i] = 0;
     __syncthreads();
     for (u32 d = tid; d < c.ndist[t]; d += 1024) {
-        const fe key = f_from_mont<F>(f_load(&c.tab[t][c.rep[t][d]]));
-        atomicAdd(&sm[lp_lower_bound_tile(T, key)], c.mult[t][d]);
+        const fe key = f_from_mont<F>(f_load(&c.tab[t][min((u64)c.rep[t][d], n - 1)]));
+        atomicAdd(&sm[min(lp_lower_bound_tile(T, key), LP_TILE - 1)], c.mult[t][d]);
     }
     __syncthreads();
     constexpr u32 PER = LP_TILE / 1024;
@@ -637,11 +637,11 @@ int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s,
         u32* leftstart = lsrc;
         u32 dlen = 64;                                     // a power of two >= every table's distinct rows: what the sort and the searches run over
         for (u32 t = 0; t < U; t++) while (dlen < c.ndist[t]) dlen <<= 1;
-        k_lp_distinct_keys<F><<<dim3(LP_TILE / 256, U), 256, 0, s>>>(c, dk0);
+        k_lp_distinct_keys<F><<<dim3(LP_TILE / 256, U), 256, 0, s>>>(c, n, dk0);
         if (dlen <= 512) {
             k_lp_small_sort<<<dim3(1, U), 512, 0, s>>>(c, dk0, dk1);
         } else k_lp_tile_sort<<<dim3(1, U), LP_SORT_THREADS, lds_keys, s>>>(dk0, dk1, LP_TILE);
-        k_lp_distinct_starts<F><<<U, 1024, 0, s>>>(c, dk1, dstart);
+        k_lp_distinct_starts<F><<<U, 1024, 0, s>>>(c, n, dk1, dstart);
         HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, (size_t)B * LP_TILE * 4, s));
         const int lds_rank = (int)(36 * dlen);
         if (lds_rank > 48 * 1024) HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_lp_rank_distinct<F>, lds_rank));

@@ -253,7 +253,7 @@ int dehalo_permute_expression_pair_ptrs_deferred_device(dehalo_ctx* ctx, int fie
 /* The same for tables of FIXED columns (every table expression of the lookup reads fixed columns only -- the reference circuit's range tables): which rows of such
  * a table are equal does not depend on theta, only the order of the compressed values does.  Per lookup y the caller passes one representative row (an index
  * < usable_rows) of every distinct table tuple and how many of the usable rows hold that tuple (DEVICE arrays of distinct_count[y] uint32 each; the multiplicities add
- * up to usable_rows; lookups that share a table pass the same arrays).  Then only the distinct compressed values are sorted -- 339 instead of 131,066 for the
+ * up to usable_rows -- otherwise the outputs are unspecified, never an out-of-bounds access; lookups that share a table pass the same arrays).  Then only the distinct compressed values are sorted -- 339 instead of 131,066 for the
  * delay-encryption circuit at k = 17 -- and the sorted table is written out from (value, multiplicity): the same A' and S'.  distinct_count[y] == 0 or > 2048 for any
  * lookup of the call: the general path.  d_status as above, or null: the call synchronises and returns DEHALO_ERR_NOT_IN_TABLE itself. */
 int dehalo_permute_expression_pair_distinct_device(dehalo_ctx* ctx, int field, const uint64_t* const* d_inputs, const uint64_t* const* d_tables, size_t usable_rows, size_t batch,
