@@ -3,6 +3,7 @@
 // (msm_*.hip, ntt_*.hip), HIP-event timing.  No CPU arithmetic path exists here: every field
 // or group operation runs on the device, and context creation fails without one.
 #include <algorithm>
+#include <atomic>
 
 #include <map>
 
@@ -413,8 +414,24 @@ int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out) 
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         const int prio = priority > 0 ? greatest : (priority < 0 ? least : 0);
-        const hipError_t e = priority == 0 ? hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)
-                                           : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
+        // Experiment (DEHALO_CU_PARTITION = P, measurements only): the i-th context created by this process gets a stream that may only use the (i mod P)-th
+        // P-th of the compute units (hipExtStreamCreateWithCUMask), so that the provers of a batch do not wait for each other's workgroups to leave a CU.
+        static const int cu_parts = [] { const char* e = getenv("DEHALO_CU_PARTITION"); return e ? atoi(e) : 0; }();
+        static std::atomic<int> cu_next{0};
+        hipError_t e;
+        if (cu_parts > 1 && cu_parts <= 16) {
+            const int part = cu_next.fetch_add(1) % cu_parts, ncu = ctx->num_cus, per = ncu / cu_parts;
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            static const bool interleave = getenv("DEHALO_CU_PARTITION_INTERLEAVE") != nullptr;
+            for (int cu = 0; cu < ncu; cu++) {
+                const bool mine = interleave ? (cu % cu_parts) == part : (cu / per) == part;
+                if (mine) mask[cu / 32] |= 1u << (cu % 32);
+            }
+            e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data());
+            if (e == hipSuccess) ctx->num_cus = per;
+        } else
+        e = priority == 0 ? hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)
+                          : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
         if (e != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
     }
     if (const char* e = getenv("DEHALO_MSM_ACC_MIN_LAYERS")) ctx->msm_acc_min_layers = std::max(1, std::min(4, atoi(e)));

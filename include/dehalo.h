@@ -80,6 +80,8 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
 /* Environment variables read by the library (measurement and tuning only; results never depend on them):
  *   DEHALO_MSM_ACC_POINTS   default of "msm_acc_points" at context creation
  *   DEHALO_MSM_ACC_BLOCK    default of "msm_acc_block" at context creation
+ *   DEHALO_CU_PARTITION     P (2 .. 16; measurements only): the i-th context this process creates gets a stream confined to the (i mod P)-th share of the compute units
+ *                           (with DEHALO_CU_PARTITION_INTERLEAVE set: CU c belongs to share c mod P; otherwise contiguous blocks) -- profiles/r04_batch_cu_partition.txt
  *   DEHALO_HOST_SPIN_US     default of "host_wait_spin_us" at context creation
  *   DEHALO_MSM_BRED_BLOCK   128 / 256: buckets per workgroup of the bucket reduction (default: 128 up to 2^13 buckets, 256 above)
  *   DEHALO_MSM_SMALL_SLICES 0: sort workgroups of 2048 scalars whatever the launch size (default: down to 256 until ~128 workgroups are there)
