@@ -5,6 +5,10 @@ PKG := delay-encryption-in-halo2_amd
 CSRC := $(PKG)/csrc
 OBJDIR := $(CSRC)/obj
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off
+# make EXPERIMENTS=1: the measurement build (tools/ab_*.sh) -- A/B switches read from the environment and wall-clock phase stamps in the kernels (csrc/internal.hpp)
+ifdef EXPERIMENTS
+HIPFLAGS += -DDEHALO_EXPERIMENTS
+endif
 LIB := $(PKG)/libdehalo.so
 UNITS := capi prover witness lookup_permute msm_bn254 msm_pallas msm_vesta ntt_bn254_fr ntt_bn254_fq ntt_pasta_fp ntt_pasta_fq
 OBJS := $(UNITS:%=$(OBJDIR)/%.o)

@@ -61,8 +61,11 @@ def parse():
     ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves with the whole-rounds rule (0 = library default: msm_acc_points)")
     ap.add_argument("--preheat-s", type=float, default=1.0, help="untimed device work of the measured kind right before every warm-up + timed region (steps one at a time / "
                     "proofs), so that the region runs at the clocks of a busy prover instead of ramping up from idle after the host-side setup (0 = off)")
-    ap.add_argument("--in-process", action="store_true", help="measure in this process (always the case under torchrun and under a profiler); by default a one-GPU run "
-                    "measures in a child process and starts ONE more if that child is killed by a signal, see main()")
+    ap.add_argument("--in-process", action="store_true", help="measure in this process: the default for one GPU (kept as a flag for the ranks torchrun starts)")
+    ap.add_argument("--supervise", action="store_true", help="opt-in: measure in a fresh child process and start ONE more if that child is killed by a signal (supervise()); "
+                    "by default a device fault ends the run with a non-zero exit code")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"), help="where the verbose record (every field, with its sentences) is written; "
+                    "stdout carries the compact line only ('' = nowhere)")
     ap.add_argument("--inflight", type=int, default=4, help="independent steps in flight, each on its own HIP stream / workspace")
     return ap.parse_args()
 
@@ -410,7 +413,7 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
         adv = np.stack([co.field_op(st.curve.scalar.id, "to_mont", st.circ.advice[i]) for i in range(cs.num_advice)])
         # the port parallelises with plain pthreads per call: on a many-core host fewer threads can be faster, so both are timed
         cpu_runs = {}
-        for th in sorted({threads, min(threads, 32)}):
+        for th in sorted({threads, min(threads, 32)} if k <= 17 else {min(threads, 32)}):      # (k = 20: one CPU proof, at the thread count that wins at every smaller size)
             t2 = time.time()
             want, _ = PO.create_proof(st.ocurve, st.srs, key, adv, [[]], PO.ScalarStream(7), rep, th)
             cpu_runs[th] = time.time() - t2
@@ -552,9 +555,10 @@ def _section_of(stderr_tail: str) -> str:
 
 
 def supervise() -> int:
-    """One-GPU runs measure in a child process (nothing in this one has touched the GPU).  A child that dies by a signal -- seen once in
-    round 3: `Memory access fault by GPU node` in one full run out of about ten, DESIGN.md section 8 -- is replaced ONCE by a FRESH child (never
-    a re-exec); the JSON line then carries "attempts": 2 and "first_attempt": {"signal", "section", "stderr_tail"} of the one that died.
+    """--supervise (opt-in since round 5; the default run measures in-process, so a device fault is a non-zero exit code the caller sees): the
+    measurement runs in a child process (nothing in this one has touched the GPU).  A child that dies by a signal -- seen once in round 3:
+    `Memory access fault by GPU node` in one full run out of about ten; 52 / 52 clean since the pageable copies went -- is replaced ONCE by a
+    FRESH child (never a re-exec); the JSON line then carries "attempts": 2 and "first_attempt": {"signal", "section"} of the one that died.
     A child that exits by itself (any code) is final."""
     import subprocess
     import tempfile
@@ -564,7 +568,7 @@ def supervise() -> int:
         if first is not None:
             env["DEHALO_BENCH_FIRST_ATTEMPT"] = json.dumps(first)
         with tempfile.TemporaryFile() as errf:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--in-process"], stdout=subprocess.PIPE, stderr=errf, env=env)
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--supervise"] + ["--in-process"], stdout=subprocess.PIPE, stderr=errf, env=env)
             errf.seek(0)
             err = errf.read().decode(errors="replace")
         sys.stderr.write(err)
@@ -604,11 +608,98 @@ def launch_ranks(n: int) -> int:
     return p.returncode if p.returncode >= 0 else 128 - p.returncode
 
 
+LINE_LIMIT = 6000      # characters: the driver keeps the last ~8 KB of stdout; tests/test_host_logic.py holds a canned record to this bound
+
+
+def _pick(d, *names):
+    return {n: d[n] for n in names if d is not None and n in d and d[n] is not None}
+
+
+def compact_proof(p):
+    """A proof section of the line: numbers and one-word tags.  The sentences (what `e2e_ms` covers, where the witness lives, which verifying key the
+    pairing check used) are in profiles/README.md, "bench line glossary", and in the verbose record (--full-out)."""
+    if p is None:
+        return None
+    name = {"D": "delay_enc", "b": "mod_pow", "p": "pose_enc"}.get(p["circuit"][0], p["circuit"]) if isinstance(p.get("circuit"), str) else None
+    out = {"circuit": name, "k": p["k"], "rows": p.get("rows_used"), "commitments": p.get("commitments"), "proof_bytes": p.get("proof_bytes"),
+           "gpu_ms": p["gpu_ms"], "gpu_ms_median": p.get("gpu_ms_median"), "phase_ms": p.get("gpu_phase_ms"), "witness": "resident"}
+    e = p.get("end_to_end")
+    if e:
+        out["e2e_ms"], out["e2e_witness_ms"] = e.get("ms"), e.get("witness_ms")
+    out.update(_pick(p, "identical_to_cpu_proof", "cpu_ms", "cpu_cores", "speedup_vs_cpu_port", "verifier_accepts"))
+    if "cpu_ms" in out:
+        out["cpu_kind"] = "port"
+    return out
+
+
+def compact_line(out):
+    """The JSON line printed on stdout: every number of the verbose record `out`, none of its prose; the contract's keys first, then the roofline and
+    cpu_baseline objects, then the proof sections with BASELINE's own metric -- the k = 17 delay_enc proof, the batch, `attempts` -- LAST, so that a
+    reader who keeps only the tail of stdout keeps them.  The three scalars of that half of the metric are also inside `config`."""
+    proof, batch = out.get("proof"), out.get("batch_proofs")
+    cfg = dict(out["config"])
+    cfg["delay_enc_k17_ms"] = proof["gpu_ms"] if proof and proof.get("k") == 17 else None
+    cfg["batch_proofs_per_s"] = batch["proofs_per_s"] if batch else None
+    cfg["attempts"] = out.get("attempts", 1)
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["dtype"] = "u256"
+    line["config"] = cfg
+    r = out["roofline"]
+    rl = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "avg_kernel_ms_overlapped", "frac_of_measured_peak")
+    rl["algorithmic_bytes"] = r.get("algorithmic_bytes_per_launch")
+    if r.get("measured_peak"):
+        rl["measured_copy_GBps"] = r["measured_peak"].get("copy_GBps")
+    rl["valu"] = _pick(r.get("valu") or {}, "achieved_tmad_per_s", "peak_tmad_per_s", "frac")
+    line["roofline"] = rl
+    if out.get("cpu_baseline"):
+        c = out["cpu_baseline"]
+        line["cpu_baseline"] = dict(_pick(c, "value", "unit", "cores", "host_cores", "kind", "msm_ms", "ntt_ms"), sample="2 x (MSM + NTT 2^%d), rank 0's inputs" % out.get("log_n", 20))
+    n = out.get("ntt_roofline")
+    if n:
+        line["ntt_roofline"] = dict(_pick(n, "bound", "achieved", "peak", "unit", "frac", "avg_transform_ms", "avg_transform_ms_overlapped"),
+                                    valu=_pick(n.get("valu") or {}, "achieved_tmad_per_s", "frac"))
+    line["preheat_s"] = (out.get("preheat") or {}).get("seconds")
+    if out.get("breakdown_ms_per_step"):
+        line["alone_ms"] = out["breakdown_ms_per_step"]
+    if out.get("breakdown_ms_per_step_overlapped"):
+        line["overlapped_ms"] = {k: v for k, v in out["breakdown_ms_per_step_overlapped"].items() if k != "note"}
+    if out.get("single_stream"):
+        line["single_stream_ms_per_step"] = out["single_stream"].get("ms_per_step")
+    if out.get("parity_of_timed_configuration"):
+        line["parity_of_timed_steps"] = "all equal the CPU port's"
+    if out.get("secondary"):
+        line["secondary"] = _pick(out["secondary"], "table_build_ms_precomputed", "msm_single_row_device_ms", "best_multiexp_host_buffers_ms")
+    if out.get("rccl_world"):
+        line["rccl_world"] = out["rccl_world"]
+    if out.get("proof_other_k"):
+        line["proof_other_k"] = [compact_proof(p) for p in out["proof_other_k"]]
+    for k in ("proof_pose_enc", "proof_mod_pow", "proof"):
+        if out.get(k):
+            line[k] = compact_proof(out[k])
+    if batch:
+        b = _pick(batch, "k", "proofs", "n_gpus", "proofs_in_flight_per_gpu", "proofs_per_s", "ms_per_proof_per_gpu")
+        if batch.get("with_witness_generation"):
+            b["with_witness_generation_proofs_per_s"] = batch["with_witness_generation"].get("proofs_per_s")
+        b["checked"] = "each proof re-made alone: identical" if batch.get("checked_after_timed_region") else None
+        line["batch_proofs"] = b
+    line["attempts"] = out.get("attempts", 1)
+    if out.get("first_attempt"):
+        f = out["first_attempt"]
+        line["first_attempt"] = {"signal": f.get("signal"), "section": (f.get("section") or "")[:60]}
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("secondary", "overlapped_ms", "proof_pose_enc", "proof_mod_pow"):      # never needed at today's sizes; the bound holds whatever a section grows to
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
 def main():
     args = parse()
     if "RANK" not in os.environ and args.gpus > 1 and not args.in_process:
         raise SystemExit(launch_ranks(args.gpus))      # a fresh torchrun child; this process never touches the GPU
-    if not args.in_process and "RANK" not in os.environ and not under_profiler():
+    if args.supervise and not args.in_process and "RANK" not in os.environ and not under_profiler():
         raise SystemExit(supervise())
     if os.environ.get("DEHALO_BENCH_SELFTEST_KILL") and os.environ.get("DEHALO_BENCH_SELFTEST_KILL") == os.environ.get("DEHALO_BENCH_ATTEMPT"):
         import signal      # tests/test_host_logic.py: the measuring process of this attempt dies by a signal, as a device fault would end it
@@ -883,11 +974,19 @@ def main():
         if args.proof_k > 0 and world == 1:      # (N > 1: rank 0 makes the headline proof only -- the other ranks wait at the final barrier meanwhile)
             out["proof_mod_pow"] = proof_numbers(pkg, co, po, ctx, 17, "mod_pow", with_cpu, verify)              # BASELINE configs[2]
             out["proof_pose_enc"] = proof_numbers(pkg, co, po, ctx, 11, "pose_enc", with_cpu, verify)            # BASELINE configs[0]
-            # north star: k in {14, 17, 20}.  k = 14 against the CPU restatement too; k = 20 (CPU proof: a minute) by the pairing check
-            out["proof_other_k"] = [proof_numbers(pkg, co, po, ctx, k, "delay_enc", with_cpu and k <= 14, verify, reps=3) for k in (14, 20) if k != args.proof_k]
+            # north star: k in {14, 17, 20}: each byte-compared with the CPU restatement's proof (k = 20: one CPU proof, about a minute) and pairing-checked
+            out["proof_other_k"] = [proof_numbers(pkg, co, po, ctx, k, "delay_enc", with_cpu, verify, reps=3) for k in (14, 20) if k != args.proof_k]
         if batch is not None:
             out["batch_proofs"] = batch
-        print(json.dumps(out), flush=True)
+        out["log_n"] = log_n
+        if args.full_out:      # the verbose record, sentences included (scratch: copied into profiles/ by hand when it is the one to keep)
+            try:
+                os.makedirs(os.path.dirname(args.full_out) or ".", exist_ok=True)
+                with open(args.full_out, "w") as fh:
+                    json.dump(out, fh, indent=1)
+            except OSError as e:
+                note("verbose record not written: %s" % e)
+        print(compact_line(out), flush=True)
 
     bases.release()
     for c in ctxs:

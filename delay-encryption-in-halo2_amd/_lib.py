@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Tuple, Optional, Sequence
 
 import numpy as np
@@ -293,6 +294,7 @@ class Context:
         if rc != 0:
             raise DehaloError(rc, "dehalo_ctx_create failed (no gfx950 device?); there is no CPU fallback")
         self.handle = h
+        self.device = device
         self._tables = {}
 
     def close(self):
@@ -326,7 +328,7 @@ class Context:
 
         a = np.ascontiguousarray(host)
         assert a.dtype.itemsize == 8, "upload: 64-bit words expected"
-        out = torch.empty(a.shape, dtype=torch.int64 if dtype is None else dtype, device="cuda")
+        out = torch.empty(a.shape, dtype=torch.int64 if dtype is None else dtype, device=torch.device("cuda", self.device))      # the CONTEXT's device, not torch's current one
         self._check(self.lib.dehalo_upload(self.handle, a.ctypes.data, a.nbytes, out.data_ptr()))
         return out
 
@@ -702,24 +704,44 @@ class Context:
 
 
 _TRANSFER = {}
+_TRANSFER_LOCK = threading.RLock()
 
 
-def transfer_context() -> "Context":
+class _TransferUse:
+    """`with transfer_context() as c:` -- the per-device transfer context, held under the module's lock for the duration of the copy: two threads cannot both create
+    one (and leak a stream), and release_transfer_contexts() cannot close a context another thread is copying through."""
+
+    def __enter__(self):
+        import torch
+
+        _TRANSFER_LOCK.acquire()
+        try:
+            dev = torch.cuda.current_device()
+            c = _TRANSFER.get(dev)
+            if c is None or c.handle is None:
+                c = _TRANSFER[dev] = Context(dev, priority=-1)
+            return c
+        except BaseException:
+            _TRANSFER_LOCK.release()
+            raise
+
+    def __exit__(self, *exc):
+        _TRANSFER_LOCK.release()
+        return False
+
+
+def transfer_context() -> "_TransferUse":
     """One context per device whose only job is moving host arrays to / from HBM through the library's staged copies (Context.upload / download_tensor) for
-    code that has no context at hand (keygen.to_device / to_host).  Its stream carries nothing else; both calls return with the copy complete."""
-    import torch
-
-    dev = torch.cuda.current_device()
-    c = _TRANSFER.get(dev)
-    if c is None or c.handle is None:
-        c = _TRANSFER[dev] = Context(dev, priority=-1)
-    return c
+    code that has no context at hand (keygen.to_device / to_host).  Its stream carries nothing else; both calls return with the copy complete.  Use as a
+    context manager (see _TransferUse)."""
+    return _TransferUse()
 
 
 def release_transfer_contexts():
     """Closes the transfer contexts (their streams count against the runtime's pool of hardware queues: a caller about to keep several proving contexts in
-    flight drops them first; the next to_device / to_host makes a new one)."""
-    for dev in list(_TRANSFER):
-        c = _TRANSFER.pop(dev)
-        if c.handle is not None:
-            c.close()
+    flight drops them first; the next to_device / to_host makes a new one).  Waits for copies in flight on other threads."""
+    with _TRANSFER_LOCK:
+        for dev in list(_TRANSFER):
+            c = _TRANSFER.pop(dev)
+            if c.handle is not None:
+                c.close()

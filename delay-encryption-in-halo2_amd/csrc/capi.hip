@@ -355,7 +355,7 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return dh_fail(ctx, DEHALO_ERR_INVALID, "window_bits must be 0 or in [4, 16]");
     uint32_t c = window_bits ? (uint32_t)window_bits : (precompute ? choose_window(n) : choose_window_single(n));
     if (!window_bits && precompute) {      // DEHALO_WINDOW_BITS: tuning experiments (results never depend on the window)
-        const char* e = getenv("DEHALO_WINDOW_BITS");
+        const char* e = DH_EXPERIMENT_ENV("DEHALO_WINDOW_BITS");
         if (e && atoi(e) >= 4 && atoi(e) <= 16) c = (uint32_t)atoi(e);
     }
     if (c < 4) c = 4;
@@ -368,7 +368,8 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
     size_t rows = precompute ? W : 1;
     hipError_t e = hipMalloc((void**)&b->table, rows * n * sizeof(affine_t));
     if (e != hipSuccess) { delete b; return dh_fail(ctx, DEHALO_ERR_OOM, std::string("bases table: ") + hipGetErrorString(e)); }
-    HostPin pin_bases(affine_xy, n * stride_bytes);         // 64 MiB of SRS points at 2^20: DMA straight from the caller's pages
+    // 64 MiB of SRS points at 2^20: DMA straight from the caller's pages -- only when these bytes are what is copied (host memory, contiguous points)
+    HostPin pin_bases(on_device || stride_bytes != 64 ? nullptr : affine_xy, n * stride_bytes);
     // (contiguous points: a plain copy -- the 2-D path took 3 of the 4.1 ms of registering 2^20 points)
     int rc = 0;
     std::vector<uint64_t> packed;      // (points with a trailing flag byte: gathered on the host, so that the upload is one contiguous copy)
@@ -390,6 +391,11 @@ int register_impl(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t 
 }
 
 }  // namespace
+
+// the limit of a precomputed table registered with window_bits = 0: n x windows < 2^30 (30-bit table indices in the sorted list, msm.cuh)
+bool dh_precomputed_table_fits(int curve, size_t n) {
+    return n < (1ull << 30) && (uint64_t)n * signed_windows(scalar_modulus_words(curve), std::max<uint32_t>(4, choose_window(n))) < (1ull << 30);
+}
 
 // ==========================================================================================
 extern "C" {
@@ -416,13 +422,13 @@ int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out) 
         const int prio = priority > 0 ? greatest : (priority < 0 ? least : 0);
         // Experiment (DEHALO_CU_PARTITION = P, measurements only): the i-th context created by this process gets a stream that may only use the (i mod P)-th
         // P-th of the compute units (hipExtStreamCreateWithCUMask), so that the provers of a batch do not wait for each other's workgroups to leave a CU.
-        static const int cu_parts = [] { const char* e = getenv("DEHALO_CU_PARTITION"); return e ? atoi(e) : 0; }();
+        static const int cu_parts = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_CU_PARTITION"); return e ? atoi(e) : 0; }();
         static std::atomic<int> cu_next{0};
         hipError_t e;
         if (cu_parts > 1 && cu_parts <= 16) {
             const int part = cu_next.fetch_add(1) % cu_parts, ncu = ctx->num_cus, per = ncu / cu_parts;
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            static const bool interleave = getenv("DEHALO_CU_PARTITION_INTERLEAVE") != nullptr;
+            static const bool interleave = DH_EXPERIMENT_ENV("DEHALO_CU_PARTITION_INTERLEAVE") != nullptr;
             for (int cu = 0; cu < ncu; cu++) {
                 const bool mine = interleave ? (cu % cu_parts) == part : (cu / per) == part;
                 if (mine) mask[cu / 32] |= 1u << (cu % 32);
@@ -434,10 +440,10 @@ int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out) 
                           : hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
         if (e != hipSuccess) { delete ctx; return DEHALO_ERR_HIP; }
     }
-    if (const char* e = getenv("DEHALO_MSM_ACC_MIN_LAYERS")) ctx->msm_acc_min_layers = std::max(1, std::min(4, atoi(e)));
-    if (const char* e = getenv("DEHALO_HOST_SPIN_US")) ctx->host_wait_spin_us = std::max(0, std::min(1000000, atoi(e)));
-    if (const char* e = getenv("DEHALO_MSM_ACC_BLOCK")) ctx->msm_acc_block = atoi(e) == 768 ? 768 : 128;                                      // launch geometry only
-    if (const char* e = getenv("DEHALO_MSM_ACC_POINTS")) ctx->msm_acc_points = std::max(0, std::min(4096, atoi(e)));   // launch geometry only (dehalo_ctx_set_tuning)
+    if (const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_ACC_MIN_LAYERS")) ctx->msm_acc_min_layers = std::max(1, std::min(4, atoi(e)));
+    if (const char* e = DH_EXPERIMENT_ENV("DEHALO_HOST_SPIN_US")) ctx->host_wait_spin_us = std::max(0, std::min(1000000, atoi(e)));
+    if (const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_ACC_BLOCK")) ctx->msm_acc_block = atoi(e) == 768 ? 768 : 128;                                      // launch geometry only
+    if (const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_ACC_POINTS")) ctx->msm_acc_points = std::max(0, std::min(4096, atoi(e)));   // launch geometry only (dehalo_ctx_set_tuning)
     *out = ctx;
     return 0;
 }
@@ -1188,7 +1194,7 @@ int dehalo_graph_evaluate_batch_device(dehalo_ctx* ctx, const dehalo_graph* cons
     if ((count && (!graphs || !d_outs)) || !in) return dh_fail(ctx, DEHALO_ERR_INVALID, "graph_evaluate_batch: null argument");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     // DEHALO_GRAPH_BATCH=0: one staging + one evaluation launch per program, as before round 4 (A/B measurements)
-    static const bool batched = [] { const char* e = getenv("DEHALO_GRAPH_BATCH"); return !(e && e[0] == '0'); }();
+    static const bool batched = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_GRAPH_BATCH"); return !(e && e[0] == '0'); }();
     bool same_field = count >= 2 && log_rows <= 30;
     for (uint32_t i = 0; same_field && i < count; i++) {
         const dehalo_graph* g = graphs[i];

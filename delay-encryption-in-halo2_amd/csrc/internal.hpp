@@ -10,6 +10,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dehalo.h"
@@ -242,7 +243,11 @@ inline hipError_t dh_stream_wait(dehalo_ctx* ctx, hipStream_t s) {
         for (;;) {
             const hipError_t q = hipStreamQuery(s);
             if (q != hipErrorNotReady) return q;
+#if defined(__x86_64__) || defined(__i386__)
             for (int i = 0; i < 64; i++) __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
             if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= ctx->host_wait_spin_us) break;
         }
     }
@@ -278,11 +283,24 @@ inline int dh_d2h(dehalo_ctx* ctx, void* h_dst, const void* d_src, size_t bytes,
     return 0;
 }
 
+// the limit of a precomputed table registered with window_bits = 0: n x windows < 2^30 (capi.hip)
+bool dh_precomputed_table_fits(int curve, size_t n);
+
+// Experiment switches.  The default build reads NO tuning from the environment: DH_EXPERIMENT_ENV("DEHALO_...") is a null pointer there and the name is not even in
+// the binary, so an environment variable cannot change which kernels a drop-in library runs (per-context tuning goes through dehalo_ctx_set_tuning, validated).
+// A measurement build (`make EXPERIMENTS=1`: -DDEHALO_EXPERIMENTS, what tools/ab_*.sh build) turns them back into getenv and compiles the wall-clock phase stamps in.
+// The default build reads three diagnostics, host side only: DEHALO_PROVER_TRACE, DEHALO_SYNTH_TRACE (timelines on stderr), DEHALO_SYNTH_THREADS (witness threads).
+#ifdef DEHALO_EXPERIMENTS
+#define DH_EXPERIMENT_ENV(name) getenv(name)
+#else
+#define DH_EXPERIMENT_ENV(name) ((const char*)nullptr)
+#endif
+
 // DEHALO_CO_LDS (bytes; experiments with co-resident contexts): every latency-bound kernel that is meant to run in the wave slot a
 // 768-thread accumulation block leaves free asks for at least this much LDS per block in all (its own + unused padding), so that no two such blocks
 // fit one compute unit (> 80 KB of the 160) and the accumulation's next block always finds its three waves per SIMD.  0 = off.
 inline size_t dh_co_lds_pad(size_t own_static, size_t own_dynamic) {
-    static const size_t want = [] { const char* e = getenv("DEHALO_CO_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    static const size_t want = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_CO_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
     if (want <= own_static + own_dynamic) return own_dynamic;
     return want - own_static;
 }

@@ -678,199 +678,26 @@ __global__ __launch_bounds__(MSM_ACC_THREADS_MAX) MSM_ACC_WAVES_ATTR void k_msm_
 // Signed-digit carries of small witness values pile thousands of points into bucket 0 (digit
 // +-1), 0/1 columns put half the column into one bucket and a grand-product column that stays
 // constant over unused rows repeats one scalar thousands of times, so the number S of partial sums
-// per bucket spans 0 .. 10^5.  Buckets are classed by S and merged by a lane group sized to it:
-//   S <= c0: one lane or quad | S <= 128: 32 lanes | S <= 512: one wave | larger: a 512-thread block;
-// chain length <= S/g + log2 g group additions instead of S.  All four classes run in ONE launch
-// (k_msm_merge_all: sections of the grid, longest chains first): these are latency-bound chains
-// on short lists, and as four launches their times added up (0.33-0.43 ms of a proof's skewed
-// commitments; one launch: the longest of the four).
-#define MSM_C1_MAX 128
-#define MSM_C2_MAX 512
-#ifndef MSM_MERGE_THREADS
-#define MSM_MERGE_THREADS 256    // one wave per SIMD per block.  A lone wave of group additions already fills its SIMD's issue slots (tools/ubench_chain.hip: 3.1 us per
-                                 // quad-cooperative addition at one wave per SIMD, 5.2-6.2 at two), and the two waves per SIMD of a 512-thread block cost 15-25 % of this
-                                 // kernel whenever its lists were short enough to leave other CUs idle (profiles/r03_tail_block_shapes.txt)
-#endif
-#define MSM_MERGE_BLOCKS_LIGHT (512 * 512 / MSM_MERGE_THREADS)
-#define MSM_MERGE_BLOCKS_G32 (512 * 512 / MSM_MERGE_THREADS)
-#define MSM_MERGE_BLOCKS_G64 (512 * 512 / MSM_MERGE_THREADS)
-#define MSM_MERGE_BLOCKS_HEAVY 256
-#ifndef MSM_LIGHT_QUAD_MAX
-#define MSM_LIGHT_QUAD_MAX 65536   // listed buckets up to which the light class runs one quad per bucket (2 waves per SIMD of quads)
-#endif
-
-// classification: one lane per bucket.  S = 0 -> identity, S = 1 -> copy; otherwise the bucket is
-// queued in the list of its class (one atomic per wave and class: a single hot counter serialises).
-// lists: [light | class 1 | class 2 | class 3], each with `cap` slots; counters[4].
-template <class CV>
-__global__ __launch_bounds__(256) void k_msm_merge_classify(u32 total_buckets, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets,
-                                                           u32* counters, u32* lists, u32 cap, u32 c0max) {
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= total_buckets) return;
-    u32 beg = rbeg[b], end = rend[b];
-    u32 S = end - beg;
-    const u32 cls = S <= 1 ? 4u : (S <= c0max ? 0u : (S <= MSM_C1_MAX ? 1u : (S <= MSM_C2_MAX ? 2u : 3u)));
-    const u32 lane = threadIdx.x & 63;
-    for (u32 c = 0; c < 4; c++) {
-        unsigned long long mask = __ballot(cls == c);
-        if (mask == 0) continue;
-        u32 leader = (u32)__ffsll((long long)mask) - 1;
-        u32 base = 0;
-        if (lane == leader) base = atomicAdd(&counters[c], (u32)__popcll(mask));
-        base = __shfl(base, (int)leader);
-        if (cls == c) lists[c * cap + base + (u32)__popcll(mask & ((1ull << lane) - 1))] = b;
-    }
-    if (cls != 4u) return;
-    xyzz29_rec rec;
-    if (S == 1) rec = partial[beg];
-    else {
-#pragma unroll
-        for (int i = 0; i < 36; i++) rec.w[i] = 0;
-    }
-    buckets[b] = rec;
-}
-
-// light class (2 .. c0 partials).  Few listed buckets (latency-bound): one QUAD per bucket,
-// quad-cooperative additions; many (throughput-bound, e.g. every bucket of a large uniform MSM):
-// one lane per bucket.  The choice is made on the device from the list length.
-template <class F>
-FP_DEV void merge_light_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list) {
-    if (count <= MSM_LIGHT_QUAD_MAX) {
-        const u32 role = threadIdx.x & 3;
-        for (u32 i = (blk * MSM_MERGE_THREADS + threadIdx.x) >> 2; i < count; i += (nblk * MSM_MERGE_THREADS) >> 2) {
-            u32 b = list[i];
-            u32 beg = rbeg[b], end = rend[b];
-            xyzz29 acc = x29_load(&partial[beg]);
-            for (u32 p = beg + 1; p < end; p++) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
-            if (role == 0) x29_store(&buckets[b], acc);
-        }
-    } else {
-        for (u32 i = blk * MSM_MERGE_THREADS + threadIdx.x; i < count; i += nblk * MSM_MERGE_THREADS) {
-            u32 b = list[i];
-            u32 beg = rbeg[b], end = rend[b];
-            xyzz29 acc = x29_load(&partial[beg]);
-            for (u32 p = beg + 1; p < end; p++) acc = x29_add<F>(acc, x29_load(&partial[p]));
-            x29_store(&buckets[b], acc);
-        }
-    }
-}
-
-// groups of G lanes (32 or 64) = G / 4 quads walk a class list: strided QUAD sums (quad-cooperative additions: four lanes share one addition, four
-// multiplication rounds instead of fourteen), then a shuffle reduction over the quads.  (Round 3; one lane per chain and a full-addition shuffle tree
-// before: a heavy bucket's 9-15 tree levels at 10-20 us each were the floor of the skewed commitment phases.)
-template <class F, int G>
-FP_DEV void merge_group_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list) {
-    const u32 groups_per_block = MSM_MERGE_THREADS / G;
-    const u32 gl = threadIdx.x & (G - 1), grp = threadIdx.x / G, q = gl >> 2, Q = G / 4;
-    for (u32 i = blk * groups_per_block + grp; i < count; i += nblk * groups_per_block) {
-        u32 b = list[i];
-        u32 beg = rbeg[b], end = rend[b];
-        xyzz29 acc = x29_identity();
-        u32 p = beg + q;
-        if (p < end) {
-            acc = x29_load(&partial[p]);
-            for (p += Q; p < end; p += Q) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
-        }
-        acc = x29_group_reduce_quad<F, G>(acc);
-        if (gl == 0) x29_store(&buckets[b], acc);
-    }
-}
-
-// whole blocks walk the heaviest class: strided quad sums, shuffle reduction over the quads of a wave, the wave results through LDS, quad reduction
-// again.  Chain: ceil(S / 128) + 4 + 3 quad-cooperative additions.
-template <class F>
-FP_DEV void merge_heavy_section(u32 blk, u32 nblk, const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, u32 count, const u32* list,
-                                xyzz29_rec* sh) {
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = threadIdx.x >> 2, Q = MSM_MERGE_THREADS / 4;
-    for (u32 i = blk; i < count; i += nblk) {
-        u32 b = list[i];
-        u32 beg = rbeg[b], end = rend[b];
-        xyzz29 acc = x29_identity();
-        u32 p = beg + q;
-        if (p < end) {
-            acc = x29_load(&partial[p]);
-            for (p += Q; p < end; p += Q) acc = x29_add_quad<F>(acc, x29_load(&partial[p]));
-        }
-        acc = x29_group_reduce_quad<F, 64>(acc);
-        if (lane == 0) x29_store(&sh[wave], acc);
-        __syncthreads();
-        if (wave == 0) {
-            constexpr u32 NW = MSM_MERGE_THREADS / 64;                              // 8 wave results, one per quad of the first 32 lanes
-            xyzz29 v = (lane >> 2) < NW ? x29_load(&sh[lane >> 2]) : x29_identity();
-            v = x29_group_reduce_quad<F, 4 * NW>(v);
-            if (lane == 0) x29_store(&buckets[b], v);
-        }
-        __syncthreads();
-    }
-}
-
-// grid = [heavy | 64-lane groups | 32-lane groups | light] sections; a block whose section's list is
-// shorter than its position leaves at once, so the sections run side by side on short lists
-template <class CV>
-__global__ __launch_bounds__(MSM_MERGE_THREADS) void k_msm_merge_all(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters,
-                                                                    const u32* lists, u32 cap, int only) {
-    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    __shared__ xyzz29_rec sh[MSM_MERGE_THREADS / 64];
-    u32 blk = blockIdx.x;
-    // `only` >= 0 (DEHALO_MSM_MERGE_SPLIT, measurements): this launch runs one section, the others leave at once
-    if (blk < MSM_MERGE_BLOCKS_HEAVY) {
-        if (only < 0 || only == 3) merge_heavy_section<F>(blk, MSM_MERGE_BLOCKS_HEAVY, rbeg, rend, partial, buckets, counters[3], lists + 3 * (size_t)cap, sh);
-        return;
-    }
-    blk -= MSM_MERGE_BLOCKS_HEAVY;
-    if (blk < MSM_MERGE_BLOCKS_G64) {
-        if (only < 0 || only == 2) merge_group_section<F, 64>(blk, MSM_MERGE_BLOCKS_G64, rbeg, rend, partial, buckets, counters[2], lists + 2 * (size_t)cap);
-        return;
-    }
-    blk -= MSM_MERGE_BLOCKS_G64;
-    if (blk < MSM_MERGE_BLOCKS_G32) {
-        if (only < 0 || only == 1) merge_group_section<F, 32>(blk, MSM_MERGE_BLOCKS_G32, rbeg, rend, partial, buckets, counters[1], lists + 1 * (size_t)cap);
-        return;
-    }
-    blk -= MSM_MERGE_BLOCKS_G32;
-    if (only < 0 || only == 0) merge_light_section<F>(blk, MSM_MERGE_BLOCKS_LIGHT, rbeg, rend, partial, buckets, counters[0], lists);
-}
+// per bucket spans 0 .. 10^5.  k_scan_offsets classes the buckets by S while it scans and k_msm_merge2
+// (msm_bred.cuh) merges every class in ONE launch with a lane group sized to it.  (The round-3 generation --
+// its own classification launch, operands in registers at 172 VGPRs -- is in the history up to round 4.)
 
 // ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
-// quad (group, t) takes buckets [t*M, t*M + M): contribution = sum (k - k0 + 1) B_k + k0 * sum B_k.
-// With few groups in flight this kernel and the tree below are pure latency (a chain of ~45
-// dependent additions / doublings on an otherwise idle chip): then every group operation is
-// quad-cooperative (ec29.cuh).  With many groups (large batches) the lanes are better spent one
-// per block (QUAD = false): quads trade 1.6x the work for 2.4x less latency.
-template <class CV, bool QUAD, int RM>
-__global__ __launch_bounds__(MSM_RED_THREADS) void k_msm_reduce_local(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* contrib) {
+// k_msm_bred (msm_bred.cuh) from 8 buckets a group up.  Windows of 1 .. 3 bits (fewer than 32 terms: upstream's rule, multiexp_serial) leave 1, 2 or 4 buckets a
+// group: one quad per group walks them from the top -- run += B_k; acc += run -- with quad-cooperative additions.
+template <class CV>
+__global__ __launch_bounds__(MSM_RED_THREADS) void k_msm_reduce_small(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* gsums) {
     typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    const u32 per_group = (nb + RM - 1) / RM;
-    u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
-    if (gid >= per_group * total_groups) return;
-    u32 grp = gid / per_group, t = gid % per_group;
-    u32 k0 = t * RM, k1 = min(k0 + RM, nb);
+    const u32 grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    if (grp >= total_groups) return;
     const xyzz29_rec* B = buckets + (u64)grp * nb;
-    // (always_inline: left to itself hipcc emits these lambdas as real functions whose 36-word point
-    // arguments travel through scratch memory -- ~230 scratch accesses per group operation)
-    auto add = [](const xyzz29& a, const xyzz29& b) __attribute__((always_inline)) { return QUAD ? x29_add_quad<F>(a, b) : x29_add<F>(a, b); };
-    auto dbl = [](const xyzz29& a) __attribute__((always_inline)) { return QUAD ? x29_double_quad<F>(a) : x29_double<F>(a); };
-    xyzz29 run = x29_load(&B[k1 - 1]);
+    xyzz29 run = x29_load(&B[nb - 1]);
     xyzz29 acc = run;
-    for (u32 k = k1 - 1; k-- > k0;) {
-        run = add(run, x29_load(&B[k]));
-        acc = add(acc, run);
+    for (u32 k = nb - 1; k-- > 0;) {
+        run = x29_add_quad<F>(run, x29_load(&B[k]));
+        acc = x29_add_quad<F>(acc, run);
     }
-    // k0 * run, MSB-first double-and-add (k0 < 2^15); nothing to weight when the block is empty.
-    // acc is parked in LDS for the duration (LDS operations of one wave complete in order, so no
-    // barrier is needed): three live points plus an addition's temporaries spill to scratch.
-    __shared__ xyzz29_rec park[MSM_RED_THREADS];
-    if (k0 && !f29_all_zero(run.zz)) {
-        x29_store(&park[threadIdx.x], acc);
-        int top = 31 - __clz(k0);
-        xyzz29 w = run;
-        for (int bit = top - 1; bit >= 0; bit--) {
-            w = dbl(w);
-            if ((k0 >> bit) & 1) w = add(w, run);
-        }
-        acc = add(x29_load(&park[threadIdx.x]), w);
-    }
-    if (!QUAD || (threadIdx.x & 3) == 0) x29_store(&contrib[gid], acc);
+    if ((threadIdx.x & 3) == 0) x29_store(&gsums[grp], acc);
 }
 
 // An MSM's result leaves as upstream's Jacobian {x, y, z} and / or, for a caller that feeds the transcript (dehalo_msm_device_affine),
@@ -890,35 +717,6 @@ FP_DEV void msm_emit(const xyzz29& p, jacobian_t* out, affine_t* out_affine) {
             a.y = f29_to_std<F>(f29_mul<F>(p.y, f29_mul<F>(ti, p.zz)));
         }
         aff_store(out_affine, a);
-    }
-}
-
-// tree sum: in[groups][cnt] -> out[groups][ceil(cnt / MSM_TREE_ITEMS)]; 64 quads per block.  The launch that leaves one sum per
-// MSM of a precomputed-table batch (fin_out / fin_affine given) writes the results itself instead of a k_msm_final launch.
-#define MSM_TREE_ITEMS 128
-template <class CV>
-__global__ __launch_bounds__(256) void k_msm_tree_sum(const xyzz29_rec* in, u32 cnt, xyzz29_rec* out, u32 out_cnt, jacobian_t* fin_out, affine_t* fin_affine) {
-    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    __shared__ xyzz29_rec sh[64];
-    const u32 qd = threadIdx.x >> 2, role = threadIdx.x & 3;
-    u32 grp = blockIdx.y;
-    const xyzz29_rec* src = in + (u64)grp * cnt;
-    u32 i0 = blockIdx.x * MSM_TREE_ITEMS + qd;
-    xyzz29 a = i0 < cnt ? x29_load(&src[i0]) : x29_identity();
-    u32 i1 = i0 + 64;
-    if (i1 < cnt) a = x29_add_quad<F>(a, x29_load(&src[i1]));
-    if (role == 0) x29_store(&sh[qd], a);
-    __syncthreads();
-    for (u32 d = 32; d > 0; d >>= 1) {
-        if (qd < d) {
-            xyzz29 x = x29_add_quad<F>(x29_load(&sh[qd]), x29_load(&sh[qd + d]));
-            if (role == 0) x29_store(&sh[qd], x);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (fin_out || fin_affine) msm_emit<F>(x29_load(&sh[0]), fin_out ? fin_out + grp : nullptr, fin_affine ? fin_affine + grp : nullptr);
-        else out[(u64)grp * out_cnt + blockIdx.x] = sh[0];
     }
 }
 
@@ -1019,7 +817,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     g.slices = (u32)std::min<size_t>(256, std::max<size_t>(1, len / 2048));
     {   // small precomputed-table launches: 2048 scalars a sort block leave a 2^14 column 8 blocks and a 2^11 column ONE for k_msm_hist / k_msm_part (21 + 34 us of
         // latency where the work is 2); down to 256 scalars a block until ~128 blocks are there (DEHALO_MSM_SMALL_SLICES=0: the A/B)
-        static const bool small_slices = [] { const char* e = getenv("DEHALO_MSM_SMALL_SLICES"); return !(e && e[0] == '0'); }();
+        static const bool small_slices = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_SMALL_SLICES"); return !(e && e[0] == '0'); }();
         if (small_slices && g.G == 1 && (size_t)g.slices * batch < 128)
             g.slices = (u32)std::max<size_t>(g.slices, std::min<size_t>(std::max<size_t>(1, len / 256), (128 + batch - 1) / batch));
     }
@@ -1051,7 +849,6 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         lanes_max = rounds_max * resident + acc_block;
     }
     const uint64_t nt0_max = lanes_max + total_buckets;        // records: one per lane + one per non-empty bucket (upper bound)
-    const u32 per_group = (g.nb + MSM_RED_M - 1) / MSM_RED_M;
     const size_t REC = sizeof(xyzz29_rec);
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
@@ -1071,8 +868,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_buckets, total_buckets * REC));
     // (the radix-2 bucket reduction keeps its node vectors in the same two buffers: BRED_VMAX records per block of 128 / 256 buckets / per cluster of 16 blocks)
     const size_t bred_blocks = std::max<size_t>(1, g.nb / BRED_BLOCK_BUCKETS_MIN);
-    TRY(dh_ensure(ctx, ctx->ws_contrib, std::max<size_t>(total_groups * per_group, total_groups * bred_blocks * BRED_VMAX) * REC));
-    TRY(dh_ensure(ctx, ctx->ws_tree, std::max<size_t>(total_groups * ((per_group + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS), total_groups * 16 * BRED_VMAX) * REC));
+    TRY(dh_ensure(ctx, ctx->ws_contrib, total_groups * bred_blocks * BRED_VMAX * REC));
+    TRY(dh_ensure(ctx, ctx->ws_tree, total_groups * 16 * BRED_VMAX * REC));
     if ((size_t)total_groups * BRED_CNT_PER_GROUP * 4 > ctx->ws_bred_cnt.cap) {      // cluster / group arrival counters: zero when allocated, left zero by every launch
         TRY(dh_ensure(ctx, ctx->ws_bred_cnt, (size_t)total_groups * BRED_CNT_PER_GROUP * 4));
         HIP_TRY(ctx, hipMemsetAsync(ctx->ws_bred_cnt.p, 0, ctx->ws_bred_cnt.cap, s));
@@ -1092,8 +889,6 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     u32* idx = (u32*)ctx->ws_idx.p;
     xyzz29_rec* partial0 = (xyzz29_rec*)ctx->ws_partial0.p;
     xyzz29_rec* buckets = (xyzz29_rec*)ctx->ws_buckets.p;
-    xyzz29_rec* contrib = (xyzz29_rec*)ctx->ws_contrib.p;
-    xyzz29_rec* tree = (xyzz29_rec*)ctx->ws_tree.p;
     xyzz29_rec* gsums = (xyzz29_rec*)ctx->ws_gsums.p;
 
     const size_t lds_hist = (size_t)g.nb * 4 * (g.G == 1 ? 1 : g.wb);
@@ -1102,13 +897,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     }
     // block sizes of the two scalar-decoding sort kernels (DEHALO_MSM_HIST_THREADS / DEHALO_MSM_PART_THREADS, 64 .. 1024): smaller blocks fit beside a
     // resident accumulation of another context (msm_acc_block = 768 leaves one 128-VGPR wave slot per SIMD: 512 threads x 62 VGPRs, 256 x 77)
-    static const u32 hist_threads = [] { const char* e = getenv("DEHALO_MSM_HIST_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
-    static const u32 part_threads = [] { const char* e = getenv("DEHALO_MSM_PART_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
+    static const u32 hist_threads = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_HIST_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
+    static const u32 part_threads = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_PART_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
     const size_t lds_part = dh_co_lds_pad(0, 512 + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS);
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_part<FS>, (int)lds_part));
     const u32 tb = (u32)total_buckets;
-    // DEHALO_MSM_MERGE2=0: the round-3 merge kernels (operands in registers, 172 VGPRs, their own classification launch) instead of k_msm_merge2, for A/B measurements
-    static const bool use_merge2 = [] { const char* e = getenv("DEHALO_MSM_MERGE2"); return !(e && e[0] == '0'); }();
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
         dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
@@ -1119,17 +912,17 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         u32* bs_t = bs_i + cs_a;
         k_msm_colscan<<<cs_a + cs_b, SCAN_THREADS, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc, bs_i, bs_t, merge_counters);
         k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, (u32)ctx->msm_acc_min_layers, off, nrank, rbeg, rend,
-                                                     use_merge2 ? merge_lists : nullptr, merge_cap);
+                                                     merge_lists, merge_cap);
         HIP_TRY(ctx, hipGetLastError());
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
         const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
         TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bucket, lds_bk));
         // slices per block: 4 (measured best on dense columns) unless DEHALO_MSM_BUCKET_SLICES says otherwise (1 / 2 / 4 / 8: A/B measurements on the
         // skewed columns of a proof, where a block's run can be 17 windows x 4 slices of ONE value)
-        static const u32 bucket_slices = [] { const char* e = getenv("DEHALO_MSM_BUCKET_SLICES"); const int v = e ? atoi(e) : MSM_BUCKET_SLICES; return (u32)(v >= 1 && v <= 16 ? v : MSM_BUCKET_SLICES); }();
+        static const u32 bucket_slices = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_BUCKET_SLICES"); const int v = e ? atoi(e) : MSM_BUCKET_SLICES; return (u32)(v >= 1 && v <= 16 ? v : MSM_BUCKET_SLICES); }();
         // ... and fewer while the grid would not give every CU a block (2^14: 16 partitions x 8 slices -- 32 blocks of 10 k pairs each took 49 us a column, round 4)
         u32 bslices = bucket_slices;
-        static const bool bucket_fill = [] { const char* e = getenv("DEHALO_MSM_BUCKET_FILL"); return !(e && e[0] == '0'); }();
+        static const bool bucket_fill = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_BUCKET_FILL"); return !(e && e[0] == '0'); }();
         while (bucket_fill && bslices > 1 && (uint64_t)P * ((g.slices + bslices - 1) / bslices) * total_groups < (uint64_t)ctx->num_cus) bslices >>= 1;
         k_msm_bucket<<<dim3(P * ((g.slices + bslices - 1) / bslices), (u32)total_groups), 256, lds_bk, s>>>(g.nb, g.c, g.slices, off, bh, pc, pairs, idx, bslices);
         HIP_TRY(ctx, hipGetLastError());
@@ -1139,87 +932,53 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         u32 blocks = (u32)((lanes_max + acc_block - 1) / acc_block);
         // DEHALO_MSM_ACC_LDS (bytes of dynamic LDS per block, unused by the kernel): caps the accumulation's resident blocks per CU so that
         // wave slots and registers stay free for the kernels of other contexts (tuning experiments; results never depend on it)
-        static const unsigned acc_lds = [] { const char* e = getenv("DEHALO_MSM_ACC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+        static const unsigned acc_lds = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_ACC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
         k_msm_accum0<CV><<<blocks, acc_block, acc_lds, s>>>(g, tb, idx, off, nrank, bases->table, partial0, cursor + MSM_MERGE_COUNTERS);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_REDUCE);
-        // partial sums -> one point per bucket (by size class)
-        // (a list of <= MSM_LIGHT_QUAD_MAX buckets runs one quad per bucket, where 23 additions are still a short chain; a longer
-        // list runs one LANE per bucket and is kept to 11 full-width additions)
-        // DEHALO_MSM_MERGE2=0: the round-3 merge kernel (operands in registers, 172 VGPRs) instead of k_msm_merge2 (operands in LDS, < 128 VGPRs, quads throughout)
-        const u32 c0max = use_merge2 || tb <= MSM_LIGHT_QUAD_MAX ? 24u : 12u;
-        if (!use_merge2) k_msm_merge_classify<CV><<<(tb + 255) / 256, 256, 0, s>>>(tb, rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, c0max);
-        if (use_merge2) {
+        // partial sums -> one point per bucket: every size class in one launch (k_msm_merge2, msm_bred.cuh: operands in LDS, < 128 VGPRs, quads throughout)
+        {
             const size_t lds_m = dh_co_lds_pad(18 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_merge2<CV>, lds_m));
+#ifdef DEHALO_EXPERIMENTS
             static const bool merge_stamps = getenv("DEHALO_MSM_MERGE_STAMPS") != nullptr;
             static const int merge_q3 = [] { const char* e = getenv("DEHALO_MSM_MERGE_Q3"); return e ? atoi(e) : 0; }();
             static bool merge_q3_set = false;
             if (merge_q3 && !merge_q3_set) { HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_merge2_q3), &merge_q3, sizeof(int))); merge_q3_set = true; }
             if (merge_stamps) { const int on = 1; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_merge2_stamps_on), &on, sizeof(on))); }
+#endif
             k_msm_merge2<CV><<<MERGE2_GRID, 256, lds_m, s>>>(rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, (xyzz29_rec*)ctx->ws_merge_parts.p, tb);
-            if (merge_stamps) {
-                std::vector<unsigned long long> st(MERGE2_GRID * 3); std::vector<u32> info(MERGE2_GRID * 3);
-                HIP_TRY(ctx, hipStreamSynchronize(s));
-                HIP_TRY(ctx, hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_merge2_stamps), st.size() * 8));
-                HIP_TRY(ctx, hipMemcpyFromSymbol(info.data(), HIP_SYMBOL(g_merge2_info), info.size() * 4));
-                unsigned long long t0 = ~0ull, t1 = 0;
-                for (u32 b = 0; b < MERGE2_GRID_SUMS; b++) { t0 = std::min(t0, st[3 * b]); t1 = std::max(t1, st[3 * b + 2]); }
-                fprintf(stderr, "k_msm_merge2 %u buckets: %.1f us from the first block's start to the last block's end;", tb, (double)(t1 - t0) / 100.0);
-                for (u32 c = 0; c < 6; c++) {
-                    u32 nb_ = 0, q_ = 0, umax = 0; unsigned long long usum = 0; double smax = 0, cmax = 0, emax = 0, longest = 0;
-                    for (u32 b = 0; b < MERGE2_GRID_SUMS; b++) {
-                        if (info[3 * b] != c || info[3 * b + 2] == 0) continue;
-                        nb_++; q_ = info[3 * b + 1]; umax = std::max(umax, info[3 * b + 2]); usum += info[3 * b + 2];
-                        smax = std::max(smax, (double)(st[3 * b] - t0) / 100.0); cmax = std::max(cmax, (double)(st[3 * b + 1] - t0) / 100.0);
-                        emax = std::max(emax, (double)(st[3 * b + 2] - t0) / 100.0); longest = std::max(longest, (double)(st[3 * b + 2] - st[3 * b + 1]) / 100.0);
-                    }
-                    if (nb_) fprintf(stderr, " class %u: Q %u, %u blocks with work (%llu units, <= %u per block), latest start %.1f, latest count read %.1f, latest end %.1f, longest block %.1f us;",
-                                     c, q_, nb_, usum, umax, smax, cmax, emax, longest);
-                }
-                unsigned long long it[64];
-                HIP_TRY(ctx, hipMemcpyFromSymbol(it, HIP_SYMBOL(g_merge2_iter), sizeof(it)));
-                fprintf(stderr, " | one quad's walk of class 3, us per iteration:");
-                for (int i = 1; i < 62 && it[i]; i++) fprintf(stderr, " %.1f", (double)(it[i] - it[i - 1]) / 100.0);
-                fprintf(stderr, "\n");
-            }
-        } else {
-            // DEHALO_MSM_MERGE_SPLIT=1 (measurements, tools/merge_split.sh): one launch per class -- block, wave, 32 lanes, light -- so that a kernel trace shows each one's time
-            static const bool merge_split = [] { const char* e = getenv("DEHALO_MSM_MERGE_SPLIT"); return e && e[0] == '1'; }();
-            for (int only = merge_split ? 3 : -1; only >= -1; only--) {
-                k_msm_merge_all<CV><<<MSM_MERGE_BLOCKS_HEAVY + MSM_MERGE_BLOCKS_G64 + MSM_MERGE_BLOCKS_G32 + MSM_MERGE_BLOCKS_LIGHT, MSM_MERGE_THREADS, 0, s>>>(
-                    rbeg, rend, partial0, buckets, merge_counters, merge_lists, merge_cap, only);
-                if (only <= 0) break;
-            }
+#ifdef DEHALO_EXPERIMENTS
+            if (merge_stamps) TRY(merge2_report_stamps(ctx, tb, s));
+#endif
         }
-        // bucket reduction.  Default (round 4): ONE launch of the radix-2 recursion (msm_bred.cuh: 2 additions per bucket, operands in LDS, < 128 VGPRs; the
-        // last block of a group weights, sums and writes the result).  DEHALO_MSM_BRED=0 runs the round-3 path for A/B measurements: k_msm_reduce_local
-        // (RM = 4 / 8 buckets per quad, double-and-add weighting) + k_msm_tree_sum launches.
-        static const bool use_bred = [] { const char* e = getenv("DEHALO_MSM_BRED"); return !(e && e[0] == '0'); }();
+        // bucket reduction: ONE launch of the radix-2 recursion (msm_bred.cuh: 2 additions per bucket, operands in LDS, < 128 VGPRs; the last block of a group
+        // weights, sums and writes the result); groups of fewer than 8 buckets (windows of 1 .. 3 bits) by k_msm_reduce_small
         bool emitted = false;
-        const xyzz29_rec* cur = contrib;
-        if (use_bred && g.nb >= 8) {
+        if (g.nb >= 8) {
             // buckets per block: 128 up to 2^13 buckets (the kernel alone 119 -> 107 us at 4096 buckets, 134 -> 125 at 16384, 153 -> 153 at 32768 where the third level costs
             // what the shorter first one saves); 256 above: measured on k = 17 proofs the 128-bucket blocks -- twice as many, beside the side context's transforms -- cost
-            // 0.1 ms (profiles/r04_bred_block_buckets.txt).  DEHALO_MSM_BRED_BLOCK = 128 | 256 forces one.
-            static const u32 bred_bb_env = [] { const char* e = getenv("DEHALO_MSM_BRED_BLOCK"); const int v = e ? atoi(e) : 0; return v == 128 || v == 256 ? (u32)v : 0u; }();
+            // 0.1 ms (profiles/r04_bred_block_buckets.txt).
+            static const u32 bred_bb_env = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_BRED_BLOCK"); const int v = e ? atoi(e) : 0; return v == 128 || v == 256 ? (u32)v : 0u; }();
             const u32 bred_bb = bred_bb_env ? bred_bb_env : (g.nb <= 8192 ? 128u : 256u);
             const u32 nblk = std::max<u32>(1, g.nb / bred_bb);
             const bool fin = g.G == 1;
             const size_t lds_b = dh_co_lds_pad(41 * 1024, 0);
             TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bred<CV>, lds_b));
+#ifdef DEHALO_EXPERIMENTS
             static const bool bred_stamps = getenv("DEHALO_MSM_BRED_STAMPS") != nullptr;
             if (bred_stamps) {
                 const int on = 1; unsigned long long init[8] = {0, 0, 0, 0, 0, 0, 0, ~0ull};
                 HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps_on), &on, sizeof(on)));
                 HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps), init, sizeof(init)));
             }
+#endif
             k_msm_bred<CV><<<dim3(nblk, (u32)total_groups), BRED_THREADS, lds_b, s>>>(g.nb, bred_bb, buckets, (xyzz29_rec*)ctx->ws_contrib.p, (xyzz29_rec*)ctx->ws_tree.p, (u32*)ctx->ws_bred_cnt.p, gsums,
                                                                                  fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
             emitted = fin;
-            cur = gsums;
+#ifdef DEHALO_EXPERIMENTS
             if (bred_stamps) {
                 unsigned long long st[8];
                 HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1228,36 +987,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
                 fprintf(stderr, "k_msm_bred nb %u groups %u, us after the first block's start (the block that finishes group 0): its start %.1f | phase 0 tree done %.1f | phase 1 %.1f | phase 2 %.1f | "
                         "doublings done %.1f | final tree %.1f | result written %.1f\n", g.nb, (unsigned)total_groups, us(0), us(1), st[2] ? us(2) : 0.0, st[3] ? us(3) : 0.0, us(5), us(4), us(6));
             }
+#endif
         } else {
-        static const int red_m_env = [] { const char* e = getenv("DEHALO_MSM_RED_M"); return e ? atoi(e) : 0; }();
-        const uint64_t quads4 = (uint64_t)((g.nb + 3) / 4) * total_groups;
-        const u32 red_m = red_m_env == 4 || red_m_env == 8 ? (u32)red_m_env : (quads4 * 4 > 65536 ? 8u : 4u);
-        const u32 per_group_r = (g.nb + red_m - 1) / red_m;
-        uint64_t nblocks4 = (uint64_t)per_group_r * total_groups;       // RM-bucket blocks
-        if (quads4 * 4 <= 192 * 1024) {   // <= ~3 waves per SIMD at 4 lanes per block (two rounds of resident quads still beat one lane per block: 0.58 -> 0.28 ms for a batch of ten 2^17 MSMs)
-            const u32 grid = (u32)((nblocks4 * 4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS);
-            if (red_m == 8) k_msm_reduce_local<CV, true, 8><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
-            else k_msm_reduce_local<CV, true, 4><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
-        } else {
-            const u32 grid = (u32)((nblocks4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS);
-            if (red_m == 8) k_msm_reduce_local<CV, false, 8><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
-            else k_msm_reduce_local<CV, false, 4><<<grid, MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, contrib);
-        }
-        u32 cnt = per_group_r;
-        xyzz29_rec* bufs[2] = {tree, contrib};  // ping-pong: contrib is free once consumed
-        int which = 0;
-        while (cnt > 1) {
-            u32 out_cnt = (cnt + MSM_TREE_ITEMS - 1) / MSM_TREE_ITEMS;
-            xyzz29_rec* o = out_cnt == 1 ? gsums : bufs[which];
-            dim3 grid(out_cnt, (u32)total_groups);
-            const bool fin = out_cnt == 1 && g.G == 1;      // one sum per MSM left: this launch also writes the results
-            k_msm_tree_sum<CV><<<grid, 256, 0, s>>>(cur, cnt, o, out_cnt, fin ? d_out : nullptr, fin ? ctx->msm_affine_out : nullptr);
-            emitted = fin;
-            cur = o; cnt = out_cnt; which ^= 1;
-        }
+            k_msm_reduce_small<CV><<<(u32)((total_groups * 4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS), MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, gsums);
         }
         if (!emitted) {
-            if (cur != gsums) HIP_TRY(ctx, hipMemcpyAsync(gsums, cur, total_groups * REC, hipMemcpyDeviceToDevice, s));
             k_msm_final<CV><<<(u32)batch, 256, 0, s>>>(g, gsums, d_out, ctx->msm_affine_out);
         }
         HIP_TRY(ctx, hipGetLastError());

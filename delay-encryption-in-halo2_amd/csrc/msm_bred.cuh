@@ -20,8 +20,13 @@
 #pragma once
 #include "ec29.cuh"
 
+// the measurement hooks (wall-clock stamps of the phases: DEHALO_MSM_BRED_STAMPS, DEHALO_MSM_MERGE_STAMPS, DEHALO_MSM_MERGE_Q3) exist in -DDEHALO_EXPERIMENTS builds only
 #ifndef DEHALO_PHASE_STAMPS
-#define DEHALO_PHASE_STAMPS 1        // 0: the measurement hooks (DEHALO_MSM_BRED_STAMPS, DEHALO_MSM_MERGE_STAMPS, DEHALO_MSM_MERGE_Q3) compiled out, for the A/B of their cost
+#ifdef DEHALO_EXPERIMENTS
+#define DEHALO_PHASE_STAMPS 1
+#else
+#define DEHALO_PHASE_STAMPS 0
+#endif
 #endif
 #define BRED_THREADS 256
 #define BRED_QUADS (BRED_THREADS / 4)
@@ -179,9 +184,15 @@ FP_DEV void bred_gather(const u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C
 // 3 (the block that holds the group's vector) weighting by 2^j and the final sum.  Every phase is one call of the tree -- one loop body.
 // measurement only (DEHALO_MSM_BRED_STAMPS=1): wall-clock stamps (100 MHz) of the block that finishes group 0 -- [0] its start, [1 + phase] the end of each phase's
 // tree, [5] the doublings of phase 3 done, [6] the result written; [7] the earliest start of any block
+#if DEHALO_PHASE_STAMPS
 __device__ unsigned long long g_bred_stamps[8];
 __device__ int g_bred_stamps_on;
+#define BRED_STAMPS_ON (g_bred_stamps_on != 0)
 #define BRED_STAMP(i) do { if (stamps_on && tid == 0 && g == 0) my_stamps[i] = wall_clock64(); } while (0)
+#else
+#define BRED_STAMPS_ON false
+#define BRED_STAMP(i) do { } while (0)
+#endif
 
 template <class CV>
 __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const xyzz29_rec* buckets, xyzz29_rec* nodes1, xyzz29_rec* nodes2, u32* counters, xyzz29_rec* gsums,
@@ -196,10 +207,12 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const
     const u32 here = nb < bb ? nb : bb;      // buckets of a block (a power of two >= 8)
     u32 m = 0;                                                               // log2 nb
     while ((1u << m) < nb) m++;
-    const bool stamps_on = DEHALO_PHASE_STAMPS && g_bred_stamps_on != 0;
+#if DEHALO_PHASE_STAMPS
+    const bool stamps_on = BRED_STAMPS_ON;
     unsigned long long my_stamps[7] = {0, 0, 0, 0, 0, 0, 0};
     BRED_STAMP(0);
     if (stamps_on && tid == 0 && g == 0) atomicMin(&g_bred_stamps[7], my_stamps[0]);
+#endif
 
     u32 children = gridDim.x;      // vectors still to combine for this group after the current phase
     u32 idx = blockIdx.x;          // this block's position among them
@@ -264,10 +277,12 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const
         const xyzz29 s = x29_load(reinterpret_cast<const xyzz29_rec*>(lds));
         if (fin_out || fin_affine) msm_emit<F>(s, fin_out ? fin_out + g : nullptr, fin_affine ? fin_affine + g : nullptr);
         else x29_store(&gsums[g], s);
+#if DEHALO_PHASE_STAMPS
         if (stamps_on && g == 0) {
             my_stamps[6] = wall_clock64();
             for (int i = 0; i < 7; i++) g_bred_stamps[i] = my_stamps[i];
         }
+#endif
     }
 }
 
@@ -290,7 +305,9 @@ FP_DEV void q_copy_out(xyzz29_rec* dst, const u32* rec, u32 role) {
 }
 
 // acc (LDS record) = sum of partial[p], p = first, first + step, ... < end  (identity if none); the next record is in flight during an addition
+#if DEHALO_PHASE_STAMPS
 __device__ unsigned long long g_merge2_iter[64];      // measurement only: the iterations of one quad's walk (first block of class 3, quad 0)
+#endif
 template <class F>
 FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 first, u32 step, u32 end, u32 role, unsigned long long* iter_stamps = nullptr) {
     if (first >= end) {
@@ -355,10 +372,15 @@ FP_DEV void q_strided_sum(u32* acc, u32* inc, const xyzz29_rec* partial, u32 fir
 // instructions against ~1,300 for the quad-cooperative one, so a wave-step takes 8-16 us against 3.6 and the four-fold lane economy is spent: the kernel took
 // ~95 us where the quads take 100 at 2^17 and the whole MSM got 20-70 us longer; a k = 17 proof +0.1-0.2 ms.  profiles/r04_merge_lanes_ab.txt)
 // measurement only (DEHALO_MSM_MERGE_STAMPS=1): per block [start, its section's count read, end] wall-clock stamps (100 MHz) and [class, Q, units it summed]
+#if DEHALO_PHASE_STAMPS
 __device__ unsigned long long g_merge2_stamps[MERGE2_GRID * 3];
 __device__ u32 g_merge2_info[MERGE2_GRID * 3];
 __device__ int g_merge2_stamps_on;
 __device__ int g_merge2_q3;
+#define MERGE2_STAMP(i) do { if (stamps_on && tid == 0) g_merge2_stamps[3 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define MERGE2_STAMP(i) do { } while (0)
+#endif
 
 template <class CV>
 __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* rend, const xyzz29_rec* partial, xyzz29_rec* buckets, const u32* counters, u32* lists, u32 cap,
@@ -389,10 +411,12 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     else if ((blk -= MERGE2_BLOCKS_PARTS) < MERGE2_BLOCKS_BLOCK) { cls = 4; nblk = MERGE2_BLOCKS_BLOCK; Q = 64; }
     else if ((blk -= MERGE2_BLOCKS_BLOCK) < MERGE2_BLOCKS_Q8) { cls = 3; nblk = MERGE2_BLOCKS_Q8; Q = 8; }
     else { blk -= MERGE2_BLOCKS_Q8; cls = 2 - blk / MERGE2_BLOCKS_LIGHT; blk %= MERGE2_BLOCKS_LIGHT; nblk = MERGE2_BLOCKS_LIGHT; Q = 1; }
-    const bool stamps_on = DEHALO_PHASE_STAMPS && g_merge2_stamps_on != 0;
-    if (stamps_on && tid == 0) g_merge2_stamps[3 * blockIdx.x] = wall_clock64();
+#if DEHALO_PHASE_STAMPS
+    const bool stamps_on = g_merge2_stamps_on != 0;
+#endif
+    MERGE2_STAMP(0);
     const u32 count = counters[cls];
-    if (stamps_on && tid == 0) g_merge2_stamps[3 * blockIdx.x + 1] = wall_clock64();
+    MERGE2_STAMP(1);
     u32 units = 0;
     // Wide groups buy latency with idle lanes (a tree level keeps half of the group's quads busy): right for the few hundred skewed buckets of a witness column,
     // wrong when EVERY bucket of a large dense MSM lands in the class (2^20 uniform scalars: 32768 buckets of ~13 records -- eight sweeps of 8-quad groups
@@ -402,9 +426,11 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
     // What bounds a populous class is issue slots, not latency: a lone wave of quad additions takes 3.6-3.8 us per step here and fills its SIMD; two per SIMD take 7.
     if (cls == 3) {
         static_assert(MERGE2_BLOCKS_Q8 == 512, "");
-        const u32 q_env = DEHALO_PHASE_STAMPS ? (u32)g_merge2_q3 : 0u;
-        if (q_env) Q = count > MERGE2_BLOCKS_Q8 * 8 * 2 ? 1 : 8;                  // (DEHALO_MSM_MERGE_Q3=1: the two-way choice of the first version, for the A/B)
-        else while (Q > 1 && count * Q > MERGE2_BLOCKS_Q8 * 64) Q >>= 1;
+#if DEHALO_PHASE_STAMPS
+        if (g_merge2_q3) Q = count > MERGE2_BLOCKS_Q8 * 8 * 2 ? 1 : 8;            // (DEHALO_MSM_MERGE_Q3=1: the two-way choice of the first version, for the A/B)
+        else
+#endif
+        while (Q > 1 && count * Q > MERGE2_BLOCKS_Q8 * 64) Q >>= 1;
     }
     if (cls == 4 && count > MERGE2_BLOCKS_BLOCK * 4) Q = 8;
     const bool wide = Q == 64;                               // quads of one unit span several waves: block barriers (these loops are uniform over the block)
@@ -427,7 +453,11 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
             dst = &buckets[b];
         }
         for (u32 round = 0; round < 2; round++) {            // (round 1: only the last block of a heavy bucket, over the bucket's parts)
+#if DEHALO_PHASE_STAMPS
             q_strided_sum<F>(acc, inc, src, beg + q, Q, end, role, stamps_on && tid == 0 && blockIdx.x == MERGE2_BLOCKS_PARTS + MERGE2_BLOCKS_BLOCK && units == 0 ? g_merge2_iter : nullptr);
+#else
+            q_strided_sum<F>(acc, inc, src, beg + q, Q, end, role);
+#endif
             if (wide) __syncthreads();
             for (u32 d = Q >> 1; d >= 1; d >>= 1) {
                 if (q < d) x29q_add_mem<F>(acc, acc, acc + 72 * d);
@@ -448,8 +478,41 @@ __global__ __launch_bounds__(256) void k_msm_merge2(const u32* rbeg, const u32* 
         }
         units++;
     }
+#if DEHALO_PHASE_STAMPS
     if (stamps_on && tid == 0) {
         g_merge2_stamps[3 * blockIdx.x + 2] = wall_clock64();
         g_merge2_info[3 * blockIdx.x] = cls; g_merge2_info[3 * blockIdx.x + 1] = Q; g_merge2_info[3 * blockIdx.x + 2] = units;
     }
+#endif
+    (void)units;
 }
+
+#if DEHALO_PHASE_STAMPS
+// measurement only: what the stamps of the last k_msm_merge2 launch say (stderr)
+static inline int merge2_report_stamps(dehalo_ctx* ctx, u32 tb, hipStream_t s) {
+    std::vector<unsigned long long> st(MERGE2_GRID * 3); std::vector<u32> info(MERGE2_GRID * 3);
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_merge2_stamps), st.size() * 8));
+    HIP_TRY(ctx, hipMemcpyFromSymbol(info.data(), HIP_SYMBOL(g_merge2_info), info.size() * 4));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (u32 b = 0; b < MERGE2_GRID_SUMS; b++) { t0 = std::min(t0, st[3 * b]); t1 = std::max(t1, st[3 * b + 2]); }
+    fprintf(stderr, "k_msm_merge2 %u buckets: %.1f us from the first block's start to the last block's end;", tb, (double)(t1 - t0) / 100.0);
+    for (u32 c = 0; c < 6; c++) {
+        u32 nb_ = 0, q_ = 0, umax = 0; unsigned long long usum = 0; double smax = 0, cmax = 0, emax = 0, longest = 0;
+        for (u32 b = 0; b < MERGE2_GRID_SUMS; b++) {
+            if (info[3 * b] != c || info[3 * b + 2] == 0) continue;
+            nb_++; q_ = info[3 * b + 1]; umax = std::max(umax, info[3 * b + 2]); usum += info[3 * b + 2];
+            smax = std::max(smax, (double)(st[3 * b] - t0) / 100.0); cmax = std::max(cmax, (double)(st[3 * b + 1] - t0) / 100.0);
+            emax = std::max(emax, (double)(st[3 * b + 2] - t0) / 100.0); longest = std::max(longest, (double)(st[3 * b + 2] - st[3 * b + 1]) / 100.0);
+        }
+        if (nb_) fprintf(stderr, " class %u: Q %u, %u blocks with work (%llu units, <= %u per block), latest start %.1f, latest count read %.1f, latest end %.1f, longest block %.1f us;",
+                         c, q_, nb_, usum, umax, smax, cmax, emax, longest);
+    }
+    unsigned long long it[64];
+    HIP_TRY(ctx, hipMemcpyFromSymbol(it, HIP_SYMBOL(g_merge2_iter), sizeof(it)));
+    fprintf(stderr, " | one quad's walk of class 3, us per iteration:");
+    for (int i = 1; i < 62 && it[i]; i++) fprintf(stderr, " %.1f", (double)(it[i] - it[i - 1]) / 100.0);
+    fprintf(stderr, "\n");
+    return 0;
+}
+#endif

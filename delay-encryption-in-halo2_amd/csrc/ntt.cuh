@@ -63,10 +63,15 @@ struct NttPassParams {
     int form_shift;      // +1 / -1: fold 2^5 / 2^-5 into the output multiplication (internal <-> standard form, see dehalo.h)
     fe pre_z;
     fe post0, post_z;
+#ifdef DEHALO_EXPERIMENTS
     unsigned long long* stamps;   // measurement only (DEHALO_NTT_STAMPS=1): 4 wall-clock stamps per workgroup -- start, tile in LDS, stages done, stores issued
-    u32 prio_mode;       // experiment (DEHALO_NTT_PRIO): issue priority by the workgroup's slot on its CU, so co-resident workgroups leave lock-step
-    u32 prio_shift;
+#endif
 };
+#ifdef DEHALO_EXPERIMENTS
+#define NTT_STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
+#else
+#define NTT_STAMP(i) do { } while (0)
+#endif
 
 FP_DEV u32 bitrev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
@@ -93,6 +98,16 @@ FP_DEV fe tw_lookup(const fe* tw, u64 e, u32 log_n, bool full) {
 // brings it back below 2p for one conditional subtraction.
 #ifndef NTT_THREADS
 #define NTT_THREADS 512
+#endif
+// measurement-only variants (tools/ab_ntt.sh rebuilds the four ntt units with one of these; results are WRONG with them, only the time means anything):
+//   NTT_X_NOSYNC   no workgroup barrier between the butterfly rounds (an upper bound on what wave-private sub-transforms could win)
+//   NTT_X_NOLOAD   the tile is filled from the index instead of from global memory (what hiding the whole load latency could win)
+//   NTT_X_NOTW     the inter-pass twiddle of the output multiplication is not loaded
+#define NTT_LOADS 4        // elements of a tile per thread (2048 / 512, 1024 / 256)
+#ifdef NTT_X_NOSYNC
+#define NTT_STAGE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define NTT_STAGE_SYNC() __syncthreads()
 #endif
 
 struct Lds29 {
@@ -138,16 +153,16 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     const u32 r = P.r, log_c = P.log_c;
     const u32 R = 1u << r, Cc = 1u << log_c;
     const u32 tile = R << log_c;
+#ifdef DEHALO_EXPERIMENTS
     unsigned long long* stamp = P.stamps ? P.stamps + 4 * ((u64)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
-    if (stamp && tid == 0) stamp[0] = wall_clock64();
-    if (P.prio_mode) {
-        const u32 slot = (P.prio_mode == 1 ? blockIdx.x >> 3 : blockIdx.x >> P.prio_shift) & 3;
-        if (slot == 1) __builtin_amdgcn_s_setprio(1);
-        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
-        else if (slot == 3) __builtin_amdgcn_s_setprio(3);
-    }
-    const fe* src = P.src + (u64)blockIdx.y * P.src_stride;
-    fe* dst = P.dst + (u64)blockIdx.y * P.dst_stride;
+#endif
+    NTT_STAMP(0);
+    // (Round 5, measured and removed: re-reading the linear workgroup id so that the batch's copies of one tile -- which gather the SAME inter-pass twiddles -- run
+    // back to back on one XCD and share its L2.  23 x 2^19: 1.18-1.20 -> 1.33-1.34 ms.  The copies' data lie exactly N x 32 bytes apart, so the 64 workgroups an XCD has
+    // in flight then hammer the same memory channels; profiles/r05_ntt_ab.txt.)
+    const u32 bx = blockIdx.x, by = blockIdx.y;
+    const fe* src = P.src + (u64)by * P.src_stride;
+    fe* dst = P.dst + (u64)by * P.dst_stride;
 
     for (u32 j = tid; j < (R >> 1); j += nthr) ltw[j] = f29_unpack(f_load(&P.tw[(u64)j << (P.log_n - r)]));
 
@@ -157,12 +172,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     const u32 log_cols = P.log_m - r;
     if (!P.is_final) {
         u32 tiles_per_sub_log = log_cols - log_c;
-        q = (u64)blockIdx.x >> tiles_per_sub_log;
-        np0 = ((u64)blockIdx.x & ((1ull << tiles_per_sub_log) - 1)) << log_c;
+        q = (u64)bx >> tiles_per_sub_log;
+        np0 = ((u64)bx & ((1ull << tiles_per_sub_log) - 1)) << log_c;
     } else {
         u32 kb_log = P.r1 - log_c;
-        k1blk = blockIdx.x & ((1u << kb_log) - 1);
-        rest = (u64)blockIdx.x >> kb_log;
+        k1blk = bx & ((1u << kb_log) - 1);
+        rest = (u64)bx >> kb_log;
     }
     const u32 log_q_per_k1 = P.log_n - r - P.r1;
 
@@ -193,32 +208,61 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             const u32 a0 = (bitrev32(j, r) << log_c) + c;
             lds29_store(L, a0, v); lds29_store(L, a0 + Cc, v); lds29_store(L, a0 + 2 * Cc, v); lds29_store(L, a0 + 3 * Cc, v);
         }
-    } else
-    for (u32 idx = tid; idx < tile; idx += nthr) {
-        u32 j, c;
-        u64 g;
-        if (!P.is_final) {
-            j = idx >> log_c; c = idx & (Cc - 1);
-            g = (q << P.log_m) + ((u64)j << log_cols) + np0 + c;
-        } else {
-            c = idx >> r; j = idx & (R - 1);
-            u64 qq = (((u64)k1blk << log_c) + c) << log_q_per_k1;
-            qq += rest;
-            g = (qq << r) + j;
-        }
-        f29 v = f29_zero();
-        if (g < P.src_len) {
-            v = f29_unpack(f_load(&src[g]));
-            if (P.pre_mode) {
-                u32 m3 = (u32)(g % 3);
-                if (m3 == 1) v = f29_mul<F9>(v, pre1);
-                else if (m3 == 2) v = f29_mul<F9>(v, pre2);
+    } else {
+        // a thread's (at most four: tile <= NTT_LOADS x threads by construction, run_ntt_t) elements: all four global loads are issued before the first is unpacked -- one memory round trip per tile instead of four
+        // (profiles/r05_ntt_elimination.txt: a tile filled without global loads is the upper bound, 7 % of the batch)
+        // (four named values, not an array: an array indexed in a loop the compiler declines to unroll -- the body holds two multiplications -- lands in scratch)
+        auto locate = [&](u32 u, u32& slot, u64& g) __attribute__((always_inline)) {
+            const u32 idx = tid + u * nthr;
+            u32 j, c;
+            if (!P.is_final) {
+                j = idx >> log_c; c = idx & (Cc - 1);
+                g = (q << P.log_m) + ((u64)j << log_cols) + np0 + c;
+            } else {
+                c = idx >> r; j = idx & (R - 1);
+                u64 qq = (((u64)k1blk << log_c) + c) << log_q_per_k1;
+                qq += rest;
+                g = (qq << r) + j;
+            }
+            slot = idx < tile && g < P.src_len ? (bitrev32(j, r) << log_c) + c : (idx < tile ? 0x80000000u | ((bitrev32(j, r) << log_c) + c) : 0xffffffffu);
+        };
+        auto fetch = [&](u32 slot, u64 g) __attribute__((always_inline)) -> fe {
+            if (slot & 0x80000000u) return f_zero();      // beyond the tile, or beyond the valid coefficients (zero-extended)
+#ifdef NTT_X_NOLOAD
+            fe x; for (int i = 0; i < 8; i++) x.v[i] = (u32)g * (2654435761u + i);
+            return x;
+#else
+            return f_load(&src[g]);
+#endif
+        };
+        auto put = [&](const fe& raw, u32 slot, u64 g) __attribute__((always_inline)) {
+            if (slot == 0xffffffffu) return;
+            lds29_store(L, slot & 0x7fffffffu, f29_unpack(raw));
+        };
+        static_assert(NTT_LOADS == 4, "");
+        u32 s0, s1, s2, s3;
+        u64 g0, g1, g2, g3;
+        locate(0, s0, g0); locate(1, s1, g1); locate(2, s2, g2); locate(3, s3, g3);
+#ifdef NTT_X_SERIAL_LOADS      // (measurement only: one memory round trip per element, as before round 5)
+        { const fe r0 = fetch(s0, g0); put(r0, s0, g0); __builtin_amdgcn_sched_barrier(0); }
+        { const fe r1 = fetch(s1, g1); put(r1, s1, g1); __builtin_amdgcn_sched_barrier(0); }
+        { const fe r2 = fetch(s2, g2); put(r2, s2, g2); __builtin_amdgcn_sched_barrier(0); }
+        { const fe r3 = fetch(s3, g3); put(r3, s3, g3); }
+#else
+        const fe r0 = fetch(s0, g0), r1 = fetch(s1, g1), r2 = fetch(s2, g2), r3 = fetch(s3, g3);
+        put(r0, s0, g0); put(r1, s1, g1); put(r2, s2, g2); put(r3, s3, g3);
+#endif
+        if (P.pre_mode) {      // x zeta^(i mod 3) of a coset transform whose input is longer than N / 4 (rare: the padded case is the branch above): one loop, one copy of the multiplication
+            for (u32 u = 0; u < NTT_LOADS; u++) {
+                const u32 sl = u == 0 ? s0 : u == 1 ? s1 : u == 2 ? s2 : s3;
+                const u32 m3 = (u32)((u == 0 ? g0 : u == 1 ? g1 : u == 2 ? g2 : g3) % 3);
+                if ((sl & 0x80000000u) || m3 == 0) continue;
+                lds29_store(L, sl, f29_mul<F9>(lds29_load(L, sl), m3 == 1 ? pre1 : pre2));      // (the thread's own slot: no barrier needed)
             }
         }
-        lds29_store(L, (bitrev32(j, r) << log_c) + c, v);
     }
     __syncthreads();
-    if (stamp && tid == 0) stamp[1] = wall_clock64();
+    NTT_STAMP(1);
 
     // ---- DIT stages, two per round ----
     u32 s = P.skip2 ? 2 : 0;
@@ -244,7 +288,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             lds29_store(L, a0, f29_norm(e0)); lds29_store(L, a1, f29_norm(e1));
             lds29_store(L, a2, f29_norm(e2)); lds29_store(L, a3, f29_norm(e3));
         }
-        __syncthreads();
+        NTT_STAGE_SYNC();
     }
     if (s < r) {   // odd r: one last radix-2 stage
         const u32 h = 1u << s;
@@ -262,7 +306,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         __syncthreads();
     }
 
-    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    NTT_STAMP(2);
     // ---- store: row k holds output digit k; one multiplication brings every element below 2p ----
     f29 post0m = f29_one<F9>(), post1m = f29_zero(), post2m = f29_zero();
     if (P.is_final && (P.post_mode || P.form_shift)) {
@@ -297,7 +341,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         if (!P.is_final) {
             u64 np = np0 + c;
             u64 e = (np * k) << (P.log_n - P.log_m);
+#ifdef NTT_X_NOTW
+            w = ltw[(u32)e & ((R >> 1) - 1)];
+#else
             w = f29_unpack(tw_lookup<F>(P.tw, e, P.log_n, P.tw_full != 0));
+#endif
             o = (q << P.log_m) + ((u64)k << log_cols) + np;
         } else {
             o = (((u64)k1blk << log_c) + c) + (revrest << P.r1) + ((u64)k << (P.log_n - r));
@@ -310,7 +358,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
         f29 t = f29_mul<F9>(v, w);   // < 30p * p / 2^261 + p < 2p
         f_store(&dst[o], f29_pack(f29_cond_sub(t, F9::P)));
     }
-    if (stamp && tid == 0) stamp[3] = wall_clock64();
+    NTT_STAMP(3);
 }
 
 // tw[j] = omega^j * 2^261 mod p (canonical, packed), j < half (`half` = the table's length: N for a full table).  Thread t fills a run of 64
@@ -392,6 +440,7 @@ int get_twiddles(dehalo_ctx* ctx, uint32_t log_n, const uint64_t omega[4], hipSt
     return 0;
 }
 
+#ifdef DEHALO_EXPERIMENTS
 // measurement only: phases of the workgroups of one pass from their wall-clock stamps (100 MHz), relative to the first workgroup's start
 static inline void ntt_report_stamps(dehalo_ctx* ctx, unsigned long long* d, uint64_t nblk, uint32_t pass, uint32_t r, uint32_t tile_log, hipStream_t s) {
     std::vector<unsigned long long> h(nblk * 4);
@@ -411,6 +460,7 @@ static inline void ntt_report_stamps(dehalo_ctx* ctx, unsigned long long* d, uin
     for (uint64_t i = 0; i < nblk; i++) { dl += (double)(h[4 * i + 1] - h[4 * i]); dc += (double)(h[4 * i + 2] - h[4 * i + 1]); ds += (double)(h[4 * i + 3] - h[4 * i + 2]); }
     fprintf(stderr, "mean per workgroup: load %.1f us, stages %.1f us, store %.1f us\n", dl / nblk / 100.0, dc / nblk / 100.0, ds / nblk / 100.0);
 }
+#endif
 
 // Transforms `batch` polynomials: src (src_len valid elements each, zero-extended to 2^log_n,
 // src_stride apart) -> dst (dst_stride apart).  src == dst allowed.
@@ -447,7 +497,7 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
     // A launch of few tiles (one 2^20 transform: 512 of 2048 elements, two per CU) leaves every CU with two workgroups that load, transform and store in
     // lock-step; half-size tiles on half-size workgroups give it four.  Launches of up to 2^22 elements take them (measured, tools/ab_ntt_tile.sh: 22 x 2^17
     // 0.300 -> 0.280 ms, one 2^20 0.142 -> 0.139, 23 x 2^19 unchanged either way); DEHALO_NTT_SMALL_TILE_LOG = log2 of that bound (0: never) for the A/B.
-    static const uint32_t small_log = [] { const char* e = getenv("DEHALO_NTT_SMALL_TILE_LOG"); return e ? (uint32_t)atoi(e) : 22u; }();
+    static const uint32_t small_log = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_NTT_SMALL_TILE_LOG"); return e ? (uint32_t)atoi(e) : 22u; }();
     const uint32_t tile_log = L > 1 && rad[0] + 1 < NTT_TILE_LOG && batch * N <= (1ull << small_log) ? NTT_TILE_LOG - 1 : NTT_TILE_LOG;
     uint32_t log_m = log_n;
     for (uint32_t p = 0; p < L; p++) {
@@ -459,7 +509,7 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
         P.is_final = last ? 1 : 0;
         P.tw_full = tw_full ? 1 : 0;
         // (DEHALO_NTT_SKIP=0: the general first pass, for A/B measurements)
-        static const bool skip_ok = [] { const char* e = getenv("DEHALO_NTT_SKIP"); return !(e && e[0] == '0'); }();
+        static const bool skip_ok = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_NTT_SKIP"); return !(e && e[0] == '0'); }();
         P.skip2 = skip_ok && first && !last && rad[p] >= 2 && src_len * 4 <= N ? 1 : 0;
         P.r1 = L > 1 ? rad[0] : 0;
         if (first) { P.src = src; P.src_len = src_len; P.src_stride = src_stride; }
@@ -487,17 +537,15 @@ int run_ntt_t(dehalo_ctx* ctx, const fe* src, uint64_t src_len, uint64_t src_str
             lds = dh_co_lds_pad(0, lds);
             TRY(dh_co_lds_attr(ctx, (const void*)k_ntt_pass<F>, lds));
         }
-        static const int prio_mode = [] { const char* e = getenv("DEHALO_NTT_PRIO"); return e ? atoi(e) : 0; }();
-        if (prio_mode && tile_log < NTT_TILE_LOG) {
-            P.prio_mode = (u32)prio_mode;
-            u32 lg = 0; while ((2ull << lg) <= tiles) lg++;
-            P.prio_shift = lg >= 2 ? lg - 2 : 0;
-        }
+#ifdef DEHALO_EXPERIMENTS
         static const bool stamps_on = getenv("DEHALO_NTT_STAMPS") != nullptr;
         if (stamps_on) HIP_TRY(ctx, hipMalloc((void**)&P.stamps, tiles * batch * 4 * sizeof(unsigned long long)));
+#endif
         k_ntt_pass<F><<<grid, NTT_THREADS >> (NTT_TILE_LOG - tile_log), lds, s>>>(P);
         HIP_TRY(ctx, hipGetLastError());
+#ifdef DEHALO_EXPERIMENTS
         if (stamps_on) ntt_report_stamps(ctx, P.stamps, tiles * batch, p, rad[p], tile_log, s);
+#endif
         log_m -= rad[p];
     }
     return 0;

@@ -192,6 +192,8 @@ extern "C" int dehalo_params_setup(dehalo_ctx* ctx, int curve, uint32_t k, const
     if (curve != DEHALO_CURVE_BN254_G1) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "params_setup: ParamsKZG needs a pairing: BN254 only");
     const HostField* f = host_field(curve_scalar_field(curve));
     if (k > f->two_adicity || k > 26) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: k out of range");
+    // checked BEFORE the 2^(k+1) fixed-base multiplications: the tables this call registers must fit (BN254: k <= 25, include/dehalo.h)
+    if (!dh_precomputed_table_fits(curve, (size_t)1 << k)) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: 2^k x windows >= 2^30: precomputed table too large");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     Fe sm;
@@ -978,7 +980,7 @@ struct dehalo_prover {
     int find_table_rows() {
         const HostCS& cs = pk->cs;
         table_rows.assign(L, TableRows{});
-        static const bool enabled = [] { const char* e = getenv("DEHALO_PROVER_TABLE_ROWS"); return !(e && e[0] == '0'); }();      // (0: every table sorted in full, for the A/B)
+        static const bool enabled = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_PROVER_TABLE_ROWS"); return !(e && e[0] == '0'); }();      // (0: every table sorted in full, for the A/B)
         if (!enabled) return 0;
         std::vector<std::vector<Fe>> colv(cs.num_fixed);
         for (uint32_t l = 0; l < L; l++) {
@@ -1126,7 +1128,7 @@ int dehalo_prover::run(const uint64_t* advice, const uint64_t* const* instances,
     // and upstream writes the point right behind the grand products' commitments with no challenge in between: so (round 4, with a side context) the helper only
     // draws and uploads, and the polynomial rides as ONE MORE COLUMN of the products' MSM launch -- a whole sort / accumulate / merge / reduce pipeline per proof
     // less, and none running beside the lookups' phase.  DEHALO_PROVER_RANDOM_SEPARATE=1: the helper commits it with an MSM of its own, as in round 3 (A/B measurements).
-    static const bool random_separate_env = [] { const char* e = getenv("DEHALO_PROVER_RANDOM_SEPARATE"); return e && e[0] == '1'; }();
+    static const bool random_separate_env = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_PROVER_RANDOM_SEPARATE"); return e && e[0] == '1'; }();
     const bool random_separate = random_separate_env;
     auto device_draw = [&](fe* dst, hipStream_t st) -> int {
         ChaKey ck;

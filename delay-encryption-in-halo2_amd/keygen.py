@@ -49,7 +49,8 @@ def to_device(arr):
     """host array of 64-bit words -> int64 tensor in HBM, through the library's staged upload (never `tensor.cuda()` of a pageable array: _lib.Context.upload)"""
     from ._lib import transfer_context
 
-    return transfer_context().upload(np.ascontiguousarray(arr, dtype=np.uint64))
+    with transfer_context() as c:
+        return c.upload(np.ascontiguousarray(arr, dtype=np.uint64))
 
 
 def to_host(t) -> np.ndarray:
@@ -57,7 +58,8 @@ def to_host(t) -> np.ndarray:
     from ._lib import transfer_context
 
     torch.cuda.current_stream().synchronize()      # what `t.cpu()` would have waited for
-    return transfer_context().download_tensor(t.contiguous())
+    with transfer_context() as c:
+        return c.download_tensor(t.contiguous())
 
 
 _RINV: dict = {}
@@ -384,4 +386,5 @@ def _keygen(ctx: Context, params: ParamsKZG, cs: plonk.ConstraintSystem, fixed_c
 def to_device_index(idx: np.ndarray):
     from ._lib import transfer_context
 
-    return transfer_context().upload(np.ascontiguousarray(idx, dtype=np.int64))
+    with transfer_context() as c:
+        return c.upload(np.ascontiguousarray(idx, dtype=np.int64))

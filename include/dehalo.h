@@ -64,41 +64,25 @@ int dehalo_ctx_create_with_priority(int device, int priority, dehalo_ctx** out);
 void dehalo_ctx_destroy(dehalo_ctx* ctx);
 /* Human-readable text of the last error on this context (a per-thread copy: valid until the calling thread's next call of this function). */
 const char* dehalo_last_error(const dehalo_ctx* ctx);
-/* Launch-geometry knobs (results never depend on them).  "msm_acc_points" (default 48; also the environment variable
- * DEHALO_MSM_ACC_POINTS at context creation): the bucket-accumulation grid of an MSM is 4, 6, 8, ... layers of one wave per SIMD,
+/* Launch-geometry knobs (results never depend on them).  "msm_acc_points" (default 48): the bucket-accumulation grid of an MSM is 4, 6, 8, ... layers of one wave per SIMD,
  * the fewest that leave a lane at most this many points; 0 selects the older rule, whole rounds of "msm_acc_waves" in [1, 4]
  * waves per SIMD (below 4 the kernel leaves wave slots and registers free for the latency-bound kernels of other contexts).
- * "msm_acc_block" (128 or 768; DEHALO_MSM_ACC_BLOCK at context creation): threads per workgroup of the bucket accumulation.  768 = one
+ * "msm_acc_block" (128 or 768): threads per workgroup of the bucket accumulation.  768 = one
  * 12-wave workgroup per compute unit, three waves per SIMD, which leaves a quarter of every SIMD's registers and all of the LDS to the
  * kernels of other contexts that need at most 128 VGPRs (the bucket reduction, the merge, the NTT's half tiles).
  * "ntt_full_table_log" (default 0, in [0, 30]): transforms of up to 2^value points keep all N powers of omega on the device
  * (32 B x N) so that an inter-pass twiddle is one load; larger ones keep N / 2 and negate (measured equal on MI355X).
- * "host_wait_spin_us" (default 400, in [0, 1000000]; DEHALO_HOST_SPIN_US at context creation): a host wait for the context's stream
+ * "host_wait_spin_us" (default 400, in [0, 1000000]): a host wait for the context's stream
  * (dehalo_download and the calls built on it: every transcript round trip of a proof) polls for up to this many microseconds before it
  * blocks in the runtime, whose wake-up comes ~15 us after the stream has drained; 0: block at once (no CPU spent waiting). */
 int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value);
-/* Environment variables read by the library (measurement and tuning only; results never depend on them):
- *   DEHALO_MSM_ACC_POINTS   default of "msm_acc_points" at context creation
- *   DEHALO_MSM_ACC_BLOCK    default of "msm_acc_block" at context creation
- *   DEHALO_CU_PARTITION     P (2 .. 16; measurements only): the i-th context this process creates gets a stream confined to the (i mod P)-th share of the compute units
- *                           (with DEHALO_CU_PARTITION_INTERLEAVE set: CU c belongs to share c mod P; otherwise contiguous blocks) -- profiles/r04_batch_cu_partition.txt
- *   DEHALO_HOST_SPIN_US     default of "host_wait_spin_us" at context creation
- *   DEHALO_MSM_BRED_BLOCK   128 / 256: buckets per workgroup of the bucket reduction (default: 128 up to 2^13 buckets, 256 above)
- *   DEHALO_MSM_SMALL_SLICES 0: sort workgroups of 2048 scalars whatever the launch size (default: down to 256 until ~128 workgroups are there)
- *   DEHALO_MSM_BUCKET_FILL  0: k_msm_bucket workgroups of 4 slices whatever the launch size (default: fewer until every compute unit has one)
- *   DEHALO_MSM_MERGE_Q3     1: the merge's 9..64-record class as 8 quads or 1 (the first version's choice) instead of the widest group that fits one sweep
- *   DEHALO_MSM_BRED_STAMPS / DEHALO_MSM_MERGE_STAMPS / DEHALO_NTT_STAMPS   1: the kernel's workgroups stamp their phases with the wall clock; a report per launch on stderr (synchronises)
- *   DEHALO_NTT_PRIO         1 / 2: workgroups of a half-tile transform pass take issue priorities by slot (experiment: flat)
- *   DEHALO_MSM_BRED         0: the round-3 bucket reduction (k_msm_reduce_local + k_msm_tree_sum launches) instead of the one-launch radix-2 recursion
- *   DEHALO_WINDOW_BITS      Pippenger window of tables registered with window_bits = 0 (4 .. 16)
- *   DEHALO_MSM_ACC_LDS      bytes of (unused) dynamic LDS per block of the bucket accumulation: caps its resident blocks per CU
- *   DEHALO_MSM_MERGE_SPLIT  1: the merge of partial sums runs one launch per bucket class (a kernel trace then shows each class's time)
- *   DEHALO_MSM_RED_M        4 / 8: buckets per quad of the bucket reduction (default: 4 up to four 2^15-bucket columns in a launch, 8 beyond)
- *   DEHALO_NTT_SKIP         0: the first pass of a zero-padded transform (input <= N / 4) runs its two copy stages like any other
- *   DEHALO_NTT_SMALL_TILE_LOG  log2 of the largest transform launch (elements) that runs on half-size tiles (default 22; 0: never)
+/* Environment variables.  The library as shipped reads THREE, all host-side diagnostics; none changes which kernels run or with what geometry:
  *   DEHALO_SYNTH_THREADS    host threads dehalo_synthesize writes the RSA regions of a proving call with (default: 8, or the machine's hardware threads if fewer; 1: none)
  *   DEHALO_SYNTH_TRACE      dehalo_synthesize writes the time of its stages to stderr
- *   DEHALO_PROVER_TRACE     dehalo_create_proof writes the host's timeline inside the phases to stderr                                        */
+ *   DEHALO_PROVER_TRACE     dehalo_create_proof writes the host's timeline inside the phases to stderr
+ * Tuning is per context and validated: dehalo_ctx_set_tuning above.  The A/B switches of the measurement scripts (tools/ab_*.sh: DEHALO_MSM_BRED_BLOCK, DEHALO_NTT_SKIP,
+ * DEHALO_CU_PARTITION, the *_STAMPS phase stamps, ...) exist only in a library built with `make EXPERIMENTS=1` (-DDEHALO_EXPERIMENTS); in the default build their
+ * names are not in the binary (tests/test_abi.py counts them). */
 /* The context's own stream (a hipStream_t): lets the caller order its own device work (copies, fills) with the library's
  * kernels by enqueueing it on the same stream. */
 void* dehalo_ctx_stream(dehalo_ctx* ctx);
@@ -125,6 +109,8 @@ int dehalo_upload(dehalo_ctx* ctx, const void* host_src, size_t bytes, void* d_d
  *   precompute    1 = also store [2^(c*w)]P_i for every window w (n * ceil(256/c) * 64 B of
  *                 HBM): all windows then share one bucket set and the per-window doublings
  *                 vanish.  0 = store the n points only.
+ * Limits: n < 2^30; with precompute = 1 also n x windows < 2^30 (30-bit table indices in the sorted list; windows = the signed-digit windows of the
+ * scalar field at the chosen c, e.g. 16 for BN254 at c = 16): the default window admits BN254 tables up to n = 2^25.  Beyond: DEHALO_ERR_INVALID.
  */
 int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes,
                           int window_bits, int precompute, dehalo_bases** out);
@@ -426,7 +412,8 @@ int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t*
                          dehalo_params** out);
 /* ParamsKZG::setup(k, rng) with the rng's draw handed over: `s` is the toxic waste as a Montgomery scalar (what `<E::Scalar>::random(rng)` returns).  g[i] = [s^i] G
  * and g_lagrange[i] = [L_i(s)] G are made on the device (fixed-base table multiplication, one batch inversion), g2 / s_g2 on the host: the reference's
- * `ParamsKZG::<Bn256>::setup(K, OsRng)` (benches/delay_enc.rs:43).  BN254 only (a KZG SRS needs the pairing). */
+ * `ParamsKZG::<Bn256>::setup(K, OsRng)` (benches/delay_enc.rs:43).  BN254 only (a KZG SRS needs the pairing); k <= 25 (the precomputed-table limit above, checked before
+ * any device work: k = 26 is DEHALO_ERR_INVALID). */
 int dehalo_params_setup(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t s[4], dehalo_params** out);
 int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out);
 size_t dehalo_params_size(const dehalo_params* params);

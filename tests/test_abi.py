@@ -76,3 +76,26 @@ def test_product_does_not_touch_the_oracle():
             if fn.endswith((".py", ".hip", ".cuh", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in txt.lower(), (fn, "mentions the oracle")
+
+
+def test_default_build_reads_no_tuning_from_the_environment(pkg):
+    """An environment variable must not change which kernels a drop-in library runs: the shipped library holds the names of three host-side diagnostics
+    (include/dehalo.h) and of no A/B switch -- those exist only under `make EXPERIMENTS=1` -- and the sources read the environment nowhere else."""
+    blob = open(pkg.library_path(), "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"DEHALO_[A-Z0-9_]{3,}", blob)))
+    env_like = [n for n in names if not n.startswith(("DEHALO_ERR_", "DEHALO_K_", "DEHALO_OK"))]
+    assert set(env_like) <= {"DEHALO_PROVER_TRACE", "DEHALO_SYNTH_THREADS", "DEHALO_SYNTH_TRACE"}, env_like
+    allowed = {"DEHALO_PROVER_TRACE", "DEHALO_SYNTH_THREADS", "DEHALO_SYNTH_TRACE"}
+    csrc = os.path.join(ROOT, "delay-encryption-in-halo2_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".cuh", ".hpp", ".h")):
+            continue
+        depth = 0      # inside #ifdef DEHALO_EXPERIMENTS / #if DEHALO_PHASE_STAMPS blocks a plain getenv is the measurement build's
+        for line in open(os.path.join(csrc, fn)):
+            t = line.strip()
+            if t.startswith("#if"):
+                depth = depth + 1 if (depth or "DEHALO_EXPERIMENTS" in t or "DEHALO_PHASE_STAMPS" in t) and not t.startswith("#ifndef") else depth
+            elif t.startswith("#endif") and depth:
+                depth -= 1
+            for name in re.findall(r'(?<![A-Z_])getenv\("([A-Z0-9_]+)"\)', line):
+                assert depth or name in allowed, "%s reads %s from the environment in the default build" % (fn, name)

@@ -55,22 +55,71 @@ def test_domain_rejects_oversized_extension(pkg):
         pkg.EvaluationDomain(NoCtx(), pkg.fields.BN254_FR, 5, 27)  # 2^29 > two-adicity 28
 
 
-def test_bench_replaces_a_measuring_process_killed_by_a_signal_once():
-    """bench.py measures in a child process; a child that exits by itself is final (here: no GPU -> exit 1 with the reason), a child killed by a signal is
+def test_bench_replaces_a_measuring_process_killed_by_a_signal_once_only_when_asked():
+    """bench.py measures in-process by default: a measuring process killed by a signal is an exit code the caller sees (no silent second attempt).  With --supervise
+    it measures in a child process; a child that exits by itself is final (here: no GPU -> exit 1 with the reason), a child killed by a signal is
     replaced ONCE (DEHALO_BENCH_SELFTEST_KILL = the attempt that kills itself)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    run = lambda extra: subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=dict(env, **extra))
+    run = lambda extra, *flags: subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", *flags], capture_output=True, text=True, timeout=600, env=dict(env, **extra))
     plain = run({})
     assert "one more" not in plain.stderr.lower()
     if plain.returncode == 0:
         pytest.skip("a GPU is present: the no-device exit path is not reachable")
     assert plain.returncode == 1 and "needs an MI355X" in plain.stderr
-    once = run({"DEHALO_BENCH_SELFTEST_KILL": "1"})
+    # default: the signal ends the run (the shell's 128 + signal convention is subprocess's negative return code), nothing is started again
+    died = run({"DEHALO_BENCH_SELFTEST_KILL": "1", "DEHALO_BENCH_ATTEMPT": "1"})
+    assert died.returncode == -6 and "one more" not in died.stderr.lower() and died.stdout == ""
+    once = run({"DEHALO_BENCH_SELFTEST_KILL": "1"}, "--supervise")
     assert once.returncode == 1 and "killed by signal 6" in once.stderr and "needs an MI355X" in once.stderr and once.stdout == ""
+
+
+def test_bench_line_fits_the_drivers_tail_and_ends_with_the_metric():
+    """The line on stdout is compact_line(record): at most 6,000 characters for a full record (tests/golden/bench_record_verbose.json: round 4's, 14.4 KB verbose),
+    BASELINE's own metric -- the k = 17 delay_enc proof, the batch, attempts -- LAST, and its three scalars inside `config`."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = json.load(open(os.path.join(root, "tests", "golden", "bench_record_verbose.json")))
+    rec["first_attempt"] = {"signal": 6, "section": "proof delay_enc k = 17: proving", "stderr_tail": ["x" * 300] * 6}
+    rec["attempts"] = 2
+    text = bench.compact_line(rec)
+    assert len(text) <= bench.LINE_LIMIT == 6000, len(text)
+    line = json.loads(text)
+    keys = list(line)
+    assert keys[-4:] == ["proof", "batch_proofs", "attempts", "first_attempt"], keys[-6:]
+    assert keys.index("proof_other_k") < keys.index("proof")
+    assert line["proof"]["k"] == 17 and line["proof"]["gpu_ms"] == rec["proof"]["gpu_ms"] and line["proof"]["phase_ms"] == rec["proof"]["gpu_phase_ms"]
+    cfg = line["config"]
+    assert cfg["delay_enc_k17_ms"] == rec["proof"]["gpu_ms"] and cfg["batch_proofs_per_s"] == rec["batch_proofs"]["proofs_per_s"] and cfg["attempts"] == 2
+    assert "model" not in cfg and cfg["workload"].startswith("1 x MSM(2^20, pallas)")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in line
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert {p["k"] for p in line["proof_other_k"]} == {14, 20}
+    assert max(len(v) for v in _strings(line)) <= 110          # no sentences: the longest string is config.workload
+    # a record whose sections grew still fits: optional sections are dropped, the metric's are not
+    rec["proof_other_k"] = rec["proof_other_k"] * 4
+    text = bench.compact_line(rec)
+    assert len(text) <= 6000 and "\"proof\":{" in text and "batch_proofs" in text
+
+
+def _strings(o):
+    if isinstance(o, str):
+        yield o
+    elif isinstance(o, dict):
+        for v in o.values():
+            yield from _strings(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _strings(v)
 
 
 def test_bench_gpus_n_starts_its_own_ranks():

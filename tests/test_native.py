@@ -168,10 +168,10 @@ def native_chain(pkg, ctx, chain):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,rl", [(6, False), (9, True), (11, False), (17, True)])
+@pytest.mark.parametrize("k,rl", [(6, False), (9, True), (11, False), (14, True), (17, True)])
 def test_native_proof_matches_oracle_and_verifies(pkg, po, ctx, chain, native_chain, k, rl):
     """dehalo_keygen + dehalo_create_proof: the verifying key's bytes and the whole proof equal the CPU restatement's, the verifier accepts
-    -- configs[0] shape at k = 11 and configs[3] shape at k = 17 included -- with and without a side context."""
+    -- configs[0] shape at k = 11, configs[3] shape at k = 17 and the north star's k = 14 included (k = 20: the next test) -- with and without a side context."""
     import plonk_oracle as PO
     from dehalo2_amd import native, prover
 
@@ -203,6 +203,48 @@ def test_native_proof_matches_oracle_and_verifies(pkg, po, ctx, chain, native_ch
     if k <= 11:
         assert oracle_verify(po, c, p1, k) and oracle_verify(po, c, p2, k) and oracle_verify(po, c, p3, k)
     P.release(); P2.release(); side.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_native_proof_k20_matches_oracle_and_verifies(pkg, po, co, ctx):
+    """The north star's largest size, k = 20 (delay_enc shape): the only size whose proof runs c = 16 windows, 32,768-bucket reduction groups and the
+    2^20-row distinct-table lookup path.  Verifying key and proof equal the CPU restatement's byte for byte (its SRS, keygen and proof take a few minutes of
+    host time), the pairing check accepts, with and without a side context.  Nothing of this size is kept for the other tests."""
+    import pairing as pr
+    import plonk_oracle as PO
+    import shapes
+    import verifier as V
+    from dehalo2_amd import circuits, native, prover
+
+    k, threads, curve = 20, 16, po.BN254
+    circ = circuits.synthesize(curve.scalar.p, k, True, seed=3)
+    desc = shapes.maingate_description(True)
+    assert desc == circ.cs.description()
+    srs = PO.setup_srs(curve, k, S_TOXIC, threads)
+    s_g2 = pr.g2_mul(S_TOXIC, pr.G2)
+    # the device's own ParamsKZG::setup from the same secret: same bytes as the CPU restatement's SRS at the size bench.py reports
+    params = native.ParamsKZG.setup(ctx, pkg.fields.BN254, k, S_TOXIC)
+    raw, n = params.write(), 1 << k
+    assert raw[4:4 + 64 * n] == np.ascontiguousarray(srs["g"]).tobytes() and raw[4 + 64 * n:4 + 128 * n] == np.ascontiguousarray(srs["g_lagrange"]).tobytes()
+    del raw
+    key = PO.keygen(curve, srs, desc, k, circ.fixed, circ.assembly.mapping, threads)
+    rep = PO.transcript_repr(curve, key, circ.selectors)
+    adv = np.stack([co.field_op(PO.Fld(curve.scalar).id, "to_mont", circ.advice[i]) for i in range(5)])
+    pk = native.ProvingKey.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
+    assert pk.vk_bytes() == PO.vk_bytes(curve, key, circ.selectors)
+    pk.transcript_repr = rep
+    want, _ = PO.create_proof(curve, srs, key, adv, [[]], PO.ScalarStream(7), rep, threads)
+    P = native.Prover(params, pk)
+    proof = P.create_proof(adv, [[]], prover.SeededRng(7)).finalize()
+    diff = [i // 32 for i in range(0, len(want), 32) if proof[i:i + 32] != want[i:i + 32]]
+    assert len(proof) == len(want) and not diff, "k = 20 proof items differ from the oracle's: %r" % diff[:8]
+    assert V.verify_proof(curve, desc, k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, s_g2, [[]], proof)
+    side = pkg.Context(0)
+    P2 = native.Prover(params, pk, ctx, side)
+    for _ in range(2):
+        assert P2.create_proof(adv, [[]], prover.SeededRng(7)).finalize() == want
+    P.release(); P2.release(); side.close(); pk.release(); params.release()
 
 
 @pytest.mark.gpu
@@ -513,8 +555,10 @@ def test_params_setup_on_the_device_equals_the_cpu_restatement(pkg, po, ctx, k):
 
 
 @pytest.mark.gpu
-def test_params_setup_k20_is_fast(pkg, ctx):
-    """The largest north-star size: 2 x 2^20 fixed-base multiplications, the tables of both vectors and the download of the points for write()."""
+def test_params_setup_k20_and_its_limits(pkg, ctx):
+    """The largest north-star size: 2 x 2^20 fixed-base multiplications, the tables of both vectors and the download of the points for write() (the time is
+    printed, not asserted: bench.py reports it as one_time_setup_s.params_setup_gpu); k = 26, whose precomputed tables would pass the 2^30 index limit, is refused
+    before any device work; a curve without a pairing is refused."""
     import time
     from dehalo2_amd import native
 
@@ -526,6 +570,9 @@ def test_params_setup_k20_is_fast(pkg, ctx):
     print("dehalo_params_setup k = 20: %.1f ms" % (1e3 * dt))
     assert len(params.write()) == 4 + 128 * (1 << 20) + 256
     params.release()
-    assert dt < 0.5
+    t0 = time.perf_counter()
+    with pytest.raises(pkg.DehaloError, match="too large"):
+        native.ParamsKZG.setup(ctx, curve, 26, 0x1234567890ABCDEF)
+    assert time.perf_counter() - t0 < 5.0, "k = 26 must be refused before the 2^27 fixed-base multiplications, not after"      # (those take tens of seconds)
     with pytest.raises(Exception):
         native.ParamsKZG.setup(ctx, pkg.fields.CURVES["pallas"], 6, 3)      # no pairing: not a KZG curve
