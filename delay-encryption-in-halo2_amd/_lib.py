@@ -322,13 +322,15 @@ class Context:
         return out
 
     def upload(self, host, dtype=None):
-        """A host array (any numpy array; 64-bit words) -> a torch tensor of the same shape in HBM, through dehalo_upload: the library's page-locked staging
+        """A host array (any numpy array of 64-bit / 32-bit words or bytes) -> a torch tensor of the same shape in HBM, through dehalo_upload: the library's page-locked staging
         chunks or a DMA from pages the library pins for the call -- never torch's / the HIP runtime's handling of a pageable source (`tensor.cuda()`)."""
         import torch
 
         a = np.ascontiguousarray(host)
-        assert a.dtype.itemsize == 8, "upload: 64-bit words expected"
-        out = torch.empty(a.shape, dtype=torch.int64 if dtype is None else dtype, device=torch.device("cuda", self.device))      # the CONTEXT's device, not torch's current one
+        assert a.dtype.itemsize in (8, 4, 1), "upload: 64-bit words (field elements, indices), 32-bit words or bytes"
+        if dtype is None:
+            dtype = {8: torch.int64, 4: torch.int32, 1: torch.uint8}[a.dtype.itemsize]
+        out = torch.empty(a.shape, dtype=dtype, device=torch.device("cuda", self.device))      # the CONTEXT's device, not torch's current one
         self._check(self.lib.dehalo_upload(self.handle, a.ctypes.data, a.nbytes, out.data_ptr()))
         return out
 

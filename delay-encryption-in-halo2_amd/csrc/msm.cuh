@@ -970,7 +970,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
 #ifdef DEHALO_EXPERIMENTS
             static const bool bred_stamps = getenv("DEHALO_MSM_BRED_STAMPS") != nullptr;
             if (bred_stamps) {
-                const int on = 1; unsigned long long init[8] = {0, 0, 0, 0, 0, 0, 0, ~0ull};
+                const int on = 1; unsigned long long init[12] = {0, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0};
                 HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps_on), &on, sizeof(on)));
                 HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bred_stamps), init, sizeof(init)));
             }
@@ -980,12 +980,13 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
             emitted = fin;
 #ifdef DEHALO_EXPERIMENTS
             if (bred_stamps) {
-                unsigned long long st[8];
+                unsigned long long st[12];
                 HIP_TRY(ctx, hipStreamSynchronize(s));
                 HIP_TRY(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_bred_stamps), sizeof(st)));
                 auto us = [&](int i) { return (double)(st[i] - st[7]) / 100.0; };
                 fprintf(stderr, "k_msm_bred nb %u groups %u, us after the first block's start (the block that finishes group 0): its start %.1f | phase 0 tree done %.1f | phase 1 %.1f | phase 2 %.1f | "
-                        "doublings done %.1f | final tree %.1f | result written %.1f\n", g.nb, (unsigned)total_groups, us(0), us(1), st[2] ? us(2) : 0.0, st[3] ? us(3) : 0.0, us(5), us(4), us(6));
+                        "doublings done %.1f | final tree %.1f | result written %.1f || hand-offs: phase 1 last arrival known %.1f, siblings in LDS %.1f | phase 2 %.1f, %.1f\n", g.nb, (unsigned)total_groups,
+                        us(0), us(1), st[2] ? us(2) : 0.0, st[3] ? us(3) : 0.0, us(5), us(4), us(6), st[8] ? us(8) : 0.0, st[9] ? us(9) : 0.0, st[10] ? us(10) : 0.0, st[11] ? us(11) : 0.0);
             }
 #endif
         } else {

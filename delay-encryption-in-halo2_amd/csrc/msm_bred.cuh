@@ -183,9 +183,10 @@ FP_DEV void bred_gather(const u32* lds, u32 aBase, u32 xBase, u32 iStride, u32 C
 // Phases of a block: 0 its 256 buckets | 1 (last block of a cluster of 16) the cluster's vectors | 2 (last cluster of the group) the clusters' vectors |
 // 3 (the block that holds the group's vector) weighting by 2^j and the final sum.  Every phase is one call of the tree -- one loop body.
 // measurement only (DEHALO_MSM_BRED_STAMPS=1): wall-clock stamps (100 MHz) of the block that finishes group 0 -- [0] its start, [1 + phase] the end of each phase's
-// tree, [5] the doublings of phase 3 done, [6] the result written; [7] the earliest start of any block
+// tree, [5] the doublings of phase 3 done, [6] the result written; [7] the earliest start of any block; the hand-offs of phases 1 / 2: [8] / [10] this block knows it
+// is the last arrival (its vector published, fence, counter), [9] / [11] the siblings' vectors are in LDS
 #if DEHALO_PHASE_STAMPS
-__device__ unsigned long long g_bred_stamps[8];
+__device__ unsigned long long g_bred_stamps[12];
 __device__ int g_bred_stamps_on;
 #define BRED_STAMPS_ON (g_bred_stamps_on != 0)
 #define BRED_STAMP(i) do { if (stamps_on && tid == 0 && g == 0) my_stamps[i] = wall_clock64(); } while (0)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const
     while ((1u << m) < nb) m++;
 #if DEHALO_PHASE_STAMPS
     const bool stamps_on = BRED_STAMPS_ON;
-    unsigned long long my_stamps[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long my_stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     BRED_STAMP(0);
     if (stamps_on && tid == 0 && g == 0) atomicMin(&g_bred_stamps[7], my_stamps[0]);
 #endif
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const
             }
             __syncthreads();
             if (!s_last) return;
+            BRED_STAMP(6 + 2 * phase);
             const u32* kids = reinterpret_cast<const u32*>(level_nodes + ((u64)g * children + (u64)cl * fan) * BRED_VMAX);
             for (u32 e = tid; e < fan * V * 36; e += BRED_THREADS) {
                 const u32 i = e / (V * 36), w = e - i * (V * 36);
@@ -254,6 +256,10 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const
             }
             C = V - 1; K = fan; xBase = V - 1; iStride = V;
             children /= fan; idx = cl;
+#if DEHALO_PHASE_STAMPS
+            __syncthreads();
+            BRED_STAMP(7 + 2 * phase);
+#endif
         } else {                   // vec = [A_0 .. A_{m-1}, X]  ->  S = X + sum_j 2^j A_j: quad j doubles A_j j times, then the 16 records are summed
             for (u32 e = tid; e < 16 * 36; e += BRED_THREADS) lds[e] = e < (m + 1) * 36 ? vec[e] : 0u;
             __syncthreads();
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const
 #if DEHALO_PHASE_STAMPS
         if (stamps_on && g == 0) {
             my_stamps[6] = wall_clock64();
-            for (int i = 0; i < 7; i++) g_bred_stamps[i] = my_stamps[i];
+            for (int i = 0; i < 12; i++) if (i != 7) g_bred_stamps[i] = my_stamps[i];
         }
 #endif
     }

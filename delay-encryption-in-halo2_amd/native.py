@@ -2,7 +2,7 @@
 library call each (include/dehalo.h, "the whole call"; csrc/prover.hip) -- the objects and the call of the reference's benches
 (benches/delay_enc.rs:41-54 params, :84-115 keys, :120-134 create_proof into a Blake2bWrite transcript).  Python is a caller
 here: it serialises the ConstraintSystem into the C descriptor and passes pointers; phases, transcript hashing and every
-launch run in C++.  (`prover.py` drives the same proof from Python through the fine-grained entry points.)"""
+launch run in C++.  (tests/fine_grained_prover.py -- test infrastructure -- drives the same proof from Python through the fine-grained entry points.)"""
 from __future__ import annotations
 
 import ctypes as C

@@ -364,7 +364,7 @@ def test_two_contexts_concurrently(pkg, co, ctx):
     h = ctx.register_bases(spec.id, bases, 0, True)
     other = pkg.Context(0)
     cols = [co.fill_scalars(spec.scalar.id, "uniform", n, 70 + i) for i in range(4)]
-    d_cols = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+    d_cols = [ctx.upload(c) for c in cols]
     d_outs = [torch.zeros((1, 12), dtype=torch.int64, device="cuda") for _ in cols]
     torch.cuda.synchronize()
     for rep in range(3):
@@ -413,7 +413,7 @@ def test_msm_device_affine_matches_msm_then_to_affine(pkg, co, ctx, precompute):
     h = ctx.register_bases(spec.id, bases, 0, precompute)
     cols = np.stack([co.fill_scalars(spec.scalar.id, "uniform", n, 77), np.zeros((n, 4), np.uint64), co.fill_scalars(spec.scalar.id, "witness", n, 78)])
     with ctx.torch_stream():
-        d = torch.from_numpy(cols.view(np.int64)).cuda()
+        d = ctx.upload(cols)
         jac = torch.zeros((3, 12), dtype=torch.int64, device="cuda")
         aff = torch.full((3, 8), -1, dtype=torch.int64, device="cuda")
         aff_only = torch.full((3, 8), -1, dtype=torch.int64, device="cuda")
@@ -454,7 +454,7 @@ def test_ntt_batched_device_entry_points(pkg, po, co, ctx):
     of = po.FIELDS[f.name]
     for k, batch in ((5, 3), (11, 4), (13, 7), (16, 2)):
         polys = np.stack([co.fill_scalars(f.id, "uniform", 1 << k, 900 + 7 * k + b) for b in range(batch)])
-        d = torch.from_numpy(polys.view(np.int64)).cuda()
+        d = ctx.upload(polys)
         omega = f.encode(of.omega(k))
         ctx.ntt_device(f.id, d.data_ptr(), k, omega, batch, 0)
         ctx.synchronize()
@@ -509,7 +509,7 @@ def test_eval_polynomial_device_batch(pkg, co, ctx):
         cols[b, :n] = co.fill_scalars(fid, "uniform", n, 40 + b)
         cols[b, n:] = co.fill_scalars(fid, "uniform", stride - n, 50 + b)      # must be ignored
     x = co.fill_scalars(fid, "uniform", 1, 60)[0]
-    d = torch.from_numpy(cols.view(np.int64)).cuda()
+    d = ctx.upload(cols)
     out = torch.zeros((batch, 4), dtype=torch.int64, device="cuda")
     ctx.eval_polynomial_device(fid, d.data_ptr(), n, stride, batch, x, out.data_ptr(), 0)
     ctx.synchronize()
@@ -562,7 +562,7 @@ def test_prefix_product_device_in_place(pkg, co, ctx):
     import torch
     fid, n = 2, 100003
     v = co.fill_scalars(fid, "uniform", n, 8)
-    d = torch.from_numpy(v.view(np.int64).copy()).cuda()
+    d = ctx.upload(v)
     ctx.prefix_product_device(fid, d.data_ptr(), n, d.data_ptr(), 0)
     ctx.synchronize()
     ones = ctx.field_op(fid, "to_mont", np.tile(np.array([[1, 0, 0, 0]], dtype=np.uint64), (n, 1)))
@@ -571,8 +571,9 @@ def test_prefix_product_device_in_place(pkg, co, ctx):
 
 # ---------------------------------------------------------------- quotient numerator
 def _dev(spec, vals):
-    import torch
-    return torch.from_numpy(spec.encode_many(list(vals)).view(np.int64).copy()).cuda()
+    """canonical ints -> device tensor (Montgomery limbs) through the library's staged upload (keygen.to_device: the per-device transfer context)"""
+    from dehalo2_amd import keygen
+    return keygen.to_device(spec.encode_many(list(vals)))
 
 
 def _host(spec, t):
@@ -776,7 +777,7 @@ def test_grand_product_batch_shares_one_inversion(pkg, co, ctx):
     num = np.stack([np.concatenate([co.fill_scalars(fid, "uniform", n, 60 + b), np.zeros((stride - n, 4), dtype=np.uint64)]) for b in range(batch)])
     den = np.stack([np.concatenate([co.fill_scalars(fid, "uniform", n, 70 + b), np.zeros((stride - n, 4), dtype=np.uint64)]) for b in range(batch)])
     den[3, 100] = 0                                                  # a zero denominator in one column must not disturb the others
-    dn, dd = torch.from_numpy(num.view(np.int64)).cuda(), torch.from_numpy(den.view(np.int64)).cuda()
+    dn, dd = ctx.upload(num), ctx.upload(den)
     dz = torch.zeros_like(dn)
     ctx.grand_product_batch_device(fid, dn.data_ptr(), dd.data_ptr(), n, batch, stride, dz.data_ptr(), 0)
     ctx.synchronize()
@@ -793,7 +794,7 @@ def test_permute_expression_pair_shared_tables_and_odd_sizes(pkg, co, ctx):
     import torch
     fid = 0
     rng = np.random.default_rng(7)
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    dev = lambda a: ctx.upload(a)
     for n in (1, 2, 2047, 2048, 2049, 4097, 6000, 100003):
         t_shared = co.fill_scalars(fid, "uniform", n, 500 + n % 89)                       # n distinct full-width values
         t_other = t_shared.copy()
@@ -848,8 +849,8 @@ def test_permute_expression_pair_tables_given_as_distinct_rows(pkg, co, ctx):
     import torch
     fid = 0
     rng = np.random.default_rng(23)
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
-    dev32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32)).cuda()
+    dev = lambda a: ctx.upload(a)
+    dev32 = lambda a: ctx.upload(np.ascontiguousarray(a, dtype=np.uint32))
 
     def distinct_rows(table):
         _, first, counts = np.unique(table, axis=0, return_index=True, return_counts=True)
@@ -950,7 +951,7 @@ def test_context_lifecycle_releases_device_memory(pkg, co):
             gr = ev.GraphEvaluator()
             gr.add_calculation(ev.MUL, gr.column(ev.ADVICE, 0), gr.column(ev.ADVICE, 0, 1))
             cg = gr.compile(c, curve.scalar)
-            d = torch.from_numpy(sc.view(np.int64).copy()).cuda()
+            d = c.upload(sc)
             o = torch.zeros_like(d)
             cg.evaluate_device([], [d.data_ptr()], [], [], None, None, None, None, 12, 1, 0, o.data_ptr())
             c.synchronize()
@@ -979,7 +980,7 @@ def test_permute_expression_pair_batch(pkg, co, ctx):
         tabs[y, :n] = np.concatenate([base, np.repeat(base[:1], n - tsize, axis=0)])
         ins[y, :n] = base[rng.integers(0, tsize, size=n)]
         tabs[y, n:], ins[y, n:] = co.fill_scalars(fid, "uniform", stride - n, 300 + y), co.fill_scalars(fid, "uniform", stride - n, 400 + y)   # beyond usable rows: ignored
-    di, dt = torch.from_numpy(ins.view(np.int64)).cuda(), torch.from_numpy(tabs.view(np.int64)).cuda()
+    di, dt = ctx.upload(ins), ctx.upload(tabs)
     oi, ot = torch.zeros_like(di), torch.zeros_like(dt)
     ctx.permute_expression_pair_batch_device(fid, di.data_ptr(), dt.data_ptr(), n, B, stride, oi.data_ptr(), ot.data_ptr(), 0)
     gi, gt = oi.cpu().numpy().view(np.uint64), ot.cpu().numpy().view(np.uint64)
@@ -988,7 +989,7 @@ def test_permute_expression_pair_batch(pkg, co, ctx):
         assert np.array_equal(gi[y, :n], want[0]) and np.array_equal(gt[y, :n], want[1]), y
         assert not gi[y, n:].any() and not gt[y, n:].any()
     ins[3, 5] = co.fill_scalars(fid, "uniform", 1, 999)[0]
-    di = torch.from_numpy(ins.view(np.int64)).cuda()
+    di = ctx.upload(ins)
     with pytest.raises(pkg.DehaloError) as e:
         ctx.permute_expression_pair_batch_device(fid, di.data_ptr(), dt.data_ptr(), n, B, stride, oi.data_ptr(), ot.data_ptr(), 0)
     assert e.value.code == -6 and "lookup 3" in str(e.value)
@@ -1005,7 +1006,7 @@ def test_internal_form_round_trip_and_flags(pkg, po, co, ctx):
     k, ext_k = 6, 8
     rows, rot_scale = 1 << ext_k, 1 << (ext_k - k)
     x = co.fill_scalars(fid, "uniform", 5000, 3)
-    dx = torch.from_numpy(x.view(np.int64).copy()).cuda()
+    dx = ctx.upload(x)
     di = torch.zeros_like(dx)
     ctx.convert_form_device(fid, dx.data_ptr(), di.data_ptr(), 5000, True)
     back = torch.zeros_like(dx)
@@ -1022,7 +1023,7 @@ def test_internal_form_round_trip_and_flags(pkg, po, co, ctx):
     dom = pkg.EvaluationDomain(ctx, spec, 5, k)
     e = spec.encode
     coeffs = co.fill_scalars(fid, "uniform", 1 << k, 9)
-    dc = torch.from_numpy(coeffs.view(np.int64).copy()).cuda()
+    dc = ctx.upload(coeffs)
     dext = torch.zeros((1 << dom.extended_k, 4), dtype=torch.int64, device="cuda")
     ctx.coset_ntt_form_device(fid, dc.data_ptr(), k, dext.data_ptr(), dom.extended_k, e(dom.extended_omega), e(dom.g_coset), 1, ev.FORM_OUT_INTERNAL)
     want_ext = co.coeff_to_extended(fid, coeffs, k, dom.extended_k, e(dom.extended_omega), e(dom.g_coset), 2)
@@ -1132,7 +1133,7 @@ def test_msm_split_by_point_range(pkg, co, ctx):
     for r in range(world):
         lo, hi = sharding.point_range_for_rank(n, r, world)
         h = ctx.register_bases(curve.id, g[lo:hi], 0, True); handles.append(h)
-        d = torch.from_numpy(sc[lo:hi].view(np.int64).copy()).cuda()
+        d = ctx.upload(sc[lo:hi])
         ctx.msm_device(h, d.data_ptr(), hi - lo, 1, parts[r].data_ptr(), 0)
         ctx.synchronize()
     assert [sharding.point_range_for_rank(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
@@ -1206,7 +1207,7 @@ def test_product_terms_vs_python_integers(pkg, co, ctx, fname):
 
     f = pkg.fields.FIELDS[fname]
     n, stride, ncols, chunk, nl = 333, 340, 7, 3, 2
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    dev = lambda a: ctx.upload(a)
     cols = [co.fill_scalars(f.id, "uniform", n, 40 + j) for j in range(ncols)]
     sig = [co.fill_scalars(f.id, "uniform", n, 60 + j) for j in range(ncols)]
     lk = [[co.fill_scalars(f.id, "witness" if t % 2 else "uniform", n, 80 + 4 * l + t) for t in range(4)] for l in range(nl)]

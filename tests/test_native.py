@@ -328,7 +328,7 @@ def test_native_device_advice_and_instances(pkg, po, ctx, chain, native_chain):
     c, d = chain(6, False), native_chain(6, False)
     want, _ = oracle_proof(po, c)
     P = native.Prover(d["params"], d["pk"])
-    dev = torch.from_numpy(c["adv"].view(np.int64)).cuda()
+    dev = ctx.upload(c["adv"])
     assert P.create_proof(dev, [[]], prover.SeededRng(7)).finalize() == want
     with pytest.raises(ValueError):
         P.create_proof(c["adv"], [], prover.SeededRng(7))

@@ -14,6 +14,8 @@ import threading
 import numpy as np
 import pytest
 
+import fine_grained_prover as fgp      # the Python driver over the fine-grained entry points: test infrastructure (was dehalo2_amd/prover.py's Prover)
+
 S_TOXIC = 0x1234567890ABCDEF1234567890ABCDEF
 
 
@@ -210,7 +212,7 @@ def device_chain(pkg, ctx, chain):
             c = chain(k, rl, threads=16)
             params = keygen.ParamsKZG(ctx, pkg.fields.BN254, k, c["srs"]["g"], c["srs"]["g_lagrange"], pr.g2_to_raw(pr.G2), pr.g2_to_raw(c["s_g2"]))
             pk = keygen.keygen(ctx, params, c["circ"].cs, c["circ"].fixed, c["circ"].assembly, c["circ"].selectors)
-            cache[(k, rl)] = dict(params=params, pk=pk, prover=prover.Prover(params, pk))
+            cache[(k, rl)] = dict(params=params, pk=pk, prover=fgp.Prover(params, pk))
         return cache[(k, rl)]
 
     yield get
@@ -259,7 +261,7 @@ def test_side_context_prover_makes_the_same_proof(pkg, po, ctx, chain, device_ch
     c, d = chain(k, rl), device_chain(k, rl)
     want, _ = oracle_proof(po, c)
     side = pkg.Context(0)
-    P2 = prover.Prover(d["params"], d["pk"], ctx, side)
+    P2 = fgp.Prover(d["params"], d["pk"], ctx, side)
     for _ in range(3):
         tr = transcript.Blake2bWrite(pkg.fields.BN254)
         P2.create_proof(c["adv"], [[]], prover.SeededRng(7), tr)
@@ -312,7 +314,7 @@ def test_formats_roundtrip(pkg, po, ctx, chain, device_chain):
     with pytest.raises(ValueError):
         keygen.ProvingKey.read(ctx, curve, cs, io.BytesIO(pkraw[:-5]), num_selectors=2)
     tr = transcript.Blake2bWrite(curve)
-    prover.Prover(p2, pk2).create_proof(c["adv"], [[]], prover.SeededRng(7), tr)
+    fgp.Prover(p2, pk2).create_proof(c["adv"], [[]], prover.SeededRng(7), tr)
     want, _ = oracle_proof(po, c)
     assert tr.finalize() == want
     p2.release()
@@ -339,7 +341,7 @@ def test_eval_polynomial_multi_vs_oracle(pkg, co, ctx, n, fname):
     batch = 5
     cols = np.stack([co.fill_scalars(f.id, "uniform", n, 300 + i) for i in range(batch)])
     pts = co.fill_scalars(f.id, "uniform", 4, 17)
-    d = torch.from_numpy(cols.view(np.int64)).cuda()
+    d = ctx.upload(cols)
     for npts in (1, 3, 4):
         out = torch.zeros((npts, batch, 4), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
@@ -371,7 +373,7 @@ def test_kate_division_batch_vs_oracle(pkg, co, ctx, n, fname):
     cnt = 4
     a = np.stack([co.fill_scalars(f.id, "uniform", n, 900 + i) for i in range(cnt)])
     pts = co.fill_scalars(f.id, "uniform", cnt, 23)
-    da = torch.from_numpy(a.view(np.int64)).cuda()
+    da = ctx.upload(a)
     dq = torch.zeros((cnt, n, 4), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     ctx.kate_division_batch_device(f.id, [da[i].data_ptr() for i in range(cnt)], n, pts, [dq[i].data_ptr() for i in range(cnt)])
@@ -393,7 +395,7 @@ def test_lincomb_and_scale_vs_oracle(pkg, co, ctx, fname):
         cols = [co.fill_scalars(f.id, "uniform", n, 100 + i) for i in range(count)]
         coefs = co.fill_scalars(f.id, "uniform", count, 5)
         sub = f.encode(424242)
-        d = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+        d = [ctx.upload(c) for c in cols]
         out = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         ctx.lincomb_device(f.id, [t.data_ptr() for t in d], coefs, n, out.data_ptr(), sub)
@@ -402,8 +404,8 @@ def test_lincomb_and_scale_vs_oracle(pkg, co, ctx, fname):
     a = co.fill_scalars(f.id, "uniform", 4096 + 5, 9)
     for period in (1, 2, 4, 8):
         pat = co.fill_scalars(f.id, "uniform", period, 70 + period)
-        d = torch.from_numpy(a.view(np.int64)).cuda()
-        fac = torch.from_numpy(co.fill_scalars(f.id, "uniform", 1, 3).view(np.int64)).cuda()
+        d = ctx.upload(a)
+        fac = ctx.upload(co.fill_scalars(f.id, "uniform", 1, 3))
         torch.cuda.synchronize()
         ctx.scale_device(f.id, d.data_ptr(), a.shape[0], pat, 0)
         ctx.synchronize()
@@ -516,7 +518,7 @@ def test_prover_intermediate_buffers_vs_oracle(pkg, po, co, ctx, chain, device_c
     c, d = chain(k, rl), device_chain(k, rl)
     f = pkg.fields.BN254_FR
     side = pkg.Context(0)
-    P = prover.Prover(d["params"], d["pk"], ctx, side)
+    P = fgp.Prover(d["params"], d["pk"], ctx, side)
     tr = transcript.Blake2bWrite(pkg.fields.BN254)
     P.create_proof(c["adv"], [[]], prover.SeededRng(7), tr)
     ctx.synchronize(); side.synchronize()

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+import fine_grained_prover as fgp      # the Python driver over the fine-grained entry points: test infrastructure (was dehalo2_amd/prover.py's Prover)
+
 from conftest import golden
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -130,7 +132,7 @@ def test_device_proof_of_the_real_pose_enc_witness(pkg, po, co, ctx):
     params = keygen.ParamsKZG(ctx, pkg.fields.BN254, 11, c["srs"]["g"], c["srs"]["g_lagrange"])
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
     tr = transcript.Blake2bWrite(pkg.fields.BN254)
-    prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
+    fgp.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
     want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(5), c["rep"], 8)
     assert tr.finalize() == want
     assert V.verify_proof(po.BN254, c["desc"], 11, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
@@ -154,7 +156,7 @@ def test_device_proof_of_the_real_delay_enc_witness(pkg, po, co, ctx):
     params = keygen.ParamsKZG(ctx, pkg.fields.BN254, 16, c["srs"]["g"], c["srs"]["g_lagrange"])
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
     tr = transcript.Blake2bWrite(pkg.fields.BN254)
-    prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
+    fgp.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
     want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(5), c["rep"], 16)
     assert tr.finalize() == want
     assert V.verify_proof(po.BN254, c["desc"], 16, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
@@ -195,7 +197,7 @@ def test_device_proof_of_the_real_mod_pow_witness(pkg, po, co, ctx):
     params = keygen.ParamsKZG(ctx, pkg.fields.BN254, k, c["srs"]["g"], c["srs"]["g_lagrange"])
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
     tr = transcript.Blake2bWrite(pkg.fields.BN254)
-    prover.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
+    fgp.Prover(params, pk).create_proof(c["adv"], [[]], prover.SeededRng(5), tr)
     want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(5), c["rep"], 16)
     proof = tr.finalize()
     assert len(proof) == 2848 and proof == want
@@ -235,7 +237,7 @@ def test_batch_mode_provers_make_the_proofs_a_lone_prover_makes(pkg, po, co, ctx
     params = keygen.ParamsKZG(ctx, curve, k, c["srs"]["g"], c["srs"]["g_lagrange"])
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
     side = pkg.Context(0)
-    lone = prover.Prover(params, pk, ctx, side)
+    lone = fgp.Prover(params, pk, ctx, side)
     seeds = list(range(100, 124))
     alone = {}
     for sd in seeds:
@@ -246,7 +248,7 @@ def test_batch_mode_provers_make_the_proofs_a_lone_prover_makes(pkg, po, co, ctx
     want, _ = PO.create_proof(po.BN254, c["srs"], c["key"], c["adv"], [[]], PO.ScalarStream(seeds[3]), c["rep"], 16)
     assert alone[seeds[3]] == want
     ctxs = [pkg.Context(0) for _ in range(4)]
-    provers = [prover.Prover(params, pk, ctx=cx) for cx in ctxs]
+    provers = [fgp.Prover(params, pk, ctx=cx) for cx in ctxs]
     got, errors = {}, []
 
     def work(j):

@@ -5,6 +5,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as entry
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import fine_grained_prover as fgp
 pkg = entry.load_package(); po, co = entry.load_oracle()
 import plonk_oracle as PO
 from dehalo2_amd import prover, keygen, transcript, native
@@ -24,7 +25,7 @@ ctx.synchronize()
 # Python-driven
 params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"])
 pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
-P = prover.Prover(params, pk, ctx, side)
+P = fgp.Prover(params, pk, ctx, side)
 def py_prove(seed):
     tr = transcript.Blake2bWrite(curve); P.create_proof(adv, [[]], prover.SeededRng(seed), tr); return tr.finalize()
 # native

@@ -14,13 +14,12 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 curve = pkg.fields.BN254
 circ, desc = bench.real_witness(curve.scalar.p, k, circuit)
 print(desc)
-srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 ctx, side = pkg.Context(0, priority=1), pkg.Context(0)
 with ctx.torch_stream():
     adv = keygen.to_device(circ.advice)
     ctx.field_op_device(curve.scalar.id, "to_mont", adv.data_ptr(), 0, adv.data_ptr(), adv.numel() // 4, 0)
 ctx.synchronize()
-params = native.ParamsKZG.create(ctx, curve, k, srs["g"], srs["g_lagrange"])
+params = native.ParamsKZG.setup(ctx, curve, k, 0x1234567890abcdef)      # ParamsKZG::setup on the device (dehalo_params_setup)
 pk = native.ProvingKey.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
 N = native.Prover(params, pk, ctx, side)
 for _ in range(5): N.create_proof(adv, [[]], prover.SeededRng(7))

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as entry
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import fine_grained_prover as fgp
 
 pkg = entry.load_package(); po, co = entry.load_oracle()
 import plonk_oracle as PO, pairing as pr
@@ -21,7 +22,7 @@ srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 with pkg.Context(0) as ctx:
     params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"])
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
-    P = prover.Prover(params, pk)
+    P = fgp.Prover(params, pk)
     with ctx.torch_stream():
         adv = keygen.to_device(circ.advice)
         ctx.field_op_device(curve.scalar.id, "to_mont", adv.data_ptr(), 0, adv.data_ptr(), adv.numel() // 4, 0)
@@ -30,7 +31,7 @@ with pkg.Context(0) as ctx:
         P.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve))
     best, best_t = 1e9, None
     for _ in range(reps):
-        tm = prover.ProofTimings()
+        tm = fgp.ProofTimings()
         P.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve), tm)
         if tm.total_ms < best:
             best, best_t = tm.total_ms, tm
@@ -48,7 +49,7 @@ with pkg.Context(0) as ctx:
         t = time.perf_counter(); P.create_proof(adv, [[]], PlainRng(7), transcript.Blake2bWrite(curve)); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
     print("without the random-polynomial helper thread: best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
     side = pkg.Context(0, priority=int(os.environ.get("SIDE_PRIO", "0")))
-    P2 = prover.Prover(params, pk, ctx, side)
+    P2 = fgp.Prover(params, pk, ctx, side)
     want = transcript.Blake2bWrite(curve); P.create_proof(adv, [[]], prover.SeededRng(7), want)
     ts = []
     for _ in range(reps + 2):
@@ -57,11 +58,11 @@ with pkg.Context(0) as ctx:
         assert tr.finalize() == want.finalize(), "side-context proof differs"
     ts = ts[2:]
     print("with a side context (NTTs and the random commitment beside the commitment phases): best %.2f ms, median %.2f ms" % (min(ts), sorted(ts)[len(ts) // 2]))
-    tm = prover.ProofTimings(); P2.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve), tm)
+    tm = fgp.ProofTimings(); P2.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve), tm)
     print("   phases", {a: round(b, 2) for a, b in tm.phases_ms.items()})
     best = None
     for _ in range(5):                                         # host timestamps inside the phases, no extra syncs
-        tm = prover.ProofTimings(fine=True)
+        tm = fgp.ProofTimings(fine=True)
         t0 = time.perf_counter(); P2.create_proof(adv, [[]], prover.SeededRng(7), transcript.Blake2bWrite(curve), tm); ctx.synchronize(); t1 = time.perf_counter()
         if best is None or t1 - t0 < best[0]:
             best = (t1 - t0, t0, tm.ticks)

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as entry
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import fine_grained_prover as fgp
 
 pkg = entry.load_package(); po, co = entry.load_oracle()
 import plonk_oracle as PO, verifier as V, pairing as pr
@@ -29,9 +30,9 @@ def run(ctx, k, rl, verify=True, threads=16):
     assert rep == pk.vk.transcript_repr, "vk transcript_repr differs"
     F = PO.Fld(ocurve.scalar)
     adv = np.stack([co.field_op(F.id, "to_mont", circ.advice[i]) for i in range(5)])
-    P = prover.Prover(params, pk)
+    P = fgp.Prover(params, pk)
     tr = transcript.Blake2bWrite(curve)
-    tm = prover.ProofTimings()
+    tm = fgp.ProofTimings()
     P.create_proof(adv, [[]], prover.SeededRng(7), tr, tm)
     proof = tr.finalize()
     t = time.time(); want, trace = PO.create_proof(ocurve, srs, key, adv, [[]], PO.ScalarStream(7), rep, threads); cpu_s = time.time() - t

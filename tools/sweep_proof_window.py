@@ -4,6 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as entry
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import fine_grained_prover as fgp
 pkg = entry.load_package(); po, co = entry.load_oracle()
 import plonk_oracle as PO
 from dehalo2_amd import prover, keygen, transcript
@@ -16,7 +17,7 @@ for c in [0] + list(range(c0, c1 + 1)):
     with pkg.Context(0) as ctx, pkg.Context(0) as side:
         params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"], window_bits=c)
         pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
-        P = prover.Prover(params, pk, side_ctx=side)
+        P = fgp.Prover(params, pk, side_ctx=side)
         with ctx.torch_stream():
             adv = keygen.to_device(circ.advice)
             ctx.field_op_device(curve.scalar.id, "to_mont", adv.data_ptr(), 0, adv.data_ptr(), adv.numel() // 4, 0)
