@@ -31,9 +31,9 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACT
   tag=$(echo $pass | cut -d' ' -f1)
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/sq_ntt_$tag -- python3 tools/ntt_pmc.py > $out/sq_ntt_$tag.log 2>&1
 done
-python3 tools/sq_summary.py $out/sq_ntt_SQ_WAVE_CYCLES $out/sq_ntt_SQ_ACTIVE_INST_ANY --group-by-launch 3 > $out/ntt_sq_counters.txt
+python3 tools/sq_summary.py $out/sq_ntt_SQ_WAVE_CYCLES $out/sq_ntt_SQ_ACTIVE_INST_ANY --group-by-launch 3 --skip-launches 180 > $out/ntt_sq_counters.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kn -o kn -- python3 tools/ntt_pmc.py > $out/kn.log 2>&1
-grep -i "ntt_pass" $out/kn/kn_kernel_stats.csv > $out/ntt_pass_durations_without_counters.txt
+python3 tools/accum0_launches.py $out/kn/kn_kernel_trace.csv k_ntt_pass 30 > $out/ntt_pass_durations_without_counters.txt
 echo "[6] batch mode: throughput by provers"
 for p in 2 3 4 6; do timeout -k 10 200 python tools/batch_trace.py 17 $p 64 0 1 | grep batch; done > $out/batch_throughput_by_provers.txt 2>/dev/null
 echo "[7] ntt bench; N = 2 from the bare command (two ranks on this one GPU, gloo for the gather)"

@@ -2,7 +2,7 @@
 """SQ counters per kernel from rocprofv3 --pmc passes (counter_collection.csv + kernel_trace.csv in DIR...): per launch the duration under collection, the
 vector-ALU time (SQ_ACTIVE_INST_VALU x 4 cycles / (2.4 GHz x 1024 SIMDs)) and how a wave's cycles split.  The eight counters do not fit one pass: give
 two directories (one --pmc pass each); a kernel's launches are matched by order.
-usage: tools/sq_summary.py DIR [DIR ...] [--group-by-launch N]   (--group-by-launch 3: launches i, i + 3, ... of k_ntt_pass are reported separately: its passes)"""
+usage: tools/sq_summary.py DIR [DIR ...] [--group-by-launch N] [--skip-launches M]   (--group-by-launch 3: launches i, i + 3, ... of k_ntt_pass are reported separately: its passes)"""
 import csv, glob, os, sys
 from collections import defaultdict
 
@@ -11,6 +11,11 @@ group = 1
 if "--group-by-launch" in args:
     i = args.index("--group-by-launch")
     group = int(args[i + 1])
+    del args[i:i + 2]
+skip = 0
+if "--skip-launches" in args:      # drop the first N launches of every kernel (warm-up at ramping clocks)
+    i = args.index("--skip-launches")
+    skip = int(args[i + 1])
     del args[i:i + 2]
 dirs = args
 per_kernel = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> [value per launch, in launch order]
@@ -50,7 +55,7 @@ for k, cs in per_kernel.items():
         continue
     step = group if ("ntt" in k and group > 1) else 1
     for g in range(step):
-        sel = lambda v: v[g::step]
+        sel = lambda v: v[skip:][g::step]
         n = len(sel(cs["SQ_ACTIVE_INST_VALU"]))
         if n == 0:
             continue
