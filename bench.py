@@ -392,7 +392,7 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
     note("proof %s k = %d: checks" % (circuit, k))
     cs = st.circ.cs
     n_evals = len(cs.advice_queries) + len(cs.fixed_queries) + 1 + len(cs.permutation_columns) + max(0, 3 * cs.num_permutation_sets() - 1) + 5 * len(cs.lookups)
-    out = {"circuit": CIRCUIT_TEXT[circuit],
+    out = {"circuit": CIRCUIT_TEXT[circuit], "circuit_name": circuit,
            "k": k, "curve": "bn254 (KZG, GWC)", "rows_used": st.circ.used_rows, "commitments": len(proof) // 32 - n_evals,
            "proof_bytes": len(proof), "gpu_ms": round(min(ts), 3), "gpu_ms_median": round(sorted(ts)[len(ts) // 2], 3),
            "gpu_phase_ms": {a: round(b, 3) for a, b in phases.items()},
@@ -620,7 +620,9 @@ def compact_proof(p):
     pairing check used) are in profiles/README.md, "bench line glossary", and in the verbose record (--full-out)."""
     if p is None:
         return None
-    name = {"D": "delay_enc", "b": "mod_pow", "p": "pose_enc"}.get(p["circuit"][0], p["circuit"]) if isinstance(p.get("circuit"), str) else None
+    name = p.get("circuit_name")
+    if name is None and isinstance(p.get("circuit"), str):      # (records written before round 5 carry the sentence only)
+        name = {"D": "delay_enc", "b": "mod_pow", "p": "pose_enc"}.get(p["circuit"][0], p["circuit"])
     out = {"circuit": name, "k": p["k"], "rows": p.get("rows_used"), "commitments": p.get("commitments"), "proof_bytes": p.get("proof_bytes"),
            "gpu_ms": p["gpu_ms"], "gpu_ms_median": p.get("gpu_ms_median"), "phase_ms": p.get("gpu_phase_ms"), "witness": "resident"}
     e = p.get("end_to_end")

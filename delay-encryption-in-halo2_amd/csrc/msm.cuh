@@ -52,10 +52,6 @@
 #define MSM_HIST_ATTR
 #endif
 #define MSM_MERGE_COUNTERS 8   // merge-class counters in ws_counters, in front of [L0 | M]
-#define MSM_RED_M 4        // buckets per lane in the bucket reduction
-#ifndef MSM_RED_THREADS
-#define MSM_RED_THREADS 256   // one wave per SIMD per block: with 128-thread blocks the second block on a CU shared SIMDs with the first (3-4 columns at c = 15: 134 -> 86 us)
-#endif
 
 // Experiment, off (round 4): the MSM's latency-bound kernels (sort, scans, merge, bucket reduction) raising their waves' issue priority with s_setprio, so that beside
 // another stream's throughput kernels (the side context's NTTs in a proof, a neighbour step's accumulation) the SIMD's arbiter takes their instructions first.
@@ -682,23 +678,8 @@ __global__ __launch_bounds__(MSM_ACC_THREADS_MAX) MSM_ACC_WAVES_ATTR void k_msm_
 // (msm_bred.cuh) merges every class in ONE launch with a lane group sized to it.  (The round-3 generation --
 // its own classification launch, operands in registers at 172 VGPRs -- is in the history up to round 4.)
 
-// ---- bucket reduction: sum_k (k + 1) * B_k per group --------------------------------------
-// k_msm_bred (msm_bred.cuh) from 8 buckets a group up.  Windows of 1 .. 3 bits (fewer than 32 terms: upstream's rule, multiexp_serial) leave 1, 2 or 4 buckets a
-// group: one quad per group walks them from the top -- run += B_k; acc += run -- with quad-cooperative additions.
-template <class CV>
-__global__ __launch_bounds__(MSM_RED_THREADS) void k_msm_reduce_small(u32 nb, u32 total_groups, const xyzz29_rec* buckets, xyzz29_rec* gsums) {
-    typedef f29_lat<typename f29_of<typename CV::Base>::type> F;   // short dependent chains at low occupancy: latency schedule
-    const u32 grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    if (grp >= total_groups) return;
-    const xyzz29_rec* B = buckets + (u64)grp * nb;
-    xyzz29 run = x29_load(&B[nb - 1]);
-    xyzz29 acc = run;
-    for (u32 k = nb - 1; k-- > 0;) {
-        run = x29_add_quad<F>(run, x29_load(&B[k]));
-        acc = x29_add_quad<F>(acc, run);
-    }
-    if ((threadIdx.x & 3) == 0) x29_store(&gsums[grp], acc);
-}
+// ---- bucket reduction: sum_k (k + 1) * B_k per group: k_msm_bred (msm_bred.cuh).  A group has 2^(c-1) >= 8 buckets: dehalo_bases_register admits windows of 4 .. 16
+// bits (upstream's 1- and 3-bit windows for fewer than 32 terms are a CPU economy; the result does not depend on the window).
 
 // An MSM's result leaves as upstream's Jacobian {x, y, z} and / or, for a caller that feeds the transcript (dehalo_msm_device_affine),
 // as the affine point: x = X / ZZ, y = Y / ZZZ with one inversion of ZZ * ZZZ -- no second kernel, no detour through Jacobian.
@@ -955,9 +936,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
 #endif
         }
         // bucket reduction: ONE launch of the radix-2 recursion (msm_bred.cuh: 2 additions per bucket, operands in LDS, < 128 VGPRs; the last block of a group
-        // weights, sums and writes the result); groups of fewer than 8 buckets (windows of 1 .. 3 bits) by k_msm_reduce_small
+        // weights, sums and writes the result)
         bool emitted = false;
-        if (g.nb >= 8) {
+        if (g.nb < 8) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm: window below 4 bits");      // (unreachable through dehalo_bases_register: c >= 4)
+        {
             // buckets per block: 128 up to 2^13 buckets (the kernel alone 119 -> 107 us at 4096 buckets, 134 -> 125 at 16384, 153 -> 153 at 32768 where the third level costs
             // what the shorter first one saves); 256 above: measured on k = 17 proofs the 128-bucket blocks -- twice as many, beside the side context's transforms -- cost
             // 0.1 ms (profiles/r04_bred_block_buckets.txt).
@@ -989,8 +971,6 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
                         us(0), us(1), st[2] ? us(2) : 0.0, st[3] ? us(3) : 0.0, us(5), us(4), us(6), st[8] ? us(8) : 0.0, st[9] ? us(9) : 0.0, st[10] ? us(10) : 0.0, st[11] ? us(11) : 0.0);
             }
 #endif
-        } else {
-            k_msm_reduce_small<CV><<<(u32)((total_groups * 4 + MSM_RED_THREADS - 1) / MSM_RED_THREADS), MSM_RED_THREADS, 0, s>>>(g.nb, (u32)total_groups, buckets, gsums);
         }
         if (!emitted) {
             k_msm_final<CV><<<(u32)batch, 256, 0, s>>>(g, gsums, d_out, ctx->msm_affine_out);
