@@ -217,35 +217,42 @@ FP_DEV u32 lp_block_scan_1024(u32 v, u32* wave_sums /* 16 words of LDS */) {
     return v + before;
 }
 // up to 512 keys sorted by counting, for every key, the keys below it (ties by position): one pass instead of the bitonic network's 66 stages of two barriers
-// each.  One block per table; only the table's `ndist` keys take part (the +infinity padding behind them stays where it is).  NO LDS: key j is the same address
+// each.  Only the table's `ndist` keys take part (the +infinity padding behind them stays where it is).  NO LDS: key j is the same address
 // for every lane, so the loop reads the keys through the scalar cache -- a block that needs 16 KB of LDS (let alone the bitonic tile's 64 KB) waits until a CU
 // whose LDS is held by two NTT tiles of the side context gives one up: 160-270 us in a proof for 5 us of work.  (Nor do the top 64 bits alone order the keys:
 // the compressed values theta * tag + value of one tag differ in their LOW bits only.)
-__global__ void __launch_bounds__(512) k_lp_small_sort(LpCols c, const fe* in, fe* out) {
+// (Round 5: one 512-thread block per table did this in 112-125 us -- every thread walked all `len` keys, eight waves on one CU, 4.8 % of a k = 17 proof's lookup
+// phase for 339 keys.  Now a QUAD per key, each lane counting over a quarter of the keys, on one-wave blocks spread over the chip: 16 keys a block.)
+#define LP_SS_THREADS 64
+__global__ void __launch_bounds__(LP_SS_THREADS) k_lp_small_sort(LpCols c, const fe* in, fe* out) {
     const u32 tb = blockIdx.y, len = c.ndist[tb];
     const fe* K = in + (u64)tb * LP_TILE;
     fe* O = out + (u64)tb * LP_TILE;
-    const u32 t = threadIdx.x;
-    for (u32 i = len + t; i < LP_TILE; i += 512) f_store(&O[i], f_load(&K[i]));
-    if (t >= len) return;
-    const fe mine = f_load(&K[t]);
+    const u32 gt = blockIdx.x * LP_SS_THREADS + threadIdx.x;
+    for (u32 i = len + gt; i < LP_TILE; i += gridDim.x * LP_SS_THREADS) f_store(&O[i], f_load(&K[i]));      // the +infinity padding stays where it is
+    const u32 t = gt >> 2, part = gt & 3;
+    const bool live = t < len;                            // (a whole quad is live or not: its lanes stay together for the shuffles below)
+    const fe mine = f_load(&K[live ? t : 0]);
+    const u32 q = (len + 3) >> 2, j_beg = part * q, j_end = min(len, j_beg + q);
     u32 rank = 0;
-    for (u32 j0 = 0; j0 < len; j0 += 8) {                 // eight keys' loads in flight at a time (one per comparison: 339 round trips to the cache, 0.4 us each)
-        fe cur[8];
+    for (u32 j0 = j_beg; j0 < j_end; j0 += 4) {           // four keys' loads in flight at a time
+        fe cur[4];
 #pragma unroll
-        for (int q = 0; q < 8; q++) cur[q] = f_load(&K[j0 + q < len ? j0 + q : len - 1]);
+        for (int x = 0; x < 4; x++) cur[x] = f_load(&K[j0 + x < j_end ? j0 + x : j_end - 1]);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int x = 0; x < 4; x++) {
             int cmp = 0;                                  // all eight words, no early exit (an early-exit compare turns into eight dependent loads)
 #pragma unroll
             for (int w = 7; w >= 0; w--) {
-                const int d = cur[q].v[w] < mine.v[w] ? -1 : (cur[q].v[w] > mine.v[w] ? 1 : 0);
+                const int d = cur[x].v[w] < mine.v[w] ? -1 : (cur[x].v[w] > mine.v[w] ? 1 : 0);
                 cmp = cmp ? cmp : d;
             }
-            if (j0 + q < len) rank += cmp < 0 || (cmp == 0 && j0 + q < t);      // equal keys: by position
+            if (j0 + x < j_end) rank += cmp < 0 || (cmp == 0 && j0 + x < t);      // equal keys: by position
         }
     }
-    f_store(&O[rank], mine);
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (live && part == 0) f_store(&O[rank], mine);
 }
 // canonical keys of the distinct rows of table t, one tile per table, padded with +infinity
 template <class F>
@@ -639,7 +646,7 @@ int lp_run(dehalo_ctx* ctx, const LpCols& c, u32 B, u32 U, u64 n, hipStream_t s,
         for (u32 t = 0; t < U; t++) while (dlen < c.ndist[t]) dlen <<= 1;
         k_lp_distinct_keys<F><<<dim3(LP_TILE / 256, U), 256, 0, s>>>(c, n, dk0);
         if (dlen <= 512) {
-            k_lp_small_sort<<<dim3(1, U), 512, 0, s>>>(c, dk0, dk1);
+            k_lp_small_sort<<<dim3((4 * dlen + LP_SS_THREADS - 1) / LP_SS_THREADS, U), LP_SS_THREADS, 0, s>>>(c, dk0, dk1);      // a quad per key
         } else k_lp_tile_sort<<<dim3(1, U), LP_SORT_THREADS, lds_keys, s>>>(dk0, dk1, LP_TILE);
         k_lp_distinct_starts<F><<<U, 1024, 0, s>>>(c, n, dk1, dstart);
         HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, (size_t)B * LP_TILE * 4, s));

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B inside one build by an environment variable: tools/ab_env.sh NAME VALUE_A VALUE_B  (VALUE "unset" leaves it unset); proofs at k = 17 / 11 / 14 and batch mode
+. tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
 name=$1; shift
 for round in 1 2; do
 for v in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/ab_env_k.sh "K1 K2 ..." NAME VALUE_A VALUE_B ...: delay_enc-shaped proofs at the given k under an environment variable, three rounds
+. tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
 ks=$1; name=$2; shift 2
 for round in 1 2 3; do
 for v in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # like tools/ab_env.sh, with the MSM + NTT step bench first: tools/ab_env_step.sh NAME VALUE_A VALUE_B ...
+. tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
 name=$1; shift
 for round in 1 2; do
 for v in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/ab_env_steponly.sh NAME VALUE_A VALUE_B ...: the MSM + NTT step bench only, four alternating rounds
+. tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
 name=$1; shift
 for round in 1 2 3 4; do for v in "$@"; do
   if [ "$v" = unset ]; then unset $name; else export $name=$v; fi

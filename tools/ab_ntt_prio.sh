@@ -1,5 +1,6 @@
 #!/bin/bash
 # lone and batched transforms with workgroup issue priorities by slot (DEHALO_NTT_PRIO), and the phases of the workgroups (DEHALO_NTT_STAMPS)
+. tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
 for round in 1 2; do
 for m in 0 1 2; do echo "== DEHALO_NTT_PRIO=$m, round $round"; DEHALO_NTT_PRIO=$m timeout -k 10 200 python tools/ntt_phases.py 2>/dev/null | grep "min"; done
 done

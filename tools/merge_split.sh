@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-class times of k_msm_merge_all (DEHALO_MSM_MERGE_SPLIT=1: one launch per class, in the order block, wave, 32 lanes, light) for one MSM shape (tools/msm_small.py arguments)
+. tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
 export TMPDIR=/tmp DEHALO_MSM_MERGE_SPLIT=1
 rm -rf gpurun_out/abk; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/abk -o abk -- python3 tools/msm_small.py "$@" > /dev/null 2>&1
 python3 - <<PY
