@@ -99,3 +99,22 @@ def test_default_build_reads_no_tuning_from_the_environment(pkg):
                 depth -= 1
             for name in re.findall(r'(?<![A-Z_])getenv\("([A-Z0-9_]+)"\)', line):
                 assert depth or name in allowed, "%s reads %s from the environment in the default build" % (fn, name)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/dehalo.h compiles as C99 (pedantic, warnings are errors) and as C++11, and a C program that only includes it and takes the
+    address of every declared function links against the library -- what a cgo / JNI / Rust `extern "C"` binding relies on."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "dehalo.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    src = tmp_path / "link_all.c"
+    syms = _declared_symbols()
+    src.write_text('#include "dehalo.h"\n#include <stdio.h>\nint main(void) {\n    const void* f[] = {%s};\n    printf("%%u\\n", (unsigned)(sizeof f / sizeof f[0]));\n    return f[0] == 0;\n}\n' %
+                   ", ".join("(const void*)%s" % s for s in syms))
+    exe = tmp_path / "link_all"
+    libdir = os.path.join(ROOT, "delay-encryption-in-halo2_amd")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), "-L", libdir, "-ldehalo",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and int(out.stdout.strip()) == len(syms), (out.returncode, out.stdout, out.stderr)
