@@ -166,43 +166,49 @@ def secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n):
 
 
 def real_witness(p, k, circuit):
-    """The reference's circuits with real witnesses (dehalo2_amd/witness.py).  `circuit`:
+    """The reference's circuits with real witnesses (dehalo2_amd/witness.py, halo2wrong's row layout).  `circuit`:
       "delay_enc"  DelayEncryptCircuit over a 2048-bit modulus with as many exponent bits as 2^k rows hold (15 bits at k = 17: the
-                   north-star shape, benches/README.md:59-60);
+                   north-star shape, benches/README.md:59-60), the all-zero message the reference's benches encrypt (benches/delay_enc.rs:68-70);
       "mod_pow"    benches/mod_pow.rs's RSACircuit: 2048-bit modulus, EXP_LIMB_BITS = 5 (:47-49), at the K = 17 the bench runs (:258);
-      "pose_enc"   PoseidonEncCircuit (benches/pose_enc.rs, K = 11)."""
+      "pose_enc"   PoseidonEncCircuit (benches/pose_enc.rs, K = 11).
+    Returns (circuit, description, rows the reference publishes for this configuration or None)."""
     import random
     from dehalo2_amd import circuits, witness as W
     rnd = random.Random(0x64656C6179)
     n_big = rnd.getrandbits(2048) | (1 << 2047) | 1
     x = rnd.getrandbits(2040)
-    message = [rnd.getrandbits(250), rnd.getrandbits(250)]
+    message = [0, 0]
     if circuit == "pose_enc":
         key = [rnd.getrandbits(250), rnd.getrandbits(250)]
         circ, info = W.pose_enc_witness(p, k, key, message)
         circ.native_spec = dict(circuit=2, k=k, key=key, message=message)
-        return circ, "PoseidonEncCircuit (benches/pose_enc.rs), %d rows in this repository's layout (halo2wrong's: %d, benches/README.md:89-92)" % (info.total_rows, 1446 + 4 * len(message))
+        return circ, "PoseidonEncCircuit (benches/pose_enc.rs), |msg| = 2: %d rows (the reference publishes the last row's index, 1,450: benches/README.md:98)" % info.total_rows, 1450
     if circuit == "mod_pow":
         e = rnd.getrandbits(5) | (1 << 4)
         circ, info = W.mod_pow_witness(p, k, n_big, e, x, 5)
         assert info.rsa_result == pow(x, e, n_big)
         circ.native_spec = dict(circuit=1, k=k, n_big=n_big, e=e, x=x, exp_bits=5)
-        return circ, "RSACircuit (benches/mod_pow.rs), 2048-bit modulus, 5-bit exponent: %d rows in this repository's layout (halo2wrong's: 41,766, benches/README.md:73)" % info.total_rows
+        return circ, "RSACircuit (benches/mod_pow.rs), 2048-bit modulus, 5-bit exponent: %d rows (published: 41,766, benches/README.md:80)" % info.total_rows, 41766
     kk = min(k, 17)
-    bits = max(1, min(15, ((1 << kk) - 6 - 6500) // 7100))
+    tail = W.hash_region_rows() + W.cipher_region_rows(len(message), True)
+    bits = max(b for b in range(1, 16) if W.rsa_region_rows(b) + tail + 1 <= (1 << kk) - 6)
     e = rnd.getrandbits(bits) | (1 << (bits - 1))
     circ, info = W.delay_enc_witness(p, kk, n_big, e, x, bits, message)
-    assert info.rsa_result == pow(x, e, n_big)
+    assert info.rsa_result == pow(x, e, n_big) and info.total_rows == W.rsa_region_rows(bits) + tail
     desc = "DelayEncryptCircuit (src/lib.rs), 2048-bit modulus, %d-bit exponent: %d RSA rows + %d hash / cipher rows" % (bits, info.rsa_rows, info.total_rows - info.rsa_rows)
+    published = None
     if bits == 15:      # the north-star shape: say what the row count is and is not
-        desc += " = %d rows in this repository's layout, where halo2wrong's layout of the same circuit takes 130,248 (benches/README.md:60): same values over the same gate, 16 %% fewer rows, same k" % info.total_rows
+        published = 130248
+        desc += (" = %d rows, halo2wrong's layout of the CHECKED-IN source; the reference publishes 130,248 for this configuration (benches/README.md:60): its RSA region is "
+                 "the same 121,579 rows, its hash region is an earlier revision's (7,217 rows where src/lib.rs:222-259 now takes 2,182)" % info.total_rows)
     spec = dict(circuit=0, k=kk, n_big=n_big, e=e, x=x, exp_bits=bits, message=message)
     circ.native_spec = spec if k == kk else None
     if k > kk:
         circ = circuits._tile(circ, k)
         circ.tiled_spec = spec          # end_to_end_tiled(): the 2^kk-row circuit is synthesized once per proof and stacked on the device
         desc += ", stacked %d times" % (1 << (k - kk))
-    return circ, desc
+        published = None
+    return circ, desc, published
 
 
 def ctx_device(ctx):
@@ -227,7 +233,7 @@ class ProofSetup:
         self.curve, self.ocurve, self.k, self.circuit = pkg.fields.BN254, po.BN254, k, circuit
         self.s = 0x64656C6179656E63 * 0x9E3779B97F4A7C15 % self.curve.scalar.p
         t0 = time.time()
-        self.circ, self.witness = real_witness(self.curve.scalar.p, k, circuit)
+        self.circ, self.witness, self.rows_reference = real_witness(self.curve.scalar.p, k, circuit)
         tw = time.time()
         # ParamsKZG::setup (benches/delay_enc.rs:43) on the device: dehalo_params_setup.  The CPU restatement builds ITS OWN SRS from the same secret when a
         # CPU leg asks for it (`srs` below), and the two are compared there: the product takes nothing from oracle/.
@@ -393,7 +399,7 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
     cs = st.circ.cs
     n_evals = len(cs.advice_queries) + len(cs.fixed_queries) + 1 + len(cs.permutation_columns) + max(0, 3 * cs.num_permutation_sets() - 1) + 5 * len(cs.lookups)
     out = {"circuit": CIRCUIT_TEXT[circuit], "circuit_name": circuit,
-           "k": k, "curve": "bn254 (KZG, GWC)", "rows_used": st.circ.used_rows, "commitments": len(proof) // 32 - n_evals,
+           "k": k, "curve": "bn254 (KZG, GWC)", "rows_used": st.circ.used_rows, "rows_reference": st.rows_reference, "commitments": len(proof) // 32 - n_evals,
            "proof_bytes": len(proof), "gpu_ms": round(min(ts), 3), "gpu_ms_median": round(sorted(ts)[len(ts) // 2], 3),
            "gpu_phase_ms": {a: round(b, 3) for a, b in phases.items()},
            "driver": "dehalo_create_proof: phases, transcript and every launch in C++ behind the C ABI; Python passes pointers",
@@ -623,7 +629,7 @@ def compact_proof(p):
     name = p.get("circuit_name")
     if name is None and isinstance(p.get("circuit"), str):      # (records written before round 5 carry the sentence only)
         name = {"D": "delay_enc", "b": "mod_pow", "p": "pose_enc"}.get(p["circuit"][0], p["circuit"])
-    out = {"circuit": name, "k": p["k"], "rows": p.get("rows_used"), "commitments": p.get("commitments"), "proof_bytes": p.get("proof_bytes"),
+    out = {"circuit": name, "k": p["k"], "rows": p.get("rows_used"), "rows_reference": p.get("rows_reference"), "commitments": p.get("commitments"), "proof_bytes": p.get("proof_bytes"),
            "gpu_ms": p["gpu_ms"], "gpu_ms_median": p.get("gpu_ms_median"), "phase_ms": p.get("gpu_phase_ms"), "witness": "resident"}
     e = p.get("end_to_end")
     if e:

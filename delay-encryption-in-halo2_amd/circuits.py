@@ -71,7 +71,7 @@ def synthesize(p: int, k: int, range_lookups: bool, seed: int = 1, fill: float =
             fixed[plonk.RC_T_TAG][r], fixed[plonk.RC_T_VALUE][r] = tag, v
     rows = max(1, min(u - 1, int(fill * u)))
     kinds = []
-    comp_bits = plonk.COMPOSITION_BIT_LENS
+    comp_bits = tuple(sorted(plonk.COMPOSITION_BIT_LENS, reverse=True))      # (8, 4, 1): the order the draws below have always indexed
     for r in range(rows):
         t = rnd.random()
         if range_lookups and t < 0.35:

@@ -1,13 +1,18 @@
 // witness.hip -- Circuit::synthesize of the reference's three circuits as VALUES, in C++: what fills the advice columns (and, at keygen,
 // the fixed columns and the permutation) before create_proof commits them -- the part of the reference's timed call that precedes the
-// first commitment [src/lib.rs:164-318 DelayEncryptCircuit::synthesize; benches/mod_pow.rs:63-110 RSACircuit; src/encryption/chip.rs:
-// 114-204 PoseidonEncCircuit].  Restated from:
+// first commitment [src/lib.rs:164-318 DelayEncryptCircuit::synthesize; benches/mod_pow.rs:79-120 RSACircuit; src/encryption/chip.rs:
+// 131-204 PoseidonEncCircuit].  Restated from:
 //   big_pow_mod (its value: read off the pow_mod rows)   src/big_integer/utils.rs:2-17
-//   BigIntChip::{mul, mul_mod, pow_mod, is_equal_muled}   src/big_integer/chip.rs:389-422, 545-632, 667-699, 825-898
-//   Grain LFSR, Cauchy MDS, the permutation       src/poseidon/grain.rs:12-157, spec.rs:170-180, permutation.rs:60-80
-//   sponge (RATE 4) and cipher                    src/hash/chip.rs:63-85, src/encryption/poseidon_enc.rs:66-133, src/lib.rs:222-316
-// The cell layout is this repository's own small layouter over the reference's gate (MainGate + RangeChip; halo2wrong's region code is
-// upstream and not in the reference tree): the same rows, in the same order, as dehalo2_amd/witness.py, which the tests compare it with
+//   BigIntChip                                    src/big_integer/chip.rs: assign_integer :64-85, assign_constant :1255-1285, max_value :141-157, add :250-300,
+//                                                 sub :313-376, mul :389-422, mul_mod :545-632, pow_mod :667-699, is_equal_fresh :778-803, is_equal_muled :825-898,
+//                                                 is_less_than :911-923, assert_in_field :1153-1161, sub_unchecked :1290-1322, div_mod_main_gate :1327-1353
+//   RSAChip::{assign_public_key, modpow_public_key}   src/rsa/chip.rs:61-73, 102-117
+//   Grain LFSR, Cauchy MDS, optimised constants and sparse matrices, the optimised permutation   src/poseidon/grain.rs:12-157, spec.rs:170-180, 325-397, permutation.rs:7-46
+//   PoseidonChip rows                             src/poseidon/chip.rs:199-419
+//   sponge (RATE 4) and cipher                    src/hash/chip.rs:63-85, src/encryption/chip.rs:72-110, src/encryption/poseidon_enc.rs:66-133, src/lib.rs:216-316
+// The cell layout follows halo2wrong's MainGate / RangeChip instruction by instruction ([UPSTREAM] maingate v2023_04_20, not in the reference tree: one `apply` row
+// per instruction, compose / decompose four terms a row, is_equal four rows, is_zero three, assert_equal one), which reproduces the row counts the reference
+// publishes (benches/README.md:56-99; tests/test_witness.py): the same rows, in the same order, as dehalo2_amd/witness.py, which the tests compare it with
 // bit for bit.  Host code only (no device work): big-integer arithmetic on 64-bit limbs, field arithmetic through hostfield.hpp.
 #include <algorithm>
 #include <cstring>
@@ -212,11 +217,63 @@ struct Grain {
     }
 };
 
+// Spec::new(r_f, r_p) (src/poseidon/spec.rs:310-397): Grain's round constants and the Cauchy MDS, then the optimised form the chip's rows follow --
+// start / partial / end constants, the pre-sparse matrix, one sparse matrix (first row, first column) per partial round.
+typedef std::vector<std::vector<Fe>> Mat;
 struct PoseidonSpec {
     Fld F;
     uint32_t t, r_f, r_p;
-    std::vector<std::vector<Fe>> constants, mds, mds_m;      // mds_m: the same matrix times R (Montgomery form): ONE Montgomery product gives m * x for a canonical x
-    Fe mds_mul(uint32_t i, uint32_t j, const Fe& x) const { return F.f->mul(mds_m[i][j], x); }
+    Mat constants, mds;                       // Grain's (canonical)
+    Mat start, end, pre_sparse;               // optimised constants; the transition matrix
+    std::vector<Fe> partial;
+    std::vector<std::vector<Fe>> sparse_row, sparse_col;      // per partial round: the sparse matrix's first row (t) and first column below it (t - 1)
+    Mat mds_m, pre_sparse_m;                  // the same matrices times R (Montgomery form): ONE Montgomery product gives m * x for a canonical x
+    std::vector<std::vector<Fe>> sparse_row_m, sparse_col_m;
+    static Mat mat_mul(const Fld& F, const Mat& a, const Mat& b) {
+        const size_t n = a.size();
+        Mat r(n, std::vector<Fe>(n, F.zero()));
+        for (size_t i = 0; i < n; i++) for (size_t j = 0; j < n; j++) for (size_t k = 0; k < n; k++) r[i][j] = F.add(r[i][j], F.mul(a[i][k], b[k][j]));
+        return r;
+    }
+    static std::vector<Fe> mat_vec(const Fld& F, const Mat& a, const std::vector<Fe>& v) {
+        std::vector<Fe> r(a.size(), F.zero());
+        for (size_t i = 0; i < a.size(); i++) for (size_t j = 0; j < v.size(); j++) r[i] = F.add(r[i], F.mul(a[i][j], v[j]));
+        return r;
+    }
+    static Mat transpose(const Mat& a) {
+        Mat r(a.size(), std::vector<Fe>(a.size()));
+        for (size_t i = 0; i < a.size(); i++) for (size_t j = 0; j < a.size(); j++) r[j][i] = a[i][j];
+        return r;
+    }
+    static Mat mat_inv(const Fld& F, const Mat& a) {      // Gauss-Jordan (src/poseidon/matrix.rs:84-121 computes the same inverse)
+        const size_t n = a.size();
+        Mat m(n, std::vector<Fe>(2 * n, F.zero()));
+        for (size_t i = 0; i < n; i++) {
+            for (size_t j = 0; j < n; j++) m[i][j] = a[i][j];
+            m[i][n + i] = F.u(1);
+        }
+        for (size_t i = 0; i < n; i++) {
+            size_t piv = i;
+            while (piv < n && m[piv][i].is_zero()) piv++;
+            if (piv == n) throw std::runtime_error("singular matrix");
+            std::swap(m[i], m[piv]);
+            const Fe inv = F.inv(m[i][i]);
+            for (auto& x : m[i]) x = F.mul(x, inv);
+            for (size_t r = 0; r < n; r++) {
+                if (r == i || m[r][i].is_zero()) continue;
+                const Fe f = m[r][i];
+                for (size_t c = 0; c < 2 * n; c++) m[r][c] = F.sub(m[r][c], F.mul(f, m[i][c]));
+            }
+        }
+        Mat r(n, std::vector<Fe>(n));
+        for (size_t i = 0; i < n; i++) for (size_t j = 0; j < n; j++) r[i][j] = m[i][n + j];
+        return r;
+    }
+    Mat to_mont(const Mat& a) const {
+        Mat r = a;
+        for (auto& row : r) for (auto& m : row) m = F.f->from_canonical(m);
+        return r;
+    }
     PoseidonSpec(const HostField* f, uint32_t t_, uint32_t rf, uint32_t rp) : F{f}, t(t_), r_f(rf), r_p(rp) {
         Grain g(f, t, r_f, r_p);
         constants.assign(r_f + r_p, std::vector<Fe>(t));
@@ -226,29 +283,85 @@ struct PoseidonSpec {
         for (auto& y : ys) y = g.field_element_mod();
         mds.assign(t, std::vector<Fe>(t));
         for (uint32_t i = 0; i < t; i++) for (uint32_t j = 0; j < t; j++) mds[i][j] = F.inv(F.add(xs[i], ys[j]));
-        mds_m = mds;
-        for (auto& row : mds_m) for (auto& m : row) m = f->from_canonical(m);
+        // calculate_optimized_constants, spec.rs:325-378
+        const uint32_t half = r_f / 2;
+        const Mat inv = mat_inv(F, mds);
+        start.push_back(constants[0]);
+        for (uint32_t i = 1; i < half; i++) start.push_back(mat_vec(F, inv, constants[i]));
+        std::vector<Fe> acc = constants[half + r_p];
+        partial.assign(r_p, F.zero());
+        for (uint32_t i = r_p; i-- > 0;) {      // constants[half .. half + r_p) walked backwards
+            std::vector<Fe> tmp = mat_vec(F, inv, acc);
+            partial[i] = tmp[0];
+            tmp[0] = F.zero();
+            for (uint32_t j = 0; j < t; j++) acc[j] = F.add(tmp[j], constants[half + i][j]);
+        }
+        start.push_back(mat_vec(F, inv, acc));
+        for (uint32_t i = half + r_p + 1; i < r_f + r_p; i++) end.push_back(mat_vec(F, inv, constants[i]));
+        // calculate_sparse_matrices, spec.rs:380-397 with factorise :203-241
+        const Mat mds_t = transpose(mds);
+        Mat acc_m = mds_t;
+        for (uint32_t r = 0; r < r_p; r++) {
+            std::vector<Fe> w(t - 1);
+            Mat hat(t - 1, std::vector<Fe>(t - 1));
+            for (uint32_t i = 1; i < t; i++) {
+                w[i - 1] = acc_m[i][0];
+                for (uint32_t j = 1; j < t; j++) hat[i - 1][j - 1] = acc_m[i][j];
+            }
+            const std::vector<Fe> w_hat = mat_vec(F, mat_inv(F, hat), w);
+            Mat prime(t, std::vector<Fe>(t, F.zero()));
+            prime[0][0] = F.u(1);
+            for (uint32_t i = 1; i < t; i++) for (uint32_t j = 1; j < t; j++) prime[i][j] = hat[i - 1][j - 1];
+            std::vector<Fe> row = {acc_m[0][0]};
+            row.insert(row.end(), w_hat.begin(), w_hat.end());
+            sparse_row.push_back(row);
+            sparse_col.push_back(std::vector<Fe>(acc_m[0].begin() + 1, acc_m[0].end()));
+            acc_m = mat_mul(F, mds_t, prime);
+        }
+        std::reverse(sparse_row.begin(), sparse_row.end());
+        std::reverse(sparse_col.begin(), sparse_col.end());
+        pre_sparse = transpose(acc_m);
+        mds_m = to_mont(mds);
+        pre_sparse_m = to_mont(pre_sparse);
+        sparse_row_m = to_mont(sparse_row);
+        sparse_col_m = to_mont(sparse_col);
     }
     Fe pow5(const Fe& x) const {
         const Fe x2 = F.mul(x, x);
         return F.mul(F.mul(x2, x2), x);
     }
-    std::vector<Fe> permute(std::vector<Fe> st) const {      // src/poseidon/permutation.rs:60-80
+    std::vector<Fe> apply_m(const Mat& m_mont, const std::vector<Fe>& st) const {
+        std::vector<Fe> nx(t, F.zero());
+        for (uint32_t i = 0; i < t; i++) for (uint32_t j = 0; j < t; j++) nx[i] = F.add(nx[i], F.f->mul(m_mont[i][j], st[j]));
+        return nx;
+    }
+    std::vector<Fe> permute(std::vector<Fe> st) const {      // src/poseidon/permutation.rs:7-46 (the optimised permutation)
         const uint32_t half = r_f / 2;
-        for (uint32_t r = 0; r < constants.size(); r++) {
-            for (uint32_t i = 0; i < t; i++) st[i] = F.add(st[i], constants[r][i]);
-            if (r < half || r >= half + r_p) for (auto& e : st) e = pow5(e);
-            else st[0] = pow5(st[0]);
+        for (uint32_t i = 0; i < t; i++) st[i] = F.add(st[i], start[0][i]);
+        for (uint32_t r = 1; r < half; r++) {
+            for (uint32_t i = 0; i < t; i++) st[i] = F.add(pow5(st[i]), start[r][i]);
+            st = apply_m(mds_m, st);
+        }
+        for (uint32_t i = 0; i < t; i++) st[i] = F.add(pow5(st[i]), start[half][i]);
+        st = apply_m(pre_sparse_m, st);
+        for (uint32_t r = 0; r < r_p; r++) {
+            st[0] = F.add(pow5(st[0]), partial[r]);
             std::vector<Fe> nx(t, F.zero());
-            for (uint32_t i = 0; i < t; i++) for (uint32_t j = 0; j < t; j++) nx[i] = F.add(nx[i], mds_mul(i, j, st[j]));
+            for (uint32_t j = 0; j < t; j++) nx[0] = F.add(nx[0], F.f->mul(sparse_row_m[r][j], st[j]));
+            for (uint32_t i = 1; i < t; i++) nx[i] = F.add(F.f->mul(sparse_col_m[r][i - 1], st[0]), st[i]);
             st = nx;
         }
-        return st;
+        for (uint32_t r = 0; r < end.size(); r++) {
+            for (uint32_t i = 0; i < t; i++) st[i] = F.add(pow5(st[i]), end[r][i]);
+            st = apply_m(mds_m, st);
+        }
+        for (uint32_t i = 0; i < t; i++) st[i] = pow5(st[i]);
+        return apply_m(mds_m, st);
     }
 };
 
-// The round constants and the MDS matrix depend on (T, R_F, R_P) only -- 325 Grain draws and 25 field inversions at the reference's parameters, 1.5 ms, most
-// of a PoseidonEnc witness -- so a process keeps each parameter set it has used (the reference rebuilds the Spec in every synthesize: src/poseidon/spec.rs).
+// The parameters depend on (T, R_F, R_P) only -- 325 Grain draws, 58 matrix inversions at the reference's parameters, a few milliseconds, many times a
+// PoseidonEnc witness -- so a process keeps each parameter set it has used (the reference rebuilds the Spec in every synthesize: src/poseidon/spec.rs).
 std::shared_ptr<const PoseidonSpec> poseidon_spec(const HostField* f, uint32_t t, uint32_t r_f, uint32_t r_p) {
     static std::mutex mu;
     static std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::shared_ptr<const PoseidonSpec>> cache;
@@ -259,12 +372,17 @@ std::shared_ptr<const PoseidonSpec> poseidon_spec(const HostField* f, uint32_t t
     return slot;
 }
 
-// ---- the MainGate / RangeChip layouter (dehalo2_amd/witness.py Layouter, row for row) ----
+// ---- the MainGate / RangeChip layouter (dehalo2_amd/witness.py Layouter, row for row): every MainGateInstructions / RangeInstructions call the
+// reference makes, laid out the way [UPSTREAM] halo2wrong maingate's `apply` lays it out (term i in column i) ----
 enum { MG_SA = 0, MG_SB, MG_SC, MG_SD, MG_SE, MG_MUL_AB, MG_MUL_CD, MG_NEXT, MG_CONST, RC_T_TAG, RC_T_VALUE, RC_TAG_COMPOSITION, RC_TAG_OVERFLOW, RC_S_COMPOSITION, RC_S_OVERFLOW, NUM_FIX };
-// RangeChip::configure(composition_bit_lens = (8, 4, 1), overflow_bit_lens = (6,)): tags 1..4 (src/lib.rs:144-149)
-constexpr unsigned COMPOSITION_BITS[3] = {8, 4, 1};
-constexpr unsigned OVERFLOW_BITS = 6;
-inline uint64_t range_tag(unsigned bits) { return bits == 8 ? 1 : bits == 4 ? 2 : bits == 1 ? 3 : bits == 6 ? 4 : 0; }
+// RangeChip::configure(composition_bit_lens = [8, 1, 8, 4], overflow_bit_lens = [0, 0, 6]) (src/lib.rs:144-149): the distinct non-zero lengths in
+// ascending order carry the tags 1..4
+constexpr unsigned RANGE_BITS[4] = {1, 4, 6, 8};
+inline uint64_t range_tag(unsigned bits) { return bits == 1 ? 1 : bits == 4 ? 2 : bits == 6 ? 3 : bits == 8 ? 4 : 0; }
+constexpr unsigned NUM_LOOKUP_LIMBS = 8;      // src/big_integer/chip.rs:1167
+inline unsigned sublimb_bit_len(unsigned bits) { return std::max(1u, bits / NUM_LOOKUP_LIMBS); }
+
+struct NotSatisfied : std::runtime_error { using std::runtime_error::runtime_error; };      // a constraint of the reference's circuit fails for these inputs
 
 struct Cell { int col = -1; uint32_t row = 0; Fe val{}; bool is_cell() const { return col >= 0; } };
 struct Arg {      // a cell (copied), a value, or nothing (0)
@@ -292,14 +410,16 @@ struct Layouter {
     std::vector<Fe> own;
     std::vector<Fe> fix[NUM_FIX];
     std::vector<Copy> copies;
+    Fe one_, m1_;
     Layouter(const HostField* f, bool fixed_too, uint64_t* advice, size_t n) : F{f}, want_fixed(fixed_too), cap(n) {
         if (!advice) own.resize(5 * n);
         Fe* base = advice ? reinterpret_cast<Fe*>(advice) : own.data();
         for (int i = 0; i < 5; i++) adv[i] = base + (size_t)i * n;
+        one_ = F.u(1); m1_ = F.neg(one_);
     }
     // a second cursor over the same columns, starting at row `start` (proving only: no fixed columns, no copies): the rows of independent regions whose
     // positions are known in advance are written by several host threads at once (BigIntChip::pow_mod)
-    Layouter(const Layouter& parent, uint32_t start) : F(parent.F), want_fixed(false), cap(parent.cap), nrows(start) {
+    Layouter(const Layouter& parent, uint32_t start) : F(parent.F), want_fixed(false), cap(parent.cap), nrows(start), one_(parent.one_), m1_(parent.m1_) {
         for (int i = 0; i < 5; i++) adv[i] = parent.adv[i];
     }
     uint32_t rows() const { return nrows; }
@@ -321,27 +441,44 @@ struct Layouter {
             for (int i = 0; i < nsel; i++) fix[sel[i].col][r] = sel[i].val;
         }
     }
-    Fe one() const { return F.u(1); }
-    Fe m1() const { return F.neg(F.u(1)); }
+    const Fe& one() const { return one_; }
+    const Fe& m1() const { return m1_; }
+    [[noreturn]] void fail(const char* what) const { throw NotSatisfied(std::string(what) + " at row " + std::to_string(nrows)); }
 
+    // --- MainGateInstructions, one row each unless said otherwise
     Cell assign_value(const Fe& v) { Cell o[5]; Arg a[1] = {Arg(v)}; row(a, 1, nullptr, 0, o); return o[0]; }
-    Cell assign_constant(const Fe& v) { Cell o[5]; Arg a[1] = {Arg(v)}; Sel s[2] = {{MG_SA, one()}, {MG_CONST, F.neg(v)}}; row(a, 1, s, 2, o); return o[0]; }
-    Cell mul_add(const Arg& a, const Arg& b, const Arg& c) {
+    Cell assign_constant(const Fe& c) { Cell o[5]; Arg a[1] = {Arg(c)}; Sel s[2] = {{MG_SA, m1()}, {MG_CONST, c}}; row(a, 1, s, 2, o); return o[0]; }      // -a + c = 0
+    Cell assign_bit(uint64_t b) {      // a b - c = 0 with a = b = c
         Cell o[5];
-        Arg x[4] = {a, b, c, Arg(F.add(F.mul(a.c.val, b.c.val), c.c.val))};
-        Sel s[3] = {{MG_MUL_AB, one()}, {MG_SC, one()}, {MG_SD, m1()}};
-        row(x, 4, s, 3, o);
-        return o[3];
+        const Fe v = F.u(b);
+        Arg x[3] = {Arg(v), Arg(v), Arg(v)};
+        Sel s[2] = {{MG_MUL_AB, one()}, {MG_SC, m1()}};
+        row(x, 3, s, 2, o);
+        if (want_fixed) { copies.push_back(Copy{0, o[0].row, 1, o[0].row}); copies.push_back(Copy{1, o[0].row, 2, o[0].row}); }
+        return o[2];
     }
-    Cell mul(const Arg& a, const Arg& b) { return mul_add(a, b, Arg()); }
-    Cell add(const Cell& a, const Cell& b, const Fe& constant) {
+    void assert_equal(const Cell& a, const Cell& b) {      // a - b = 0
+        if (!(a.val == b.val)) fail("assert_equal on different values");
+        Cell o[5];
+        Arg x[2] = {Arg(a), Arg(b)};
+        Sel s[2] = {{MG_SA, one()}, {MG_SB, m1()}};
+        row(x, 2, s, 2, o);
+    }
+    void assert_one(const Cell& a) {
+        if (!(a.val == one())) fail("assert_one fails");
+        Cell o[5];
+        Arg x[1] = {Arg(a)};
+        Sel s[2] = {{MG_SA, one()}, {MG_CONST, m1()}};
+        row(x, 1, s, 2, o);
+    }
+    Cell add_with_constant(const Cell& a, const Cell& b, const Fe& constant) {
         Cell o[5];
         Arg x[3] = {Arg(a), Arg(b), Arg(F.add(F.add(a.val, b.val), constant))};
         Sel s[4] = {{MG_SA, one()}, {MG_SB, one()}, {MG_SC, m1()}, {MG_CONST, constant}};
         row(x, 3, s, 4, o);
         return o[2];
     }
-    Cell add(const Cell& a, const Cell& b) { return add(a, b, F.zero()); }
+    Cell add(const Cell& a, const Cell& b) { return add_with_constant(a, b, F.zero()); }
     Cell sub(const Cell& a, const Cell& b) {
         Cell o[5];
         Arg x[3] = {Arg(a), Arg(b), Arg(F.sub(a.val, b.val))};
@@ -351,143 +488,241 @@ struct Layouter {
     }
     Cell add_constant(const Cell& a, const Fe& constant) {
         Cell o[5];
-        Arg x[3] = {Arg(a), Arg(), Arg(F.add(a.val, constant))};
-        Sel s[3] = {{MG_SA, one()}, {MG_SC, m1()}, {MG_CONST, constant}};
+        Arg x[2] = {Arg(a), Arg(F.add(a.val, constant))};
+        Sel s[3] = {{MG_SA, one()}, {MG_SB, m1()}, {MG_CONST, constant}};
+        row(x, 2, s, 3, o);
+        return o[1];
+    }
+    Cell mul(const Arg& a, const Arg& b) {
+        Cell o[5];
+        Arg x[3] = {a, b, Arg(F.mul(a.c.val, b.c.val))};
+        Sel s[2] = {{MG_MUL_AB, one()}, {MG_SC, m1()}};
+        row(x, 3, s, 2, o);
+        return o[2];
+    }
+    Cell mul_add(const Arg& a, const Arg& b, const Arg& c) {
+        Cell o[5];
+        Arg x[4] = {a, b, c, Arg(F.add(F.mul(a.c.val, b.c.val), c.c.val))};
+        Sel s[3] = {{MG_MUL_AB, one()}, {MG_SC, one()}, {MG_SD, m1()}};
+        row(x, 4, s, 3, o);
+        return o[3];
+    }
+    Cell mul_add_constant(const Cell& a, const Cell& b, const Fe& constant) {
+        Cell o[5];
+        Arg x[3] = {Arg(a), Arg(b), Arg(F.add(F.mul(a.val, b.val), constant))};
+        Sel s[3] = {{MG_MUL_AB, one()}, {MG_SC, m1()}, {MG_CONST, constant}};
         row(x, 3, s, 3, o);
         return o[2];
     }
-    void assert_equal(const Cell& a, const Cell& b) { if (want_fixed) copies.push_back(Copy{(uint32_t)a.col, a.row, (uint32_t)b.col, b.row}); }
-    Cell assign_bit(uint64_t v) {      // a b - a = 0 with a == b
+    Cell and_(const Cell& a, const Cell& b) { return mul(Arg(a), Arg(b)); }
+    Cell not_(const Cell& c) {      // c + not_c - 1 = 0
         Cell o[5];
-        Arg x[2] = {Arg(F.u(v)), Arg(F.u(v))};
-        Sel s[2] = {{MG_MUL_AB, one()}, {MG_SA, m1()}};
-        row(x, 2, s, 2, o);
-        if (want_fixed) copies.push_back(Copy{0, o[0].row, 1, o[0].row});
-        return o[0];
+        Arg x[2] = {Arg(c), Arg(F.sub(one(), c.val))};
+        Sel s[3] = {{MG_SA, one()}, {MG_SB, one()}, {MG_CONST, m1()}};
+        row(x, 2, s, 3, o);
+        return o[1];
     }
-    Cell select(const Cell& a, const Cell& b, const Cell& cond) {      // a cond - cond b + b - res = 0
+    Cell select(const Cell& a, const Cell& b, const Cell& cond) {      // cond a - cond b + b - res = 0, columns | cond | a | cond | b | res |
         Cell o[5];
-        Arg x[5] = {Arg(a), Arg(cond), Arg(cond), Arg(b), Arg(cond.val.is_zero() ? b.val : a.val)};
+        Arg x[5] = {Arg(cond), Arg(a), Arg(cond), Arg(b), Arg(cond.val.is_zero() ? b.val : a.val)};
         Sel s[4] = {{MG_MUL_AB, one()}, {MG_MUL_CD, m1()}, {MG_SD, one()}, {MG_SE, m1()}};
         row(x, 5, s, 4, o);
         return o[4];
     }
-    Cell is_equal(const Cell& x, const Cell& y) {
-        const Cell d = sub(x, y);
-        const Fe bit = F.u(d.val.is_zero() ? 1 : 0), inv = F.inv(d.val);
+    Cell is_equal(const Cell& a, const Cell& b) {      // four rows: r (a bit), dif = a - b, u = r - r x + x, dif u + r - 1 = 0  (x = 1 / dif, or 1 when dif = 0)
+        const Fe dv = F.sub(a.val, b.val);
+        const bool eq = dv.is_zero();
+        const Fe x = eq ? one() : F.inv(dv);
+        const Cell r = assign_bit(eq ? 1 : 0);
+        const Cell dif = sub(a, b);
         Cell o[5], o2[5];
-        Arg a[3] = {Arg(d), Arg(inv), Arg(bit)};
-        Sel s[3] = {{MG_MUL_AB, one()}, {MG_SC, one()}, {MG_CONST, m1()}};      // d inv + bit - 1 = 0
-        row(a, 3, s, 3, o);
-        Arg b[2] = {Arg(d), Arg(o[2])};
-        Sel s2[1] = {{MG_MUL_AB, one()}};                                       // d bit = 0
-        row(b, 2, s2, 1, o2);
-        return o[2];
+        Arg t[5] = {Arg(r), Arg(x), Arg(r), Arg(x), Arg(x)};      // u = r - r x + x = x in both cases (r = 0: x; r = 1: x = 1)
+        Sel s[4] = {{MG_MUL_AB, one()}, {MG_SC, m1()}, {MG_SD, m1()}, {MG_SE, one()}};
+        row(t, 5, s, 4, o);
+        Arg t2[3] = {Arg(dif), Arg(o[4]), Arg(r)};
+        Sel s2[3] = {{MG_MUL_AB, one()}, {MG_SC, one()}, {MG_CONST, m1()}};
+        row(t2, 3, s2, 3, o2);
+        return r;
     }
-    // s = q 2^width + r over the integers (the value is far below p)
-    void div_mod(const Cell& s, unsigned width, Cell& q, Cell& r) {
-        Fe qv{{0, 0, 0, 0}}, rv{{0, 0, 0, 0}};
-        const unsigned wl = width >> 6, wb = width & 63;      // (width < 256)
-        for (unsigned i = 0; i < 4; i++) {
-            if (i < wl) rv.v[i] = s.val.v[i];
-            else if (i == wl && wb) rv.v[i] = s.val.v[i] & (((uint64_t)1 << wb) - 1);
-            if (i + wl < 4) {
-                qv.v[i] = s.val.v[i + wl] >> wb;
-                if (wb && i + wl + 1 < 4) qv.v[i] |= s.val.v[i + wl + 1] << (64 - wb);
-            }
-        }
-        Cell o[5];
-        Arg a[3] = {Arg(qv), Arg(rv), Arg(s)};
-        Sel sl[3] = {{MG_SA, F.pow2(width)}, {MG_SB, one()}, {MG_SC, m1()}};
-        row(a, 3, sl, 3, o);
-        q = o[0];
-        r = o[1];
+    Cell is_zero(const Cell& a) {      // MainGate::invert's flag, three rows: r (a bit), a a' + r - 1 = 0, r a' - r = 0
+        const bool z = a.val.is_zero();
+        const Fe a_inv = z ? one() : F.inv(a.val);
+        const Cell r = assign_bit(z ? 1 : 0);
+        Cell o[5], o2[5];
+        Arg t[3] = {Arg(a), Arg(a_inv), Arg(r)};
+        Sel s[3] = {{MG_MUL_AB, one()}, {MG_SC, one()}, {MG_CONST, m1()}};
+        row(t, 3, s, 3, o);
+        Arg t2[3] = {Arg(r), Arg(o[1]), Arg(r)};
+        Sel s2[2] = {{MG_MUL_AB, one()}, {MG_SC, m1()}};
+        row(t2, 3, s2, 2, o2);
+        return r;
     }
-    std::vector<Cell> to_bits(const Cell& v, unsigned nbits) {
-        std::vector<Cell> bits;
-        for (unsigned i = 0; i < nbits; i++) bits.push_back(assign_bit((v.val.v[i >> 6] >> (i & 63)) & 1));
-        Fe acc = F.zero();
-        Cell o[5];
-        for (unsigned g = 0; g < nbits; g += 4) {      // four bits a row, the running value carried through e / e(next row)
-            const unsigned cnt = std::min(4u, nbits - g);
-            Arg a[5];
-            Sel s[6];
-            int ns = 0;
-            s[ns++] = {MG_SE, one()};
-            s[ns++] = {MG_NEXT, m1()};
-            for (unsigned i = 0; i < cnt; i++) {
-                a[i] = Arg(bits[g + i]);
-                s[ns++] = {MG_SA + (int)i, F.pow2(g + i)};
-            }
-            a[4] = Arg(acc);
-            row(a, 5, s, ns, o);
-            for (unsigned i = 0; i < cnt; i++)
-                if (!bits[g + i].val.is_zero()) acc = F.add(acc, F.pow2(g + i));
-        }
-        Arg a[5];
-        a[4] = Arg(acc);
-        row(a, 5, nullptr, 0, o);
-        assert_equal(o[4], v);
-        return bits;
-    }
-    // RangeChip::assign(value, 8-bit sub-limbs, bit_len): sub-limbs four to a row (tagged lookups on a..d), a 6-bit overflow limb on its
-    // own row, the running sum carried through e.  value < 2^bit_len <= 2^128.
-    Cell range_assign(u128 value, unsigned bit_len) {
-        const unsigned nsub = bit_len / 8, rem = bit_len % 8;
-        u128 acc = 0;
-        Cell o[5];
-        for (unsigned g = 0; g < nsub; g += 4) {
+    // compose: four terms a row, column e holds what is still to be added (the total in the first row).  prod[i] = coeff[i] * cells[i].val (the caller's
+    // cheapest way to it); coeff is only read at keygen
+    Cell compose(const Cell* cells, const Fe* coeff, const Fe* prod, int n, const Fe& constant) {
+        Fe remaining = constant;
+        for (int i = 0; i < n; i++) remaining = F.add(remaining, prod[i]);
+        Cell result, o[5];
+        for (int g = 0; g < n; g += 4) {
+            const int cnt = std::min(4, n - g);
+            const bool last = g + 4 >= n;
             Arg a[5];
             Sel s[8];
             int ns = 0;
-            s[ns++] = {MG_SE, one()};
-            s[ns++] = {MG_NEXT, m1()};
-            s[ns++] = {RC_S_COMPOSITION, one()};
-            s[ns++] = {RC_TAG_COMPOSITION, F.u(range_tag(8))};
-            u128 part = 0;
-            for (unsigned i = 0; i < 4; i++) {
-                const uint64_t sub = g + i < nsub ? (uint64_t)((value >> (8 * (g + i))) & 0xFF) : 0;
-                a[i] = Arg(F.u(sub));
-                s[ns++] = {MG_SA + (int)i, g + i < nsub ? F.pow2(8 * (g + i)) : F.zero()};
-                if (g + i < nsub) part += (u128)sub << (8 * (g + i));
+            for (int i = 0; i < cnt; i++) {
+                a[i] = Arg(cells[g + i]);
+                if (want_fixed) s[ns++] = {MG_SA + i, coeff[g + i]};
             }
-            a[4] = Arg(F.from_u128(acc));
+            a[4] = Arg(remaining);
+            s[ns++] = {MG_SE, m1()};
+            if (!last) s[ns++] = {MG_NEXT, one()};
+            if (g == 0) s[ns++] = {MG_CONST, constant};
             row(a, 5, s, ns, o);
-            acc += part;
+            if (g == 0) { result = o[4]; remaining = F.sub(remaining, constant); }
+            for (int i = 0; i < cnt; i++) remaining = F.sub(remaining, prod[g + i]);
         }
-        if (rem) {
-            const uint64_t top = (uint64_t)(value >> (8 * nsub));
+        return result;
+    }
+    std::vector<Cell> to_bits(const Cell& v, unsigned nbits) {
+        if (nbits < 64 ? (v.val.v[0] >> nbits) != 0 || v.val.v[1] || v.val.v[2] || v.val.v[3] : (v.val.v[1] || v.val.v[2] || v.val.v[3])) fail("to_bits: the value does not fit");
+        std::vector<Cell> bits;
+        std::vector<Fe> coeff, prod;
+        for (unsigned i = 0; i < nbits; i++) {
+            bits.push_back(assign_bit((v.val.v[0] >> i) & 1));
+            coeff.push_back(F.pow2(i));
+            prod.push_back(bits.back().val.is_zero() ? F.zero() : coeff.back());
+        }
+        assert_equal(compose(bits.data(), coeff.data(), prod.data(), (int)nbits, F.zero()), v);
+        return bits;
+    }
+    // RangeInstructions::assign: `limb_bits`-bit limbs four to a row with the composition lookup on a..d, the (bit_len mod limb_bits)-bit overflow limb
+    // last, alone in column a of its row, with the overflow lookup.  value < 2^bit_len <= 2^128; the first row's e is the value, the later rows' what is left.
+    Cell range_assign(u128 value, unsigned limb_bits, unsigned bit_len) {
+        if (bit_len < 128 && (value >> bit_len)) fail("range_assign: the value does not fit");
+        const unsigned full = bit_len / limb_bits, over = bit_len % limb_bits, nl = full + (over ? 1 : 0);
+        if (over && full % 4) throw std::runtime_error("the overflow limb must open a row");
+        const u128 mask = ((u128)1 << limb_bits) - 1;
+        Cell result, o[5];
+        for (unsigned g = 0; g < nl; g += 4) {
+            const unsigned cnt = std::min(4u, nl - g);
+            const bool last = g + 4 >= nl;
             Arg a[5];
-            a[0] = Arg(F.u(top));
-            a[4] = Arg(F.from_u128(acc));
-            Sel s[5] = {{MG_SA, F.pow2(8 * nsub)}, {MG_SE, one()}, {MG_NEXT, m1()}, {RC_S_OVERFLOW, one()}, {RC_TAG_OVERFLOW, F.u(range_tag(rem))}};
-            row(a, 5, s, 5, o);
-            acc += (u128)top << (8 * nsub);
+            Sel s[10];
+            int ns = 0;
+            for (unsigned i = 0; i < cnt; i++) {
+                a[i] = Arg(F.u((uint64_t)((value >> (limb_bits * (g + i))) & mask)));
+                if (want_fixed) s[ns++] = {MG_SA + (int)i, F.pow2(limb_bits * (g + i))};
+            }
+            const unsigned sh = limb_bits * g;
+            a[4] = Arg(F.from_u128(sh ? (value >> sh) << sh : value));
+            if (want_fixed) {
+                s[ns++] = {MG_SE, m1()};
+                if (!last) s[ns++] = {MG_NEXT, one()};
+                s[ns++] = {RC_S_COMPOSITION, one()};
+                s[ns++] = {RC_TAG_COMPOSITION, F.u(range_tag(limb_bits))};
+                if (last && over) { s[ns++] = {RC_S_OVERFLOW, one()}; s[ns++] = {RC_TAG_OVERFLOW, F.u(range_tag(over))}; }
+            }
+            row(a, 5, s, ns, o);
+            if (g == 0) result = o[4];
         }
-        Arg a[5];
-        a[4] = Arg(F.from_u128(value));
-        row(a, 5, nullptr, 0, o);
-        return o[4];
+        return result;
     }
 };
 
 unsigned synth_threads();
 
-// ---- BigIntChip ----
+// ---- BigIntChip (src/big_integer/chip.rs) ----
 struct BigIntChip {
     Layouter& lay;
     size_t num_limbs;
-    std::vector<Cell> assign_integer(const Big& x) {
+    Big to_big(const std::vector<Cell>& limbs) const {
+        Big r;
+        for (auto& c : limbs) r.push_back(c.val.v[0]);
+        return r;
+    }
+    Cell range_limb(uint64_t v) { return lay.range_assign(v, sublimb_bit_len(LIMB_WIDTH), LIMB_WIDTH); }
+    std::vector<Cell> assign_integer(const Big& x, size_t n) {      // :64-85
         std::vector<Cell> out;
-        for (uint64_t v : big_limbs(x, num_limbs)) out.push_back(lay.range_assign(v, LIMB_WIDTH));
+        for (uint64_t v : big_limbs(x, n)) out.push_back(range_limb(v));
         return out;
     }
-    std::vector<Cell> assign_constant(const Big& x) {
+    // :1255-1285: one row per limb the integer HAS, then one zero row whose cell pads the rest
+    std::vector<Cell> assign_constant(Big x, size_t max_num_limbs) {
+        big_trim(x);
+        if (x.size() > max_num_limbs) throw std::runtime_error("assign_constant: too many limbs");
         std::vector<Cell> out;
-        for (uint64_t v : big_limbs(x, num_limbs)) out.push_back(lay.assign_constant(lay.F.u(v)));
+        for (uint64_t v : x) out.push_back(lay.assign_constant(lay.F.u(v)));
+        const Cell zero = lay.assign_constant(lay.F.zero());
+        while (out.size() < max_num_limbs) out.push_back(zero);
         return out;
     }
-    // src/big_integer/chip.rs:389-422: limb i of the product = sum_{j + k = i} a_j b_k by a chain of mul_add rows
+    std::vector<Cell> max_value(size_t n) {
+        std::vector<Cell> out;
+        for (size_t i = 0; i < n; i++) out.push_back(lay.assign_constant(lay.F.u(~(uint64_t)0)));
+        return out;
+    }
+    // :250-300: limb sums with range-checked (c, carry) pairs; max(n1, n2) + 1 limbs
+    std::vector<Cell> add(std::vector<Cell> a, std::vector<Cell> b) {
+        const size_t max_n = std::max(a.size(), b.size());
+        const Cell zero = lay.assign_constant(lay.F.zero());
+        a.resize(max_n, zero);
+        b.resize(max_n, zero);
+        Cell carry = zero;
+        const Cell limb_max = lay.assign_constant(lay.F.pow2(LIMB_WIDTH));
+        std::vector<Cell> out;
+        for (size_t i = 0; i < max_n; i++) {
+            const Cell s = lay.add(lay.add(a[i], b[i]), carry);
+            const Cell c = range_limb(s.val.v[0]);
+            if (s.val.v[2] | s.val.v[3]) lay.fail("add: a limb sum left 128 bits");
+            carry = range_limb(s.val.v[1]);
+            lay.assert_equal(s, lay.mul_add(Arg(carry), Arg(limb_max), Arg(c)));
+            out.push_back(c);
+        }
+        out.push_back(carry);
+        return out;
+    }
+    static Big big_sub(const Big& a, const Big& b, bool& negative) {      // a - b over max(len) limbs
+        const size_t n = std::max(a.size(), b.size());
+        Big r(n, 0);
+        u128 borrow = 0;
+        for (size_t i = 0; i < n; i++) {
+            const u128 d = (u128)(i < a.size() ? a[i] : 0) - (i < b.size() ? b[i] : 0) - borrow;
+            r[i] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+        }
+        negative = borrow != 0;
+        return r;
+    }
+    // :1290-1322: c = a - b as fresh limbs, then a = b + c
+    std::vector<Cell> sub_unchecked(const std::vector<Cell>& a, const std::vector<Cell>& b) {
+        bool neg = false;
+        const Big c_big = big_sub(to_big(a), to_big(b), neg);
+        if (neg) lay.fail("sub_unchecked: a < b");
+        std::vector<Cell> c;
+        for (uint64_t v : big_limbs(c_big, a.size())) c.push_back(range_limb(v));
+        assert_equal_fresh(a, add(b, c));
+        return c;
+    }
+    // :313-376: (|a - b|, is_overflowed) through a + max - b
+    std::vector<Cell> sub(const std::vector<Cell>& a, const std::vector<Cell>& b, Cell& is_overflowed) {
+        const size_t n2 = b.size();
+        const std::vector<Cell> max_int = max_value(n2);
+        const std::vector<Cell> inflated_subed = sub_unchecked(add(a, max_int), b);
+        const Cell one = lay.assign_bit(1);
+        const Cell is_not_overflowed = lay.is_equal(inflated_subed[n2], one);
+        is_overflowed = lay.not_(is_not_overflowed);
+        const size_t num_l = inflated_subed.size(), num_r = std::max(a.size(), n2);
+        const Cell zero = lay.assign_constant(lay.F.zero());
+        std::vector<Cell> sel_l, sel_r;
+        for (size_t i = 0; i < num_l; i++) sel_l.push_back(lay.select(inflated_subed[i], i >= n2 ? zero : b[i], is_not_overflowed));
+        for (size_t i = 0; i < num_r; i++) {
+            if (i >= a.size()) sel_r.push_back(lay.select(max_int[i], zero, is_not_overflowed));
+            else if (i >= n2) sel_r.push_back(lay.select(zero, a[i], is_not_overflowed));
+            else sel_r.push_back(lay.select(max_int[i], a[i], is_not_overflowed));
+        }
+        return sub_unchecked(sel_l, sel_r);
+    }
+    // :389-422: limb i of the product = sum_{j + k = i} a_j b_k by a chain of mul_add rows
     std::vector<Cell> mul(const std::vector<Cell>& a, const std::vector<Cell>& b) {
         const size_t d0 = a.size(), d1 = b.size();
         std::vector<Cell> out;
@@ -527,16 +762,36 @@ struct BigIntChip {
         }
         return out;
     }
-    // src/big_integer/chip.rs:825-898 (is_equal_muled) + the final assertion: a - b + word_max carried limb by limb
+    // :1327-1353 with n = 2^64 (its only use), five rows: q, a mod n assigned; n q; a - n q; equal to a mod n.  a is far below p.
+    void div_mod_limb(const Cell& a, const Cell& limb_max, Cell& q, Cell& r) {
+        const Fe qv{{a.val.v[1], a.val.v[2], a.val.v[3], 0}}, rv{{a.val.v[0], 0, 0, 0}};
+        q = lay.assign_value(qv);
+        r = lay.assign_value(rv);
+        lay.assert_equal(r, lay.sub(a, lay.mul(Arg(limb_max), Arg(q))));
+    }
+    Cell is_equal_fresh(const std::vector<Cell>& a, const std::vector<Cell>& b) {      // :778-803
+        const size_t n1 = a.size(), n2 = b.size();
+        Cell eq = lay.assign_bit(1);
+        for (size_t i = 0; i < std::max(n1, n2); i++) {
+            Cell flag;
+            if (n1 > n2 && i >= n2) flag = lay.is_zero(a[i]);
+            else if (n1 <= n2 && i >= n1) flag = lay.is_zero(b[i]);
+            else flag = lay.is_equal(a[i], b[i]);
+            eq = lay.and_(eq, flag);
+        }
+        return eq;
+    }
+    void assert_equal_fresh(const std::vector<Cell>& a, const std::vector<Cell>& b) { lay.assert_one(is_equal_fresh(a, b)); }
+    // :825-898 + assert_one (:1056-1066): a - b + word_max carried limb by limb, carries range-checked
     void assert_equal_muled(const std::vector<Cell>& a, const std::vector<Cell>& b, size_t n1, size_t n2) {
         Fld& F = lay.F;
         const size_t min_n = std::min(n1, n2);
         // word_max = min_n * limb_max^2 + limb_max (compute_mul_word_max): below 2^134 for 32 limbs
-        const u128 limb_max = ~(uint64_t)0;
+        const u128 limb_max_v = ~(uint64_t)0;
         Fe word_max;
         {
-            const Fe lm2 = F.mul(F.from_u128(limb_max), F.from_u128(limb_max));
-            word_max = F.add(F.mul(F.u(min_n), lm2), F.from_u128(limb_max));
+            const Fe lm2 = F.mul(F.from_u128(limb_max_v), F.from_u128(limb_max_v));
+            word_max = F.add(F.mul(F.u(min_n), lm2), F.from_u128(limb_max_v));
         }
         unsigned wm_bits = 256;      // bit length of 2 * word_max
         {
@@ -544,37 +799,40 @@ struct BigIntChip {
             while (wm_bits && !((two_wm.v[(wm_bits - 1) >> 6] >> ((wm_bits - 1) & 63)) & 1)) wm_bits--;
         }
         const unsigned carry_bits = wm_bits - LIMB_WIDTH;
+        const Cell limb_max = lay.assign_constant(F.pow2(LIMB_WIDTH));
         Cell accumulated_extra = lay.assign_constant(F.zero());
         Cell carry = lay.assign_constant(F.zero());
         Cell eq_bit = lay.assign_bit(1);
         const size_t num = n1 + n2 - 1;
         for (size_t i = 0; i < num; i++) {
-            const Cell a_b = lay.sub(a[i], b[i]);
-            const Cell s = lay.add(a_b, carry, word_max);
+            const Cell s = lay.add_with_constant(lay.sub(a[i], b[i]), carry, word_max);
+            if (s.val.v[3]) lay.fail("is_equal_muled: the carried sum left the integers");
             Cell new_carry, c, q_acc, mod_acc;
-            lay.div_mod(s, LIMB_WIDTH, new_carry, c);
+            div_mod_limb(s, limb_max, new_carry, c);
             accumulated_extra = lay.add_constant(accumulated_extra, word_max);
-            lay.div_mod(accumulated_extra, LIMB_WIDTH, q_acc, mod_acc);
-            eq_bit = lay.mul(Arg(eq_bit), Arg(lay.is_equal(c, mod_acc)));
+            div_mod_limb(accumulated_extra, limb_max, q_acc, mod_acc);
+            eq_bit = lay.and_(eq_bit, lay.is_equal(c, mod_acc));
             accumulated_extra = q_acc;
             if (i + 1 < num) {
+                if (new_carry.val.v[2] | new_carry.val.v[3]) lay.fail("is_equal_muled: a carry left 128 bits");
                 const u128 nc = ((u128)new_carry.val.v[1] << 64) | new_carry.val.v[0];
-                const Cell ranged = lay.range_assign(nc, carry_bits);
-                eq_bit = lay.mul(Arg(eq_bit), Arg(lay.is_equal(new_carry, ranged)));
+                const Cell ranged = lay.range_assign(nc, sublimb_bit_len(carry_bits), carry_bits);
+                eq_bit = lay.and_(eq_bit, lay.is_equal(new_carry, ranged));
             } else {
-                eq_bit = lay.mul(Arg(eq_bit), Arg(lay.is_equal(new_carry, accumulated_extra)));
+                eq_bit = lay.and_(eq_bit, lay.is_equal(new_carry, accumulated_extra));
             }
             carry = new_carry;
         }
-        lay.assert_equal(eq_bit, lay.assign_constant(F.u(1)));
+        lay.assert_one(eq_bit);
+    }
+    // :911-923, :1153-1161: (a <= b through sub's overflow flag) and not (a == b), asserted
+    void assert_in_field(const std::vector<Cell>& a, const std::vector<Cell>& n) {
+        Cell is_overflowed;
+        sub(a, n, is_overflowed);
+        lay.assert_one(lay.and_(is_overflowed, lay.not_(is_equal_fresh(a, n))));
     }
     std::vector<Cell> pow_mod_threads(std::vector<Cell> acc, std::vector<Cell> squared, const std::vector<Cell>& e_bits, const std::vector<Cell>& n, const Big& n_big);
-    Big to_big(const std::vector<Cell>& limbs) const {
-        Big r;
-        for (auto& c : limbs) r.push_back(c.val.v[0]);
-        return r;
-    }
-    // src/big_integer/chip.rs:545-632
+    // :545-632
     std::vector<Cell> mul_mod(const std::vector<Cell>& a, const std::vector<Cell>& b, const std::vector<Cell>& n, const Big& n_big) {
         Big q_big, r_big;
         big_divmod(big_mul(to_big(a), to_big(b)), n_big, q_big, r_big);
@@ -584,18 +842,20 @@ struct BigIntChip {
     std::vector<Cell> mul_mod_rows(const std::vector<Cell>& a, const std::vector<Cell>& b, const std::vector<Cell>& n, const Big& q_big, const Big& r_big) {
         const size_t n1 = a.size(), n2 = b.size();
         std::vector<Cell> q, r;
-        for (uint64_t v : big_limbs(q_big, n2)) q.push_back(lay.range_assign(v, LIMB_WIDTH));
-        for (uint64_t v : big_limbs(r_big, n1)) r.push_back(lay.range_assign(v, LIMB_WIDTH));
+        for (uint64_t v : big_limbs(q_big, n2)) q.push_back(range_limb(v));
+        for (uint64_t v : big_limbs(r_big, n1)) r.push_back(range_limb(v));
         const std::vector<Cell> ab = mul(a, b), qn = mul(q, n);
         std::vector<Cell> eq_b;
         for (size_t i = 0; i + 1 < n1 + n2; i++) eq_b.push_back(i < n1 ? lay.add(qn[i], r[i]) : qn[i]);
         assert_equal_muled(ab, eq_b, n1, n2);
         return r;
     }
-    // src/big_integer/chip.rs:667-699: per exponent bit (LSB first) acc * squared, select, squared^2
-    std::vector<Cell> pow_mod(const std::vector<Cell>& a, const std::vector<Cell>& e_bits, const std::vector<Cell>& n, const Big& n_big) {
-        std::vector<Cell> acc;
-        for (uint64_t v : big_limbs(Big{1}, num_limbs)) acc.push_back(lay.range_assign(v, LIMB_WIDTH));      // assign_constant_fresh(1)
+    // :667-699: the exponent's limbs into bits, then per bit (LSB first) acc * squared, select, squared^2
+    std::vector<Cell> pow_mod(const std::vector<Cell>& a, const std::vector<Cell>& e, const std::vector<Cell>& n, const Big& n_big, unsigned exp_limb_bits) {
+        std::vector<Cell> e_bits;
+        for (auto& limb : e)
+            for (auto& b : lay.to_bits(limb, exp_limb_bits)) e_bits.push_back(b);
+        std::vector<Cell> acc = assign_constant(Big{1}, num_limbs);      // assign_constant_fresh(1)
         std::vector<Cell> squared = a;
         if (!lay.want_fixed && e_bits.size() >= 3 && synth_threads() > 1) return pow_mod_threads(acc, squared, e_bits, n, n_big);
         for (auto& bit : e_bits) {
@@ -703,7 +963,7 @@ std::vector<Cell> BigIntChip::pow_mod_threads(std::vector<Cell> acc, std::vector
     uint32_t tail_end = end_row;
     const std::vector<Cell> powed = cells_of(a_cur);
     std::atomic<size_t> next{0};
-    std::atomic<bool> ok{true};
+    std::atomic<bool> ok{true}, unsat{false};
     auto work = [&]() {
         for (;;) try {
             size_t t = next.fetch_add(1);
@@ -731,6 +991,7 @@ std::vector<Cell> BigIntChip::pow_mod_threads(std::vector<Cell> acc, std::vector
                 for (size_t j = 0; j < ac.size(); j++) sub.select(muled[j], ac[j], e_bits[i]);
                 if (sub.nrows != start + len_a) ok = false;
             }
+        } catch (const NotSatisfied&) { unsat = true; ok = false; return;
         } catch (...) { ok = false; return; }
     };
     const unsigned nthreads = synth_threads();
@@ -744,91 +1005,106 @@ std::vector<Cell> BigIntChip::pow_mod_threads(std::vector<Cell> acc, std::vector
     }
     auto T3 = std::chrono::steady_clock::now();
     if (getenv("DEHALO_SYNTH_TRACE")) fprintf(stderr, "pow_mod: chain %.3f ms, bit 0 %.3f ms, %zu regions on %u threads %.3f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count(), tasks, nthreads, std::chrono::duration<double, std::milli>(T3 - T2).count());
+    if (unsat) throw NotSatisfied("a constraint behind the first exponent bit fails");
     if (!ok) throw std::runtime_error("pow_mod: a region's length depends on its values");
     lay.nrows = with_tail ? tail_end : end_row;
     lay.after_pow_done = with_tail;
     return powed;
 }
 
-// ---- PoseidonChip rows: x^5 as three multiplication rows, every MDS output as two rows of a five-term sum ----
-struct PoseidonRows {
+// ---- PoseidonChip (src/poseidon/chip.rs): the optimised permutation as MainGate rows -- 5 (absorb) + 8 x (15 + 10) + 57 x (3 + 6) = 718 rows for T = 5 ----
+struct PoseidonChip {
     Layouter& lay;
     const PoseidonSpec& sp;
-    Cell pow5(const Cell& x) {
-        const Cell x2 = lay.mul(Arg(x), Arg(x));
-        const Cell x4 = lay.mul(Arg(x2), Arg(x2));
-        return lay.mul(Arg(x4), Arg(x));
+    std::vector<Cell> state;
+    void sbox(Cell& w, const Fe& constant) {      // :199-222: w^2, w^4, w^4 w + constant
+        Cell t = lay.mul(Arg(w), Arg(w));
+        t = lay.mul(Arg(t), Arg(t));
+        w = lay.mul_add_constant(t, w, constant);
     }
-    Cell linear(const std::vector<Cell>& st, uint32_t mds_row, const Fe& constant) {
-        Fld& F = lay.F;
-        const std::vector<Fe>& coeffs = sp.mds[mds_row];
-        Fe part = F.zero();
-        for (int i = 0; i < 4; i++) part = F.add(part, sp.mds_mul(mds_row, i, st[i].val));
-        Cell o[5];
-        Arg a[5] = {Arg(st[0]), Arg(st[1]), Arg(st[2]), Arg(st[3]), Arg(F.zero())};
-        Sel s[6] = {{MG_SA, coeffs[0]}, {MG_SB, coeffs[1]}, {MG_SC, coeffs[2]}, {MG_SD, coeffs[3]}, {MG_SE, lay.one()}, {MG_NEXT, lay.m1()}};
-        lay.row(a, 5, s, 6, o);
-        const bool five = st.size() > 4;
-        const Fe total = F.add(F.add(part, five ? sp.mds_mul(mds_row, 4, st[4].val) : F.zero()), constant);
-        Arg b[5] = {five ? Arg(st[4]) : Arg(), Arg(total), Arg(), Arg(), Arg(part)};
-        Sel s2[4] = {{MG_SA, five ? coeffs[4] : F.zero()}, {MG_SB, lay.m1()}, {MG_SE, lay.one()}, {MG_CONST, constant}};
-        lay.row(b, 5, s2, 4, o);
-        return o[1];
+    void sbox_full(const std::vector<Fe>& constants) { for (uint32_t i = 0; i < sp.t; i++) sbox(state[i], constants[i]); }
+    // :225-262: word 0 + c0; the inputs added to the words behind it with their constants; the rest + constant (+ 1 on the first of them when hashing)
+    void absorb_with_pre_constants(const std::vector<Cell>& inputs, const std::vector<Fe>& pre, bool h_flag) {
+        const size_t offset = inputs.size() + 1;
+        state[0] = lay.add_constant(state[0], pre[0]);
+        for (size_t i = 0; i < inputs.size(); i++) state[1 + i] = lay.add_with_constant(state[1 + i], inputs[i], pre[1 + i]);
+        for (size_t i = offset; i < sp.t; i++) state[i] = lay.add_constant(state[i], h_flag && i == offset ? lay.F.add(pre[i], lay.one()) : pre[i]);
     }
-    // Round r: add constants, S-box (all words in a full round, word 0 in a partial one), MDS.  The constants of round r + 1 ride on
-    // round r's linear layer, so only the first round adds them on rows of their own.
-    std::vector<Cell> permutation(std::vector<Cell> st) {
-        const uint32_t half = sp.r_f / 2, rounds = (uint32_t)sp.constants.size();
-        for (size_t i = 0; i < st.size(); i++) st[i] = lay.add_constant(st[i], sp.constants[0][i]);
-        for (uint32_t r = 0; r < rounds; r++) {
-            const bool full = r < half || r >= half + sp.r_p;
-            std::vector<Cell> s = st;
-            if (full) for (auto& x : s) x = pow5(x);
-            else s[0] = pow5(st[0]);
-            std::vector<Cell> nx;
-            for (uint32_t i = 0; i < sp.t; i++) nx.push_back(linear(s, i, r + 1 < rounds ? sp.constants[r + 1][i] : lay.F.zero()));
-            st = nx;
+    Cell linear(const Cell* cells, const Fe* coeff, const Fe* coeff_m, int n) {
+        Fe prod[8];
+        for (int i = 0; i < n; i++) prod[i] = lay.F.f->mul(coeff_m[i], cells[i].val);
+        return lay.compose(cells, coeff, prod, n, lay.F.zero());
+    }
+    void apply_mds(const Mat& m, const Mat& m_mont) {      // :264-288: every output word a compose over the five state words (two rows)
+        std::vector<Cell> nx;
+        for (uint32_t i = 0; i < sp.t; i++) nx.push_back(linear(state.data(), m[i].data(), m_mont[i].data(), (int)sp.t));
+        state = nx;
+    }
+    void apply_sparse_mds(uint32_t r) {      // :291-330: word 0 a compose over the state, word i a compose of (word 0, col_hat) and (word i, 1)
+        std::vector<Cell> nx = {linear(state.data(), sp.sparse_row[r].data(), sp.sparse_row_m[r].data(), (int)sp.t)};
+        const Fe one_m = lay.F.f->one;
+        for (uint32_t i = 1; i < sp.t; i++) {
+            const Cell c[2] = {state[0], state[i]};
+            const Fe k[2] = {sp.sparse_col[r][i - 1], lay.one()}, km[2] = {sp.sparse_col_m[r][i - 1], one_m};
+            nx.push_back(linear(c, k, km, 2));
         }
-        return st;
+        state = nx;
+    }
+    void permutation(const std::vector<Cell>& inputs, bool h_flag) {      // :333-419
+        const uint32_t half = sp.r_f / 2;
+        absorb_with_pre_constants(inputs, sp.start[0], h_flag);
+        for (uint32_t r = 1; r < half; r++) {
+            sbox_full(sp.start[r]);
+            apply_mds(sp.mds, sp.mds_m);
+        }
+        sbox_full(sp.start[half]);
+        apply_mds(sp.pre_sparse, sp.pre_sparse_m);
+        for (uint32_t r = 0; r < sp.r_p; r++) {
+            sbox(state[0], sp.partial[r]);
+            apply_sparse_mds(r);
+        }
+        for (auto& c : sp.end) {
+            sbox_full(c);
+            apply_mds(sp.mds, sp.mds_m);
+        }
+        sbox_full(std::vector<Fe>(sp.t, lay.F.zero()));
+        apply_mds(sp.mds, sp.mds_m);
     }
 };
 
-struct NativeCipher {      // PoseidonCipher::{initial_state, encrypt} (src/encryption/poseidon_enc.rs:66-133), MESSAGE_CAPACITY = 2, T = 5
-    const PoseidonSpec& sp;
-    Fe key[2];
-    std::vector<Fe> encrypt(const std::vector<Fe>& message, uint64_t nonce) const {
-        const Fld& F = sp.F;
-        std::vector<Fe> st = {F.zero(), F.zero(), key[0], key[1], F.u(nonce)};
+// PoseidonCipher::{initial_state, encrypt} (src/encryption/poseidon_enc.rs:66-133), T = 5, RATE = 4, MESSAGE_CAPACITY = message.size(): the message is added
+// to a COPY of the state (`state.words()`, :108-119); a full chunk is then absorbed and permuted (update), a short one permutes the state as it is (squeeze(0)
+// with an empty absorbing line)
+std::vector<Fe> native_encrypt(const PoseidonSpec& sp, const Fe key[2], const std::vector<Fe>& message, uint64_t nonce, uint32_t rate) {
+    const Fld& F = sp.F;
+    std::vector<Fe> st = sp.permute({F.zero(), F.zero(), key[0], key[1], F.u(nonce)});
+    std::vector<Fe> cipher;
+    for (size_t c0 = 0; c0 < message.size(); c0 += rate) {
+        const size_t cnt = std::min<size_t>(rate, message.size() - c0);
+        for (size_t j = 0; j < cnt; j++) cipher.push_back(F.add(st[1 + j], message[c0 + j]));
+        if (cnt == rate) for (size_t j = 0; j < cnt; j++) st[1 + j] = F.add(st[1 + j], message[c0 + j]);
         st = sp.permute(st);
-        std::vector<Fe> cipher;
-        for (size_t i = 0; i < message.size(); i++) {
-            st[1 + i] = F.add(st[1 + i], message[i]);
-            cipher.push_back(st[1 + i]);
-        }
-        st = sp.permute(st);
-        cipher.push_back(st[1]);
-        return cipher;
     }
-};
+    cipher.push_back(st[1]);
+    return cipher;
+}
 
-// src/lib.rs:179-206 / benches/mod_pow.rs:63-110: assign n, e, x; x^e mod n in-circuit; equal to the native big_pow_mod
-// the expected value x^e mod n as constants, constrained equal to the exponentiation's result (src/lib.rs:205-219)
+// the expected value x^e mod n as constants, asserted equal to the exponentiation's result (src/lib.rs:205-215)
 std::vector<Cell> rsa_expected_rows(Layouter& lay, const std::vector<Cell>& powed) {
     BigIntChip chip{lay, powed.size()};
-    Big want = chip.to_big(powed);
-    big_trim(want);
-    const std::vector<Cell> valid = chip.assign_constant(want);
-    for (size_t i = 0; i < powed.size(); i++) lay.assert_equal(powed[i], valid[i]);
+    const std::vector<Cell> valid = chip.assign_constant(chip.to_big(powed), powed.size());
+    chip.assert_equal_fresh(powed, valid);
     return valid;
 }
 
+// src/lib.rs:179-215 / benches/mod_pow.rs:91-116: assign (n, e), x; x < n; x^e mod n in-circuit; equal to the native big_pow_mod
 std::vector<Cell> rsa_region(Layouter& lay, const Big& n_big, uint64_t e, const Big& x, unsigned exp_bits, size_t num_limbs, Big& want) {
     BigIntChip chip{lay, num_limbs};
-    const std::vector<Cell> n_limbs = chip.assign_integer(n_big);
-    const Cell e_cell = exp_bits % 8 == 0 ? lay.range_assign(e, 8 * ((exp_bits + 7) / 8)) : lay.assign_value(lay.F.u(e));
-    const std::vector<Cell> e_bits = lay.to_bits(e_cell, exp_bits);
-    const std::vector<Cell> x_limbs = chip.assign_integer(x);
-    const std::vector<Cell> powed = chip.pow_mod(x_limbs, e_bits, n_limbs, n_big);
+    const std::vector<Cell> n_limbs = chip.assign_integer(n_big, num_limbs);      // assign_public_key: n, then the one-limb exponent
+    const std::vector<Cell> e_limbs = chip.assign_integer(Big{e}, 1);
+    const std::vector<Cell> x_limbs = chip.assign_integer(x, num_limbs);
+    chip.assert_in_field(x_limbs, n_limbs);                                        // modpow_public_key, src/rsa/chip.rs:109
+    const std::vector<Cell> powed = chip.pow_mod(x_limbs, e_limbs, n_limbs, n_big, exp_bits);
     // the native big_pow_mod(x, e, n) the reference assigns as the expected value: the rows above hold exactly its square-and-multiply chain (every
     // mul_mod's remainder came from the same big-integer division), so its value is read off them instead of being computed a second time
     want = chip.to_big(powed);
@@ -837,29 +1113,58 @@ std::vector<Cell> rsa_region(Layouter& lay, const Big& n_big, uint64_t e, const 
     return rsa_expected_rows(lay, powed);
 }
 
-// src/lib.rs:261-316 / src/encryption/chip.rs:72-110: the Poseidon cipher in-circuit, constrained equal to the native one
-std::vector<Cell> cipher_region(Layouter& lay, const PoseidonSpec& spec, const Fe key_vals[2], const std::vector<Fe>& message, const Cell* key_cells) {
-    PoseidonRows rows{lay, spec};
-    NativeCipher native{spec, {key_vals[0], key_vals[1]}};
+// src/lib.rs:261-316 / src/encryption/chip.rs:150-200: the Poseidon cipher in-circuit, constrained equal to the native one.  pose_enc (no key cells): the
+// initial state is five constants (new_enc); delay_enc: five witnesses (new_enc_de), words 2 and 3 equal to the digest.
+std::vector<Cell> cipher_region(Layouter& lay, const PoseidonSpec& spec, const Fe key_vals[2], const std::vector<Fe>& message, const Cell* key_cells, uint32_t rate) {
     std::vector<Cell> expected;
-    for (auto& v : native.encrypt(message, 1)) expected.push_back(lay.assign_value(v));
-    std::vector<Cell> st = {lay.assign_constant(lay.F.zero()), lay.assign_constant(lay.F.zero()), lay.assign_value(key_vals[0]), lay.assign_value(key_vals[1]),
-                            lay.assign_constant(lay.F.u(1))};
+    for (auto& v : native_encrypt(spec, key_vals, message, 1, rate)) expected.push_back(lay.assign_value(v));
+    const Fe init[5] = {lay.F.zero(), lay.F.zero(), key_vals[0], key_vals[1], lay.F.u(1)};
+    PoseidonChip chip{lay, spec, {}};
+    for (auto& v : init) chip.state.push_back(key_cells ? lay.assign_value(v) : lay.assign_constant(v));
     if (key_cells) {
-        lay.assert_equal(st[2], key_cells[0]);
-        lay.assert_equal(st[3], key_cells[1]);
+        lay.assert_equal(chip.state[2], key_cells[0]);
+        lay.assert_equal(chip.state[3], key_cells[1]);
     }
-    st = rows.permutation(st);
-    std::vector<Cell> msg;
+    chip.permutation({}, false);
+    std::vector<Cell> msg, cipher;
     for (auto& m : message) msg.push_back(lay.assign_value(m));
-    std::vector<Cell> nx = {st[0]};
-    for (uint32_t i = 0; i + 1 < spec.t; i++) nx.push_back(i < msg.size() ? lay.add(st[1 + i], msg[i]) : st[1 + i]);
-    st = nx;
-    std::vector<Cell> cipher(st.begin() + 1, st.begin() + 1 + (long)msg.size());
-    st = rows.permutation(st);
-    cipher.push_back(st[1]);
+    for (size_t c0 = 0; c0 < msg.size(); c0 += rate) {      // absorb_and_relese, src/encryption/chip.rs:72-110
+        const std::vector<Cell> chunk(msg.begin() + (long)c0, msg.begin() + (long)std::min<size_t>(msg.size(), c0 + rate));
+        for (size_t j = 0; j < chunk.size(); j++) {
+            chip.state[1 + j] = lay.add(chip.state[1 + j], chunk[j]);
+            cipher.push_back(chip.state[1 + j]);
+        }
+        chip.permutation(chunk, false);
+    }
+    cipher.push_back(chip.state[1]);
     for (size_t i = 0; i < cipher.size(); i++) lay.assert_equal(cipher[i], expected[i]);
     return cipher;
+}
+
+// src/lib.rs:222-259: limbs packed three to a field element, HasherChip::hash (src/hash/chip.rs:63-85) with perm_hash's padding; returns the two key words
+void hash_region(Layouter& L, const PoseidonSpec& spec, const std::vector<Cell>& rsa_out, uint32_t rate, Cell key_cells[2]) {
+    Fld& F = L.F;
+    PoseidonChip chip{L, spec, {}};
+    chip.state.push_back(L.assign_constant(F.pow2(64)));      // State::default: capacity word 2^64
+    for (uint32_t i = 1; i < spec.t; i++) chip.state.push_back(L.assign_constant(F.zero()));
+    const Cell base1 = L.assign_constant(F.pow2(LIMB_WIDTH));
+    const Cell base2 = L.mul(Arg(base1), Arg(base1));
+    std::vector<Cell> inputs;
+    for (size_t i = 0; i < rsa_out.size() / 3; i++) {
+        const Cell a = L.mul_add(Arg(rsa_out[3 * i + 1]), Arg(base1), Arg(rsa_out[3 * i]));
+        inputs.push_back(L.mul_add(Arg(rsa_out[3 * i + 2]), Arg(base2), Arg(a)));
+    }
+    if (rsa_out.size() % 3 == 2) inputs.push_back(L.mul_add(Arg(rsa_out[rsa_out.size() - 1]), Arg(base1), Arg(rsa_out[rsa_out.size() - 2])));      // limbs 30, 31 of the reference's 32
+    else if (rsa_out.size() % 3 == 1) inputs.push_back(rsa_out.back());
+    size_t padding_offset = 0;
+    for (size_t c0 = 0; c0 < inputs.size(); c0 += rate) {
+        const std::vector<Cell> chunk(inputs.begin() + (long)c0, inputs.begin() + (long)std::min<size_t>(inputs.size(), c0 + rate));
+        padding_offset = rate - chunk.size();
+        chip.permutation(chunk, true);
+    }
+    if (padding_offset == 0) chip.permutation({}, true);
+    key_cells[0] = chip.state[1];
+    key_cells[1] = chip.state[2];
 }
 
 // permutation::keygen::Assembly::copy [UPSTREAM plonk/permutation/keygen.rs]: cycles over cells, the smaller cycle relabelled
@@ -908,7 +1213,6 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         if (getenv("DEHALO_SYNTH_TRACE")) fprintf(stderr, "synthesize: %-28s +%.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     Layouter lay(f, keygen_outputs, advice, n);
-    Fld F{f};
     std::vector<Fe> message;
     for (uint32_t i = 0; i < in->message_len; i++) {
         Fe m = fe_from(in->message + 4 * i);
@@ -922,43 +1226,21 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         const std::shared_ptr<const PoseidonSpec> spec_ref = poseidon_spec(f, t, r_f, r_p);
         const PoseidonSpec& spec = *spec_ref;
         const Fe key[2] = {fe_from(in->key), fe_from(in->key + 4)};
-        for (auto& c : cipher_region(lay, spec, key, message, nullptr)) cipher_vals.push_back(c.val);
+        for (auto& c : cipher_region(lay, spec, key, message, nullptr, rate)) cipher_vals.push_back(c.val);
     } else {
         if (!in->n || !in->x || in->bits_len % LIMB_WIDTH || in->bits_len == 0 || in->bits_len > 8192 || in->exp_bits == 0 || in->exp_bits > 64) return DEHALO_ERR_INVALID;
         const size_t num_limbs = in->bits_len / LIMB_WIDTH;
         Big n_big(in->n, in->n + num_limbs), x(in->x, in->x + num_limbs);
         { Big t0 = n_big; big_trim(t0); if (t0.empty()) return DEHALO_ERR_INVALID; }
         if (in->exp_bits < 64 && (in->e >> in->exp_bits)) return DEHALO_ERR_INVALID;
-        // hash region: limbs packed three to a field element (src/lib.rs:222-249), sponge with RATE 4 (src/hash/chip.rs:63-85); then the cipher keyed by the digest
+        // hash region, then the cipher keyed by the digest's words 1 and 2 (src/lib.rs:216-316)
         auto hash_and_cipher = [&](Layouter& L, const std::vector<Cell>& rsa_out) {
             const std::shared_ptr<const PoseidonSpec> spec_ref = poseidon_spec(f, t, r_f, r_p);
             const PoseidonSpec& spec = *spec_ref;
-            PoseidonRows rows{L, spec};
-            const Cell base1 = L.assign_constant(F.pow2(LIMB_WIDTH));
-            const Cell base2 = L.mul(Arg(base1), Arg(base1));
-            std::vector<Cell> inputs;
-            for (size_t i = 0; i < rsa_out.size() / 3; i++) {
-                const Cell a = L.mul_add(Arg(rsa_out[3 * i + 1]), Arg(base1), Arg(rsa_out[3 * i]));
-                inputs.push_back(L.mul_add(Arg(rsa_out[3 * i + 2]), Arg(base2), Arg(a)));
-            }
-            if (rsa_out.size() % 3 == 2) inputs.push_back(L.mul_add(Arg(rsa_out[rsa_out.size() - 1]), Arg(base1), Arg(rsa_out[rsa_out.size() - 2])));
-            std::vector<Cell> state = {L.assign_constant(F.pow2(64))};      // Poseidon::new: capacity word 2^64
-            for (uint32_t i = 1; i < t; i++) state.push_back(L.assign_constant(F.zero()));
-            for (size_t c0 = 0; c0 < inputs.size(); c0 += rate) {
-                const size_t cnt = std::min<size_t>(rate, inputs.size() - c0);
-                std::vector<Cell> nxt = {state[0]};
-                for (uint32_t i = 0; i < rate; i++) nxt.push_back(i < cnt ? L.add(state[1 + i], inputs[c0 + i]) : state[1 + i]);
-                if (cnt < rate) nxt[1 + cnt] = L.add_constant(nxt[1 + cnt], F.u(1));      // padding: + 1 after the last input
-                state = rows.permutation(nxt);
-            }
-            if (inputs.size() % rate == 0) {
-                std::vector<Cell> nxt = state;
-                nxt[1] = L.add_constant(state[1], F.u(1));
-                state = rows.permutation(nxt);
-            }
-            const Cell key_cells[2] = {state[1], state[2]};
-            const Fe key_vals[2] = {state[1].val, state[2].val};
-            for (auto& c : cipher_region(L, spec, key_vals, message, key_cells)) cipher_vals.push_back(c.val);
+            Cell key_cells[2];
+            hash_region(L, spec, rsa_out, rate, key_cells);
+            const Fe key_vals[2] = {key_cells[0].val, key_cells[1].val};
+            for (auto& c : cipher_region(L, spec, key_vals, message, key_cells, rate)) cipher_vals.push_back(c.val);
         };
         const bool with_hash = in->circuit == DEHALO_CIRCUIT_DELAY_ENC;
         uint32_t rsa_rows_beside = 0;
@@ -996,9 +1278,8 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         for (uint32_t c = 0; c < num_fixed; c++) memcpy(fixed + (size_t)c * n * 4, lay.fix[c].data(), rows * 32);
         if (range_lookups) {      // RangeChip::load_table rows (tag, value): the disabled row (0, 0), then every value of every bit length
             size_t r = 1;
-            const unsigned lens[4] = {COMPOSITION_BITS[0], COMPOSITION_BITS[1], COMPOSITION_BITS[2], OVERFLOW_BITS};
             for (unsigned ti = 0; ti < 4; ti++)
-                for (uint64_t v = 0; v < ((uint64_t)1 << lens[ti]); v++, r++) {
+                for (uint64_t v = 0; v < ((uint64_t)1 << RANGE_BITS[ti]); v++, r++) {
                     if (r >= u) return DEHALO_ERR_INVALID;
                     fixed[((size_t)RC_T_TAG * n + r) * 4] = ti + 1;
                     fixed[((size_t)RC_T_VALUE * n + r) * 4] = v;
@@ -1023,4 +1304,6 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         }
     }
     return 0;
+} catch (const NotSatisfied&) {
+    return DEHALO_ERR_INVALID;      // a constraint of the reference's circuit does not hold for these inputs (x >= n, an exponent wider than exp_bits, a non-zero message)
 } catch (...) { return DEHALO_ERR_OOM; }

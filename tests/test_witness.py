@@ -48,7 +48,7 @@ def small_delay_witness(pkg):
 
     v = rsa_vectors()[0]
     p = pkg.fields.BN254_FR.p
-    return W.delay_enc_witness(p, 14, int(v["n"]), 0b1, int(v["signature"]), 1, [11, 22]), int(v["n"]), int(v["signature"])
+    return W.delay_enc_witness(p, 14, int(v["n"]), 0b1, int(v["signature"]), 1, [0, 0]), int(v["n"]), int(v["signature"])
 
 
 def test_delay_enc_rows_satisfy_the_constraint_system(pkg, small_delay_witness):
@@ -60,8 +60,9 @@ def test_delay_enc_rows_satisfy_the_constraint_system(pkg, small_delay_witness):
     assert W.check_rows(circ, p) == info.total_rows
     # the native cipher of the same key gives the in-circuit ciphertext (src/lib.rs:270-312)
     assert len(info.cipher) == 3
-    # about 3.5 k rows per mul_mod (reference: 3.99 k, benches/README.md:77-78), two mul_mod per exponent bit
-    assert 6000 < info.rsa_rows < 9000
+    # 3,974 rows per mul_mod, two of them and 32 selects per exponent bit (benches/README.md:77-78: 7,981 rows per bit), 1,860 rows around them
+    assert info.rsa_rows == W.rsa_region_rows(1) == 1860 + 7981 + 1 and W.mul_mod_rows() == 3974
+    assert info.total_rows == info.rsa_rows + W.hash_region_rows() + W.cipher_region_rows(2, True) == info.rsa_rows + 2182 + 1453
     # value classes of the witness: mostly small values
     from dehalo2_amd.keygen import array_to_ints
     vals = [v for c in range(5) for v in array_to_ints(circ.advice[c])[:circ.used_rows]]
@@ -76,10 +77,14 @@ def test_pose_enc_witness_fits_the_reference_k(pkg):
     from dehalo2_amd import witness as W
 
     p = pkg.fields.BN254_FR.p
-    circ, info = W.pose_enc_witness(p, 11, [5, 7], [11, 22])
+    circ, info = W.pose_enc_witness(p, 11, [5, 7], [0, 0])
     assert circ.cs.num_fixed == 9 and not circ.cs.lookups and info.total_rows < (1 << 11) - 6
     assert W.check_rows(circ, p) == info.total_rows
-    assert info.cipher == W.NativeCipher(W.PoseidonSpec(p, 5, 8, 57), [5, 7]).encrypt([11, 22], 1)
+    assert info.cipher == W.NativeCipher(W.PoseidonSpec(p, 5, 8, 57), [5, 7]).encrypt([0, 0], 1)
+    # the in-circuit cipher adds the message twice, the native one never to the state it permutes (witness.py's header): a non-zero message is
+    # unsatisfiable in the reference's own circuit, and refused here as MockProver would refuse it
+    with pytest.raises(W.NotSatisfied):
+        W.pose_enc_witness(p, 11, [5, 7], [11, 22])
 
 
 def test_a_broken_witness_is_caught(pkg, small_delay_witness):
@@ -127,7 +132,7 @@ def test_device_proof_of_the_real_pose_enc_witness(pkg, po, co, ctx):
     import verifier as V
     from dehalo2_amd import keygen, prover, transcript, witness as W
 
-    circ, info = W.pose_enc_witness(pkg.fields.BN254_FR.p, 11, [0xABCDEF, 0x123456], [42, 43])
+    circ, info = W.pose_enc_witness(pkg.fields.BN254_FR.p, 11, [0xABCDEF, 0x123456], [0, 0])
     c = _oracle_chain(po, co, circ, 11, 8)
     params = keygen.ParamsKZG(ctx, pkg.fields.BN254, 11, c["srs"]["g"], c["srs"]["g_lagrange"])
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
@@ -150,7 +155,7 @@ def test_device_proof_of_the_real_delay_enc_witness(pkg, po, co, ctx):
 
     v = rsa_vectors()[1]
     n, x = int(v["n"]), int(v["signature"])
-    circ, info = W.delay_enc_witness(pkg.fields.BN254_FR.p, 16, n, 0b10011, x, 5, [123456789, 987654321])
+    circ, info = W.delay_enc_witness(pkg.fields.BN254_FR.p, 16, n, 0b10011, x, 5, [0, 0])
     assert info.rsa_result == pow(x, 0b10011, n)
     c = _oracle_chain(po, co, circ, 16, 16)
     params = keygen.ParamsKZG(ctx, pkg.fields.BN254, 16, c["srs"]["g"], c["srs"]["g_lagrange"])
@@ -161,6 +166,52 @@ def test_device_proof_of_the_real_delay_enc_witness(pkg, po, co, ctx):
     assert tr.finalize() == want
     assert V.verify_proof(po.BN254, c["desc"], 16, c["key"]["fixed_commitments"], c["key"]["perm_commitments"], c["rep"], (1, 2), pr.G2, c["s_g2"], [[]], want)
     params.release()
+
+
+@pytest.mark.gpu
+def test_device_proof_of_the_metrics_own_witness_k17(pkg, po, co, ctx):
+    """BASELINE's metric configuration itself (configs[3]; benches/delay_enc.rs:123-131, benches/README.md:60): DelayEncryptCircuit, 2048-bit modulus, 15-bit
+    exponent, k = 17 -- 125,214 rows in halo2wrong's layout of the checked-in source (RSA region 121,579 = the published 121,578 + 1).  The witness is
+    synthesized by the library (dehalo_synthesize), checked by the checker's own MockProver, proved through the reference's call shape
+    (dehalo_create_proof_circuit): proof bytes equal the CPU restatement's, the verifier accepts."""
+    import pairing as pr
+    import plonk_oracle as PO
+    import rowcheck
+    import shapes
+    import verifier as V
+    from dehalo2_amd import native, plonk, prover
+
+    v = rsa_vectors()[1]
+    n, x, k, bits = int(v["n"]), int(v["signature"]), 17, 15
+    e = 0b101101110010111
+    inputs = dict(n_big=n, e=e, x=x, exp_bits=bits, message=[0, 0])
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, k, keygen=True, **inputs)
+    assert nat["rsa_result"] == pow(x, e, n) and (nat["rsa_rows"], nat["rows"]) == (121579, 125214)
+    desc = shapes.maingate_description(True)
+    p = pkg.fields.BN254_FR.p
+    rowcheck.verify(desc, k, p, nat["fixed"], nat["advice"], nat["mapping"], nat["rows"])
+    rowcheck.verify_range_table(nat["fixed"], k)
+    cs = plonk.maingate_cs(True)
+    assert desc == cs.description()
+    asm = plonk.Assembly(6, 1 << k)
+    asm.mapping = nat["mapping"].astype(np.int64)
+    s = 0x5EED5EED5EED5EED
+    srs = PO.setup_srs(po.BN254, k, s, 16)
+    key = PO.keygen(po.BN254, srs, desc, k, nat["fixed"], asm.mapping, 16)
+    rep = PO.transcript_repr(po.BN254, key, nat["selectors"])
+    params = native.ParamsKZG.setup(ctx, pkg.fields.BN254, k, s)
+    pk = native.ProvingKey.keygen(ctx, params, cs, nat["fixed"], asm, nat["selectors"])
+    assert pk.vk_bytes() == PO.vk_bytes(po.BN254, key, nat["selectors"])
+    pk.transcript_repr = rep
+    side = pkg.Context(0)
+    P = native.Prover(params, pk, ctx, side)
+    tr, info = P.create_proof_circuit(native.CIRCUIT_DELAY_ENC, [[]], prover.SeededRng(5), **inputs)
+    proof = tr.finalize()
+    adv_m = np.stack([co.field_op(0, "to_mont", nat["advice"][i]) for i in range(5)])
+    want, _ = PO.create_proof(po.BN254, srs, key, adv_m, [[]], PO.ScalarStream(5), rep, 16)
+    assert len(proof) == 2848 and proof == want and info["rows"] == nat["rows"] and info["cipher"] == nat["cipher"]
+    assert V.verify_proof(po.BN254, desc, k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(s, pr.G2), [[]], proof)
+    P.release(); pk.release(); params.release(); side.close()
 
 
 def test_mod_pow_rows_satisfy_the_constraint_system(pkg):
@@ -192,7 +243,7 @@ def test_device_proof_of_the_real_mod_pow_witness(pkg, po, co, ctx):
     k = 17
     circ, info = W.mod_pow_witness(pkg.fields.BN254_FR.p, k, n, e, x, 5)
     assert info.rsa_result == pow(x, e, n) and info.total_rows == info.rsa_rows
-    assert info.rsa_rows == 322 + 5 * 6971 + 2 == 35179             # this layouter (tests/test_witness.py::test_row_counts...); halo2wrong's: 41,766 (benches/README.md:73)
+    assert info.rsa_rows == 41766 + 1                               # benches/README.md:73 (K = 16 there: the published figure is the last used row's index)
     c = _oracle_chain(po, co, circ, k, 16)
     params = keygen.ParamsKZG(ctx, pkg.fields.BN254, k, c["srs"]["g"], c["srs"]["g_lagrange"])
     pk = keygen.keygen(ctx, params, circ.cs, circ.fixed, circ.assembly, circ.selectors)
@@ -231,7 +282,7 @@ def test_batch_mode_provers_make_the_proofs_a_lone_prover_makes(pkg, po, co, ctx
 
     v = rsa_vectors()[0]
     k = 14
-    circ, info = W.delay_enc_witness(pkg.fields.BN254_FR.p, k, int(v["n"]), 0b1, int(v["signature"]), 1, [11, 22])
+    circ, info = W.delay_enc_witness(pkg.fields.BN254_FR.p, k, int(v["n"]), 0b1, int(v["signature"]), 1, [0, 0])
     c = _oracle_chain(po, co, circ, k, 16)
     curve = pkg.fields.BN254
     params = keygen.ParamsKZG(ctx, curve, k, c["srs"]["g"], c["srs"]["g_lagrange"])
@@ -295,13 +346,13 @@ def test_native_synthesize_equals_witness_py_bit_for_bit(pkg):
     v = rsa_vectors()
     n, x = int(v[0]["n"]), int(v[0]["signature"])
     # delay_enc, 1-bit exponent, k = 14
-    circ, info = W.delay_enc_witness(p, 14, n, 0b1, x, 1, [11, 22])
-    _same_circuit(native.synthesize(native.CIRCUIT_DELAY_ENC, 14, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22], keygen=True), circ, info)
+    circ, info = W.delay_enc_witness(p, 14, n, 0b1, x, 1, [0, 0])
+    _same_circuit(native.synthesize(native.CIRCUIT_DELAY_ENC, 14, n_big=n, e=1, x=x, exp_bits=1, message=[0, 0], keygen=True), circ, info)
     # the reference's checked-in parameters: 5-bit exponent, k = 16 (src/lib.rs:122-124); other modulus, other message
     n2, x2 = int(v[1]["n"]), int(v[1]["signature"])
-    circ, info = W.delay_enc_witness(p, 16, n2, 0b10011, x2, 5, [123456789, p - 5])
+    circ, info = W.delay_enc_witness(p, 16, n2, 0b10011, x2, 5, [0, 0])
     t = time.perf_counter()
-    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 16, n_big=n2, e=0b10011, x=x2, exp_bits=5, message=[123456789, p - 5], keygen=True)
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 16, n_big=n2, e=0b10011, x=x2, exp_bits=5, message=[0, 0], keygen=True)
     assert time.perf_counter() - t < 2.0
     _same_circuit(nat, circ, info)
     assert nat["rsa_result"] == pow(x2, 0b10011, n2)
@@ -311,16 +362,16 @@ def test_native_synthesize_equals_witness_py_bit_for_bit(pkg):
     circ, info = W.mod_pow_witness(p, 17, n2, 0xA7, x2, 8)
     _same_circuit(native.synthesize(native.CIRCUIT_MOD_POW, 17, n_big=n2, e=0xA7, x=x2, exp_bits=8, keygen=True), circ, info)
     # pose_enc, K = 11 (MainGate only: 9 fixed columns, no selectors)
-    circ, info = W.pose_enc_witness(p, 11, [0xABCDEF, p - 1], [42, 43])
-    _same_circuit(native.synthesize(native.CIRCUIT_POSE_ENC, 11, key=[0xABCDEF, p - 1], message=[42, 43], keygen=True), circ, info)
+    circ, info = W.pose_enc_witness(p, 11, [0xABCDEF, p - 1], [0, 0])
+    _same_circuit(native.synthesize(native.CIRCUIT_POSE_ENC, 11, key=[0xABCDEF, p - 1], message=[0, 0], keygen=True), circ, info)
     # advice alone (what a proof needs) is the same array; a circuit that does not fit is refused
-    adv_only = native.synthesize(native.CIRCUIT_DELAY_ENC, 14, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22])
-    assert np.array_equal(adv_only["advice"], W.delay_enc_witness(p, 14, n, 0b1, x, 1, [11, 22])[0].advice)
+    adv_only = native.synthesize(native.CIRCUIT_DELAY_ENC, 14, n_big=n, e=1, x=x, exp_bits=1, message=[0, 0])
+    assert np.array_equal(adv_only["advice"], W.delay_enc_witness(p, 14, n, 0b1, x, 1, [0, 0])[0].advice)
     # (the proving call writes the multiplication rows by a word-arithmetic fast path, the keygen call by the general one: the same rows, and zeros behind them)
-    fast = native.synthesize(native.CIRCUIT_DELAY_ENC, 16, n_big=n2, e=0b10011, x=x2, exp_bits=5, message=[123456789, p - 5])
+    fast = native.synthesize(native.CIRCUIT_DELAY_ENC, 16, n_big=n2, e=0b10011, x=x2, exp_bits=5, message=[0, 0])
     assert np.array_equal(fast["advice"], nat["advice"]) and fast["rsa_result"] == nat["rsa_result"] == pow(x2, 0b10011, n2) and fast["cipher"] == nat["cipher"]
     with pytest.raises(ValueError):
-        native.synthesize(native.CIRCUIT_DELAY_ENC, 13, n_big=n, e=1, x=x, exp_bits=1, message=[11, 22])
+        native.synthesize(native.CIRCUIT_DELAY_ENC, 13, n_big=n, e=1, x=x, exp_bits=1, message=[0, 0])
 
 
 def test_native_synthesize_is_fast_at_the_north_star_size(pkg):
@@ -334,10 +385,11 @@ def test_native_synthesize_is_fast_at_the_north_star_size(pkg):
     best = None
     for _ in range(3):
         t = time.perf_counter()
-        nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 17, n_big=n_big, e=e, x=x, exp_bits=15, message=[7, 8])
+        nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 17, n_big=n_big, e=e, x=x, exp_bits=15, message=[0, 0])
         el = time.perf_counter() - t
         best = el if best is None or el < best else best
-    assert nat["rsa_result"] == pow(x, e, n_big) and nat["rows"] == 109673 and nat["rsa_rows"] == 104891      # (halo2wrong's layout: 130,248, benches/README.md:60)
+    # the RSA region is the published mod_pow figure (benches/README.md:84: 121,578 = the last row's index); hash and cipher regions of the checked-in source behind it
+    assert nat["rsa_result"] == pow(x, e, n_big) and nat["rsa_rows"] == 121578 + 1 and nat["rows"] == 121579 + 2182 + 1453 == 125214
     print("native synthesize, k = 17, 15-bit exponent: %.1f ms for %d rows" % (1e3 * best, nat["rows"]))
     assert best < 0.5
 
@@ -418,7 +470,7 @@ def test_host_code_under_address_and_ub_sanitizers(pkg):
     xl = [nxt() for _ in range(32)]
     nl[31] |= 1 << 63; nl[0] |= 1; xl[31] >>= 8
     n_big, x_big = sum(v << (64 * i) for i, v in enumerate(nl)), sum(v << (64 * i) for i, v in enumerate(xl))
-    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 15, n_big=n_big, e=(1 << 2) | 1, x=x_big, exp_bits=3, message=[11, 22], keygen=True)
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 15, n_big=n_big, e=(1 << 2) | 1, x=x_big, exp_bits=3, message=[0, 0], keygen=True)
     assert nat["rows"] == int(rows) and nat["rsa_result"] == pow(x_big, 5, n_big)
     r = CRng()
     r.kind, r.pcg_state[0], r.pcg_inc[0] = 1, 123, 457
@@ -430,29 +482,78 @@ def test_host_code_under_address_and_ub_sanitizers(pkg):
     assert h.hexdigest() == digest
 
 
-def test_row_counts_are_exactly_this_layouters_and_not_halo2wrongs(pkg):
-    """The number of rows a circuit takes is a property of the LAYOUTER.  The reference's come from halo2wrong's MainGate / RangeChip region code (upstream, not in
-    the container) and are published in benches/README.md:56-99; this repository's layouter (witness.py, csrc/witness.hip) writes the same values over the same gate
-    in fewer rows, and these are its counts, exactly -- stated beside the reference's so that nobody mistakes one for the other (the table
-    "rows per gadget"; tools/witness_rows.py prints it)."""
+def test_row_counts_match_reference_readme(pkg, oracles):
+    """The rows a circuit takes are a property of the layouter: the reference's come from halo2wrong's MainGate / RangeChip and are published in
+    benches/README.md:56-99 (32 (configuration -> advice rows) pairs; held as data by the checker, oracle/rowcheck.py).  witness.py / csrc/witness.hip lay every
+    instruction out the way halo2wrong does, and reproduce them:
+      * mod_pow, 13 of 13: published = rows - 1 (the published figure is the index of the last used row: the count less one);
+      * pose_enc, 10 of 11 by the same rule (718 rows per permutation, 4 per message word); the 11th (|msg| = 17: 4,394) repeats the figure of |msg| = 20
+        in the table itself -- 17 words take 4,382;
+      * delay_enc, 8 of 8 up to ONE constant: published = rows - 1 + 5,035.  The RSA region is mod_pow's exactly (row 1 with e = 0, whose result has one
+        limb; row 4's "7-bit" is the 14-bit figure: 122,267 needs k = 17); the constant is the hash region of an earlier revision of src/lib.rs -- the
+        checked-in one packs the 32 limbs three to a field element (src/lib.rs:222-249: 11 inputs, 3 permutations, 2,182 rows), the published table
+        was made when that region took 7,217 rows (ten permutations' worth).  DESIGN.md section 5 carries the table."""
     import random
+    import rowcheck
     from dehalo2_amd import native, witness as W
     p = pkg.fields.BN254_FR.p
     rnd = random.Random(1)
     n_big, x = rnd.getrandbits(2048) | (1 << 2047) | 1, rnd.getrandbits(2040)
-    per_bit, fixed = 6971, 322                           # per bit: two mul_mod of 3,469 rows + 32 select rows + the bit's row; + a composition row per 4 bits;
-                                                         # the reference: 7,981 per bit (README:77-78: 129,559 - 121,578)
-    published_mod_pow = {2: 17822, 5: 41766, 15: 121578}
-    for bits in (1, 2, 5, 15):
+    assert len(rowcheck.README_MOD_POW) + len(rowcheck.README_DELAY_ENC) + len(rowcheck.README_POSE_ENC) == 32
+    for k, published, bits in rowcheck.README_MOD_POW:
         e = (1 << (bits - 1)) | 1
-        nat = native.synthesize(native.CIRCUIT_MOD_POW, 18, n_big=n_big, e=e, x=x, exp_bits=bits)
-        assert nat["rows"] == fixed + per_bit * bits + (bits + 3) // 4
-        if bits in published_mod_pow:
-            assert nat["rows"] < published_mod_pow[bits]
-    _, info = W.mod_pow_witness(p, 18, n_big, 0b10101, x, 5)
-    assert info.total_rows == 35179                      # the reference's bench constants (5-bit exponent): 41,766 there
-    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 17, n_big=n_big, e=(1 << 14) | 1, x=x, exp_bits=15, message=[3, 4])
-    assert (nat["rows"], nat["rsa_rows"]) == (109673, 104891)       # the reference: 130,248 (README:60)
-    for msg in (1, 2, 3, 4):
-        _, info = W.pose_enc_witness(p, 11, [5, 6], list(range(1, msg + 1)))
-        assert info.total_rows == 1898 + 3 * msg            # the reference: 1,446 + 4 msg (README:89-92)
+        nat = native.synthesize(native.CIRCUIT_MOD_POW, k, n_big=n_big, e=e, x=x, exp_bits=bits)
+        assert nat["rows"] == W.rsa_region_rows(bits) == published + 1, (k, bits)
+        assert nat["rsa_result"] == pow(x, e, n_big) and nat["rsa_result"] >> 1984            # a 32-limb result, as a random one is
+    # the layouter itself (Python) on the small ones, and the closed form against it
+    for bits in (1, 2):
+        _, info = W.mod_pow_witness(p, 15, n_big, (1 << (bits - 1)) | 1, x, bits)
+        assert info.total_rows == W.rsa_region_rows(bits)
+    hash_and_cipher = W.hash_region_rows() + W.cipher_region_rows(2, True)
+    assert hash_and_cipher == 2182 + 1453
+    residuals = set()
+    for k, published, bits_printed, msg in rowcheck.README_DELAY_ENC:
+        bits = 14 if (k, bits_printed) == (17, 7) else bits_printed
+        e = 0 if bits == 2 else (1 << (bits - 1)) | 1                  # the published 2-bit run drew e = 0: x^0 = 1 is a one-limb constant, 31 rows fewer
+        nat = native.synthesize(native.CIRCUIT_DELAY_ENC, k, n_big=n_big, e=e, x=x, exp_bits=bits, message=[0] * msg)
+        assert nat["rsa_rows"] == W.rsa_region_rows(bits, 1 if e == 0 else 32) and nat["rows"] == nat["rsa_rows"] + hash_and_cipher
+        residuals.add(published - (nat["rows"] - 1))
+    assert residuals == {5035} and 5035 == 7217 - 2182                 # one constant for all eight: the earlier revision's hash region
+    spec = W.poseidon_spec(p)
+    for k, published, msg in rowcheck.README_POSE_ENC:
+        lay = W.Layouter(p)
+        W.cipher_region(lay, spec, [5, 6], [0] * msg)
+        assert lay.rows == W.cipher_region_rows(msg, False) and lay.rows + 1 <= (1 << k) - 6
+        assert lay.rows == (4382 if msg == 17 else published) + 1, msg
+
+
+def test_synthesized_circuits_pass_the_checkers_own_row_check(pkg, oracles):
+    """What dehalo_synthesize (C++) lays out -- advice, fixed columns, permutation -- checked by oracle/rowcheck.py, a MockProver written from
+    oracle/shapes.py alone: every gate row, every lookup input, every copy constraint, the range table; and a broken cell is caught."""
+    import rowcheck
+    import shapes
+    from dehalo2_amd import native
+    p = pkg.fields.BN254_FR.p
+    v = rsa_vectors()
+    n, x = int(v[0]["n"]), int(v[0]["signature"])
+    nat = native.synthesize(native.CIRCUIT_DELAY_ENC, 15, n_big=n, e=0b10, x=x, exp_bits=2, message=[0, 0], keygen=True)
+    desc = shapes.maingate_description(True)
+    got = rowcheck.verify(desc, 15, p, nat["fixed"], nat["advice"], nat["mapping"], nat["rows"])
+    assert got["rows"] == (1 << 15) - 6 and got["cells_in_cycles"] > nat["rows"]
+    rowcheck.verify_range_table(nat["fixed"], 15)
+    assert nat["rsa_result"] == pow(x, 2, n)
+    row = 1000 + int(np.nonzero(nat["fixed"][shapes.SD, 1000:].any(axis=1))[0][0])            # a row whose column d enters the gate
+    bad = nat["advice"].copy()
+    bad[3, row, 0] ^= np.uint64(1)
+    with pytest.raises(AssertionError):
+        rowcheck.verify(desc, 15, p, nat["fixed"], bad, nat["mapping"], nat["rows"])
+    nat = native.synthesize(native.CIRCUIT_MOD_POW, 14, n_big=n, e=1, x=x, exp_bits=1, keygen=True)
+    rowcheck.verify(desc, 14, p, nat["fixed"], nat["advice"], nat["mapping"], nat["rows"])
+    nat = native.synthesize(native.CIRCUIT_POSE_ENC, 11, key=[5, 6], message=[0, 0], keygen=True)
+    rowcheck.verify(shapes.maingate_description(False), 11, p, nat["fixed"], nat["advice"], nat["mapping"], nat["rows"])
+    # what the reference's circuit cannot satisfy is refused: x >= n (assert_in_field), an exponent wider than exp_bits (to_bits), a non-zero message
+    for bad_inputs in (dict(x=n + 5), dict(e=7), dict(message=[1, 2])):
+        kw = dict(n_big=n, e=1, x=x, exp_bits=1, message=[0, 0])
+        kw.update(bad_inputs)
+        with pytest.raises(ValueError):
+            native.synthesize(native.CIRCUIT_DELAY_ENC, 14, **kw)

@@ -14,7 +14,7 @@ batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 with_side = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
 prio_mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # 1: contexts alternate between the highest / default / lowest stream priority
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, "delay_enc")
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 ctx = pkg.Context(0)
 with ctx.torch_stream():

@@ -10,7 +10,7 @@ from dehalo2_amd import prover, native, keygen
 import bench
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, 17, "delay_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, 17, "delay_enc")
 srs = PO.setup_srs(po.BN254, 17, 0x1234567890abcdef, 16)
 ctx, side = pkg.Context(0, priority=1), pkg.Context(0, priority=-1)
 params = native.ParamsKZG.create(ctx, curve, 17, srs["g"], srs["g_lagrange"])

@@ -12,7 +12,7 @@ import bench, torch
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, "delay_enc")
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 ctx, side = pkg.Context(0, priority=1), pkg.Context(0, priority=-1)
 params = native.ParamsKZG.create(ctx, curve, k, srs["g"], srs["g_lagrange"])

@@ -11,7 +11,7 @@ from dehalo2_amd import prover, keygen, transcript
 import bench
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, "delay_enc")
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 with pkg.Context(0) as ctx, pkg.Context(0) as side:
     params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"])

@@ -14,7 +14,7 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 circuit = sys.argv[2] if len(sys.argv) > 2 else "delay_enc"
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, circuit)
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, circuit)
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 ctx, side = pkg.Context(0, priority=1), pkg.Context(0)
 import torch

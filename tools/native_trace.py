@@ -11,7 +11,7 @@ import bench
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 circuit = sys.argv[2] if len(sys.argv) > 2 else "delay_enc"
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, circuit)
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, circuit)
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 ctx, side = pkg.Context(0), pkg.Context(0)
 with ctx.torch_stream():

@@ -16,7 +16,7 @@ rl = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 curve = pkg.fields.BN254
 import bench                                            # the bench's witness: the real DelayEncryptCircuit / PoseidonEncCircuit values
-circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc" if rl else "pose_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, "delay_enc" if rl else "pose_enc")
 print(desc)
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 with pkg.Context(0) as ctx:

@@ -10,7 +10,7 @@ from dehalo2_amd import prover, keygen, native
 import bench
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, "delay_enc")
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 ctx = pkg.Context(0)
 with ctx.torch_stream():

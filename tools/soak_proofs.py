@@ -14,7 +14,7 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 rl = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
 count = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc" if rl else "pose_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, "delay_enc" if rl else "pose_enc")
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 with pkg.Context(0) as ctx, pkg.Context(0) as side:
     params = keygen.ParamsKZG(ctx, curve, k, srs["g"], srs["g_lagrange"])

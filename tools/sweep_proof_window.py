@@ -11,7 +11,7 @@ from dehalo2_amd import prover, keygen, transcript
 import bench
 k, rl, c0, c1 = int(sys.argv[1]), bool(int(sys.argv[2])), int(sys.argv[3]), int(sys.argv[4])
 curve = pkg.fields.BN254
-circ, desc = bench.real_witness(curve.scalar.p, k, "delay_enc" if rl else "pose_enc")
+circ, desc, _ = bench.real_witness(curve.scalar.p, k, "delay_enc" if rl else "pose_enc")
 srs = PO.setup_srs(po.BN254, k, 0x1234567890abcdef, 16)
 for c in [0] + list(range(c0, c1 + 1)):
     with pkg.Context(0) as ctx, pkg.Context(0) as side:

@@ -10,9 +10,9 @@ v = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 n, x = int(v["n"]), int(v["signature"])
 e = 0b101101110010111
 buf = np.empty((5, 1<<17, 4), dtype=np.uint64)
-for _ in range(3): out = native.synthesize(native.CIRCUIT_DELAY_ENC if hasattr(native,'CIRCUIT_DELAY_ENC') else 0, 17, n_big=n, e=e, x=x, exp_bits=15, message=[1,2], key=[3,4], out=buf)
+for _ in range(3): out = native.synthesize(native.CIRCUIT_DELAY_ENC if hasattr(native,'CIRCUIT_DELAY_ENC') else 0, 17, n_big=n, e=e, x=x, exp_bits=15, message=[0,0], key=[3,4], out=buf)
 ts=[]
 for _ in range(20):
-    t=time.perf_counter(); out = native.synthesize(native.CIRCUIT_DELAY_ENC if hasattr(native,'CIRCUIT_DELAY_ENC') else 0, 17, n_big=n, e=e, x=x, exp_bits=15, message=[1,2], key=[3,4], out=buf); ts.append(time.perf_counter()-t)
+    t=time.perf_counter(); out = native.synthesize(native.CIRCUIT_DELAY_ENC if hasattr(native,'CIRCUIT_DELAY_ENC') else 0, 17, n_big=n, e=e, x=x, exp_bits=15, message=[0,0], key=[3,4], out=buf); ts.append(time.perf_counter()-t)
 print(os.environ.get("DEHALO_SYNTH_THREADS"), "min %.3f ms median %.3f ms" % (1e3*min(ts), 1e3*sorted(ts)[10]), out["rows"], out["rsa_result"] == pow(x, e, n))
 import hashlib; print(hashlib.sha256(buf.tobytes()).hexdigest()[:16])
