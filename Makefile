@@ -3,13 +3,19 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 PKG := delay-encryption-in-halo2_amd
 CSRC := $(PKG)/csrc
-OBJDIR := $(CSRC)/obj
-HIPFLAGS ?= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off
+# make EXPERIMENTS=1 builds into its own object directory and library file: objects do not depend on the flags, so sharing a directory would let a later plain
+# `make` link stale -DDEHALO_EXPERIMENTS objects into the shipped library (and the reverse)
+ifdef EXPERIMENTS
+OBJDIR ?= gpurun_out/ab/exp/obj
+LIB ?= gpurun_out/ab/exp/libdehalo.so
+endif
+OBJDIR ?= $(CSRC)/obj
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Werror=unused-variable -Werror=pass-failed -ffp-contract=off
 # make EXPERIMENTS=1: the measurement build (tools/ab_*.sh) -- A/B switches read from the environment and wall-clock phase stamps in the kernels (csrc/internal.hpp)
 ifdef EXPERIMENTS
 HIPFLAGS += -DDEHALO_EXPERIMENTS
 endif
-LIB := $(PKG)/libdehalo.so
+LIB ?= $(PKG)/libdehalo.so
 UNITS := capi prover witness lookup_permute msm_bn254 msm_pallas msm_vesta ntt_bn254_fr ntt_bn254_fq ntt_pasta_fp ntt_pasta_fq
 OBJS := $(UNITS:%=$(OBJDIR)/%.o)
 HDRS := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/dehalo.h

@@ -56,9 +56,11 @@ def parse():
     ap.add_argument("--force-device", type=int, default=-1)
     ap.add_argument("--proof-k", type=int, default=17, help="k of the delay_enc-shaped create_proof (0 = skip every proof section)")
     ap.add_argument("--proofs", type=int, default=-1, help="batch mode: total proofs dealt round-robin to the ranks (default 32 per GPU; 0 = skip)")
+    ap.add_argument("--fixed-batch", type=int, default=64, help="batch mode: a second timed batch of exactly this many proofs whatever the number of GPUs (BASELINE configs[4]: 64; 0 = skip)")
     ap.add_argument("--proofs-inflight", type=int, default=4, help="batch mode: proofs in flight per GPU (one context + host thread each)")
     ap.add_argument("--no-verify", action="store_true", help="skip the pairing check of the proofs (the byte comparison with the oracle stays)")
     ap.add_argument("--acc-waves", type=int, default=0, help="dehalo_ctx_set_tuning msm_acc_waves with the whole-rounds rule (0 = library default: msm_acc_points)")
+    ap.add_argument("--sort-block", type=int, default=0, choices=[0, 512, 1024], help="dehalo_ctx_set_tuning msm_sort_block on every context (0 = library default, 512)")
     ap.add_argument("--preheat-s", type=float, default=1.0, help="untimed device work of the measured kind right before every warm-up + timed region (steps one at a time / "
                     "proofs), so that the region runs at the clocks of a busy prover instead of ramping up from idle after the host-side setup (0 = off)")
     ap.add_argument("--in-process", action="store_true", help="measure in this process: the default for one GPU (kept as a flag for the ranks torchrun starts)")
@@ -73,8 +75,8 @@ def parse():
 PREHEAT_S = 1.0     # --preheat-s
 
 
-def preheat(fn, sync=None):
-    """Calls fn until PREHEAT_S seconds have passed (at least once).  The device clocks ramp up over ~0.2 s of load: 20 timed steps after
+def preheat(fn, sync=None, seconds=None):
+    """Calls fn until PREHEAT_S (or `seconds`) seconds have passed (at least once).  The device clocks ramp up over ~0.2 s of load: 20 timed steps after
     5 / 60 / 200 warm-up steps measured 737-743 / 758 / 777 Mpoints/s on one box (gpurun_out/warmup_sweep.txt -> DESIGN.md 6)."""
     t0 = time.perf_counter()
     n = 0
@@ -83,7 +85,7 @@ def preheat(fn, sync=None):
         n += 1
         if sync is not None and n % 8 == 0:
             sync()
-        if time.perf_counter() - t0 >= PREHEAT_S:
+        if time.perf_counter() - t0 >= (PREHEAT_S if seconds is None else seconds):
             break
     if sync is not None:
         sync()
@@ -135,6 +137,67 @@ def cpu_baseline(co, po, curve, field, log_n, bases, scalars, a):
         "sample": "%d x (2^%d-term MSM + 2^%d-point NTT) on rank 0's own inputs, oracle/oracle.c best_multiexp+best_fft, %d threads (the faster of 64 / all host threads)" % (reps, log_n, log_n, threads),
         "msm_ms": round(1e3 * msm_s, 2), "ntt_ms": round(1e3 * ntt_s, 2),
     }, co.to_affine(curve.id, msm_res), ntt_res
+
+
+def by_k_numbers(pkg, po, co, ctx, curve, field, bases_by_k, threads):
+    """The north star's reporting sentence: "throughput on synthetic witnesses at k in {14, 17, 20} ... as absolute numbers and as fraction of the HBM
+    roofline" (BASELINE.json), with SURVEY.md 8(d)'s three scalar distributions and the NTT at n and at the extended size 4n.  One launch at a time on one
+    context (HIP events on its stream around the sort / accumulate / reduce regions and the NTT passes), after a short preheat of the same launches; every
+    timed result is then compared with the CPU port (oracle.c best_multiexp / best_fft) -- `ok`.
+      msm_mpts[d]  = 2^k / (device ms of one MSM of 2^k terms over the resident table), d in u(niform) / w(itness-like) / l(ookup-like)
+      msm_frac[d]  = 96 B x 2^k / that time / 8 TB/s      (64 B base + 32 B scalar per term)
+      ntt_ms       = [2^k points, 2^(k+2) points];   ntt_frac = 64 B x N / that time / 8 TB/s"""
+    import numpy as np
+    import torch
+    from dehalo2_amd import _lib
+    out = []
+    kids = (_lib.K_MSM_SORT, _lib.K_MSM_ACCUMULATE, _lib.K_MSM_REDUCE)
+    for k in sorted(bases_by_k):
+        n = 1 << k
+        bases_h, bases = bases_by_k[k]
+        d_out = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+        rec = {"k": k, "msm_mpts": {}, "msm_frac": {}, "ntt_ms": [], "ntt_frac": [], "ok": True}
+        reps = 24 if k <= 17 else 8
+        for tag, dist in (("u", "uniform"), ("w", "witness"), ("l", "lookup")):
+            sc_h = co.fill_scalars(curve.scalar.id, dist, n, 7000 + k)
+            d_sc = ctx.upload(sc_h)
+            run = lambda: ctx.msm_device(bases, d_sc.data_ptr(), n, 1, d_out.data_ptr(), 0)
+            preheat(run, ctx.synchronize, 0.15)
+            ctx.timing_reset(); ctx.timing_enable(True)
+            for _ in range(reps):
+                run()
+            ctx.synchronize()
+            ctx.timing_enable(False)
+            ms = sum(ctx.timing_get(kid)[0] for kid in kids) / reps
+            rec["msm_mpts"][tag] = round(n / ms / 1e3, 1)
+            rec["msm_frac"][tag] = round(MSM_BYTES_PER_TERM * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            got = ctx.to_affine(curve.id, ctx.download_tensor(d_out))
+            want = co.to_affine(curve.id, co.best_multiexp(curve.id, sc_h, bases_h, threads))
+            rec["ok"] = rec["ok"] and bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)))
+        for log_n in (k, k + 2):
+            N = 1 << log_n
+            a_h = co.fill_scalars(field.id, "uniform", N, 8000 + log_n)
+            omega = field.encode(po.FIELDS[field.name].omega(log_n))
+            d_a = ctx.upload(a_h)
+            d_w = torch.empty_like(d_a)
+            def run():
+                d_w.copy_(d_a)
+                ctx.ntt_device(field.id, d_w.data_ptr(), log_n, omega, 1, 0)
+            with ctx.torch_stream():
+                preheat(run, ctx.synchronize, 0.15)
+                ctx.timing_reset(); ctx.timing_enable(True)
+                for _ in range(reps):
+                    run()
+                ctx.synchronize()
+                ctx.timing_enable(False)
+            ms = ctx.timing_get(_lib.K_NTT_PASS)[0] / reps
+            rec["ntt_ms"].append(round(ms, 4))
+            rec["ntt_frac"].append(round(NTT_BYTES_PER_ELEM * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            want = co.best_fft(field.id, a_h, omega, log_n, threads)
+            rec["ok"] = rec["ok"] and bool(np.array_equal(ctx.download_tensor(d_w), want))
+            del d_a, d_w
+        out.append(rec)
+    return out
 
 
 def secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n):
@@ -439,17 +502,18 @@ def proof_numbers(pkg, co, po, ctx, k, circuit, with_cpu, verify, reps=5):
     return out
 
 
-def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, check=True):
+def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, check=True, also_total=0):
     """configs[4]: a batch of delay_enc proofs dealt round-robin to the ranks (proof p -> rank p mod N, SRS and proving key
     replicated), `inflight` provers per GPU (one context + one library thread each: dehalo_create_proofs, no interpreter in the loop),
     then ONE all-gather of every proof's commitments (31 x 32 B compressed each).  After the timed region every rank re-makes each of
     ITS proofs alone (one prover with a side context, nothing else in flight) from the same seed and requires the batch-made proof and
-    the gathered blob to hold exactly that proof; rank 0 also puts one batch-made proof through the pairing check."""
+    the gathered blob to hold exactly that proof; rank 0 also puts one batch-made proof through the pairing check.
+    `total` is the weak-scaling batch (32 proofs per GPU); `also_total` > 0 times a second batch of exactly that many proofs over the same
+    setup -- BASELINE configs[4] read literally: 64 proofs whatever the number of GPUs -- returned under "fixed_batch"."""
     import torch
     from dehalo2_amd import native, prover, sharding
     note("batch mode: setup")
     st = ProofSetup(pkg, ctx, k, "delay_enc", max(8, min(host_cores(), 256) // max(1, world)))      # (every rank builds the synthetic SRS on the host at once: share the cores)
-    mine = sharding.units_for_rank(total, rank, world)
     if os.environ.get("DEHALO_BENCH_KEEP_TRANSFER") is None:
         from dehalo2_amd import _lib as _l
         _l.release_transfer_contexts()                        # (its stream would count against the pool of hardware queues the provers' streams are mapped onto)
@@ -458,53 +522,65 @@ def batch_proofs(pkg, ctx, k, total, rank, world, backend, device, inflight, che
     prios = (1, 0, -1) if os.environ.get("DEHALO_BENCH_FLAT_PRIORITIES") is None else (0,)      # (see main(): hardware queues are pooled per priority)
     ctxs = [pkg.Context(device, priority=prios[i % len(prios)]) for i in range(max(1, inflight))]
     provers = [native.Prover(st.params, st.pk, c) for c in ctxs]
-    preheat(lambda: native.create_proofs(provers, st.advice, [prover.SeededRng(999 - i) for i in range(2 * len(provers))]))      # warm-up of every prover's buffers, clocks up
-    fence_all(world)
-    note("batch mode: timed region")
-    t0 = time.perf_counter()
-    full = native.create_proofs(provers, st.advice, [prover.SeededRng(1000 + unit) for unit in mine])          # every proof its own blinding
-    blobs = [prover.proof_commitments(cs, pf) for pf in full]
-    allc = sharding.gather_proof_commitments(blobs, total, rank, world, "cuda" if backend == "nccl" else "cpu")
-    per = len(allc[0]) // 32
-    fence_all(world)
-    elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
-    assert len(allc) == total and all(len(b) == 32 * per for b in allc)
-    # the same batch with every proof's circuit synthesized inside its call (dehalo_create_proofs_circuit: witness generation of one proof beside the device
-    # work of the others) -- reported beside the figure above, whose witness is resident
-    synth = None
-    spec = getattr(st.circ, "native_spec", None)
-    if spec is not None:      # (every rank takes this branch: the fences inside are collective)
-        kw = {a: b for a, b in spec.items() if a not in ("circuit", "k")}
+    alone_cache = {}
+
+    def run(total, with_synth):
+        mine = sharding.units_for_rank(total, rank, world)
+        preheat(lambda: native.create_proofs(provers, st.advice, [prover.SeededRng(999 - i) for i in range(2 * len(provers))]))      # warm-up of every prover's buffers, clocks up
         fence_all(world)
-        t1 = time.perf_counter()
-        full_s = native.create_proofs_circuit(provers, spec["circuit"], [kw] * len(mine), [prover.SeededRng(1000 + unit) for unit in mine])
+        note("batch mode: timed region, %d proofs" % total)
+        t0 = time.perf_counter()
+        full = native.create_proofs(provers, st.advice, [prover.SeededRng(1000 + unit) for unit in mine])          # every proof its own blinding
+        blobs = [prover.proof_commitments(cs, pf) for pf in full]
+        allc = sharding.gather_proof_commitments(blobs, total, rank, world, "cuda" if backend == "nccl" else "cpu")
+        per = len(allc[0]) // 32
         fence_all(world)
-        el_s = sharding.max_over_ranks(time.perf_counter() - t1)
-        assert full_s == full, "batch proofs from circuits synthesized inside the calls differ from those of the resident witness"
-        synth = {"proofs_per_s": round(total / el_s, 2), "ms_per_proof_per_gpu": round(1e3 * el_s / max(1, len(mine)), 3),
-                 "what": "dehalo_create_proofs_circuit: the same proofs (bytes asserted equal), each circuit synthesized inside its call"}
-    checked = None
-    note("batch mode: checks")
-    if check:
-        for j, unit in enumerate(mine):                       # this rank's units, re-made alone: the gathered vector holds them at [unit]
-            alone = st.prove(1000 + unit)
-            assert alone == full[j], "batch-mode proof %d differs from the same proof made alone" % unit
-            assert allc[unit] == prover.proof_commitments(cs, alone), "gathered commitments of proof %d differ from the proof made alone" % unit
-        checked = "every proof of this rank re-made alone from its seed: proof bytes and gathered commitments identical"
-        if rank == 0 and mine:
-            assert verify_with_device_vk(st, full[-1]), "the verifier rejected a batch-made proof"
-            checked += "; verifier accepts a batch-made proof"
+        elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+        assert len(allc) == total and all(len(b) == 32 * per for b in allc)
+        # the same batch with every proof's circuit synthesized inside its call (dehalo_create_proofs_circuit: witness generation of one proof beside the device
+        # work of the others) -- reported beside the figure above, whose witness is resident
+        synth = None
+        spec = getattr(st.circ, "native_spec", None)
+        if with_synth and spec is not None:      # (every rank takes this branch: the fences inside are collective)
+            kw = {a: b for a, b in spec.items() if a not in ("circuit", "k")}
+            fence_all(world)
+            t1 = time.perf_counter()
+            full_s = native.create_proofs_circuit(provers, spec["circuit"], [kw] * len(mine), [prover.SeededRng(1000 + unit) for unit in mine])
+            fence_all(world)
+            el_s = sharding.max_over_ranks(time.perf_counter() - t1)
+            assert full_s == full, "batch proofs from circuits synthesized inside the calls differ from those of the resident witness"
+            synth = {"proofs_per_s": round(total / el_s, 2), "ms_per_proof_per_gpu": round(1e3 * el_s / max(1, len(mine)), 3),
+                     "what": "dehalo_create_proofs_circuit: the same proofs (bytes asserted equal), each circuit synthesized inside its call"}
+        checked = None
+        note("batch mode: checks")
+        if check:
+            for j, unit in enumerate(mine):                       # this rank's units, re-made alone: the gathered vector holds them at [unit]
+                if unit not in alone_cache:
+                    alone_cache[unit] = st.prove(1000 + unit)
+                alone = alone_cache[unit]
+                assert alone == full[j], "batch-mode proof %d differs from the same proof made alone" % unit
+                assert allc[unit] == prover.proof_commitments(cs, alone), "gathered commitments of proof %d differ from the proof made alone" % unit
+            checked = "every proof of this rank re-made alone from its seed: proof bytes and gathered commitments identical"
+            if rank == 0 and mine:
+                assert verify_with_device_vk(st, full[-1]), "the verifier rejected a batch-made proof"
+                checked += "; verifier accepts a batch-made proof"
+        return {"k": k, "proofs": total, "proofs_total": total, "n_gpus": world, "proofs_in_flight_per_gpu": len(provers), "proofs_per_s": round(total / elapsed, 2),
+                "ms_per_proof_per_gpu": round(1e3 * elapsed / max(1, len(mine)), 3),
+                "driver": "dehalo_create_proofs: one library thread per prover, no interpreter in the loop",
+                "gathered": "%d proofs x %d compressed commitments (32 B each) on every rank, one all_gather" % (total, per),
+                "with_witness_generation": synth,
+                "checked_after_timed_region": checked,
+                "parallelism": "proof p -> rank p mod N; SRS / proving key replicated; no data-path collective"}
+
+    out = run(total, True)
+    if also_total > 0:
+        out["fixed_batch"] = run(also_total, False) if also_total != total else dict(out, with_witness_generation=None)
     for p in provers:
         p.release()
     for c in ctxs:
         c.close()
     st.release()
-    return {"k": k, "proofs": total, "n_gpus": world, "proofs_in_flight_per_gpu": len(provers), "proofs_per_s": round(total / elapsed, 2), "ms_per_proof_per_gpu": round(1e3 * elapsed / max(1, len(mine)), 3),
-            "driver": "dehalo_create_proofs: one library thread per prover, no interpreter in the loop",
-            "gathered": "%d proofs x %d compressed commitments (32 B each) on every rank, one all_gather" % (total, per),
-            "with_witness_generation": synth,
-            "checked_after_timed_region": checked,
-            "parallelism": "proof p -> rank p mod N; SRS / proving key replicated; no data-path collective"}
+    return out
 
 
 def measured_copy_ceiling():
@@ -654,6 +730,8 @@ def compact_line(out):
     line["config"] = cfg
     r = out["roofline"]
     rl = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "avg_kernel_ms_overlapped", "frac_of_measured_peak")
+    if r.get("traffic") is not None:      # not measured by this run: read from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; the kernel revision is checked)
+        rl["traffic_src"] = "pmc " + KERNEL_REV
     rl["algorithmic_bytes"] = r.get("algorithmic_bytes_per_launch")
     if r.get("measured_peak"):
         rl["measured_copy_GBps"] = r["measured_peak"].get("copy_GBps")
@@ -677,6 +755,8 @@ def compact_line(out):
         line["parity_of_timed_steps"] = "all equal the CPU port's"
     if out.get("secondary"):
         line["secondary"] = _pick(out["secondary"], "table_build_ms_precomputed", "msm_single_row_device_ms", "best_multiexp_host_buffers_ms")
+    if out.get("by_k"):      # north star's per-k / per-distribution figures (by_k_numbers): MSM Mpoints/s and HBM fraction for u / w / l scalars, NTT at n and 4n
+        line["by_k"] = out["by_k"]
     if out.get("rccl_world"):
         line["rccl_world"] = out["rccl_world"]
     if out.get("proof_other_k"):
@@ -685,17 +765,21 @@ def compact_line(out):
         if out.get(k):
             line[k] = compact_proof(out[k])
     if batch:
-        b = _pick(batch, "k", "proofs", "n_gpus", "proofs_in_flight_per_gpu", "proofs_per_s", "ms_per_proof_per_gpu")
+        b = _pick(batch, "k", "proofs", "proofs_total", "n_gpus", "proofs_in_flight_per_gpu", "proofs_per_s", "ms_per_proof_per_gpu")
         if batch.get("with_witness_generation"):
             b["with_witness_generation_proofs_per_s"] = batch["with_witness_generation"].get("proofs_per_s")
         b["checked"] = "each proof re-made alone: identical" if batch.get("checked_after_timed_region") else None
+        fb = batch.get("fixed_batch")
+        if fb:      # configs[4] read literally: 64 proofs whatever the number of GPUs
+            b["batch%d_proofs_per_s" % fb["proofs"]] = fb["proofs_per_s"]
+            b["batch%d_checked" % fb["proofs"]] = bool(fb.get("checked_after_timed_region"))
         line["batch_proofs"] = b
     line["attempts"] = out.get("attempts", 1)
     if out.get("first_attempt"):
         f = out["first_attempt"]
         line["first_attempt"] = {"signal": f.get("signal"), "section": (f.get("section") or "")[:60]}
     text = json.dumps(line, separators=(",", ":"))
-    for drop in ("secondary", "overlapped_ms", "proof_pose_enc", "proof_mod_pow"):      # never needed at today's sizes; the bound holds whatever a section grows to
+    for drop in ("secondary", "overlapped_ms", "proof_pose_enc", "proof_mod_pow", "by_k"):      # never needed at today's sizes; the bound holds whatever a section grows to
         if len(text) <= LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -745,6 +829,8 @@ def main():
     pkg = entry.load_package()
     po, co = entry.load_oracle()  # synthetic-input generators + the cpu_baseline leg only
     from dehalo2_amd import _lib, sharding
+    if args.sort_block:
+        _lib.Context.default_tuning["msm_sort_block"] = args.sort_block
 
     curve = pkg.fields.CURVES[args.curve]
     field = pkg.fields.FIELDS[args.ntt_field]
@@ -861,7 +947,7 @@ def main():
     n_proofs = args.proofs if args.proofs >= 0 else 32 * world
     batch = None
     if args.proof_k > 0 and n_proofs > 0:
-        batch = batch_proofs(pkg, ctx, args.proof_k, n_proofs, rank, world, args.dist_backend, local_rank, args.proofs_inflight)
+        batch = batch_proofs(pkg, ctx, args.proof_k, n_proofs, rank, world, args.dist_backend, local_rank, args.proofs_inflight, also_total=args.fixed_batch)
 
     if rank == 0:
         def tsum(kid):
@@ -975,6 +1061,19 @@ def main():
             out["parity_of_timed_configuration"] = "all %d timed MSM results and the 2^%d NTT equal the CPU port's (checked after the timed region)" % (args.steps, log_n)
             if world == 1:
                 out["secondary"] = secondary_numbers(pkg, co, ctx, curve, bases_h, scalars_h, log_n)
+                # north star: "throughput on synthetic witnesses at k in {14, 17, 20} ... as fraction of the HBM roofline": three sizes x three scalar distributions x two NTT sizes
+                note("by_k: MSM / NTT at k = 14, 17, 20, three scalar distributions")
+                tables = {}
+                for kk in (14, 17, 20):
+                    if kk == log_n:
+                        tables[kk] = (bases_h, bases)
+                    else:
+                        bh_k = co.synth_bases(curve.id, 1 << kk)
+                        tables[kk] = (bh_k, ctx.register_bases(curve.id, bh_k, 0, True))
+                out["by_k"] = by_k_numbers(pkg, po, co, ctx, curve, field, tables, out["cpu_baseline"]["cores"])
+                for kk, (_, b) in tables.items():
+                    if kk != log_n:
+                        b.release()
         if args.proof_k > 0:
             with_cpu = not args.no_cpu_baseline
             verify = not args.no_verify

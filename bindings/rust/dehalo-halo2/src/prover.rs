@@ -78,7 +78,8 @@ impl Drop for DehaloProvingKey<'_> {
 /// `dehalo_rng` with `DEHALO_RNG_CALLBACK`: blinding scalars are drawn from the caller's `RngCore` in upstream's order.  (The random polynomial's `n` scalars are
 /// requested early, from a helper thread, with their `position` in that order: a generator that cannot seek sees them out of order -- the proof is equally valid;
 /// byte identity with a CPU run of the same seeded generator needs a seekable one, which `DEHALO_RNG_PCG64` is.)
-unsafe extern "C" fn fill_from<R: RngCore>(user: *mut c_void, out: *mut u64, count: usize, _position: u64) -> i32 {
+/// `R: Send`: include/dehalo.h lets the library call `fill` from a helper thread of its own, so the generator crosses threads (`ThreadRng` is refused at compile time).
+unsafe extern "C" fn fill_from<R: RngCore + Send>(user: *mut c_void, out: *mut u64, count: usize, _position: u64) -> i32 {
     let rng = &mut *(user as *mut R);
     for i in 0..count {
         let s = Fr::random(&mut *rng);
@@ -101,9 +102,19 @@ impl<'c> DehaloProver<'c> {
         Ok(DehaloProver { ctx, raw })
     }
 
+    /// ONE proof on several GPUs (`dehalo_prover_set_shard`): of every multi-column commitment phase this process runs the MSMs of its share of the columns only and
+    /// `gather` (an all-gather of at most ten affine points over RCCL / xGMI, see include/dehalo.h) fills in the rest; every process must then call `create_proof`
+    /// with the same advice, instances and the same seeded generator.  `world == 1` switches it off.
+    ///
+    /// # Safety
+    /// `gather` is called on the proving thread with `user`; both must stay valid for as long as the prover may prove.
+    pub unsafe fn set_shard(&self, rank: u32, world: u32, gather: sys::dehalo_gather_fn, user: *mut c_void) -> Result<(), DehaloError> {
+        self.ctx.check(sys::dehalo_prover_set_shard(self.raw, rank, world, gather, user))
+    }
+
     /// `create_proof(&params, &pk, &[circuit], &[instances], rng, &mut transcript)` for ONE circuit: `advice` = what `circuit.synthesize` assigned
     /// (`num_advice x 2^k` Montgomery elements, column after column, host memory); returns the transcript bytes (`transcript.finalize()`).
-    pub fn create_proof<R: RngCore>(&self, advice: &[Fr], instances: &[&[Fr]], rng: &mut R) -> Result<Vec<u8>, DehaloError> {
+    pub fn create_proof<R: RngCore + Send>(&self, advice: &[Fr], instances: &[&[Fr]], rng: &mut R) -> Result<Vec<u8>, DehaloError> {
         let inst_ptrs: Vec<*const u64> = instances.iter().map(|c| c.as_ptr() as *const u64).collect();
         let inst_lens: Vec<usize> = instances.iter().map(|c| c.len()).collect();
         let mut r = sys::dehalo_rng { kind: sys::DEHALO_RNG_CALLBACK, pcg_state: [0; 2], pcg_inc: [0; 2], fill: Some(fill_from::<R>), user: rng as *mut R as *mut c_void };
@@ -124,8 +135,8 @@ impl<'c> DehaloProver<'c> {
     }
 
     /// The reference's call shape in one entry point: the circuit's own inputs instead of its advice columns -- synthesized inside the call by the library's restatement
-    /// of the three circuits (csrc/witness.hip; its own layouter, so it pairs with a key from `keygen` over ITS fixed columns: `dehalo_synthesize`).
-    pub fn create_proof_circuit<R: RngCore>(&self, inputs: &sys::dehalo_circuit_inputs, rng: &mut R) -> Result<(Vec<u8>, sys::dehalo_synthesis_info), DehaloError> {
+    /// of the three circuits (csrc/witness.hip: halo2wrong's layout instruction by instruction, unverified cell for cell against the crates -- pair it with a key from `keygen` over ITS fixed columns: `dehalo_synthesize`).
+    pub fn create_proof_circuit<R: RngCore + Send>(&self, inputs: &sys::dehalo_circuit_inputs, rng: &mut R) -> Result<(Vec<u8>, sys::dehalo_synthesis_info), DehaloError> {
         let mut r = sys::dehalo_rng { kind: sys::DEHALO_RNG_CALLBACK, pcg_state: [0; 2], pcg_inc: [0; 2], fill: Some(fill_from::<R>), user: rng as *mut R as *mut c_void };
         let mut info: sys::dehalo_synthesis_info = unsafe { core::mem::zeroed() };
         let mut t = core::ptr::null_mut();
@@ -160,7 +171,7 @@ impl Drop for DehaloProver<'_> {
 
 /// The bench's flow end to end (benches/delay_enc.rs:41-54, 84-131) for a caller that holds upstream's objects: SRS file bytes, the circuit's constraint system, its
 /// fixed columns / permutation mapping, the advice columns of one proof.  One-time objects are built once and reused by the caller; shown as one function for the reader.
-pub fn create_proof<R: RngCore>(device: i32, params_raw_bytes: &[u8], cs: &ConstraintSystem<Fr>, fixed: &[Fr], mapping: &[u64], selectors: &[Vec<u8>],
+pub fn create_proof<R: RngCore + Send>(device: i32, params_raw_bytes: &[u8], cs: &ConstraintSystem<Fr>, fixed: &[Fr], mapping: &[u64], selectors: &[Vec<u8>],
                                 transcript_repr: &Fr, advice: &[Fr], instances: &[&[Fr]], rng: &mut R) -> Result<Vec<u8>, DehaloError> {
     let ctx = Context::new(device)?;
     let side = Context::with_priority(device, 1)?;

@@ -29,7 +29,7 @@ SYMBOLS = [
     "dehalo_pk_get_transcript_repr", "dehalo_pk_info", "dehalo_pk_release", "dehalo_rng_scalars", "dehalo_field_info", "dehalo_synthesize",
     "dehalo_transcript_create", "dehalo_transcript_common_scalar", "dehalo_transcript_write_scalar", "dehalo_transcript_write_point",
     "dehalo_transcript_squeeze_challenge", "dehalo_transcript_len", "dehalo_transcript_finalize", "dehalo_transcript_release",
-    "dehalo_prover_create", "dehalo_prover_release", "dehalo_create_proof", "dehalo_prover_last_timings", "dehalo_create_proofs",
+    "dehalo_prover_create", "dehalo_prover_release", "dehalo_create_proof", "dehalo_prover_set_shard", "dehalo_prover_last_timings", "dehalo_create_proofs",
     "dehalo_graph_create", "dehalo_graph_release", "dehalo_graph_evaluate_device", "dehalo_graph_evaluate_batch_device", "dehalo_permutation_h_device", "dehalo_lookup_h_device",
 ]
 
@@ -93,6 +93,7 @@ class CSynthesisInfo(C.Structure):
 
 
 RNG_FILL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32)      # dehalo_gather_fn
 
 
 class CRng(C.Structure):
@@ -249,6 +250,7 @@ def load_library():
     lib.dehalo_create_proof_circuit.argtypes = [P, C.POINTER(CCircuitInputs), C.POINTER(CSynthesisInfo), C.POINTER(C.c_void_p), C.POINTER(sz), u32, C.POINTER(CRng), P]
     lib.dehalo_create_proofs_circuit.argtypes = [C.POINTER(C.c_void_p), u32, C.POINTER(CCircuitInputs), u32, C.POINTER(CRng), C.POINTER(C.c_void_p), sz, C.POINTER(sz)]
     lib.dehalo_prover_last_timings.argtypes = [P, C.POINTER(C.c_double)]
+    lib.dehalo_prover_set_shard.argtypes = [P, C.c_uint32, C.c_uint32, GATHER_FN, P]
     lib.dehalo_create_proofs.argtypes = [C.POINTER(C.c_void_p), u32, C.POINTER(C.c_void_p), u32, C.POINTER(CRng), u32, C.POINTER(C.c_void_p), sz, C.POINTER(sz)]
     lib.dehalo_timing_enable.argtypes = [P, C.c_int]
     lib.dehalo_timing_reset.argtypes = [P]
@@ -286,6 +288,8 @@ class Bases:
 
 
 class Context:
+    default_tuning: dict = {}
+
     def __init__(self, device: int = 0, priority: int = 0):
         """priority > 0: highest stream priority of the device (short kernels beside another context's long ones), < 0: lowest."""
         self.lib = load_library()
@@ -296,6 +300,8 @@ class Context:
         self.handle = h
         self.device = device
         self._tables = {}
+        for key, value in Context.default_tuning.items():      # launch-geometry knobs every new context starts with (bench.py's A/B flags)
+            self.set_tuning(key, value)
 
     def close(self):
         if self.handle is not None:

@@ -498,6 +498,11 @@ int dehalo_ctx_set_tuning(dehalo_ctx* ctx, const char* key, int value) {
         ctx->host_wait_spin_us = value;
         return 0;
     }
+    if (!strcmp(key, "msm_sort_block")) {
+        if (value != 512 && value != 1024) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_sort_block must be 512 or 1024");
+        ctx->msm_sort_block = value;
+        return 0;
+    }
     if (!strcmp(key, "msm_acc_block")) {
         if (value != 128 && value != 768) return dh_fail(ctx, DEHALO_ERR_INVALID, "msm_acc_block must be 128 or 768");
         ctx->msm_acc_block = value;

@@ -523,7 +523,6 @@ int graph_evaluate_batch_t(dehalo_ctx* ctx, const dehalo_graph* const* graphs, u
     const size_t lds = (size_t)max_lds * EVH_SLOT_BYTES;
     if (lds > 48 * 1024) HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_graph_eval_batch<F>, EVH_LDS_BYTES));
     for (u32 first = 0; first < count; first += EVH_GRAPH_BATCH) {
-        const u32 cnt = std::min<u32>(EVH_GRAPH_BATCH, count - first);
         // (the tables of consecutive groups must not overlap in time: a group of its own region each)
         const size_t region = (size_t)(first / EVH_GRAPH_BATCH);
         TRY(dh_ensure(ctx, ctx->ws_evh[0], (region + 1) * EVH_GRAPH_BATCH * (size_t)tstride * sizeof(fe)));

@@ -168,16 +168,20 @@ FP_DEV bool wave_value_groups(const fe& s, bool active, u32 lane, u32 max_groups
 // grid (slices, G, batch); dynamic LDS nb * 4 B.  Each block stores its whole local histogram
 // (plain coalesced stores): bh[group][slice][bucket].  No global atomics anywhere in the sort:
 // 256 blocks claiming runs in the same 2^15 counters with returning atomics cost 0.2 ms.
-template <class FS>
+// PACK16: two 16-bit counters a word -- half the LDS (64 KiB for 2^15 buckets, so that a sort block shares a compute unit with an NTT tile or the merge /
+// reduction blocks of another context instead of waiting for a CU with all of its LDS free); the host selects it only when a block's scalars times the window
+// count stay below 2^16, so no counter can carry into its neighbour.
+template <class FS, bool PACK16>
 __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(MsmGeom g, const fe* scalars, u32* bh, u32* pc) {
     msm_tail_prio();
     extern __shared__ u32 lhist[];
+    auto count_of = [&](const u32* base, u32 b) -> u32 { return PACK16 ? (base[b >> 1] >> ((b & 1u) << 4)) & 0xffffu : base[b]; };
     // G == 1: the block counts every window into the one bucket set.  G == W: it covers windows [w_lo, w_hi), one bucket set each
     // (a scalar is decoded once per block, not once per window: ceil(W / wb) passes over the scalars instead of W).
     const u32 bat = blockIdx.z;
     const u32 w_lo = g.G == 1 ? 0 : blockIdx.y * g.wb, w_hi = g.G == 1 ? g.W : min(g.W, w_lo + g.wb);
     const u32 ng = g.G == 1 ? 1 : w_hi - w_lo, grp0 = g.G == 1 ? 0 : w_lo;
-    for (u32 b = threadIdx.x; b < ng * g.nb; b += blockDim.x) lhist[b] = 0;
+    for (u32 b = threadIdx.x; b < (PACK16 ? ng * g.nb / 2 : ng * g.nb); b += blockDim.x) lhist[b] = 0;
     __syncthreads();
     const fe* sc = scalars + (u64)bat * g.n;
     const u32 per = (g.n + g.slices - 1) / g.slices;
@@ -199,7 +203,11 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
             if (!grouped) weight = 1;
             const bool counts = grouped ? valid && (threadIdx.x & 63) == gl : valid;
             if (counts)
-                for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool) { atomicAdd(&lhist[(one ? 0u : (w - w_lo) * g.nb) + bucket], weight); });
+                for_each_digit<FS>(s4[j], g.c, w_lo, w_hi, [&](u32 w, u32 bucket, bool) {
+                    const u32 slot = (one ? 0u : (w - w_lo) * g.nb) + bucket;
+                    if (PACK16) atomicAdd(&lhist[slot >> 1], weight << ((slot & 1u) << 4));
+                    else atomicAdd(&lhist[slot], weight);
+                });
         }
     }
     __syncthreads();
@@ -207,14 +215,14 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
     const u32 ways = sub >= 3 ? 8 : 1, chunk = (1u << sub) / ways;   // 8 lanes share a partition's 2^sub counters
     for (u32 gi = 0; gi < ng; gi++) {
         const u64 gidx = (u64)bat * g.G + grp0 + gi;
-        const u32* lh = lhist + gi * g.nb;
+        const u32* lh = lhist + (PACK16 ? gi * g.nb / 2 : gi * g.nb);
         u32* out = bh + (gidx * g.slices + blockIdx.x) * g.nb;
-        for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) out[b] = lh[b];
+        for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) out[b] = count_of(lh, b);
         // partition = the bucket's top bits; its count for this slice (second sort level, see k_msm_part)
         u32* pout = pc + (gidx * g.slices + blockIdx.x) * P;
         for (u32 t = threadIdx.x; t < P * ways; t += blockDim.x) {
             u32 q = t / ways, part = t % ways, sum = 0;
-            for (u32 j = 0; j < chunk; j++) sum += lh[(q << sub) + part * chunk + j];
+            for (u32 j = 0; j < chunk; j++) sum += count_of(lh, (q << sub) + part * chunk + j);
             if (ways == 8) {
                 sum += __shfl_down(sum, 4, 8);
                 sum += __shfl_down(sum, 2, 8);
@@ -795,7 +803,11 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     g.n = (u32)len; g.table_n = (u32)bases->n; g.c = bases->c; g.W = bases->W; g.nb = 1u << (g.c - 1);
     g.G = bases->precomp ? 1 : g.W;
     g.batch = (u32)batch;
-    g.slices = (u32)std::min<size_t>(256, std::max<size_t>(1, len / 2048));
+    // sort blocks (k_msm_hist, k_msm_part): msm_sort_block threads, two scalars a thread until the grid has 256 K threads, then longer slices.  512-thread
+    // blocks: 64 KiB (packed 16-bit histogram) and 58 KiB (eight waves' staging) of LDS, against 128 and 115 KiB for 1024 threads -- which need a compute
+    // unit to themselves and wait for every NTT tile / merge / reduction block of another context on it to drain
+    const u32 sort_threads = ctx->msm_sort_block == 1024 ? 1024u : 512u;
+    g.slices = (u32)std::min<size_t>(256 * (1024 / sort_threads), std::max<size_t>(1, len / (2 * sort_threads)));
     {   // small precomputed-table launches: 2048 scalars a sort block leave a 2^14 column 8 blocks and a 2^11 column ONE for k_msm_hist / k_msm_part (21 + 34 us of
         // latency where the work is 2); down to 256 scalars a block until ~128 blocks are there (DEHALO_MSM_SMALL_SLICES=0: the A/B)
         static const bool small_slices = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_SMALL_SLICES"); return !(e && e[0] == '0'); }();
@@ -872,21 +884,27 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     xyzz29_rec* buckets = (xyzz29_rec*)ctx->ws_buckets.p;
     xyzz29_rec* gsums = (xyzz29_rec*)ctx->ws_gsums.p;
 
-    const size_t lds_hist = (size_t)g.nb * 4 * (g.G == 1 ? 1 : g.wb);
+    // packed 16-bit counters when no bucket of a block can be counted 2^16 times: every scalar of the slice in every window of the block (all windows for G == 1)
+    const u32 per_slice = (u32)((len + g.slices - 1) / g.slices);
+    const bool pack16 = g.nb >= 2 && (uint64_t)per_slice * (g.G == 1 ? g.W : g.wb) <= 65535;
+    const size_t lds_hist = (size_t)g.nb * (pack16 ? 2 : 4) * (g.G == 1 ? 1 : g.wb);
+    const void* hist_fn = pack16 ? (const void*)k_msm_hist<FS, true> : (const void*)k_msm_hist<FS, false>;
     if (lds_hist > 48 * 1024) {
-        HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_hist<FS>, (int)lds_hist));
+        HIP_TRY(ctx, dh_func_lds(ctx, hist_fn, (int)lds_hist));
     }
     // block sizes of the two scalar-decoding sort kernels (DEHALO_MSM_HIST_THREADS / DEHALO_MSM_PART_THREADS, 64 .. 1024): smaller blocks fit beside a
     // resident accumulation of another context (msm_acc_block = 768 leaves one 128-VGPR wave slot per SIMD: 512 threads x 62 VGPRs, 256 x 77)
-    static const u32 hist_threads = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_HIST_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
-    static const u32 part_threads = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_PART_THREADS"); const int v = e ? atoi(e) : MSM_SORT_THREADS; return (u32)std::max(64, std::min(MSM_SORT_THREADS, v & ~63)); }();
+    static const u32 hist_threads_env = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_HIST_THREADS"); const int v = e ? atoi(e) : 0; return (u32)std::max(0, std::min(MSM_SORT_THREADS, v & ~63)); }();
+    static const u32 part_threads_env = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_PART_THREADS"); const int v = e ? atoi(e) : 0; return (u32)std::max(0, std::min(MSM_SORT_THREADS, v & ~63)); }();
+    const u32 hist_threads = hist_threads_env ? hist_threads_env : sort_threads, part_threads = part_threads_env ? part_threads_env : sort_threads;
     const size_t lds_part = dh_co_lds_pad(0, 512 + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS);
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_part<FS>, (int)lds_part));
     const u32 tb = (u32)total_buckets;
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
         dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
-        k_msm_hist<FS><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
+        if (pack16) k_msm_hist<FS, true><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
+        else k_msm_hist<FS, false><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
         const u32 cs_a = (tb + 255) / 256, cs_b = ((u32)total_groups * P + 255) / 256;
         TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)cs_a * 2 * sizeof(u32)));
         u32* bs_i = (u32*)ctx->ws_bsum.p;

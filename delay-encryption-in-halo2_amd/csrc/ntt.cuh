@@ -240,6 +240,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             lds29_store(L, slot & 0x7fffffffu, f29_unpack(raw));
         };
         static_assert(NTT_LOADS == 4, "");
+        static_assert(NTT_TILE <= NTT_LOADS * NTT_THREADS, "a thread fills at most NTT_LOADS slots of a tile: a larger tile / thread ratio would leave LDS slots unfilled (the half-tile launch keeps the ratio)");
         u32 s0, s1, s2, s3;
         u64 g0, g1, g2, g3;
         locate(0, s0, g0); locate(1, s1, g1); locate(2, s2, g2); locate(3, s3, g3);

@@ -165,8 +165,7 @@ __global__ __launch_bounds__(POLY_THREADS) void k_poly_eval_multi(PolyPtrs polys
     }
     const fe* c0 = coeffs ? coeffs + (u64)blockIdx.y * stride : polys.p[blockIdx.y];       // level 0: one device pointer per polynomial
     const u32 want = polys.m[blockIdx.y];                                                   // (uniform in the block) points nobody asked for are skipped
-#pragma unroll
-    for (int j = POLY_EVAL_EPT - 1; j >= 0; j--) {
+    for (int j = POLY_EVAL_EPT - 1; j >= 0; j--) {      // (a rolled loop: eight rounds of up to four multiplications are past the unroller's size limit, and nothing is indexed by j)
         const bool in = base + j < len;
         // level >= 1: every point has its own partial sums (point_stride apart); level 0: one coefficient array for all points
         f29 cj = in && !point_stride ? f29_unpack(f_load(&c0[base + j])) : f29_zero();
@@ -302,8 +301,7 @@ __global__ __launch_bounds__(POLY_THREADS) void k_pp_block(const fe* in, u64 in_
     totals += (u64)blockIdx.y * gridDim.x;
     const u64 base = (u64)blockIdx.x * POLY_PTILE + (u64)t * POLY_K;
     f29 T = f29_one<F9>();
-#pragma unroll
-    for (int j = 0; j < POLY_K; j++) {
+    for (int j = 0; j < POLY_K; j++) {      // (rolled: see k_poly_eval_multi)
         if (base + j < len) {
             f29 a = poly_load<F9>(&in[base + j]);
             if (mul_by) a = f29_mul<F9>(a, poly_load<F9>(&mul_by[base + j]));
@@ -348,22 +346,18 @@ __global__ __launch_bounds__(POLY_THREADS) void k_pp_apply(const fe* in, u64 in_
     bprefix += (u64)blockIdx.y * gridDim.x;
     const u64 base = (u64)blockIdx.x * POLY_PTILE + (u64)t * POLY_K;
     if (base >= len) return;
-    f29 a[POLY_K];
-#pragma unroll
-    for (int j = 0; j < POLY_K; j++) {
-        a[j] = f29_one<F9>();
-        if (base + j < len) {
-            a[j] = poly_load<F9>(&in[base + j]);
-            if (mul_by) a[j] = f29_mul<F9>(a[j], poly_load<F9>(&mul_by[base + j]));
-        }
-    }
+    // Element by element -- load a_j, store the running product, multiply -- so that no register array is indexed by a loop the unroller refuses (the
+    // four-element array of the first version lived in 160 bytes of scratch per lane); a thread owns its POLY_K elements, so `out` may be `in`.
     f29 run = f29_mul<F9>(poly_load_packed(&bprefix[blockIdx.x]), poly_load_packed(&scratch_e[(u64)blockIdx.x * POLY_THREADS + t]));
-#pragma unroll
     for (int j = 0; j < POLY_K; j++) {
-        if (base + j < len) {
-            poly_store<F9>(&out[base + j], run);
-            if (j + 1 < POLY_K) run = f29_mul<F9>(run, a[j]);
+        if (base + j >= len) break;
+        f29 a = f29_one<F9>();
+        if (j + 1 < POLY_K) {
+            a = poly_load<F9>(&in[base + j]);
+            if (mul_by) a = f29_mul<F9>(a, poly_load<F9>(&mul_by[base + j]));
         }
+        poly_store<F9>(&out[base + j], run);
+        if (j + 1 < POLY_K) run = f29_mul<F9>(run, a);
     }
 }
 

@@ -757,6 +757,11 @@ struct dehalo_prover {
     // host staging
     std::vector<uint64_t> blind_host, host_aff, host_jac, host_evals;
     double timings[8] = {};
+    // single-proof sharding (dehalo_prover_set_shard): this process computes columns [count * rank / world, count * (rank + 1) / world) of every multi-column
+    // commitment and exchanges the points through the caller's all-gather
+    uint32_t shard_rank = 0, shard_world = 1;
+    dehalo_gather_fn shard_gather = nullptr;
+    void* shard_user = nullptr;
     bool trace = false;      // DEHALO_PROVER_TRACE=1: host timestamps inside the phases go to stderr after each proof
     std::vector<std::pair<const char*, double>> ticks;
     clk::time_point t0;
@@ -1055,7 +1060,11 @@ struct dehalo_prover {
     // commit `count` columns starting at `src`, read back, normalise, absorb (and append to the proof)
     // `flags` > 0: that many int32 status words sit behind the points in `jac` (deferred lookup permutation) and come back with them; any non-zero one fails the call
     int commit(dehalo_transcript* tr, const fe* src, size_t count, bool lagrange, const std::function<int()>& before_sync = nullptr, size_t flags = 0) {
-        TRY(dehalo_msm_device(ctx, lagrange ? params->bases_gl : params->bases_g, (const uint64_t*)src, n, count, jac.u64(), nullptr));
+        // sharded (dehalo_prover_set_shard): this process's share of the columns only; everything else of the proof is computed by every process
+        const bool sharded = shard_world > 1 && shard_gather && count > 1;
+        const size_t lo = sharded ? count * shard_rank / shard_world : 0, hi = sharded ? count * (shard_rank + 1) / shard_world : count;
+        if (hi > lo)
+            TRY(dehalo_msm_device(ctx, lagrange ? params->bases_gl : params->bases_g, (const uint64_t*)(src + lo * n), n, hi - lo, jac.u64() + 12 * lo, nullptr));
         tk("commit queued");
         if (before_sync) TRY(before_sync());
         tk("side work queued");
@@ -1064,7 +1073,17 @@ struct dehalo_prover {
         for (size_t i = 0; i < flags; i++)
             if (reinterpret_cast<const int32_t*>(host_jac.data() + 12 * count)[i])
                 return dh_fail(ctx, DEHALO_ERR_NOT_IN_TABLE, "permute_expression_pair: an input value of lookup " + std::to_string(i) + " is not in the table (ConstraintSystemFailure)");
-        if (!normalize_host(host_jac.data(), count, host_aff.data())) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
+        if (hi > lo && !normalize_host(host_jac.data() + 12 * lo, hi - lo, host_aff.data() + 8 * lo)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
+        if (sharded) {      // every process ends with all `count` affine points, in column order
+            std::vector<uint32_t> first(shard_world), num(shard_world);
+            for (uint32_t r = 0; r < shard_world; r++) {
+                first[r] = (uint32_t)(count * r / shard_world);
+                num[r] = (uint32_t)(count * (r + 1) / shard_world) - first[r];
+            }
+            if (shard_gather(shard_user, host_aff.data(), (uint32_t)count, first.data(), num.data(), shard_world) != 0)
+                return dh_fail(ctx, DEHALO_ERR_INVALID, "the shard gather callback failed");
+            tk("points gathered");
+        }
         for (size_t i = 0; i < count; i++)
             if (!tr->write_point(host_aff.data() + 8 * i)) return dh_fail(ctx, DEHALO_ERR_INVALID, "cannot write points at infinity to the transcript");
         return 0;
@@ -1617,6 +1636,12 @@ extern "C" int dehalo_create_proof(dehalo_prover* p, const uint64_t* advice, con
         if (p->side) (void)hipStreamSynchronize(p->side->stream);
     }
     return rc;
+} catch (...) { return DEHALO_ERR_OOM; }
+
+extern "C" int dehalo_prover_set_shard(dehalo_prover* p, uint32_t rank, uint32_t world, dehalo_gather_fn gather, void* user) try {
+    if (!p || world == 0 || rank >= world || (world > 1 && !gather)) return DEHALO_ERR_INVALID;
+    p->shard_rank = rank; p->shard_world = world; p->shard_gather = world > 1 ? gather : nullptr; p->shard_user = user;
+    return 0;
 } catch (...) { return DEHALO_ERR_OOM; }
 
 extern "C" int dehalo_prover_last_timings(const dehalo_prover* p, double out[8]) try {

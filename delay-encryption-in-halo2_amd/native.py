@@ -297,6 +297,25 @@ class Prover:
         self.handle = C.c_void_p()
         _check(self.ctx, load_library().dehalo_prover_create(self.ctx.handle, side_ctx.handle if side_ctx is not None else None, params.handle, pk.handle, C.byref(self.handle)))
 
+    def set_shard(self, rank: int, world: int, gather=None):
+        """dehalo_prover_set_shard: this process runs the MSMs of its share of every multi-column commitment phase only; `gather(points, first, num)` --
+        points a (count, 8) uint64 array whose rows [first[rank], first[rank] + num[rank]) are filled -- must fill in the other rows in place (an all-gather:
+        sharding.gather_points).  Every process must prove with the same inputs and the same seeded rng.  world = 1 switches it off."""
+        from ._lib import GATHER_FN
+
+        def thunk(_user, pts, count, first, num, w):
+            try:
+                arr = np.ctypeslib.as_array(pts, shape=(count, 8))
+                gather(arr, [first[i] for i in range(w)], [num[i] for i in range(w)])
+                return 0
+            except Exception:      # noqa: BLE001  (an exception must not unwind through the C frames)
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        self._gather_cb = GATHER_FN(thunk) if world > 1 else GATHER_FN()      # kept alive as long as the prover may call it
+        _check(self.ctx, load_library().dehalo_prover_set_shard(self.handle, rank, world, self._gather_cb, None))
+
     def create_proof(self, advice, instances: Sequence[Sequence[int]] = ((),), rng=None, transcript: Optional[Blake2bWrite] = None, canonical: bool = False) -> Blake2bWrite:
         """advice: (num_advice, n, 4) u64 Montgomery (or plain integers < p with canonical=True: what native.synthesize returns) -- a host
         array or a device tensor (anything with .data_ptr()).  instances: one list of canonical ints per instance column.  rng: None = OS

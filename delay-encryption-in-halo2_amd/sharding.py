@@ -93,3 +93,31 @@ def combine_partial_msm(ctx, curve_id: int, local_partial, rank: int, world: int
     ctx.point_sum_device(curve_id, parts.data_ptr(), parts.shape[0], out.data_ptr(), 0)
     ctx.synchronize()
     return out
+
+
+# ---- one proof sharded by commitment columns (SURVEY.md 8e "single-proof mode"; dehalo_prover_set_shard) -------------
+def column_range_for_rank(count: int, rank: int, world: int):
+    """[first, first + num) of the `count` columns of a commitment phase whose MSMs rank `rank` runs (the library's own rule)."""
+    first = count * rank // world
+    return first, count * (rank + 1) // world - first
+
+
+def gather_points(points, first, num, rank: int, world: int, device="cpu"):
+    """The exchange dehalo_prover_set_shard's callback has to make: `points` is a (count, 8) int64 / uint64 array of affine points of which
+    rows [first[rank], first[rank] + num[rank]) are this rank's; on return every row holds its owner's point.  ONE all_gather of equal padded
+    blocks (at most ceil(count / world) points a rank: a few hundred bytes -- latency-bound over xGMI)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    per = max(int(x) for x in num)
+    pad = torch.zeros((max(per, 1), 8), dtype=torch.int64)
+    mine = np.asarray(points[int(first[rank]):int(first[rank]) + int(num[rank])]).view(np.int64)
+    pad[: mine.shape[0]] = torch.from_numpy(np.ascontiguousarray(mine))
+    out = torch.empty((world * pad.shape[0], 8), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, pad.to(device))
+    out = out.cpu().numpy().reshape(world, pad.shape[0], 8)
+    for r in range(world):
+        if r != rank and num[r]:
+            points[int(first[r]):int(first[r]) + int(num[r])] = out[r, : int(num[r])].view(points.dtype)
+    return points

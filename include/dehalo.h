@@ -509,6 +509,16 @@ int dehalo_prover_release(dehalo_prover* prover);
 enum { DEHALO_PROOF_ADVICE_ON_DEVICE = 1, DEHALO_PROOF_ADVICE_CANONICAL = 2 /* plain integers < p: converted on the device */ };
 int dehalo_create_proof(dehalo_prover* prover, const uint64_t* advice, const uint64_t* const* instances, const size_t* instance_lens, uint32_t num_instance_columns,
                         dehalo_rng* rng, dehalo_transcript* transcript, uint32_t flags);
+/* ONE proof on several GPUs ("single-proof mode -- round-robin columns of the current phase across GPUs"): every one of `world` processes runs
+ * the same dehalo_create_proof on its own GPU with the same inputs and the same seeded random stream (DEHALO_RNG_PCG64, or a callback that hands every process the
+ * same scalars); of every commitment phase with more than one column (advice, permuted lookup columns, the grand products, the quotient's pieces, the openings) a
+ * process runs the MSM of columns [count * rank / world, count * (rank + 1) / world) only, and `gather` -- called on the proving thread with `points` = count affine
+ * points (8 u64 each, Montgomery) of which this process's own slots [first[rank], first[rank] + num[rank]) are filled -- must fill in the others (an all-gather of
+ * num[r] points from process r, e.g. ncclAllGather over xGMI: at most ten points a phase) and return 0.  Every process then writes the same points to its transcript,
+ * squeezes the same challenges and ends with the same proof bytes as a lone prover.  Everything that is not an MSM is computed by every process (no column travels).
+ * world = 1 (or gather = NULL with world = 1) switches it off. */
+typedef int (*dehalo_gather_fn)(void* user, uint64_t* points, uint32_t count, const uint32_t* first, const uint32_t* num, uint32_t world);
+int dehalo_prover_set_shard(dehalo_prover* prover, uint32_t rank, uint32_t world, dehalo_gather_fn gather, void* user);
 /* Host wall-clock milliseconds the last create_proof on this prover spent per phase (advice, lookups, products, random, quotient, evaluations,
  * openings, total): out[8]. */
 int dehalo_prover_last_timings(const dehalo_prover* prover, double out[8]);

@@ -90,9 +90,15 @@ def test_bench_line_fits_the_drivers_tail_and_ends_with_the_metric():
     rec = json.load(open(os.path.join(root, "tests", "golden", "bench_record_verbose.json")))
     rec["first_attempt"] = {"signal": 6, "section": "proof delay_enc k = 17: proving", "stderr_tail": ["x" * 300] * 6}
     rec["attempts"] = 2
+    # the north star's per-k section (bench.by_k_numbers): three sizes x (three scalar distributions + two transform sizes), at most 700 characters
+    rec["by_k"] = [{"k": k, "msm_mpts": {"u": 123.4, "w": 234.5, "l": 345.6}, "msm_frac": {"u": 0.00148, "w": 0.00281, "l": 0.00415}, "ntt_ms": [0.0123, 0.0456],
+                    "ntt_frac": [0.0123, 0.0234], "ok": True} for k in (14, 17, 20)]
+    rec["roofline"]["traffic"] = 1646269061
     text = bench.compact_line(rec)
     assert len(text) <= bench.LINE_LIMIT == 6000, len(text)
     line = json.loads(text)
+    assert [e["k"] for e in line["by_k"]] == [14, 17, 20] and len(json.dumps(line["by_k"], separators=(",", ":"))) <= 700
+    assert line["roofline"]["traffic_src"].startswith("pmc ")
     keys = list(line)
     assert keys[-4:] == ["proof", "batch_proofs", "attempts", "first_attempt"], keys[-6:]
     assert keys.index("proof_other_k") < keys.index("proof")

@@ -85,11 +85,12 @@ def rs_class(ty):
 
 def rs_functions():
     t = open(SYS_RS).read()
+    fn_aliases = set(re.findall(r"pub type (\w+) = Option<unsafe extern", t))      # a callback passed as a parameter is named by its alias
     out = {}
     for m in re.finditer(r"pub fn (dehalo_[a-z0-9_]+)\(([^)]*)\)(?:\s*->\s*([^;]+))?;", t):
         name, args, ret = m.group(1), m.group(2).strip(), m.group(3)
         params = [] if not args else [a.split(":", 1)[1] for a in args.split(", ")]
-        out[name] = ("void" if ret is None else rs_class(ret), [rs_class(p) for p in params])
+        out[name] = ("void" if ret is None else rs_class(ret), ["fnptr" if p.strip() in fn_aliases else rs_class(p) for p in params])
     return out
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # interleaved CU shares with several provers per share
 . tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
+need_switch DEHALO_CU_PARTITION DEHALO_CU_PARTITION_INTERLEAVE 
 run() { timeout -k 10 200 python tools/batch_trace.py 17 $1 64 0 1 2>/dev/null | grep batch; }
 export DEHALO_CU_PARTITION_INTERLEAVE=1
 for round in 1 2; do

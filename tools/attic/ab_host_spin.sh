@@ -1,6 +1,7 @@
 #!/bin/bash
 # host waits that poll before they block (DEHALO_HOST_SPIN_US) against the runtime's blocking wait (0): K = 11, k = 17 proofs and the 64-proof batch, two rounds
 . tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
+need_switch DEHALO_HOST_SPIN_US 
 for round in 1 2; do for v in 0 300 5000; do
   export DEHALO_HOST_SPIN_US=$v
   echo "== DEHALO_HOST_SPIN_US=$v, round $round"

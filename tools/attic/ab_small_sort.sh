@@ -2,6 +2,7 @@
 # small MSM launches: sort blocks of 256 scalars (DEHALO_MSM_SMALL_SLICES, default on) and k_msm_bucket blocks of fewer slices (DEHALO_MSM_BUCKET_FILL, default on) against the fixed
 # 2048 scalars / 4 slices: kernels by shape at 2^11 and 2^14, then K = 11 and k = 14 proofs
 . tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
+need_switch DEHALO_MSM_BUCKET_FILL DEHALO_MSM_SMALL_SLICES 
 export TMPDIR=/tmp
 out=gpurun_out/small_sort; mkdir -p $out
 for v in 0 1; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # lookup tables of fixed columns handed to the permutation as distinct rows + multiplicities (default) against sorted in full every proof (DEHALO_PROVER_TABLE_ROWS=0)
 . tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
+need_switch DEHALO_PROVER_TABLE_ROWS 
 for round in 1 2; do for v in 0 1; do
   export DEHALO_PROVER_TABLE_ROWS=$v
   echo "== DEHALO_PROVER_TABLE_ROWS=$v, round $round"

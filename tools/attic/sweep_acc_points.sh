@@ -1,6 +1,7 @@
 #!/bin/bash
 # points-per-lane rule of the accumulation (DEHALO_MSM_ACC_POINTS; 0 = rounds of msm_acc_waves waves): headline line and the k=17 proof
 . tools/exp_lib.sh      # the switches below exist in the measurement build only (make EXPERIMENTS=1)
+need_switch DEHALO_MSM_ACC_POINTS 
 for p in 0 36 44 48 56 64; do
   export DEHALO_MSM_ACC_POINTS=$p
   echo "== acc_points $p"

@@ -10,3 +10,14 @@ if [ -z "$DEHALO_LIBRARY" ]; then
   export DEHALO_LIBRARY=$PWD/gpurun_out/ab/exp/libdehalo.so
   echo "# measurement build: $DEHALO_LIBRARY"
 fi
+
+# need_switch NAME ...: every DEHALO_* switch an A/B script sets must still be a string of the measurement library -- a switch deleted from the sources
+# would make both arms of the A/B the same code and the script would print noise as if it were a result
+need_switch() {
+  for name in "$@"; do
+    if ! strings "$DEHALO_LIBRARY" | grep -qx "$name"; then
+      echo "exp_lib: the measurement library does not read $name (switch removed from the sources?)" >&2
+      exit 2
+    fi
+  done
+}

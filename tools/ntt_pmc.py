@@ -12,7 +12,7 @@ spec = pkg.fields.FIELDS["bn254_fr"]
 batch = 23
 d = ctx.upload(co.fill_scalars(spec.id, "uniform", batch << 19, 3))
 om = spec.encode(po.FIELDS["bn254_fr"].omega(19))
-warm = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+warm = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("NTT_PMC_WARM", "60"))      # (the same number tools/refresh_profiles_r05.sh hands to sq_summary.py --skip-launches)
 for _ in range(warm + 5): ctx.ntt_device(spec.id, d.data_ptr(), 19, om, batch, 0)
 ctx.synchronize()
 dom = pkg.EvaluationDomain(ctx, spec, 5, 17)

@@ -27,11 +27,15 @@ find gpurun_out/final -name "*kernel_trace.csv" -delete
 find gpurun_out/final -name "*agent_info*" -delete
 elif [ "$part" = b ]; then
 echo "[5] SQ counters: k_ntt_pass"
+WARM=${WARM:-60}      # untimed launches of ntt_pmc.py (NTT_PMC_WARM): the counters' window starts 3 passes x WARM launches in
+export NTT_PMC_WARM=$WARM
 for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"; do
   tag=$(echo $pass | cut -d' ' -f1)
+  rm -rf $out/sq_ntt_$tag      # (a re-run must not leave an earlier run's CSVs for sq_summary.py to pick up)
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/sq_ntt_$tag -- python3 tools/ntt_pmc.py > $out/sq_ntt_$tag.log 2>&1
 done
-python3 tools/sq_summary.py $out/sq_ntt_SQ_WAVE_CYCLES $out/sq_ntt_SQ_ACTIVE_INST_ANY --group-by-launch 3 --skip-launches 180 > $out/ntt_sq_counters.txt
+python3 tools/sq_summary.py $out/sq_ntt_SQ_WAVE_CYCLES $out/sq_ntt_SQ_ACTIVE_INST_ANY --group-by-launch 3 --skip-launches $((3 * WARM)) > $out/ntt_sq_counters.txt
+rm -rf $out/kn
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kn -o kn -- python3 tools/ntt_pmc.py > $out/kn.log 2>&1
 python3 tools/accum0_launches.py $out/kn/kn_kernel_trace.csv k_ntt_pass 30 > $out/ntt_pass_durations_without_counters.txt
 echo "[6] batch mode: throughput by provers"
