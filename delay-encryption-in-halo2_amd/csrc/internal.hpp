@@ -118,7 +118,8 @@ struct dehalo_ctx {
                                // dehalo_ctx_set_tuning "host_wait_spin_us" / DEHALO_HOST_SPIN_US): the runtime's blocking wait wakes the thread ~15 us after the stream
                                // drained -- five waits of a K = 11 proof: 1.73 -> 1.65 ms; waits longer than this (a k = 17 commitment) block as before, where it was measured to make no difference
     int msm_acc_min_layers = 4; // the fewest layers of one wave per SIMD the accumulation's grid has (msm_acc_points > 0): 2 .. 4 (DEHALO_MSM_ACC_MIN_LAYERS)
-    int msm_sort_block = 512; // threads per workgroup of the sort's two scalar-decoding kernels: 512 (64 / 58 KiB of LDS: shares a CU) or 1024 (128 / 115 KiB) (dehalo_ctx_set_tuning)
+    int msm_sort_block = 1024; // threads per workgroup of the sort's two scalar-decoding kernels: 1024 (128 / 115 KiB of LDS, a CU to itself) or 512 (64 / 58 KiB: shares a CU with an NTT
+                               // tile / the tails of another context -- measured 2.3 % SLOWER in the step and equal in the proofs, profiles/r06_sort_block_ab.txt) (dehalo_ctx_set_tuning)
     int msm_acc_block = 128; // threads per block of k_msm_accum0: 128, or 768 = one 12-wave block per CU (3 waves per SIMD; dehalo_ctx_set_tuning / DEHALO_MSM_ACC_BLOCK)
     int ntt_full_table_log = 0;    // transforms up to this size keep all N twiddles (32 B x N; one load per inter-pass twiddle), larger ones N / 2 and a
                                    // negation.  Measured equal at 23 x 2^19 with warm clocks (1.19 ms either way: the negation hides behind the load), so

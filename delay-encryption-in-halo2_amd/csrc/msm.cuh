@@ -803,10 +803,12 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     g.n = (u32)len; g.table_n = (u32)bases->n; g.c = bases->c; g.W = bases->W; g.nb = 1u << (g.c - 1);
     g.G = bases->precomp ? 1 : g.W;
     g.batch = (u32)batch;
-    // sort blocks (k_msm_hist, k_msm_part): msm_sort_block threads, two scalars a thread until the grid has 256 K threads, then longer slices.  512-thread
-    // blocks: 64 KiB (packed 16-bit histogram) and 58 KiB (eight waves' staging) of LDS, against 128 and 115 KiB for 1024 threads -- which need a compute
-    // unit to themselves and wait for every NTT tile / merge / reduction block of another context on it to drain
-    const u32 sort_threads = ctx->msm_sort_block == 1024 ? 1024u : 512u;
+    // sort blocks (k_msm_hist, k_msm_part): msm_sort_block threads, two scalars a thread until the grid has 256 K threads, then longer slices.  1024-thread
+    // blocks (the default) take 128 and 115 KiB of LDS and so a compute unit to themselves; 512-thread blocks take 64 KiB (packed 16-bit histogram) and 58 KiB
+    // (eight waves' staging) and start beside an NTT tile / merge / reduction block of another context -- which removes the sort's waiting and nothing else:
+    // the chip is throughput-bound, the time moves to the kernels the sort now shares a CU with, and twice the per-slice histograms cost 26 us of the lone sort
+    // (profiles/r06_sort_block_ab.txt; DESIGN.md sections 4 and 8)
+    const u32 sort_threads = ctx->msm_sort_block == 512 ? 512u : 1024u;
     g.slices = (u32)std::min<size_t>(256 * (1024 / sort_threads), std::max<size_t>(1, len / (2 * sort_threads)));
     {   // small precomputed-table launches: 2048 scalars a sort block leave a 2^14 column 8 blocks and a 2^11 column ONE for k_msm_hist / k_msm_part (21 + 34 us of
         // latency where the work is 2); down to 256 scalars a block until ~128 blocks are there (DEHALO_MSM_SMALL_SLICES=0: the A/B)

@@ -67,6 +67,8 @@ const char* dehalo_last_error(const dehalo_ctx* ctx);
 /* Launch-geometry knobs (results never depend on them).  "msm_acc_points" (default 48): the bucket-accumulation grid of an MSM is 4, 6, 8, ... layers of one wave per SIMD,
  * the fewest that leave a lane at most this many points; 0 selects the older rule, whole rounds of "msm_acc_waves" in [1, 4]
  * waves per SIMD (below 4 the kernel leaves wave slots and registers free for the latency-bound kernels of other contexts).
+ * "msm_sort_block" (1024, the default, or 512): threads per workgroup of the MSM sort's two scalar-decoding kernels; 512 halves their LDS (64 + 58 KiB instead of
+ * 128 + 115 KiB: the histogram packs two 16-bit counters a word) so that they start on a compute unit another context's NTT tile or bucket reduction occupies.
  * "msm_acc_block" (128 or 768): threads per workgroup of the bucket accumulation.  768 = one
  * 12-wave workgroup per compute unit, three waves per SIMD, which leaves a quarter of every SIMD's registers and all of the LDS to the
  * kernels of other contexts that need at most 128 VGPRs (the bucket reduction, the merge, the NTT's half tiles).

@@ -355,6 +355,30 @@ def test_msm_full_size_2_20(pkg, co, ctx, cname):
     assert np.array_equal(ctx.to_affine(spec.id, jab)[0], s)
 
 
+def test_msm_sort_in_512_thread_workgroups_with_packed_histogram(pkg, co):
+    """dehalo_ctx_set_tuning("msm_sort_block", 512): the sort's scalar-decoding kernels in 512-thread workgroups -- k_msm_hist counts into two 16-bit counters a word
+    (64 KiB of LDS) whenever a block's scalars times its windows stay below 2^16, k_msm_part stages on eight waves.  The same results as the CPU port for sizes on
+    both sides of the packed / plain switch, for both table kinds, three distributions, and the one-value column whose counts come closest to a 16-bit counter's
+    limit (every scalar of a block in ONE bucket of every window: 2048 x 16 = 2^15 per counter)."""
+    c5 = pkg.Context(0)
+    c5.set_tuning("msm_sort_block", 512)
+    with pytest.raises(pkg.DehaloError):
+        c5.set_tuning("msm_sort_block", 256)
+    spec = pkg.fields.PALLAS
+    for n, dist in ((1, "uniform"), (777, "witness"), (1 << 12, "lookup"), ((1 << 14) + 17, "uniform"), (1 << 17, "witness"), (1 << 20, "uniform")):
+        bases = co.synth_bases(spec.id, n)
+        scalars = co.fill_scalars(spec.scalar.id, dist, n, 4242 + n)
+        if n == 1 << 17:      # one value everywhere, all 16 digits the same bucket: the densest counter a block can see
+            scalars[:] = spec.scalar.encode(int("0001" * 16, 16) % spec.scalar.p)
+        want = co.to_affine(spec.id, co.best_multiexp(spec.id, scalars, bases, 16))
+        for precompute in ((True, False) if n <= 1 << 17 else (True,)):
+            h = c5.register_bases(spec.id, bases, 16 if n == 1 << 17 else 0, precompute)
+            got = c5.to_affine(spec.id, c5.msm(h, scalars))[0]
+            h.release()
+            assert np.array_equal(got, want), (n, dist, precompute)
+    c5.close()
+
+
 def test_two_contexts_concurrently(pkg, co, ctx):
     """bench.py keeps several steps in flight, one context (stream + workspace) each, sharing one SRS."""
     import torch

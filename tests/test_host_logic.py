@@ -97,7 +97,7 @@ def test_bench_line_fits_the_drivers_tail_and_ends_with_the_metric():
     text = bench.compact_line(rec)
     assert len(text) <= bench.LINE_LIMIT == 6000, len(text)
     line = json.loads(text)
-    assert [e["k"] for e in line["by_k"]] == [14, 17, 20] and len(json.dumps(line["by_k"], separators=(",", ":"))) <= 700
+    assert [e["k"] for e in line["roofline"]["by_k"]] == [14, 17, 20] and len(json.dumps(line["roofline"]["by_k"], separators=(",", ":"))) <= 700
     assert line["roofline"]["traffic_src"].startswith("pmc ")
     keys = list(line)
     assert keys[-4:] == ["proof", "batch_proofs", "attempts", "first_attempt"], keys[-6:]
