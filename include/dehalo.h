@@ -534,14 +534,16 @@ int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, co
  * What the reference's timed create_proof does BEFORE its first commitment: DelayEncryptCircuit::synthesize (src/lib.rs:164-318: RSA
  * time-lock x^e mod n over BigIntChip rows, Poseidon sponge of the packed result, Poseidon cipher of the message under the hash's two
  * outputs), benches/mod_pow.rs:63-110's RSACircuit (the RSA region alone) and PoseidonEncCircuit (src/encryption/chip.rs:114-204, the
- * cipher region alone) -- laid out over MainGate + RangeChip by this library's own layouter (halo2wrong's region code is upstream and
- * not in the reference tree), so the columns belong to THIS library's keygen of the same constraint system.
+ * cipher region alone) -- laid out over MainGate + RangeChip instruction by instruction the way halo2wrong lays them out (row counts: the ones the reference
+ * publishes, benches/README.md:56-99; cell for cell identity with upstream's synthesize is unverified -- the crates are not in the tree), so the columns belong
+ * with a key made by dehalo_keygen from THIS call's fixed columns and mapping.  The reference's circuit is satisfiable only for x < n, e < 2^exp_bits and the
+ * all-zero message its benches encrypt (its in-circuit cipher adds the message twice, its native one never to the state it permutes): other inputs are refused.
  *   advice     out, 5 x 2^k x 4 u64, CANONICAL values (pass DEHALO_PROOF_ADVICE_CANONICAL to dehalo_create_proof), rows beyond the
  *              circuit zero; NULL = not wanted
  *   fixed      out, (15 | 9 for pose_enc) x 2^k x 4 u64 canonical (DEHALO_KEYGEN_FIXED_CANONICAL), range table included; NULL = not wanted
  *   mapping    out, 6 x 2^k u64: the permutation assembly for dehalo_keygen; NULL = not wanted
  *   selectors  out, two arrays of 2^k bytes (s_composition, s_overflow; none for pose_enc); NULL = not wanted
- * Per proof only `advice` is needed; the other three are keygen's.  DEHALO_ERR_INVALID when the circuit does not fit 2^k rows. */
+ * Per proof only `advice` is needed; the other three are keygen's.  DEHALO_ERR_INVALID when the circuit does not fit 2^k rows or a constraint cannot hold. */
 typedef enum { DEHALO_CIRCUIT_DELAY_ENC = 0, DEHALO_CIRCUIT_MOD_POW = 1, DEHALO_CIRCUIT_POSE_ENC = 2 } dehalo_circuit_kind;
 typedef struct {
     uint32_t circuit, k;
