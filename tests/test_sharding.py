@@ -92,7 +92,7 @@ def test_point_ranges_cover_without_overlap(pkg):
 @pytest.mark.parametrize("world", [2, 8])
 def test_all_gather_over_gloo(tmp_path, world):
     """world 2, and the node's own size 8 (rendezvous, every collective of the layer and the column-shard exchange at eight ranks -- on the CPU: the pool allows
-    six processes on a card, so an eight-rank rehearsal cannot touch the GPU)."""
+    six processes on a card, the launcher included, so an eight-rank rehearsal cannot touch the GPU)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     for attempt in range(2):  # a probed-free port can be taken before the rendezvous binds it

@@ -9,6 +9,6 @@ r=r06; F=gpurun_out/final6
 for f in accum0_launch_durations.txt create_proof_k17_phases_under_rocprof.txt create_proof_k17_kernel_timeline.txt create_proof_k17_device_idle.txt create_proof_k17_phases.txt create_proof_k17_host_timeline.txt synthesize_k17.txt; do
   [ -f $F/$f ] && grep -v 'amdgpu.ids' $F/$f > profiles/${r}_$f
 done
-[ -f $F/bench_gpus6_bare_command.json ] && tail -1 $F/bench_gpus6_bare_command.json > profiles/${r}_bench_gpus6_bare_command.json      # (gloo prints a connection notice on stdout before the line)
-[ -f $F/bench_gpus6_bare_command.err ] && grep -v 'socket.cpp\|amdgpu.ids' $F/bench_gpus6_bare_command.err | tail -40 > profiles/${r}_bench_gpus6_bare_command.log
+[ -f $F/bench_gpus5_bare_command.json ] && tail -1 $F/bench_gpus5_bare_command.json > profiles/${r}_bench_gpus5_bare_command.json      # (gloo prints a connection notice on stdout before the line)
+[ -f $F/bench_gpus5_bare_command.err ] && grep -v 'socket.cpp\|amdgpu.ids' $F/bench_gpus5_bare_command.err | tail -40 > profiles/${r}_bench_gpus5_bare_command.log
 ls profiles | grep $r

@@ -21,8 +21,8 @@ timeout -k 10 300 python tools/profile_native_proof.py 17 delay_enc 40 > $out/cr
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info*" -delete
 else
-echo "[4] N = 6 from the bare command (six ranks on this one GPU -- the pool's process guard allows six --, gloo for the gather): both batches, every proof re-made alone"
-timeout -k 10 1000 python3 bench.py --gpus 6 --dist-backend gloo --force-device 0 --proofs 12 --fixed-batch 64 --no-cpu-baseline --full-out "" > $out/bench_gpus6_bare_command.json 2> $out/bench_gpus6_bare_command.err; echo "rc=$?" >> $out/bench_gpus6_bare_command.err
+echo "[4] N = 5 from the bare command (five ranks on this one GPU, gloo for the gather: the pool allows six processes on a card and the launcher is one of them): both batches, every proof re-made alone"
+timeout -k 10 1000 python3 bench.py --gpus 5 --dist-backend gloo --force-device 0 --proofs 10 --fixed-batch 64 --no-cpu-baseline --full-out "" > $out/bench_gpus5_bare_command.json 2> $out/bench_gpus5_bare_command.err; echo "rc=$?" >> $out/bench_gpus5_bare_command.err
 echo "[5] synthesize at the metric's size"
 python tools/synth_bench.py > $out/synthesize_k17.txt 2>&1
 fi
