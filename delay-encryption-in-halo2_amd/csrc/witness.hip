@@ -377,8 +377,30 @@ std::shared_ptr<const PoseidonSpec> poseidon_spec(const HostField* f, uint32_t t
 enum { MG_SA = 0, MG_SB, MG_SC, MG_SD, MG_SE, MG_MUL_AB, MG_MUL_CD, MG_NEXT, MG_CONST, RC_T_TAG, RC_T_VALUE, RC_TAG_COMPOSITION, RC_TAG_OVERFLOW, RC_S_COMPOSITION, RC_S_OVERFLOW, NUM_FIX };
 // RangeChip::configure(composition_bit_lens = [8, 1, 8, 4], overflow_bit_lens = [0, 0, 6]) (src/lib.rs:144-149): the distinct non-zero lengths in
 // ascending order carry the tags 1..4
-constexpr unsigned RANGE_BITS[4] = {1, 4, 6, 8};
-inline uint64_t range_tag(unsigned bits) { return bits == 1 ? 1 : bits == 4 ? 2 : bits == 6 ? 3 : bits == 8 ? 4 : 0; }
+// -- {1, 4, 6, 8} for the reference's 2048-bit modulus.  Only the carries' overflow length depends on the modulus length (compute_range_lens(num_limbs):
+// 2 x (num_limbs (2^64 - 1)^2 + 2^64 - 1) has 134 bits at 32 limbs -- 70-bit carries, a 6-bit overflow limb --, 133 at 16 limbs -- 5 bits).
+struct RangeLens {
+    unsigned bits[5] = {0, 0, 0, 0, 0};
+    unsigned count = 0;
+    explicit RangeLens(size_t num_limbs) {
+        // bit length of 2 * word_max = 1 + bit length of num_limbs * (2^64 - 1)^2 + (2^64 - 1), which is 128 + bit length of num_limbs, less one when num_limbs is
+        // a power of two (num_limbs * (2^64 - 1)^2 + 2^64 - 1 < num_limbs * 2^128 for every num_limbs >= 1)
+        unsigned bl = 0;
+        for (size_t v = num_limbs; v; v >>= 1) bl++;
+        const bool pow2 = num_limbs && !(num_limbs & (num_limbs - 1));
+        const unsigned wm_bits = 1 + 128 + bl - (pow2 ? 1 : 0);
+        const unsigned carry_bits = wm_bits - 64, comp = std::max(1u, carry_bits / 8), over = carry_bits % comp;
+        unsigned cand[5] = {1, 4, 8, comp, over};
+        std::sort(cand, cand + 5);
+        for (unsigned c : cand)
+            if (c && (count == 0 || bits[count - 1] != c)) bits[count++] = c;
+    }
+    uint64_t tag(unsigned b) const {
+        for (unsigned i = 0; i < count; i++)
+            if (bits[i] == b) return i + 1;
+        return 0;
+    }
+};
 constexpr unsigned NUM_LOOKUP_LIMBS = 8;      // src/big_integer/chip.rs:1167
 inline unsigned sublimb_bit_len(unsigned bits) { return std::max(1u, bits / NUM_LOOKUP_LIMBS); }
 
@@ -411,6 +433,8 @@ struct Layouter {
     std::vector<Fe> fix[NUM_FIX];
     std::vector<Copy> copies;
     Fe one_, m1_;
+    RangeLens range{32};             // the RangeChip table this circuit configures (dehalo_synthesize sets it from the modulus length)
+    uint64_t range_tag(unsigned bits) const { return range.tag(bits); }
     Layouter(const HostField* f, bool fixed_too, uint64_t* advice, size_t n) : F{f}, want_fixed(fixed_too), cap(n) {
         if (!advice) own.resize(5 * n);
         Fe* base = advice ? reinterpret_cast<Fe*>(advice) : own.data();
@@ -419,7 +443,7 @@ struct Layouter {
     }
     // a second cursor over the same columns, starting at row `start` (proving only: no fixed columns, no copies): the rows of independent regions whose
     // positions are known in advance are written by several host threads at once (BigIntChip::pow_mod)
-    Layouter(const Layouter& parent, uint32_t start) : F(parent.F), want_fixed(false), cap(parent.cap), nrows(start), one_(parent.one_), m1_(parent.m1_) {
+    Layouter(const Layouter& parent, uint32_t start) : F(parent.F), want_fixed(false), cap(parent.cap), nrows(start), one_(parent.one_), m1_(parent.m1_), range(parent.range) {
         for (int i = 0; i < 5; i++) adv[i] = parent.adv[i];
     }
     uint32_t rows() const { return nrows; }
@@ -601,6 +625,7 @@ struct Layouter {
         if (bit_len < 128 && (value >> bit_len)) fail("range_assign: the value does not fit");
         const unsigned full = bit_len / limb_bits, over = bit_len % limb_bits, nl = full + (over ? 1 : 0);
         if (over && full % 4) throw std::runtime_error("the overflow limb must open a row");
+        if (!range_tag(limb_bits) || (over && !range_tag(over))) fail("range_assign: the range table has no rows for this bit length");
         const u128 mask = ((u128)1 << limb_bits) - 1;
         Cell result, o[5];
         for (unsigned g = 0; g < nl; g += 4) {
@@ -1230,6 +1255,7 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
     } else {
         if (!in->n || !in->x || in->bits_len % LIMB_WIDTH || in->bits_len == 0 || in->bits_len > 8192 || in->exp_bits == 0 || in->exp_bits > 64) return DEHALO_ERR_INVALID;
         const size_t num_limbs = in->bits_len / LIMB_WIDTH;
+        lay.range = RangeLens(num_limbs);
         Big n_big(in->n, in->n + num_limbs), x(in->x, in->x + num_limbs);
         { Big t0 = n_big; big_trim(t0); if (t0.empty()) return DEHALO_ERR_INVALID; }
         if (in->exp_bits < 64 && (in->e >> in->exp_bits)) return DEHALO_ERR_INVALID;
@@ -1278,8 +1304,8 @@ extern "C" int dehalo_synthesize(const dehalo_circuit_inputs* in, uint64_t* advi
         for (uint32_t c = 0; c < num_fixed; c++) memcpy(fixed + (size_t)c * n * 4, lay.fix[c].data(), rows * 32);
         if (range_lookups) {      // RangeChip::load_table rows (tag, value): the disabled row (0, 0), then every value of every bit length
             size_t r = 1;
-            for (unsigned ti = 0; ti < 4; ti++)
-                for (uint64_t v = 0; v < ((uint64_t)1 << RANGE_BITS[ti]); v++, r++) {
+            for (unsigned ti = 0; ti < lay.range.count; ti++)
+                for (uint64_t v = 0; v < ((uint64_t)1 << lay.range.bits[ti]); v++, r++) {
                     if (r >= u) return DEHALO_ERR_INVALID;
                     fixed[((size_t)RC_T_TAG * n + r) * 4] = ti + 1;
                     fixed[((size_t)RC_T_VALUE * n + r) * 4] = v;

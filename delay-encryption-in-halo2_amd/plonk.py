@@ -225,6 +225,16 @@ COMPOSITION_BIT_LENS, OVERFLOW_BIT_LENS = (1, 4, 8), (6,)
 RANGE_BIT_LENS = tuple(sorted(set(COMPOSITION_BIT_LENS + OVERFLOW_BIT_LENS)))
 
 
+def range_bit_lens(num_limbs: int = 32, limb_width: int = 64) -> Tuple[int, ...]:
+    """The distinct table bit lengths of RSAChip::compute_range_lens(num_limbs) in tag order.  Only the carries' overflow length depends on the
+    modulus: 2 x (num_limbs (2^64 - 1)^2 + 2^64 - 1) has 134 bits for the reference's 32 limbs (70-bit carries: eight 8-bit limbs + 6 bits), 133 for 16
+    limbs (5 bits), ..."""
+    word_max = num_limbs * ((1 << limb_width) - 1) ** 2 + (1 << limb_width) - 1
+    carry_bits = (2 * word_max).bit_length() - limb_width
+    comp = max(1, carry_bits // 8)
+    return tuple(sorted({1, 4, 8, comp} | ({carry_bits % comp} - {0})))
+
+
 def maingate_cs(range_lookups: bool = True) -> ConstraintSystem:
     cs = ConstraintSystem(num_advice=5, num_fixed=15 if range_lookups else 9, num_instance=1)
     for i in range(5):                                        # MainGate::configure: equality on a..e and the instance column
@@ -244,16 +254,16 @@ def maingate_cs(range_lookups: bool = True) -> ConstraintSystem:
     return cs
 
 
-def range_table() -> List[Tuple[int, int]]:
+def range_table(num_limbs: int = 32) -> List[Tuple[int, int]]:
     """RangeChip::load_table rows (tag, value): the disabled row (0, 0), then every value of every bit length, shortest first."""
     rows = [(0, 0)]
-    for tag, bits in enumerate(RANGE_BIT_LENS, start=1):
+    for tag, bits in enumerate(range_bit_lens(num_limbs), start=1):
         rows += [(tag, v) for v in range(1 << bits)]
     return rows
 
 
-def range_tag(bits: int) -> int:
-    return 1 + RANGE_BIT_LENS.index(bits)
+def range_tag(bits: int, num_limbs: int = 32) -> int:
+    return 1 + range_bit_lens(num_limbs).index(bits)
 
 
 # ---- permutation::keygen::Assembly ----------------------------------------------------------------------------

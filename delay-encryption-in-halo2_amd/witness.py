@@ -256,8 +256,8 @@ class Layouter:
     plus the RangeChip's tagged lookups; `copies` are the permutation's equalities.  One method per MainGateInstructions /
     RangeInstructions call the reference makes, each laid out as [UPSTREAM] maingate's `apply` lays it out."""
 
-    def __init__(self, p: int):
-        self.p = p
+    def __init__(self, p: int, num_limbs: int = NUM_LIMBS):
+        self.p, self.num_limbs = p, num_limbs                    # num_limbs: which RangeChip table the circuit configures (RSAChip::compute_range_lens)
         self.adv: List[List[int]] = [[] for _ in range(5)]
         self.fix: List[List[int]] = [[] for _ in range(15)]
         self.copies: List[Tuple[int, int, int, int]] = []
@@ -404,12 +404,12 @@ class Layouter:
         terms = [((value >> (limb_bits * i)) & mask, 1 << (limb_bits * i)) for i in range(nlimbs + (1 if over else 0))]
         if over:
             assert nlimbs % 4 == 0, "the overflow limb must open a row (column a carries the overflow lookup)"
-        comp_tag = plonk.range_tag(limb_bits)
+        comp_tag = plonk.range_tag(limb_bits, self.num_limbs)
 
         def extra(last: bool) -> dict:
             d = {plonk.RC_S_COMPOSITION: 1, plonk.RC_TAG_COMPOSITION: comp_tag}
             if last and over:
-                d[plonk.RC_S_OVERFLOW], d[plonk.RC_TAG_OVERFLOW] = 1, plonk.range_tag(over)
+                d[plonk.RC_S_OVERFLOW], d[plonk.RC_TAG_OVERFLOW] = 1, plonk.range_tag(over, self.num_limbs)
             return d
 
         return self._compose_rows(terms, 0, extra)[0]
@@ -674,7 +674,7 @@ def _finish(lay: Layouter, k: int, info: WitnessInfo, range_lookups: bool = True
     fixed = [col + [0] * pad for col in lay.fix[:cs.num_fixed]]
     if not range_lookups:
         assert not any(any(col) for col in lay.fix[cs.num_fixed:]), "range rows in a MainGate-only circuit"
-    for r, (tag, v) in enumerate(plonk.range_table() if range_lookups else []):
+    for r, (tag, v) in enumerate(plonk.range_table(lay.num_limbs) if range_lookups else []):
         fixed[plonk.RC_T_TAG][r], fixed[plonk.RC_T_VALUE][r] = tag, v
     adv = [col + [0] * pad for col in lay.adv]
     asm = plonk.Assembly(len(cs.permutation_columns), n)
@@ -700,8 +700,8 @@ def rsa_region(lay: Layouter, n_big: int, e: int, x: int, exp_bits: int, num_lim
 
 
 def mod_pow_witness(p: int, k: int, n_big: int, e: int, x: int, exp_bits: int, num_limbs: int = NUM_LIMBS):
-    """benches/mod_pow.rs's RSACircuit (RSA region only): BASELINE configs[2]."""
-    lay = Layouter(p)
+    """benches/mod_pow.rs's RSACircuit (RSA region only): BASELINE configs[2].  num_limbs = BITS_LEN / 64: 32 in the checked-in bench (:47), 16 for a 1024-bit modulus."""
+    lay = Layouter(p, num_limbs)
     _, want = rsa_region(lay, n_big, e, x, exp_bits, num_limbs)
     return _finish(lay, k, WitnessInfo(lay.rows, lay.rows, want, []))
 
@@ -767,7 +767,7 @@ def delay_enc_witness(p: int, k: int, n_big: int, e: int, x: int, exp_bits: int,
                       num_limbs: int = NUM_LIMBS):
     """DelayEncryptCircuit::synthesize (src/lib.rs:164-318): RSA time-lock -> Poseidon hash of the packed result -> the two
     hash outputs key a Poseidon cipher over `message`.  Three regions stacked by the SimpleFloorPlanner (same five columns)."""
-    lay = Layouter(p)
+    lay = Layouter(p, num_limbs)
     rsa_out, want = rsa_region(lay, n_big, e, x, exp_bits, num_limbs)
     rsa_rows = lay.rows
     spec = poseidon_spec(p, t, r_f, r_p)
@@ -820,7 +820,7 @@ def check_rows(circ: SyntheticCircuit, p: int) -> int:
 
     fx = [array_to_ints(circ.fixed[i]) for i in range(circ.fixed.shape[0])]
     ad = [array_to_ints(circ.advice[i]) for i in range(5)]
-    table = set(plonk.range_table())
+    table = set(zip(fx[plonk.RC_T_TAG], fx[plonk.RC_T_VALUE])) if len(fx) > plonk.RC_T_VALUE else set()      # the circuit's own table columns
     P = plonk
     for r in range(circ.used_rows):
         a, b, c, d, e = (ad[i][r] for i in range(5))

@@ -547,7 +547,7 @@ int dehalo_create_proofs(dehalo_prover* const* provers, uint32_t num_provers, co
 typedef enum { DEHALO_CIRCUIT_DELAY_ENC = 0, DEHALO_CIRCUIT_MOD_POW = 1, DEHALO_CIRCUIT_POSE_ENC = 2 } dehalo_circuit_kind;
 typedef struct {
     uint32_t circuit, k;
-    uint32_t bits_len, exp_bits;        /* RSA: modulus bits (BITS_LEN = 2048, limbs of 64 bits), exponent bits (<= 64) */
+    uint32_t bits_len, exp_bits;        /* RSA: modulus bits (the reference's BITS_LEN = 2048; any multiple of 64 -- the RangeChip table follows compute_range_lens(bits_len / 64)), exponent bits (<= 64) */
     const uint64_t *n, *x;              /* modulus and base, bits_len / 64 limbs, little-endian */
     uint64_t e;                         /* exponent */
     const uint64_t* message; uint32_t message_len;   /* <= 2 canonical field elements (4 u64 each) */

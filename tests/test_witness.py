@@ -214,6 +214,45 @@ def test_device_proof_of_the_metrics_own_witness_k17(pkg, po, co, ctx):
     P.release(); pk.release(); params.release(); side.close()
 
 
+@pytest.mark.gpu
+def test_device_proof_of_a_1024_bit_mod_pow_witness(pkg, po, co, ctx):
+    """BASELINE configs[2] as BASELINE.json words it -- a 1024-bit RSA mod-exp circuit (the checked-in bench's constant is 2048: test_device_proof_of_the_real_mod_pow_witness):
+    16 limbs, the RangeChip table compute_range_lens(16) gives (5-bit overflow limbs), 5-bit exponent, k = 14: synthesized inside the call, proof bytes equal the CPU
+    restatement's, verifier accepts."""
+    import random
+    import pairing as pr
+    import plonk_oracle as PO
+    import shapes
+    import verifier as V
+    from dehalo2_amd import native, plonk, prover
+
+    rnd = random.Random(1024)
+    n16, x16, e, k = rnd.getrandbits(1024) | (1 << 1023) | 1, rnd.getrandbits(1000), 0b10111, 14
+    inputs = dict(n_big=n16, e=e, x=x16, exp_bits=5, bits_len=1024)
+    nat = native.synthesize(native.CIRCUIT_MOD_POW, k, keygen=True, **inputs)
+    assert nat["rsa_result"] == pow(x16, e, n16) and nat["rows"] == 15671
+    desc = shapes.maingate_description(True)
+    cs = plonk.maingate_cs(True)
+    asm = plonk.Assembly(6, 1 << k)
+    asm.mapping = nat["mapping"].astype(np.int64)
+    s = 0x5EED5EED5EED5EED
+    srs = PO.setup_srs(po.BN254, k, s, 16)
+    key = PO.keygen(po.BN254, srs, desc, k, nat["fixed"], asm.mapping, 16)
+    rep = PO.transcript_repr(po.BN254, key, nat["selectors"])
+    params = native.ParamsKZG.setup(ctx, pkg.fields.BN254, k, s)
+    pk = native.ProvingKey.keygen(ctx, params, cs, nat["fixed"], asm, nat["selectors"])
+    pk.transcript_repr = rep
+    side = pkg.Context(0)
+    P = native.Prover(params, pk, ctx, side)
+    tr, info = P.create_proof_circuit(native.CIRCUIT_MOD_POW, [[]], prover.SeededRng(5), **inputs)
+    adv_m = np.stack([co.field_op(0, "to_mont", nat["advice"][i]) for i in range(5)])
+    want, _ = PO.create_proof(po.BN254, srs, key, adv_m, [[]], PO.ScalarStream(5), rep, 16)
+    proof = tr.finalize()
+    assert proof == want and info["rows"] == nat["rows"]
+    assert V.verify_proof(po.BN254, desc, k, key["fixed_commitments"], key["perm_commitments"], rep, (1, 2), pr.G2, pr.g2_mul(s, pr.G2), [[]], proof)
+    P.release(); pk.release(); params.release(); side.close()
+
+
 def test_mod_pow_rows_satisfy_the_constraint_system(pkg):
     """benches/mod_pow.rs's RSACircuit (RSA region only, :63-110) on a small exponent: rows check out and x^e mod n is right."""
     from dehalo2_amd import witness as W
@@ -551,6 +590,19 @@ def test_synthesized_circuits_pass_the_checkers_own_row_check(pkg, oracles):
     rowcheck.verify(desc, 14, p, nat["fixed"], nat["advice"], nat["mapping"], nat["rows"])
     nat = native.synthesize(native.CIRCUIT_POSE_ENC, 11, key=[5, 6], message=[0, 0], keygen=True)
     rowcheck.verify(shapes.maingate_description(False), 11, p, nat["fixed"], nat["advice"], nat["mapping"], nat["rows"])
+    # BASELINE configs[2] names a 1024-bit modulus (the checked-in bench has BITS_LEN = 2048): 16 limbs configure another RangeChip table (5-bit overflow limbs
+    # instead of 6: compute_range_lens) -- same layouter, C++ == Python bit for bit, the checker's MockProver and its own statement of that table agree
+    import random
+    from dehalo2_amd import witness as W
+    rnd = random.Random(1024)
+    n16, x16 = rnd.getrandbits(1024) | (1 << 1023) | 1, rnd.getrandbits(1000)
+    nat = native.synthesize(native.CIRCUIT_MOD_POW, 14, n_big=n16, e=0b11, x=x16, exp_bits=2, bits_len=1024, keygen=True)
+    circ, info = W.mod_pow_witness(p, 14, n16, 0b11, x16, 2, num_limbs=16)
+    _same_circuit(nat, circ, info)
+    assert nat["rows"] == W.rsa_region_rows(2, 16, 16) and nat["rsa_result"] == pow(x16, 3, n16)
+    rowcheck.verify(desc, 14, p, nat["fixed"], nat["advice"], nat["mapping"], nat["rows"])
+    rowcheck.verify_range_table(nat["fixed"], 14, 16)
+    assert [b for b in sorted({t for t, _ in rowcheck.expected_range_table(16)})] == [0, 1, 2, 3, 4] and len(rowcheck.expected_range_table(16)) == 1 + 2 + 16 + 32 + 256
     # what the reference's circuit cannot satisfy is refused: x >= n (assert_in_field), an exponent wider than exp_bits (to_bits), a non-zero message
     for bad_inputs in (dict(x=n + 5), dict(e=7), dict(message=[1, 2])):
         kw = dict(n_big=n, e=1, x=x, exp_bits=1, message=[0, 0])
