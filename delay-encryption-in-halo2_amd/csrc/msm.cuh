@@ -398,27 +398,29 @@ static __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(const u32*
 // place -- wave-synchronous, no block barrier), reserves its share of every partition run with one
 // returning atomic per partition, and copies the staged pairs out in staging order: a store
 // instruction then touches ~8-16 cache lines instead of 64 (these kernels wait to ISSUE stores).
-#define MSM_PART_WAVE_LDS (4 * 128 * 4 + 512 * 8 + 512 * 2)
+// LDS of one wave: the staging of 512 pairs (8 B + a 2-B partition tag each) and four words per list (count, first slot, cursor, reserved position); `lists` = 128,
+// or 256 for the 256 partitions of a 17-bit window
+#define MSM_PART_WAVE_LDS(lists) (4 * (lists) * 4 + 512 * 8 + 512 * 2)
 template <class FS>
-__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const fe* scalars, const u32* off, const u32* pc, unsigned long long* pairs) {
+__global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const fe* scalars, const u32* off, const u32* pc, unsigned long long* pairs, u32 lists) {
     msm_tail_prio();
     extern __shared__ __align__(8) unsigned char part_smem[];
     const u32 bat = blockIdx.z;
     const u32 sub = msm_sub_bits(g.c), P = g.nb >> sub, submask = (1u << sub) - 1;
-    // windows [w_lo, w_hi) of this block and their bucket groups (k_msm_hist): the runs of (group, partition) pairs, PT <= 128 of them
+    // windows [w_lo, w_hi) of this block and their bucket groups (k_msm_hist): the runs of (group, partition) pairs, PT <= lists of them
     const u32 w_lo = g.G == 1 ? 0 : blockIdx.y * g.wb, w_hi = g.G == 1 ? g.W : min(g.W, w_lo + g.wb);
     const u32 ng = g.G == 1 ? 1 : w_hi - w_lo, grp0 = g.G == 1 ? 0 : w_lo;
     const u32 PT = ng * P;
     const bool one = g.G == 1;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    u32* pcur = reinterpret_cast<u32*>(part_smem);                               // block-shared run cursors [128]
-    unsigned char* wbase = part_smem + 512 + (size_t)wave * MSM_PART_WAVE_LDS;  // this wave's slice
+    u32* pcur = reinterpret_cast<u32*>(part_smem);                               // block-shared run cursors [lists]
+    unsigned char* wbase = part_smem + 4 * lists + (size_t)wave * MSM_PART_WAVE_LDS(lists);  // this wave's slice
     unsigned long long* stage = reinterpret_cast<unsigned long long*>(wbase);   // [512]
-    u32* lcnt = reinterpret_cast<u32*>(wbase + 512 * 8);                         // [128] pairs per partition
-    u32* lbase = lcnt + 128;                                                     // first staging slot
-    u32* lcur = lbase + 128;                                                     // placement cursor
-    u32* gbase = lcur + 128;                                                     // reserved global position
-    unsigned short* stageq = reinterpret_cast<unsigned short*>(gbase + 128);     // [512] partition of a staged pair
+    u32* lcnt = reinterpret_cast<u32*>(wbase + 512 * 8);                         // [lists] pairs per partition
+    u32* lbase = lcnt + lists;                                                   // first staging slot
+    u32* lcur = lbase + lists;                                                   // placement cursor
+    u32* gbase = lcur + lists;                                                   // reserved global position
+    unsigned short* stageq = reinterpret_cast<unsigned short*>(gbase + lists);   // [512] partition of a staged pair
     for (u32 qq = threadIdx.x; qq < PT; qq += blockDim.x) {
         const u32 gi = qq / P, q = qq - gi * P;
         const u64 gidx = (u64)bat * g.G + grp0 + gi;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
             for (int j = 0; j < 8; j++)
                 if (bk[j] != 0xffffffffu) atomicAdd(&lcnt[(one ? 0u : (w0 + j - w_lo) * P) + (bk[j] >> sub)], 1u);
             __builtin_amdgcn_wave_barrier();
-            // scan (PT <= 128: two entries per lane) and reservation in the partition runs
+            // scan (PT <= 256: up to four entries per lane) and reservation in the partition runs
             u32 run = 0;
             for (u32 q0 = 0; q0 < PT; q0 += 64) {
                 const u32 q = q0 + lane;
@@ -816,6 +818,10 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         if (small_slices && g.G == 1 && (size_t)g.slices * batch < 128)
             g.slices = (u32)std::max<size_t>(g.slices, std::min<size_t>(std::max<size_t>(1, len / 256), (128 + batch - 1) / batch));
     }
+    if ((size_t)g.nb * 4 > 128 * 1024) {      // a 17-bit window (2^16 buckets: precomputed tables only): the histogram fits the LDS only as packed 16-bit counters --
+        if (g.G != 1) return dh_fail(ctx, DEHALO_ERR_INVALID, "a 17-bit window needs a precomputed table");
+        g.slices = (u32)std::max<uint64_t>(g.slices, ((uint64_t)len * g.W + 65534) / 65535);      // -- so a slice's scalars times the windows stay below 2^16
+    }
     {   // single-row tables: windows per sort block -- the block's histograms fit 128 KiB of LDS and its (group, partition) runs the 128 staging lists
         const u32 sb = g.c - 1 < 8 ? g.c - 1 : 8, Pg = g.nb >> sb;
         const u32 fit = std::min<u32>(std::min<u32>(g.W, 128 / Pg), (128u * 1024 / 4) / g.nb);
@@ -899,7 +905,8 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     static const u32 hist_threads_env = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_HIST_THREADS"); const int v = e ? atoi(e) : 0; return (u32)std::max(0, std::min(MSM_SORT_THREADS, v & ~63)); }();
     static const u32 part_threads_env = [] { const char* e = DH_EXPERIMENT_ENV("DEHALO_MSM_PART_THREADS"); const int v = e ? atoi(e) : 0; return (u32)std::max(0, std::min(MSM_SORT_THREADS, v & ~63)); }();
     const u32 hist_threads = hist_threads_env ? hist_threads_env : sort_threads, part_threads = part_threads_env ? part_threads_env : sort_threads;
-    const size_t lds_part = dh_co_lds_pad(0, 512 + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS);
+    const u32 part_lists = (g.G == 1 ? P : 128u) > 128u ? 256u : 128u;      // (G == W: wb windows x Pg partitions <= 128 by the choice of wb above)
+    const size_t lds_part = dh_co_lds_pad(0, 4 * (size_t)part_lists + (size_t)(part_threads / 64) * MSM_PART_WAVE_LDS(part_lists));
     HIP_TRY(ctx, dh_func_lds(ctx, (const void*)k_msm_part<FS>, (int)lds_part));
     const u32 tb = (u32)total_buckets;
     {
@@ -915,7 +922,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, (u32)ctx->msm_acc_min_layers, off, nrank, rbeg, rend,
                                                      merge_lists, merge_cap);
         HIP_TRY(ctx, hipGetLastError());
-        k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs);
+        k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs, part_lists);
         const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
         TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bucket, lds_bk));
         // slices per block: 4 (measured best on dense columns) unless DEHALO_MSM_BUCKET_SLICES says otherwise (1 / 2 / 4 / 8: A/B measurements on the

@@ -261,11 +261,12 @@ __global__ __launch_bounds__(BRED_THREADS) void k_msm_bred(u32 nb, u32 bb, const
             BRED_STAMP(7 + 2 * phase);
 #endif
         } else {                   // vec = [A_0 .. A_{m-1}, X]  ->  S = X + sum_j 2^j A_j: quad j doubles A_j j times, then the 16 records are summed
-            for (u32 e = tid; e < 16 * 36; e += BRED_THREADS) lds[e] = e < (m + 1) * 36 ? vec[e] : 0u;
+            const u32 slots = m + 1 <= 16 ? 16u : 32u;      // (2^16 buckets -- a 17-bit window --: 17 records, one more level of the final tree)
+            for (u32 e = tid; e < slots * 36; e += BRED_THREADS) lds[e] = e < (m + 1) * 36 ? vec[e] : 0u;
             __syncthreads();
             if (quad < m)
                 for (u32 i = 0; i < quad; i++) x29q_double_mem<F>(lds + 36 * quad, lds + 36 * quad);
-            C = 0; K = 16; xBase = 0; iStride = 1;
+            C = 0; K = slots; xBase = 0; iStride = 1;
         }
         __syncthreads();
         if (phase == 3) BRED_STAMP(5);

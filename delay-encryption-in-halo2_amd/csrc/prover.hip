@@ -191,7 +191,8 @@ extern "C" int dehalo_params_setup(dehalo_ctx* ctx, int curve, uint32_t k, const
     if (!ctx || !out || !s) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: null argument");
     if (curve != DEHALO_CURVE_BN254_G1) return dh_fail(ctx, DEHALO_ERR_UNSUPPORTED, "params_setup: ParamsKZG needs a pairing: BN254 only");
     const HostField* f = host_field(curve_scalar_field(curve));
-    if (k > f->two_adicity || k > 26) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: k out of range");
+    if (k > f->two_adicity) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: k out of range");
+    if (k > 25) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: k > 25: the SRS tables would be too large (include/dehalo.h)");      // (2 x 15 x 2^26 x 64 B = 128 GB at k = 26: fits the index and the card, never exercised)
     // checked BEFORE the 2^(k+1) fixed-base multiplications: the tables this call registers must fit (BN254: k <= 25, include/dehalo.h)
     if (!dh_precomputed_table_fits(curve, (size_t)1 << k)) return dh_fail(ctx, DEHALO_ERR_INVALID, "params_setup: 2^k x windows >= 2^30: precomputed table too large");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);

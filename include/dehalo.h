@@ -107,12 +107,12 @@ int dehalo_upload(dehalo_ctx* ctx, const void* host_src, size_t bytes, void* d_d
  * benches/delay_enc.rs:41-54].  Bases are constant per SRS, so they are uploaded once and
  * stay resident in HBM.
  *   affine_xy     n points, `stride_bytes` apart (>= 64; 64 for halo2curves' {x, y} structs)
- *   window_bits   0 = choose from n; otherwise the Pippenger window c in [4, 16]
+ *   window_bits   0 = choose from n (17 from 2^20 points with precompute = 1, 15 from 2^17, 13 below); otherwise the Pippenger window c in [4, 16], or 17 with precompute = 1
  *   precompute    1 = also store [2^(c*w)]P_i for every window w (n * ceil(256/c) * 64 B of
  *                 HBM): all windows then share one bucket set and the per-window doublings
  *                 vanish.  0 = store the n points only.
  * Limits: n < 2^30; with precompute = 1 also n x windows < 2^30 (30-bit table indices in the sorted list; windows = the signed-digit windows of the
- * scalar field at the chosen c, e.g. 16 for BN254 at c = 16): the default window admits BN254 tables up to n = 2^25.  Beyond: DEHALO_ERR_INVALID.
+ * scalar field at the chosen c, e.g. 15 for BN254 and the Pasta fields at c = 17): the default window admits tables up to n = 2^26.  Beyond: DEHALO_ERR_INVALID.
  */
 int dehalo_bases_register(dehalo_ctx* ctx, int curve, const uint64_t* affine_xy, size_t n, size_t stride_bytes,
                           int window_bits, int precompute, dehalo_bases** out);
@@ -414,8 +414,8 @@ int dehalo_params_create(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t*
                          dehalo_params** out);
 /* ParamsKZG::setup(k, rng) with the rng's draw handed over: `s` is the toxic waste as a Montgomery scalar (what `<E::Scalar>::random(rng)` returns).  g[i] = [s^i] G
  * and g_lagrange[i] = [L_i(s)] G are made on the device (fixed-base table multiplication, one batch inversion), g2 / s_g2 on the host: the reference's
- * `ParamsKZG::<Bn256>::setup(K, OsRng)` (benches/delay_enc.rs:43).  BN254 only (a KZG SRS needs the pairing); k <= 25 (the precomputed-table limit above, checked before
- * any device work: k = 26 is DEHALO_ERR_INVALID). */
+ * `ParamsKZG::<Bn256>::setup(K, OsRng)` (benches/delay_enc.rs:43).  BN254 only (a KZG SRS needs the pairing); k <= 25 (checked before any device work: k = 26, whose two tables
+ * would take 128 GB, is DEHALO_ERR_INVALID). */
 int dehalo_params_setup(dehalo_ctx* ctx, int curve, uint32_t k, const uint64_t s[4], dehalo_params** out);
 int dehalo_params_read(dehalo_ctx* ctx, int curve, const uint8_t* bytes, size_t len, dehalo_params** out);
 size_t dehalo_params_size(const dehalo_params* params);

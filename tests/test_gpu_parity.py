@@ -216,7 +216,7 @@ def test_msm_vs_c_oracle(pkg, co, ctx, cname, n, dist):
         assert np.array_equal(got, want), (cname, n, dist, precompute)
 
 
-@pytest.mark.parametrize("c", [4, 5, 8, 11, 13, 16])
+@pytest.mark.parametrize("c", [4, 5, 8, 11, 13, 16, 17])
 def test_msm_every_window_size(pkg, co, ctx, c):
     spec = pkg.fields.PALLAS
     n = 3000
@@ -227,11 +227,14 @@ def test_msm_every_window_size(pkg, co, ctx, c):
     special = [r - 1, r - 2, (1 << 254) - 1, (1 << 253), int("f" * 62, 16) % r, int("8" * 63, 16) % r, 1, 0]
     scalars[: len(special)] = spec.scalar.encode_many(special)
     want = co.to_affine(spec.id, co.best_multiexp(spec.id, scalars, bases, 8))
-    for precompute in (True, False):
+    for precompute in ((True, False) if c <= 16 else (True,)):      # (17 bits: 2^16 buckets, precomputed rows only -- 15 windows for the Pasta scalar fields)
         h = ctx.register_bases(spec.id, bases, c, precompute)
         got = ctx.to_affine(spec.id, ctx.msm(h, scalars))[0]
         h.release()
         assert np.array_equal(got, want), (c, precompute)
+    if c == 17:
+        with pytest.raises(pkg.DehaloError):
+            ctx.register_bases(spec.id, bases, 17, False)
 
 
 def test_msm_prefix_and_batch(pkg, co, ctx):
@@ -353,6 +356,29 @@ def test_msm_full_size_2_20(pkg, co, ctx, cname):
     pa, pb = ctx.to_affine(spec.id, ja)[0], ctx.to_affine(spec.id, jb)[0]
     s = co.to_affine(spec.id, co.best_multiexp(spec.id, np.stack([one, one]), np.stack([pa, pb]), 1))
     assert np.array_equal(ctx.to_affine(spec.id, jab)[0], s)
+
+
+@pytest.mark.parametrize("cname", ["pallas", "bn254", "vesta"])
+def test_msm_17_bit_windows_at_2_20(pkg, co, ctx, cname):
+    """Precomputed tables with 17-bit windows: 15 rows instead of 16, 2^16 buckets -- the histogram as packed 16-bit counters (128 KiB), 256 partitions in the
+    scatter, a full three-level bucket reduction.  2^20 points, uniform and skewed scalars, and a batch of two columns, against the CPU port."""
+    spec = pkg.fields.CURVES[cname]
+    n = 1 << 20
+    bases = co.synth_bases(spec.id, n)
+    h = ctx.register_bases(spec.id, bases, 17, True)
+    assert (h.window_bits, h.windows) == (17, 15)
+    for dist, seed in (("uniform", 11), ("lookup", 12)):
+        sc = co.fill_scalars(spec.scalar.id, dist, n, seed)
+        want = co.to_affine(spec.id, co.best_multiexp(spec.id, sc, bases, 16))
+        assert np.array_equal(ctx.to_affine(spec.id, ctx.msm(h, sc))[0], want), (cname, dist)
+    # a prefix (commit uses the first len bases) and edge scalars: r - 1, the all-ones windows, one value everywhere
+    m = (1 << 17) + 5
+    sc = co.fill_scalars(spec.scalar.id, "witness", m, 13)
+    r = spec.scalar.p
+    sc[:4] = spec.scalar.encode_many([r - 1, (1 << 254) - 1, int("1ffff" * 12, 16) % r, 0])
+    want = co.to_affine(spec.id, co.best_multiexp(spec.id, sc, bases[:m], 16))
+    assert np.array_equal(ctx.to_affine(spec.id, ctx.msm(h, sc))[0], want)
+    h.release()
 
 
 def test_msm_sort_in_512_thread_workgroups_with_packed_histogram(pkg, co):
