@@ -23,6 +23,7 @@ uint32_t choose_window(size_t n) {
     // 2^20 and up: 17 bits -- 15 rows instead of 16 (6 % fewer additions), 2^16 buckets whose histogram fits the LDS as packed 16-bit counters; four alternating pairs
     // at 2^20: 760.7 -> 779.1 Mpoints/s in the step, one MSM alone 1.55 -> 1.48 ms (profiles/r06_window_17.txt)
     if (l >= 20) return 17;
+    if (l >= 19) return 16;      // k = 19 proofs 25.7 -> 25.0 ms against 15 bits (17: 26.4); k = 17 / 18 stay at 15 (7.25 / 12.9 ms against 7.5 / 13.0 at 16): profiles/r06_window_sweep_proofs.txt
     if (l >= 17) return 15;
     if (l >= 10) return 13;
     return std::max<uint32_t>(6, l + 1);

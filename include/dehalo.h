@@ -107,7 +107,7 @@ int dehalo_upload(dehalo_ctx* ctx, const void* host_src, size_t bytes, void* d_d
  * benches/delay_enc.rs:41-54].  Bases are constant per SRS, so they are uploaded once and
  * stay resident in HBM.
  *   affine_xy     n points, `stride_bytes` apart (>= 64; 64 for halo2curves' {x, y} structs)
- *   window_bits   0 = choose from n (17 from 2^20 points with precompute = 1, 15 from 2^17, 13 below); otherwise the Pippenger window c in [4, 16], or 17 with precompute = 1
+ *   window_bits   0 = choose from n (with precompute = 1: 17 from 2^20 points, 16 at 2^19, 15 from 2^17, 13 below); otherwise the Pippenger window c in [4, 16], or 17 with precompute = 1
  *   precompute    1 = also store [2^(c*w)]P_i for every window w (n * ceil(256/c) * 64 B of
  *                 HBM): all windows then share one bucket set and the per-window doublings
  *                 vanish.  0 = store the n points only.
