@@ -216,8 +216,13 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
     for (u32 gi = 0; gi < ng; gi++) {
         const u64 gidx = (u64)bat * g.G + grp0 + gi;
         const u32* lh = lhist + (PACK16 ? gi * g.nb / 2 : gi * g.nb);
-        u32* out = bh + (gidx * g.slices + blockIdx.x) * g.nb;
-        for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) out[b] = count_of(lh, b);
+        if (PACK16) {      // the packed words as they are: a 16-bit count per bucket in memory (half the bytes written here and read by the column scan)
+            u32* out = bh + ((gidx * g.slices + blockIdx.x) * g.nb) / 2;      // (bh: the 16-bit array's base, run_msm_t)
+            for (u32 w = threadIdx.x; w < g.nb / 2; w += blockDim.x) out[w] = lh[w];
+        } else {
+            u32* out = bh + (gidx * g.slices + blockIdx.x) * g.nb;
+            for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) out[b] = lh[b];
+        }
         // partition = the bucket's top bits; its count for this slice (second sort level, see k_msm_part)
         u32* pout = pc + (gidx * g.slices + blockIdx.x) * P;
         for (u32 t = threadIdx.x; t < P * ways; t += blockDim.x) {
@@ -235,16 +240,19 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
 
 // column scan: for every bucket, exclusive prefix over the slices (in place) and the total count.  One launch covers two tables:
 // blocks [0, blocks_a) the per-bucket histograms (bh, counts out), the rest the per-partition counts (pc, no totals).
-FP_DEV u32 colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 gb) {
+// (src16: the counts as 16-bit values, k_msm_hist<PACK16>; null: they sit in `bh` itself and are replaced by their prefixes)
+template <bool SRC16>
+FP_DEV u32 colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, const unsigned short* src16, u32* count, u32 gb) {
     if (gb >= total_buckets) return 0;
     u32 grp = gb / nb, b = gb - grp * nb;
     u32* col = bh + (u64)grp * slices * nb + b;
+    const unsigned short* col16 = SRC16 ? src16 + (u64)grp * slices * nb + b : nullptr;
     u32 run = 0;
     u32 k = 0;
     for (; k + 16 <= slices; k += 16) {   // 16 independent loads in flight per lane, then the prefix
         u32 v[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = col[(u64)(k + j) * nb];
+        for (int j = 0; j < 16; j++) v[j] = SRC16 ? (u32)col16[(u64)(k + j) * nb] : col[(u64)(k + j) * nb];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             col[(u64)(k + j) * nb] = run;
@@ -252,7 +260,7 @@ FP_DEV u32 colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* coun
         }
     }
     for (; k < slices; k++) {
-        u32 v = col[(u64)k * nb];
+        u32 v = SRC16 ? (u32)col16[(u64)k * nb] : col[(u64)k * nb];
         col[(u64)k * nb] = run;
         run += v;
     }
@@ -262,15 +270,16 @@ FP_DEV u32 colscan_one(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* coun
 // (256 threads.)  A block of the first table also leaves the sums of its 256 buckets -- points and non-empty buckets -- for the scan below:
 // bsum_items / bsum_tasks [blockIdx] (until round 4 a launch of its own, k_scan_block_sums).
 #define SCAN_THREADS 256
-static __global__ __launch_bounds__(SCAN_THREADS) void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, u32* count, u32 blocks_a, u32 P, u32 total_parts, u32* pc,
-                                                                     u32* bsum_items, u32* bsum_tasks, u32* merge_counters) {
+static __global__ __launch_bounds__(SCAN_THREADS) void k_msm_colscan(u32 nb, u32 slices, u32 total_buckets, u32* bh, const unsigned short* bh16, u32* count, u32 blocks_a, u32 P,
+                                                                     u32 total_parts, u32* pc, u32* bsum_items, u32* bsum_tasks, u32* merge_counters) {
     msm_tail_prio();
     if (blockIdx.x == 0 && threadIdx.x < MSM_MERGE_COUNTERS) merge_counters[threadIdx.x] = 0;      // (k_scan_offsets counts the merge classes: zero before it starts, no fill launch)
     if (blockIdx.x >= blocks_a) {
-        colscan_one(P, slices, total_parts, pc, nullptr, (blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
+        colscan_one<false>(P, slices, total_parts, pc, nullptr, nullptr, (blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
         return;
     }
-    const u32 v = colscan_one(nb, slices, total_buckets, bh, count, blockIdx.x * blockDim.x + threadIdx.x);
+    const u32 gb0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 v = bh16 ? colscan_one<true>(nb, slices, total_buckets, bh, bh16, count, gb0) : colscan_one<false>(nb, slices, total_buckets, bh, nullptr, count, gb0);
     u32 si = v, st = v ? 1u : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { si += __shfl_down(si, d); st += __shfl_down(st, d); }
@@ -854,7 +863,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
 
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
     TRY(dh_ensure(ctx, ctx->ws_counters, 64));                                   // 8 merge-class counters | L0 | M
-    TRY(dh_ensure(ctx, ctx->ws_bhist, total_buckets * (size_t)g.slices * 4));   // per-block histograms
+    TRY(dh_ensure(ctx, ctx->ws_bhist, total_buckets * (size_t)g.slices * 6));   // per-block histograms: the prefixes (u32), and behind them the packed 16-bit counts when k_msm_hist writes those
     const u32 sub_bits = g.c - 1 < 8 ? g.c - 1 : 8, P = g.nb >> sub_bits;
     TRY(dh_ensure(ctx, ctx->ws_pcount, total_groups * (size_t)g.slices * P * 4));   // per-(slice, partition) counts
     TRY(dh_ensure(ctx, ctx->ws_pairs, Mmax * 8));                                   // partition-sorted (sub-bucket, reference) pairs
@@ -912,13 +921,14 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     {
         ScopedTimer t(ctx, s, DEHALO_K_MSM_SORT);
         dim3 grid(g.slices, g.G == 1 ? 1 : (g.G + g.wb - 1) / g.wb, (u32)batch);
-        if (pack16) k_msm_hist<FS, true><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
+        unsigned short* bh16 = reinterpret_cast<unsigned short*>(bh + total_buckets * (size_t)g.slices);
+        if (pack16) k_msm_hist<FS, true><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, reinterpret_cast<u32*>(bh16), pc);
         else k_msm_hist<FS, false><<<grid, hist_threads, lds_hist, s>>>(g, d_scalars, bh, pc);
         const u32 cs_a = (tb + 255) / 256, cs_b = ((u32)total_groups * P + 255) / 256;
         TRY(dh_ensure(ctx, ctx->ws_bsum, (size_t)cs_a * 2 * sizeof(u32)));
         u32* bs_i = (u32*)ctx->ws_bsum.p;
         u32* bs_t = bs_i + cs_a;
-        k_msm_colscan<<<cs_a + cs_b, SCAN_THREADS, 0, s>>>(g.nb, g.slices, tb, bh, count, cs_a, P, (u32)total_groups * P, pc, bs_i, bs_t, merge_counters);
+        k_msm_colscan<<<cs_a + cs_b, SCAN_THREADS, 0, s>>>(g.nb, g.slices, tb, bh, pack16 ? bh16 : nullptr, count, cs_a, P, (u32)total_groups * P, pc, bs_i, bs_t, merge_counters);
         k_scan_offsets<<<cs_a, SCAN_THREADS, 0, s>>>(count, tb, bs_i, bs_t, cs_a, cursor + MSM_MERGE_COUNTERS, (u32)resident, (u32)lmax, lcap, (u32)ctx->msm_acc_min_layers, off, nrank, rbeg, rend,
                                                      merge_lists, merge_cap);
         HIP_TRY(ctx, hipGetLastError());
