@@ -141,7 +141,8 @@ struct DigitStream {
 };
 
 // second-level split of the bucket index: buckets = partitions x 2^sub sub-buckets
-FP_DEV u32 msm_sub_bits(u32 c) { return c - 1 < 8 ? c - 1 : 8; }
+// (17-bit windows: 512 sub-buckets, so that the 2^16 buckets are still 128 partitions -- k_msm_part's lists -- and a k_msm_bucket round is still 2048 pairs)
+__host__ __device__ inline u32 msm_sub_bits(u32 c) { return c - 1 < 8 ? c - 1 : (c >= 17 ? 9u : 8u); }
 
 // Groups of equal scalars inside a wave.  A grand-product column over unused rows, a permuted lookup column's runs of equal inputs and a sorted table hand a
 // wave ONE value -- or two or three where runs meet; lanes that hold the same scalar have the same digits, so per window one lane per GROUP counts / reserves
@@ -175,7 +176,6 @@ template <class FS, bool PACK16>
 __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(MsmGeom g, const fe* scalars, u32* bh, u32* pc) {
     msm_tail_prio();
     extern __shared__ u32 lhist[];
-    auto count_of = [&](const u32* base, u32 b) -> u32 { return PACK16 ? (base[b >> 1] >> ((b & 1u) << 4)) & 0xffffu : base[b]; };
     // G == 1: the block counts every window into the one bucket set.  G == W: it covers windows [w_lo, w_hi), one bucket set each
     // (a scalar is decoded once per block, not once per window: ceil(W / wb) passes over the scalars instead of W).
     const u32 bat = blockIdx.z;
@@ -212,7 +212,6 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
     }
     __syncthreads();
     const u32 sub = msm_sub_bits(g.c), P = g.nb >> sub;
-    const u32 ways = sub >= 3 ? 8 : 1, chunk = (1u << sub) / ways;   // 8 lanes share a partition's 2^sub counters
     for (u32 gi = 0; gi < ng; gi++) {
         const u64 gidx = (u64)bat * g.G + grp0 + gi;
         const u32* lh = lhist + (PACK16 ? gi * g.nb / 2 : gi * g.nb);
@@ -225,15 +224,19 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) MSM_HIST_ATTR void k_msm_hist(Msm
         }
         // partition = the bucket's top bits; its count for this slice (second sort level, see k_msm_part)
         u32* pout = pc + (gidx * g.slices + blockIdx.x) * P;
-        for (u32 t = threadIdx.x; t < P * ways; t += blockDim.x) {
-            u32 q = t / ways, part = t % ways, sum = 0;
-            for (u32 j = 0; j < chunk; j++) sum += count_of(lh, (q << sub) + part * chunk + j);
-            if (ways == 8) {
-                sum += __shfl_down(sum, 4, 8);
-                sum += __shfl_down(sum, 2, 8);
-                sum += __shfl_down(sum, 1, 8);
+        // one wave per partition at a time: its 64 lanes read consecutive LDS words (eight lanes striding through a partition's counters, as until round 6, put
+        // all of them on one bank: 14 us of this kernel with the 512 counters of a 17-bit window's partitions)
+        const u32 nsub = 1u << sub, lane = threadIdx.x & 63;
+        for (u32 q = threadIdx.x >> 6; q < P; q += blockDim.x >> 6) {
+            u32 sum = 0;
+            if (PACK16) {
+                for (u32 w = lane; w < nsub / 2; w += 64) { const u32 x = lh[(q << sub) / 2 + w]; sum += (x & 0xffffu) + (x >> 16); }
+            } else {
+                for (u32 b = lane; b < nsub; b += 64) sum += lh[(q << sub) + b];
             }
-            if (part == 0) pout[q] = sum;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+            if (lane == 0) pout[q] = sum;
         }
     }
 }
@@ -536,8 +539,8 @@ __global__ __launch_bounds__(MSM_SORT_THREADS) void k_msm_part(MsmGeom g, const 
 static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 slices, const u32* off, const u32* bh, const u32* pc,
                                                           const unsigned long long* pairs, u32* idx_out, u32 per_block) {
     msm_tail_prio();
-    __shared__ u32 lcur[256], lfirst[256];
-    const u32 sub = msm_sub_bits(c), P = nb >> sub, nsub = 1u << sub;
+    __shared__ u32 lcur[512], lfirst[512];
+    const u32 sub = msm_sub_bits(c), P = nb >> sub, nsub = 1u << sub;      // nsub <= 512
     const u32 chunks = (slices + per_block - 1) / per_block;      // per_block: consecutive slices one block walks (MSM_BUCKET_SLICES, or fewer: run_msm_t)
     const u64 gidx = blockIdx.y;
     u32 p, ch;
@@ -560,7 +563,7 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
     __syncthreads();
     // Rounds of <= 2048 pairs: grouped by sub-bucket in LDS (count, scan, place), then copied out in
     // staging order -- a store instruction touches ~8 lines (32-byte runs) instead of 64.
-    __shared__ u32 cnt[256], sbase[256], scur[256], wsum[4];
+    __shared__ u32 cnt[512], sbase[512], scur[512], wsum[4];
     __shared__ u32 stage[2048];
     __shared__ unsigned short stageq[2048];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -568,6 +571,7 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
         const u32 rend = min(r0 + 2048u, end);
         unsigned long long pr[8];
         if (tid < nsub) cnt[tid] = 0;
+        if (tid + 256 < nsub) cnt[tid + 256] = 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -582,7 +586,7 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
             } else if (v) atomicAdd(&cnt[sb], 1u);
         }
         __syncthreads();
-        {   // exclusive scan of the (<= 256) counts: one per thread
+        if (nsub <= 256) {   // exclusive scan of the (<= 256) counts: one per thread
             u32 v = tid < nsub ? cnt[tid] : 0, x = v;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
@@ -591,6 +595,18 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
             u32 before = 0;
             for (u32 w = 0; w < wave; w++) before += wsum[w];
             if (tid < nsub) { sbase[tid] = before + x - v; scur[tid] = before + x - v; }
+        } else {             // 512 counts (17-bit windows): two consecutive ones per thread
+            const u32 v0 = cnt[2 * tid], v1 = cnt[2 * tid + 1];
+            u32 x = v0 + v1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+            if (lane == 63) wsum[wave] = x;
+            __syncthreads();
+            u32 before = 0;
+            for (u32 w = 0; w < wave; w++) before += wsum[w];
+            const u32 e0 = before + x - v0 - v1;
+            sbase[2 * tid] = e0; scur[2 * tid] = e0;
+            sbase[2 * tid + 1] = e0 + v0; scur[2 * tid + 1] = e0 + v0;
         }
         __syncthreads();
 #pragma unroll
@@ -617,6 +633,7 @@ static __global__ __launch_bounds__(256) void k_msm_bucket(u32 nb, u32 c, u32 sl
         }
         __syncthreads();
         if (tid < nsub) lcur[tid] += cnt[tid];     // the next round continues where this one ended
+        if (tid + 256 < nsub) lcur[tid + 256] += cnt[tid + 256];
     }
 }
 
@@ -832,7 +849,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
         g.slices = (u32)std::max<uint64_t>(g.slices, ((uint64_t)len * g.W + 65534) / 65535);      // -- so a slice's scalars times the windows stay below 2^16
     }
     {   // single-row tables: windows per sort block -- the block's histograms fit 128 KiB of LDS and its (group, partition) runs the 128 staging lists
-        const u32 sb = g.c - 1 < 8 ? g.c - 1 : 8, Pg = g.nb >> sb;
+        const u32 sb = msm_sub_bits(g.c), Pg = g.nb >> sb;
         const u32 fit = std::min<u32>(std::min<u32>(g.W, 128 / Pg), (128u * 1024 / 4) / g.nb);
         const u32 fill = (u32)((uint64_t)g.W * g.slices * batch / 256);        // ... while the grid keeps >= 256 blocks (2^14: one window per block as before)
         g.wb = g.G == 1 ? g.W : std::max<u32>(1, std::min<u32>(fit, fill));
@@ -864,7 +881,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
     TRY(dh_ensure(ctx, ctx->ws_count, total_buckets * 4));
     TRY(dh_ensure(ctx, ctx->ws_counters, 64));                                   // 8 merge-class counters | L0 | M
     TRY(dh_ensure(ctx, ctx->ws_bhist, total_buckets * (size_t)g.slices * 6));   // per-block histograms: the prefixes (u32), and behind them the packed 16-bit counts when k_msm_hist writes those
-    const u32 sub_bits = g.c - 1 < 8 ? g.c - 1 : 8, P = g.nb >> sub_bits;
+    const u32 sub_bits = msm_sub_bits(g.c), P = g.nb >> sub_bits;
     TRY(dh_ensure(ctx, ctx->ws_pcount, total_groups * (size_t)g.slices * P * 4));   // per-(slice, partition) counts
     TRY(dh_ensure(ctx, ctx->ws_pairs, Mmax * 8));                                   // partition-sorted (sub-bucket, reference) pairs
     TRY(dh_ensure(ctx, ctx->ws_off, (total_buckets + 1) * 4));
@@ -933,7 +950,7 @@ int run_msm_t(dehalo_ctx* ctx, const dehalo_bases* bases, const fe* d_scalars, s
                                                      merge_lists, merge_cap);
         HIP_TRY(ctx, hipGetLastError());
         k_msm_part<FS><<<grid, part_threads, lds_part, s>>>(g, d_scalars, off, pc, pairs, part_lists);
-        const size_t lds_bk = dh_co_lds_pad(17 * 1024, 0);
+        const size_t lds_bk = dh_co_lds_pad(22 * 1024, 0);
         TRY(dh_co_lds_attr(ctx, (const void*)k_msm_bucket, lds_bk));
         // slices per block: 4 (measured best on dense columns) unless DEHALO_MSM_BUCKET_SLICES says otherwise (1 / 2 / 4 / 8: A/B measurements on the
         // skewed columns of a proof, where a block's run can be 17 windows x 4 slices of ONE value)
