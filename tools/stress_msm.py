@@ -14,8 +14,12 @@ ctx = pkg.Context(0)
 for trial in range(trials):
     spec = curves[trial % 3]
     n = int(rng.integers(1, 3000)) if trial % 3 else int(rng.integers(3000, 70000))
-    c = int(rng.choice([0, 4, 5, 7, 9, 10, 12, 13, 14, 15, 16]))
-    precompute = bool(rng.integers(0, 2))
+    c = int(rng.choice([0, 4, 5, 7, 9, 10, 12, 13, 14, 15, 16, 17]))
+    precompute = bool(rng.integers(0, 2)) or c == 17      # (17 bits: precomputed rows only)
+    if trial % 7 == 3:                                     # every seventh trial with the sort in 512-thread workgroups
+        ctx.set_tuning("msm_sort_block", 512)
+    elif trial % 7 == 4:
+        ctx.set_tuning("msm_sort_block", 1024)
     batch = int(rng.choice([1, 1, 2, 3, 6, 9]))
     bases = co.synth_bases(spec.id, n)
     h = ctx.register_bases(spec.id, bases, c, precompute)
