@@ -103,6 +103,7 @@ FP_DEV fe tw_lookup(const fe* tw, u64 e, u32 log_n, bool full) {
 //   NTT_X_NOSYNC   no workgroup barrier between the butterfly rounds (an upper bound on what wave-private sub-transforms could win)
 //   NTT_X_NOLOAD   the tile is filled from the index instead of from global memory (what hiding the whole load latency could win)
 //   NTT_X_NOTW     the inter-pass twiddle of the output multiplication is not loaded
+//   NTT_X_LINEAR_FILL  the last pass fills its tile row-wise (no LDS bank conflicts in the transposing fill)
 #define NTT_LOADS 4        // elements of a tile per thread (2048 / 512, 1024 / 256)
 #ifdef NTT_X_NOSYNC
 #define NTT_STAGE_SYNC() __builtin_amdgcn_wave_barrier()
@@ -129,6 +130,16 @@ FP_DEV void lds29_store(const Lds29& L, u32 i, const f29& v) {
     L.p8[i] = v.v[8];
 }
 
+// Where element (row, column c) of the R x C tile sits in a plane: the column is XORed with the row's TOP log2 C bits.  A row is still C consecutive slots (every
+// round, the row-wise fills and the store touch whole rows: conflict-free as before), but a COLUMN -- the last pass fills its tile down the columns, 64 lanes with
+// consecutive j writing rows bitrev(j) of one column -- no longer lies on two banks (64 LDS cycles per store instruction instead of 4: measured by elimination,
+// profiles/r06_ntt_transposing_fill.txt, 1.2-2.7 % of a transform).
+#ifdef NTT_NO_SWIZZLE      // (tools/attic/ab_ntt.sh "-DNTT_NO_SWIZZLE": the plain layout of rounds 1-5, for the A/B)
+FP_DEV u32 ntt_at(u32 row, u32 c, u32 log_c, u32) { return (row << log_c) + c; }
+#else
+FP_DEV u32 ntt_at(u32 row, u32 c, u32 log_c, u32 sw_shift) { return (row << log_c) + (c ^ ((row >> sw_shift) & ((1u << log_c) - 1))); }
+#endif
+
 // DIT butterfly on lazily reduced limbs; v may carry limbs < 2^31, w is normalized
 template <class F9>
 FP_DEV void bfly29(f29& u, f29& v, const f29& w, bool mul) {
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     const u32 r = P.r, log_c = P.log_c;
     const u32 R = 1u << r, Cc = 1u << log_c;
     const u32 tile = R << log_c;
+    const u32 sw = r > log_c ? r - log_c : 0;      // ntt_at's shift: the row's top log_c bits
 #ifdef DEHALO_EXPERIMENTS
     unsigned long long* stamp = P.stamps ? P.stamps + 4 * ((u64)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
 #endif
@@ -205,8 +217,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
                     else if (m3 == 2) v = f29_mul<F9>(v, pre2);
                 }
             }
-            const u32 a0 = (bitrev32(j, r) << log_c) + c;
-            lds29_store(L, a0, v); lds29_store(L, a0 + Cc, v); lds29_store(L, a0 + 2 * Cc, v); lds29_store(L, a0 + 3 * Cc, v);
+            const u32 b0 = bitrev32(j, r);
+            lds29_store(L, ntt_at(b0, c, log_c, sw), v); lds29_store(L, ntt_at(b0 + 1, c, log_c, sw), v); lds29_store(L, ntt_at(b0 + 2, c, log_c, sw), v); lds29_store(L, ntt_at(b0 + 3, c, log_c, sw), v);
         }
     } else {
         // a thread's (at most four: tile <= NTT_LOADS x threads by construction, run_ntt_t) elements: all four global loads are issued before the first is unpacked -- one memory round trip per tile instead of four
@@ -224,7 +236,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
                 qq += rest;
                 g = (qq << r) + j;
             }
-            slot = idx < tile && g < P.src_len ? (bitrev32(j, r) << log_c) + c : (idx < tile ? 0x80000000u | ((bitrev32(j, r) << log_c) + c) : 0xffffffffu);
+#ifdef NTT_X_LINEAR_FILL      // (measurement only, WRONG results: the last pass's fill written row-wise instead of down a column -- what its LDS bank conflicts cost)
+            if (P.is_final) { j = idx >> log_c; c = idx & (Cc - 1); }
+#endif
+            const u32 at = ntt_at(bitrev32(j, r), c, log_c, sw);
+            slot = idx < tile && g < P.src_len ? at : (idx < tile ? 0x80000000u | at : 0xffffffffu);
         };
         auto fetch = [&](u32 slot, u64 g) __attribute__((always_inline)) -> fe {
             if (slot & 0x80000000u) return f_zero();      // beyond the tile, or beyond the valid coefficients (zero-extended)
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             u32 c = gidx & (Cc - 1), gq = gidx >> log_c;          // gq in [0, R/4)
             u32 pos = gq & (h - 1);
             u32 i0 = ((gq >> s) << (s + 2)) | pos;
-            u32 a0 = (i0 << log_c) + c, a1 = a0 + (h << log_c), a2 = a1 + (h << log_c), a3 = a2 + (h << log_c);
+            const u32 a0 = ntt_at(i0, c, log_c, sw), a1 = ntt_at(i0 + h, c, log_c, sw), a2 = ntt_at(i0 + 2 * h, c, log_c, sw), a3 = ntt_at(i0 + 3 * h, c, log_c, sw);
             f29 e0 = lds29_load(L, a0), e1 = lds29_load(L, a1), e2 = lds29_load(L, a2), e3 = lds29_load(L, a3);
             // stage s: (e0, e1) and (e2, e3), twiddle w_R^(pos * R / 2h)
             f29 w = ltw[pos << (r - 1 - s)];
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
             u32 c = bidx & (Cc - 1), b = bidx >> log_c;
             u32 pos = b & (h - 1);
             u32 i0 = ((b >> s) << (s + 1)) | pos;
-            u32 a0 = (i0 << log_c) + c, a1 = a0 + (h << log_c);
+            const u32 a0 = ntt_at(i0, c, log_c, sw), a1 = ntt_at(i0 + h, c, log_c, sw);
             f29 e0 = lds29_load(L, a0), e1 = lds29_load(L, a1);
             f29 w = ltw[pos << (r - 1 - s)];
             bfly29<F9>(e0, e1, w, s != 0);
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams P) {
     }
     for (u32 idx = tid; idx < tile; idx += nthr) {
         u32 k = idx >> log_c, c = idx & (Cc - 1);
-        f29 v = lds29_load(L, (k << log_c) + c);
+        f29 v = lds29_load(L, ntt_at(k, c, log_c, sw));
         u64 o;
         f29 w;
         if (!P.is_final) {
