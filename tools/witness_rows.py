@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Rows per gadget of this repository's MainGate / RangeChip layouter (witness.py; csrc/witness.hip writes the same rows) beside the row counts the
-reference publishes (benches/README.md:56-99).  CPU only.   python tools/witness_rows.py"""
+"""Rows per gadget of the MainGate / RangeChip layouter (witness.py; csrc/witness.hip writes the same rows) and the totals of the reference's circuits beside the
+row counts the reference publishes (benches/README.md:56-99): the table behind DESIGN.md section 5.  CPU only.   python tools/witness_rows.py"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
@@ -15,61 +15,49 @@ x = rnd.getrandbits(2040)
 def rows_of(fn):
     lay = W.Layouter(p)
     chip = W.BigIntChip(lay)
-    before = fn(lay, chip, setup=True)
+    state = fn(lay, chip, True, None)
     r0 = lay.rows
-    fn(lay, chip, setup=False, state=before)
+    fn(lay, chip, False, state)
     return lay.rows - r0
 
 
-def g_assign(lay, chip, setup, state=None):
-    if setup: return None
-    chip.assign_integer(x)
-def g_mul(lay, chip, setup, state=None):
-    if setup: return (chip.assign_integer(x), chip.assign_integer(x >> 3))
-    chip.mul(*state)
-def g_mul_mod(lay, chip, setup, state=None):
-    if setup: return (chip.assign_integer(x), chip.assign_integer(x >> 3), chip.assign_integer(n_big))
-    chip.mul_mod(state[0], state[1], state[2], n_big)
-def g_eq(lay, chip, setup, state=None):
-    if setup:
-        a, b, n = chip.assign_integer(x), chip.assign_integer(x >> 3), chip.assign_integer(n_big)
-        to_big = lambda limbs: sum(c.val << (64 * i) for i, c in enumerate(limbs))
-        full = to_big(a) * to_big(b)
-        q = [lay.range_assign(v, 64) for v in W.limbs_of(full // n_big, 32)]
-        r = [lay.range_assign(v, 64) for v in W.limbs_of(full % n_big, 32)]
-        ab, qn = chip.mul(a, b), chip.mul(q, n)
-        eq_b = [lay.add(qn[i], r[i]) if i < 32 else qn[i] for i in range(63)]
-        return ab, eq_b
-    chip.assert_equal_muled(state[0], state[1], 32, 32)
-def g_range64(lay, chip, setup, state=None):
-    if setup: return None
-    lay.range_assign(x & (2**64 - 1), 64)
-def g_range70(lay, chip, setup, state=None):
-    if setup: return None
-    lay.range_assign(x & (2**70 - 1), 70)
-def g_select(lay, chip, setup, state=None):
-    if setup: return (chip.assign_integer(x), chip.assign_integer(x >> 3), lay.assign_bit(1))
-    [lay.select(state[0][j], state[1][j], state[2]) for j in range(32)]
-def g_bits(lay, chip, setup, state=None):
-    if setup: return lay.assign_value(21)
-    lay.to_bits(state, 5)
+def gadget(setup_fn, run_fn):
+    return lambda lay, chip, setup, state: setup_fn(lay, chip) if setup else run_fn(lay, chip, state)
 
+
+three = lambda lay, chip: (chip.assign_integer(x), chip.assign_integer(x >> 3), chip.assign_integer(n_big))
+gadgets = [
+    ("RangeChip::assign of one 64-bit limb (eight 8-bit limbs)", gadget(lambda l, c: None, lambda l, c, s: c.range_limb(x & (2**64 - 1)))),
+    ("RangeChip::assign of one 70-bit carry (eight 8-bit limbs + a 6-bit overflow limb)", gadget(lambda l, c: None, lambda l, c, s: l.range_assign(x & (2**70 - 1), 8, 70))),
+    ("is_equal / is_zero / select / assert_equal", gadget(lambda l, c: (l.assign_value(5), l.assign_value(5), l.assign_bit(1)),
+                                                         lambda l, c, s: (l.is_equal(s[0], s[1]), l.is_zero(s[0]), l.select(s[0], s[1], s[2]), l.assert_equal(s[0], s[1])))),
+    ("div_mod_main_gate", gadget(lambda l, c: (l.assign_value(x & (2**100 - 1)), l.assign_constant(1 << 64)), lambda l, c, s: c.div_mod_main_gate(*s))),
+    ("assign_integer (32 range-checked limbs)", gadget(lambda l, c: None, lambda l, c, s: c.assign_integer(x))),
+    ("mul 32 x 32 limbs (63 product limbs)", gadget(three, lambda l, c, s: c.mul(s[0], s[1]))),
+    ("add 32 + 32 limbs", gadget(three, lambda l, c, s: c.add(s[0], s[1]))),
+    ("sub (a + max - b, selects, two sub_unchecked)", gadget(three, lambda l, c, s: c.sub(s[2], s[1]))),
+    ("assert_in_field (x < n)", gadget(three, lambda l, c, s: c.assert_in_field(s[1], s[2]))),
+    ("mul_mod (quotient + remainder limbs, two mul, carried equality)", gadget(three, lambda l, c, s: c.mul_mod(s[0], s[1], s[2]))),
+    ("to_bits of a 5-bit exponent limb", gadget(lambda l, c: l.assign_value(21), lambda l, c, s: l.to_bits(s, 5))),
+    ("one Poseidon permutation (T = 5, R_F = 8, R_P = 57)", gadget(lambda l, c: W.PoseidonChip(l, W.poseidon_spec(p), [l.assign_value(i) for i in range(5)]), lambda l, c, s: s.permutation([]))),
+]
 print("rows per gadget (32 limbs of 64 bits, 2048-bit modulus):")
-for name, fn in (("range_assign of one 64-bit limb (8-bit sub-limbs)", g_range64), ("range_assign of one 70-bit carry (8 sub-limbs + a 6-bit overflow limb)", g_range70),
-                 ("assign_integer (32 range-checked limbs)", g_assign), ("mul 32 x 32 limbs (63 product limbs)", g_mul),
-                 ("assert_equal_muled (63 carried limbs)", g_eq), ("mul_mod (quotient + remainder limbs, two mul, carried equality)", g_mul_mod),
-                 ("select of 32 limbs on one exponent bit", g_select), ("to_bits of a 5-bit exponent", g_bits)):
-    print("  %-78s %6d" % (name, rows_of(fn)))
-print("totals of whole circuits, this layouter | the reference's README:")
-ref_mod_pow = {1: None, 2: 17822, 5: 41766}
-for bits in (1, 2, 3, 5, 8, 15):
+for name, fn in gadgets:
+    print("  %-84s %6d" % (name, rows_of(fn)))
+print("closed forms: mul_mod %d, RSA region 1,860 + 7,981 bits + ceil(bits / 4) = %s, hash region %d, cipher region (2 words, keyed by the digest) %d" %
+      (W.mul_mod_rows(), [W.rsa_region_rows(b) for b in (1, 2, 15)], W.hash_region_rows(), W.cipher_region_rows(2, True)))
+print("totals of whole circuits | the reference's README (the published figure is the last used row's index: rows - 1):")
+published = {2: 17822, 3: 25803, 5: 41766, 8: 65709, 15: 121578}
+for bits in (1, 2, 3, 5):
     e = (1 << (bits - 1)) | 1
     _, info = W.mod_pow_witness(p, 18, n_big, e, x, bits)
-    print("  mod_pow, %2d-bit exponent: %7d rows | %s" % (bits, info.total_rows, {2: "17,822 (README:70)", 5: "41,766 (README:73)", 8: "65,709", 15: "121,578 (README:77)"}.get(bits, "-")))
-for bits in (2, 15):
-    e = (1 << (bits - 1)) | 1
-    _, info = W.delay_enc_witness(p, 18, n_big, e, x, bits, [3, 4])
-    print("  delay_enc, %2d-bit exponent: %7d rows (%d RSA + %d hash / cipher) | %s" % (bits, info.total_rows, info.rsa_rows, info.total_rows - info.rsa_rows, {2: "26,461 (README:56)", 15: "130,248 (README:60)"}[bits]))
-for msg in (1, 2, 3, 4):
-    _, info = W.pose_enc_witness(p, 11, [5, 6], list(range(1, msg + 1)))
-    print("  pose_enc, %d message element(s): %6d rows | %d (README:89-92: 1,446 + 4 msg)" % (msg, info.total_rows, 1446 + 4 * msg))
+    print("  mod_pow, %2d-bit exponent: %7d rows | %s" % (bits, info.total_rows, published.get(bits, "-")))
+for bits in (8, 15):
+    print("  mod_pow, %2d-bit exponent: %7d rows (closed form) | %s" % (bits, W.rsa_region_rows(bits), published[bits]))
+for bits, pub in ((2, 26461), (15, 130248)):
+    total = W.rsa_region_rows(bits) + W.hash_region_rows() + W.cipher_region_rows(2, True)
+    print("  delay_enc, %2d-bit exponent: %7d rows (closed form) | %d: +5,035 = the hash region of the revision the table was made with (DESIGN.md section 5)%s" %
+          (bits, total, pub, "; the published run drew e = 0 (31 rows fewer)" if bits == 2 else ""))
+for msg in (1, 2, 3, 4, 5, 16, 31):
+    _, info = W.pose_enc_witness(p, 13, [5, 6], [0] * msg)
+    print("  pose_enc, %2d message word(s): %6d rows | %d" % (msg, info.total_rows, {1: 1446, 2: 1450, 3: 1454, 4: 1458, 5: 2180, 16: 3660, 31: 6592}[msg]))
