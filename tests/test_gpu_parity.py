@@ -381,6 +381,21 @@ def test_msm_17_bit_windows_at_2_20(pkg, co, ctx, cname):
     h.release()
 
 
+def test_msm_2_21_points_with_the_librarys_window(pkg, co, ctx):
+    """Beyond the bench's size: 2^21 points, the window the library chooses (17 bits: the per-slice histogram stays packed 16-bit by cutting more slices -- 481 instead
+    of 256), uniform scalars and a long run of one value, against the CPU port."""
+    spec = pkg.fields.PALLAS
+    n = 1 << 21
+    bases = co.synth_bases(spec.id, n)
+    h = ctx.register_bases(spec.id, bases, 0, True)
+    assert (h.window_bits, h.windows) == (17, 15)
+    sc = co.fill_scalars(spec.scalar.id, "uniform", n, 2121)
+    sc[1000:700000] = spec.scalar.encode(int("00ff" * 16, 16) % spec.scalar.p)
+    want = co.to_affine(spec.id, co.best_multiexp(spec.id, sc, bases, 16))
+    assert np.array_equal(ctx.to_affine(spec.id, ctx.msm(h, sc))[0], want)
+    h.release()
+
+
 def test_msm_sort_in_512_thread_workgroups_with_packed_histogram(pkg, co):
     """dehalo_ctx_set_tuning("msm_sort_block", 512): the sort's scalar-decoding kernels in 512-thread workgroups -- k_msm_hist counts into two 16-bit counters a word
     (64 KiB of LDS) whenever a block's scalars times its windows stay below 2^16, k_msm_part stages on eight waves.  The same results as the CPU port for sizes on
